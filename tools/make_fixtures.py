@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generate the committed fixtures under tests/golden/ (run in the BUILD container only).
+
+For each fixture: (1) build a synthetic chain, (2) compact it with the UNMODIFIED reference
+(oracle/_ref/upside_<variant>, cavity_radial at T=0.9), (3) write the final
+`.up` configuration (no cavity) and (4) record golden vectors from the compiled reference through its
+C-ABI: total energy, (n_atom,3) derivative, every node's output/sens, the rotamer node's named values
+and the canonical pair list.  Nothing here is needed at test time; tests read only tests/golden/.
+
+usage: python tools/make_fixtures.py [name ...]
+"""
+import os
+import subprocess
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+cfg = pkg.config
+REF = os.path.join(ROOT, 'oracle', '_ref')
+PARAM = '/root/reference/parameters'
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+HBOND = float(open(os.path.join(PARAM, 'ff_1', 'hbond')).read())
+
+# name: (sequence or n_res, variant, sidechain lib, cavity radius, seed, per-residue rama maps)
+FIXTURES = {
+    'trpcage20_7A': (cfg.TRP_CAGE, '7A', 'ff_1/sidechain.h5', 9.0, 11, True),
+    'proteinG56_7A': (cfg.PROTEIN_G, '7A', 'ff_1/sidechain.h5', 12.5, 12, True),
+    'syn150_10A': (150, '10A', 'packing/sidechain_10A_cutoff.h5', 18.5, 13, False),
+    'syn300_10A': (300, '10A', 'packing/sidechain_10A_cutoff.h5', 22.0, 14, False),
+    'syn300_7A': (300, '7A', 'ff_1/sidechain.h5', 22.0, 14, False),
+}
+
+NODES = ['rama_coord', 'affine_alignment', 'infer_H_O', 'placement_fixed_point_vector_only',
+         'placement_fixed_point_vector_only_CB', 'placement_fixed_point_vector_scalar', 'placement_scalar',
+         'protein_hbond', 'weighted_pos', 'environment_coverage', 'hbond_coverage',
+         'hbond_coverage_hydrophobe']
+POTENTIALS = ['rama_map_pot', 'rama_map_pot_ref', 'angle_spring', 'backbone_pairs', 'dihedral_spring',
+              'dist_spring', 'hbond_energy', 'nonlinear_coupling_environment', 'rotamer']
+
+
+def rg(pos):
+    return float(np.sqrt(((pos - pos.mean(axis=0)) ** 2).sum(axis=1).mean()))
+
+
+def make(name):
+    seq, variant, sclib, r_cavity, seed, per_res = FIXTURES[name]
+    fasta = cfg.fasta_from_one_letter(seq) if isinstance(seq, str) else cfg.random_fasta(seq, seed)
+    n_res = len(fasta)
+    rama_ref = cfg.load_rama_reference(os.path.join(PARAM, 'common', 'rama_reference.pkl'))
+    kw = dict(sidechain_lib=os.path.join(PARAM, sclib),
+              environment_lib=os.path.join(PARAM, 'ff_1', 'environment.h5'),
+              rama_ref=rama_ref, hbond_energy=HBOND, rama_seed=seed, per_residue_rama=per_res)
+    out = os.path.join(GOLD, name + '.up')
+    coords_file = os.path.join(GOLD, name + '.coords.npy')
+    if os.path.exists(coords_file):
+        pos = np.load(coords_file).astype('f8')
+    else:
+        pos0 = cfg.random_chain(n_res, seed)
+        tmp = '/tmp/_compact_%s.up' % name
+        cfg.write_config(tmp, fasta, pos0, cavity_radius=r_cavity, **kw)
+        exe = os.path.join(REF, 'upside_' + variant)
+        subprocess.check_call([exe, '--duration', '200', '--frame-interval', '20', '--temperature', '0.9',
+                               '--seed', '1', '--disable-recentering', tmp], stdout=subprocess.DEVNULL)
+        pos = cfg.read_last_frame(tmp).astype('f8')
+        pos -= pos.mean(axis=0)
+        os.remove(tmp)
+        np.save(coords_file, pos.astype('f4'))
+    info = cfg.write_config(out, fasta, pos, **kw)
+    print('%s: n_res %i beads %i Rg %.2f  file %.2f MB' % (name, n_res, info['n_bead'], rg(pos),
+                                                          os.path.getsize(out) / 1e6))
+
+    # golden vectors from the compiled reference
+    lib = pkg.UpsideLibrary(os.path.join(REF, 'libupside_%s.so' % variant))
+    up = pkg.Upside(out, library=lib)
+    x = up.initial_pos.copy()
+    g = dict(pos=x, energy=np.float32(up.energy(x)), deriv=up.deriv(x))
+    for nm in NODES:
+        g['out/' + nm] = up.get_output(nm)
+        g['sens/' + nm] = up.get_sens(nm)
+    for nm in POTENTIALS:
+        g['pot/' + nm] = up.get_output(nm)[0, 0]
+    n_node = int(up.get_value_by_name((1,), 'rotamer', 'n_node')[0])
+    g['rotamer/n_node'] = np.int32(n_node)
+    g['rotamer/node_energy'] = up.get_value_by_name((n_node, 6), 'rotamer', 'node_energy')
+    g['rotamer/rotamer_free_energy'] = up.get_value_by_name((n_node,), 'rotamer', 'rotamer_free_energy')
+    g['rotamer/rotamer_1body_energy'] = up.get_value_by_name((n_node, 3), 'rotamer', 'rotamer_1body_energy')
+    n_type = 20
+    g['rotamer/count_edges_by_type'] = up.get_value_by_name((n_type, n_type), 'rotamer', 'count_edges_by_type')
+    for nm in ('hbond_coverage', 'hbond_coverage_hydrophobe'):
+        shp = (2 if nm == 'hbond_coverage' else 3, 20)
+        g['edges/' + nm] = up.get_value_by_name(shp, nm, 'count_edges_by_type')
+    if n_res <= 60:
+        em = up.get_value_by_name((n_node, n_node, 6, 6), 'rotamer', 'edge_marginal_in_graph_order')
+        g['rotamer/node_marginal'] = np.stack([em[i, i].diagonal() for i in range(n_node)])
+    # a second, perturbed evaluation through the cached pair list (no rebuild)
+    rs = np.random.RandomState(seed + 100)
+    x2 = (x + 0.05 * rs.normal(size=x.shape)).astype('f4')
+    g['pos2'] = x2
+    g['energy2'] = np.float32(up.energy(x2))
+    g['deriv2'] = up.deriv(x2)
+    up.close()
+
+    # pair list (rotamer graph), both passes
+    dump = '/tmp/_pairs_%s.txt' % name
+    subprocess.check_call([os.path.join(REF, 'pairlist_dump_' + variant), out, dump])
+    lines = open(dump).read().split('\n')
+    hdr = lines[0].split()
+    n_edge = int(hdr[1])
+    g['pairlist/cutoff'] = np.float32(hdr[3])
+    arr = np.array([ln.split() for ln in lines[1:1 + n_edge]], dtype='f8').reshape(n_edge, 5)
+    g['pairlist/edges'] = arr[:, :4].astype('i4')
+    g['pairlist/value'] = arr[:, 4].astype('f4')
+    os.remove(dump)
+    np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
+    print('   energy %.4f  |deriv| %.3f  rotamer edges %i  golden %.2f MB' % (
+        g['energy'], np.abs(g['deriv']).max(), n_edge,
+        os.path.getsize(os.path.join(GOLD, name + '.golden.npz')) / 1e6))
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(FIXTURES)
+    for nm in names:
+        make(nm)

@@ -1,0 +1,384 @@
+"""python3 configuration writer for the README force field.
+
+Restates the subset of the reference's Python-2/PyTables generator that the README MD recipe uses
+(/root/reference/README.md:143-153), writing the same `/input` schema through libhdf5 (h5lite):
+
+    write_dist_spring       /root/reference/py/upside_config.py:480-498
+    write_angle_spring      ...:500-512
+    write_dihedral_spring   ...:514-525
+    write_rotamer_placement ...:885-1006
+    write_infer_H_O         ...:187-212
+    write_count_hbond       ...:295-378
+    write_environment       ...:215-292
+    write_rama_map_pot      ...:692-734 (+ reference-state block 1480-1491)
+    write_backbone_pair     ...:149-165
+    write_rotamer           ...:1009-1035
+    write_rama_coord        ...:855-863
+    write_affine_alignment  ...:168-184
+    write_cavity_radial     ...:37-43   (only used to compact synthetic chains)
+    random_initial_config   ...:414-476
+
+`parameters/common/rama.dat` is a missing blob in the reference checkout, so Ramachandran maps are
+synthetic: -log(reference-state map) plus a smooth per-residue Fourier perturbation (seeded).
+"""
+import numpy as np
+from . import h5lite
+
+three_letter_aa = dict(
+    A='ALA', C='CYS', D='ASP', E='GLU', F='PHE', G='GLY', H='HIS', I='ILE', K='LYS', L='LEU',
+    M='MET', N='ASN', P='PRO', Q='GLN', R='ARG', S='SER', T='THR', V='VAL', W='TRP', Y='TYR')
+aa_sorted = sorted(three_letter_aa.values())
+deg = np.deg2rad(1.)
+n_bit_rotamer = 4
+
+TRP_CAGE = "NLYIQWLKDGGPSSGRPPPS"
+PROTEIN_G = "MTYKLILNGKTLKGETTTEAVDAATAEKVFKQYANDNGVDGEWTYDDATKTFTVTE"
+
+
+def fasta_from_one_letter(s):
+    return np.array([three_letter_aa[c] for c in s])
+
+
+def random_fasta(n_res, seed):
+    """uniform random sequence over the alphabetical 3-letter codes."""
+    idx = np.random.RandomState(seed).randint(0, 20, n_res)
+    return np.array([aa_sorted[i] for i in idx])
+
+
+# ---------------------------------------------------------------------------------------------
+# structure generation (upside_config.py:414-476)
+def _tab_matrices(phi, theta, bond_length):
+    r = np.zeros(phi.shape + (4, 4))
+    cp, sp, ct, st, l = np.cos(phi), np.sin(phi), np.cos(theta), np.sin(theta), bond_length
+    r[..., 0, 0] = -ct;    r[..., 0, 1] = -st;     r[..., 0, 2] = 0;   r[..., 0, 3] = -l * ct
+    r[..., 1, 0] = cp * st; r[..., 1, 1] = -cp * ct; r[..., 1, 2] = -sp; r[..., 1, 3] = l * cp * st
+    r[..., 2, 0] = sp * st; r[..., 2, 1] = -sp * ct; r[..., 2, 2] = cp;  r[..., 2, 3] = l * sp * st
+    r[..., 3, 3] = 1
+    return r
+
+
+def chain_from_rama(rama):
+    """rama (n_res,2) phi,psi in radians -> (3*n_res,3) N,CA,C positions with ideal geometry."""
+    n_res = rama.shape[0]
+    r3 = np.zeros((n_res, 3))
+    r3[:, 0:2] = rama
+    r3[:, 2] = np.pi
+    angles = np.zeros_like(r3)
+    lengths = np.zeros_like(r3)
+    angles[:, 0] = 120.0 * deg
+    angles[:, 1] = 120.0 * deg
+    angles[:, 2] = 109.5 * deg
+    lengths[:, 0] = 1.453
+    lengths[:, 1] = 1.526
+    lengths[:, 2] = 1.300
+    t = np.zeros(3 * n_res)
+    t[3::3] = r3[:-1, 1]
+    t[4::3] = r3[:-1, 2]
+    t[5::3] = r3[1:, 0]
+    tr = _tab_matrices(t, angles.ravel(), lengths.ravel())
+    cur = np.eye(4)
+    pos = np.zeros((3 * n_res, 3))
+    for i, m in enumerate(tr):
+        cur = cur.dot(m)
+        pos[i] = cur[:3, 3]
+    return pos - pos.mean(axis=0)
+
+
+def random_chain(n_res, seed):
+    rs = np.random.RandomState(seed)
+    return chain_from_rama(rs.random_sample((n_res, 2)) * 2 * np.pi - np.pi)
+
+
+def helix_chain(n_res):
+    return chain_from_rama(np.tile(np.array([[-60. * deg, -45. * deg]]), (n_res, 1)))
+
+
+# ---------------------------------------------------------------------------------------------
+def synthetic_rama_maps(n_res, ref_map, seed, amplitude=1.0):
+    """(n_res,72,72) potentials: -log(ref) + smooth seeded perturbation, then the reference's
+    normalisation (upside_config.py:730)."""
+    rs = np.random.RandomState(seed)
+    nx = ref_map.shape[0]
+    base = -np.log(ref_map)
+    phi = np.linspace(-np.pi, np.pi, nx, endpoint=False)[:, None]
+    psi = np.linspace(-np.pi, np.pi, nx, endpoint=False)[None, :]
+    pots = np.zeros((n_res, nx, nx))
+    for i in range(n_res):
+        c = rs.normal(size=(3, 3, 2)) * amplitude / 3.
+        p = base.copy()
+        for a in range(3):
+            for b in range(3):
+                if a == 0 and b == 0:
+                    continue
+                p += c[a, b, 0] * np.cos(a * phi + b * psi) + c[a, b, 1] * np.sin(a * phi + b * psi)
+        pots[i] = p
+    pots += np.log(np.exp(-pots).sum(axis=(-2, -1), keepdims=True))   # exp(-pot) sums to 1 per map
+    pots -= (pots * np.exp(-pots)).sum(axis=(-2, -1), keepdims=True)
+    return pots
+
+
+def load_rama_reference(path):
+    import pickle
+    with open(path, 'rb') as f:
+        return np.asarray(pickle.load(f, encoding='latin1'), dtype='f8')
+
+
+# ---------------------------------------------------------------------------------------------
+def _args(g, names):
+    g.set_attr('arguments', list(names))
+
+
+def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref, hbond_energy,
+                 rama_seed=0, cavity_radius=0., rotamer_damping=0.4, bond_stiffness=48.,
+                 angle_stiffness=175., per_residue_rama=True):
+    """fasta: array of 3-letter codes; init_pos (3*n_res,3); sidechain_lib / environment_lib: paths to
+    the parameter HDF5 libraries; rama_ref: (72,72) reference-state probabilities."""
+    fasta = np.asarray(fasta)
+    n_res = len(fasta)
+    n_atom = 3 * n_res
+    assert init_pos.shape == (n_atom, 3)
+
+    with h5lite.open_file(sidechain_lib) as lib:
+        restype_order = [x.decode() for x in lib.read('restype_order')]
+        bead_order = [x.decode() for x in lib.read('bead_order')]
+        rotamer_center_fixed = lib.read('rotamer_center_fixed', 'f8')
+        rotamer_prob = lib.read('rotamer_prob', 'f8')
+        start_stop = lib.read('rotamer_start_stop_bead', 'i8')
+        pair_interaction = lib.read('pair_interaction', 'f8')
+        coverage_interaction = lib.read('coverage_interaction', 'f8')
+        hydrophobe_placement = lib.read('hydrophobe_placement', 'f8')
+        hydrophobe_interaction = lib.read('hydrophobe_interaction', 'f8')
+    with h5lite.open_file(environment_lib) as lib:
+        env_energies = lib.read('energies', 'f8')
+        env_offset = float(lib.get_attr('offset', 'energies'))
+        env_inv_dx = float(lib.get_attr('inv_dx', 'energies'))
+        env_restype = dict((x.decode(), i) for i, x in enumerate(lib.read('restype_order')))
+        env_coverage_param = lib.read('coverage_param', 'f8')
+    restype_num = dict((aa, i) for i, aa in enumerate(restype_order))
+    bead_num = dict((k, i) for i, k in enumerate(bead_order))
+
+    f = h5lite.open_file(path, 'w')
+    inp = f.create_group('input')
+    inp.write('sequence', fasta)
+    inp.write('pos', init_pos.reshape(n_atom, 3, 1).astype('f4'))
+    pot = inp.create_group('potential')
+
+    # --- bonded springs -------------------------------------------------------------------
+    g = pot.create_group('dist_spring'); _args(g, ['pos'])
+    ids = np.arange(n_atom - 1)
+    ids = np.column_stack((ids, ids + 1))
+    eq = np.zeros(ids.shape[0]); eq[0::3] = 1.453; eq[1::3] = 1.526; eq[2::3] = 1.300
+    g.write('id', ids.astype('i4')); g.write('equil_dist', eq)
+    g.write('spring_const', bond_stiffness * np.ones(ids.shape[0]))
+    g.write('bonded_atoms', np.ones(ids.shape[0], dtype='i4'))
+
+    g = pot.create_group('angle_spring'); _args(g, ['pos'])
+    ids = np.arange(n_atom - 2)
+    ids = np.column_stack((ids, ids + 2, ids + 1))
+    eq = np.zeros(ids.shape[0])
+    eq[0::3] = np.cos(109.5 * deg); eq[1::3] = np.cos(120.0 * deg); eq[2::3] = np.cos(120.0 * deg)
+    g.write('id', ids.astype('i4')); g.write('equil_dist', eq)
+    g.write('spring_const', angle_stiffness * np.ones(ids.shape[0]))
+
+    g = pot.create_group('dihedral_spring'); _args(g, ['pos'])
+    ids = np.arange(1, n_atom - 3, 3)
+    ids = np.column_stack((ids, ids + 1, ids + 2, ids + 3))
+    g.write('id', ids.astype('i4'))
+    g.write('equil_dist', np.where(fasta[1:] == 'CPR', 0. * deg, 180. * deg))
+    g.write('spring_const', 30.0 * np.ones(ids.shape[0]))
+
+    # --- rotamer placement (fixed placement, dynamic 1-body) ---------------------------------
+    placement_pos = rotamer_center_fixed
+    placement_energy = -np.log(rotamer_prob.transpose((2, 0, 1)))[..., None]
+    rama_residue, affine_residue, layer_index, beadtype_seq, id_seq = [], [], [], [], []
+    count_by_n_rot = dict()
+    for rnum, aa in enumerate(fasta):
+        start, stop, n_bead = [int(x) for x in start_stop[restype_num[aa]]]
+        assert (stop - start) % n_bead == 0
+        n_rot = (stop - start) // n_bead
+        base_id = (count_by_n_rot.get(n_rot, 0) << n_bit_rotamer) + n_rot
+        count_by_n_rot[n_rot] = count_by_n_rot.get(n_rot, 0) + 1
+        rama_residue.extend([rnum] * (stop - start))
+        affine_residue.extend([rnum] * (stop - start))
+        layer_index.extend(range(start, stop))
+        beadtype_seq.extend(['%s_%i' % (aa, i) for i in range(n_bead)] * n_rot)
+        id_seq.extend(np.arange(stop - start) // n_bead + (base_id << n_bit_rotamer))
+    affine_residue = np.array(affine_residue, dtype='i4')
+    n_sc = len(affine_residue)
+
+    sc_node_name, pl_node_name = 'placement_fixed_point_vector_only', 'placement_scalar'
+    g = pot.create_group(sc_node_name); _args(g, ['affine_alignment'])
+    g.write('rama_residue', np.array(rama_residue, dtype='i4'))
+    g.write('affine_residue', affine_residue)
+    g.write('layer_index', np.array(layer_index, dtype='i4'))
+    g.write('placement_data', placement_pos[..., :6])
+    g.write('beadtype_seq', np.array(beadtype_seq))
+    g.write('id_seq', np.array(id_seq, dtype='i4'))
+
+    g = pot.create_group(pl_node_name); _args(g, ['affine_alignment', 'rama_coord'])
+    g.write('rama_residue', np.array(rama_residue, dtype='i4'))
+    g.write('affine_residue', affine_residue)
+    g.write('layer_index', np.array(layer_index, dtype='i4'))
+    g.write('placement_data', placement_energy.astype('f4'))
+
+    # --- hydrogen bonds -------------------------------------------------------------------
+    donor_res = np.array([i for i in range(n_res) if i > 0 and fasta[i] != 'PRO'], dtype='i4')
+    acc_res = np.array([i for i in range(n_res) if i < n_res - 1], dtype='i4')
+    n_donor, n_acceptor = len(donor_res), len(acc_res)
+    g = pot.create_group('infer_H_O'); _args(g, ['pos'])
+    don = g.create_group('donors'); acc = g.create_group('acceptors')
+    don.write('residue', donor_res); acc.write('residue', acc_res)
+    don.write('bond_length', 0.88 * np.ones(n_donor)); acc.write('bond_length', 1.24 * np.ones(n_acceptor))
+    don.write('id', (np.array((-1, 0, 1))[None, :] + 3 * donor_res[:, None]).astype('i4'))
+    acc.write('id', (np.array((1, 2, 3))[None, :] + 3 * acc_res[:, None]).astype('i4'))
+
+    g = pot.create_group('protein_hbond'); _args(g, ['infer_H_O'])
+    g.write('index1', np.arange(n_donor, dtype='i4')); g.write('type1', np.zeros(n_donor, dtype='i4'))
+    g.write('id1', donor_res)
+    g.write('index2', np.arange(n_donor, n_donor + n_acceptor, dtype='i4'))
+    g.write('type2', np.zeros(n_acceptor, dtype='i4')); g.write('id2', acc_res)
+    g.write('interaction_param', np.array([[[1.4, 1. / 0.10, 2.5, 1. / 0.125, 0.682, 1. / 0.05, 0., 0.]]]))
+
+    g = pot.create_group('hbond_coverage'); _args(g, ['protein_hbond', sc_node_name])
+    g.write('interaction_param', coverage_interaction)
+    g.write('index1', np.arange(n_donor + n_acceptor, dtype='i4'))
+    g.write('type1', (1 * (np.arange(n_donor + n_acceptor) >= n_donor)).astype('i4'))
+    g.write('id1', np.concatenate([donor_res, acc_res]))
+    g.write('index2', np.arange(n_sc, dtype='i4'))
+    g.write('type2', np.array([bead_num[s] for s in beadtype_seq], dtype='i4'))
+    g.write('id2', affine_residue)
+
+    g = pot.create_group('placement_fixed_point_vector_scalar'); _args(g, ['affine_alignment'])
+    g.write('affine_residue', (np.arange(3 * n_res) // 3).astype('i4'))
+    g.write('layer_index', (np.arange(3 * n_res) % 3).astype('i4'))
+    g.write('placement_data', hydrophobe_placement)
+
+    g = pot.create_group('hbond_coverage_hydrophobe')
+    _args(g, ['placement_fixed_point_vector_scalar', sc_node_name])
+    g.write('interaction_param', hydrophobe_interaction)
+    g.write('index1', np.arange(3 * n_res, dtype='i4'))
+    g.write('type1', (np.arange(3 * n_res) % 3).astype('i4'))
+    g.write('id1', (np.arange(3 * n_res) // 3).astype('i4'))
+    g.write('index2', np.arange(n_sc, dtype='i4'))
+    g.write('type2', np.array([bead_num[s] for s in beadtype_seq], dtype='i4'))
+    g.write('id2', affine_residue)
+
+    g = pot.create_group('hbond_energy'); _args(g, ['protein_hbond'])
+    g.set_attr('protein_hbond_energy', float(hbond_energy))
+
+    # --- environment ----------------------------------------------------------------------
+    g = pot.create_group('placement_fixed_point_vector_only_CB'); _args(g, ['affine_alignment'])
+    ref_pos = np.zeros((4, 3))
+    ref_pos[0] = (-1.19280531, -0.83127186, 0.)
+    ref_pos[1] = (0., 0., 0.)
+    ref_pos[2] = (1.25222632, -0.87268266, 0.)
+    ref_pos[3] = (0., 0.94375626, 1.2068012)
+    ref_pos -= ref_pos.mean(axis=0, keepdims=1)   # sic: the reference centres on all four atoms here
+    pd = np.zeros((1, 6))
+    pd[0, 0:3] = ref_pos[3]
+    v = ref_pos[3] - ref_pos[2]
+    pd[0, 3:6] = v / np.sqrt((v ** 2).sum())
+    g.write('affine_residue', np.arange(n_res, dtype='i4'))
+    g.write('layer_index', np.zeros(n_res, dtype='i4'))
+    g.write('placement_data', pd)
+
+    g = pot.create_group('weighted_pos'); _args(g, [sc_node_name, pl_node_name])
+    g.write('index_pos', np.arange(n_sc, dtype='i4')); g.write('index_weight', np.arange(n_sc, dtype='i4'))
+
+    g = pot.create_group('environment_coverage')
+    _args(g, ['placement_fixed_point_vector_only_CB', 'weighted_pos'])
+    g.write('index1', np.arange(n_res, dtype='i4'))
+    g.write('type1', np.array([env_restype[s] for s in fasta], dtype='i4'))
+    g.write('id1', np.arange(n_res, dtype='i4'))
+    g.write('index2', np.arange(n_sc, dtype='i4'))
+    g.write('type2', np.zeros(n_sc, dtype='i4'))
+    g.write('id2', affine_residue)
+    g.write('interaction_param', env_coverage_param)
+
+    g = pot.create_group('nonlinear_coupling_environment'); _args(g, ['environment_coverage'])
+    g.write('coeff', env_energies)
+    g.set_attr('spline_offset', env_offset, 'coeff')
+    g.set_attr('spline_inv_dx', env_inv_dx, 'coeff')
+    g.write('coupling_types', np.array([env_restype[s] for s in fasta], dtype='i4'))
+
+    # --- Ramachandran maps ------------------------------------------------------------------
+    g = pot.create_group('rama_map_pot'); _args(g, ['rama_coord'])
+    if per_residue_rama:
+        rama_pot = synthetic_rama_maps(n_res, rama_ref, rama_seed)
+        map_id = np.arange(n_res, dtype='i4')
+    else:
+        rama_pot = synthetic_rama_maps(20, rama_ref, rama_seed)
+        map_id = np.array([aa_sorted.index(s if s != 'CPR' else 'PRO') for s in fasta], dtype='i4')
+    g.write('residue_id', np.arange(n_res, dtype='i4'))
+    g.write('rama_map_id', map_id)
+    g.write('rama_pot', rama_pot.astype('f4'))
+
+    ref_cor = np.log(rama_ref)
+    ref_cor -= ref_cor.mean()
+    g = pot.create_group('rama_map_pot_ref'); _args(g, ['rama_coord'])
+    g.set_attr('log_pot', 0)
+    g.write('residue_id', np.arange(n_res, dtype='i4'))
+    g.write('rama_map_id', np.zeros(n_res, dtype='i4'))
+    g.write('rama_pot', ref_cor[None])
+
+    if cavity_radius:
+        g = pot.create_group('cavity_radial'); _args(g, ['pos'])
+        g.write('id', np.arange(n_atom, dtype='i4'))
+        g.write('radius', np.ones(n_atom) * cavity_radius)
+        g.write('spring_constant', np.ones(n_atom) * 5.)
+
+    # --- backbone sterics -------------------------------------------------------------------
+    g = pot.create_group('backbone_pairs'); _args(g, ['affine_alignment'])
+    rp = np.zeros((n_res, 4, 3))
+    rp[:, 0] = (-1.19280531, -0.83127186, 0.)
+    rp[:, 1] = (0., 0., 0.)
+    rp[:, 2] = (1.25222632, -0.87268266, 0.)
+    rp[:, 3] = (0., 0.94375626, 1.2068012)
+    rp[fasta == 'GLY', 3] = np.nan
+    rp -= rp[:, :3].mean(axis=1)[:, None]
+    g.write('id', np.arange(n_res, dtype='i4'))
+    g.write('ref_pos', rp)
+    g.write('n_atom', np.isfinite(rp.sum(axis=-1)).sum(axis=-1).astype('i4'))
+
+    # --- rotamer ---------------------------------------------------------------------------
+    g = pot.create_group('rotamer')
+    _args(g, [sc_node_name, pl_node_name, 'hbond_coverage', 'hbond_coverage_hydrophobe'])
+    g.set_attr('max_iter', 1000); g.set_attr('tol', 1e-3)
+    g.set_attr('damping', float(rotamer_damping)); g.set_attr('iteration_chunk_size', 2)
+    pg = g.create_group('pair_interaction')
+    pg.write('interaction_param', pair_interaction.astype('f4'))
+    pg.write('index', np.arange(n_sc, dtype='i4'))
+    pg.write('type', np.array([bead_num[s] for s in beadtype_seq], dtype='i4'))
+    pg.write('id', np.array(id_seq, dtype='i4'))
+
+    # --- backbone-derived coordinates -------------------------------------------------------
+    g = pot.create_group('rama_coord'); _args(g, ['pos'])
+    N_id = 3 * np.arange(n_res)
+    ids = np.column_stack((N_id - 1, N_id, N_id + 1, N_id + 2, N_id + 3))
+    ids[ids >= n_atom] = -1
+    g.write('id', ids.astype('i4'))
+
+    g = pot.create_group('affine_alignment'); _args(g, ['pos'])
+    rg = np.zeros((n_res, 3, 3))
+    rg[:, 0] = (-1.19280531, -0.83127186, 0.)
+    rg[:, 1] = (0., 0., 0.)
+    rg[:, 2] = (1.25222632, -0.87268266, 0.)
+    rg -= rg.mean(axis=1)[:, None]
+    g.write('atoms', np.column_stack((N_id, N_id + 1, N_id + 2)).astype('i4'))
+    g.write('ref_geom', rg)
+
+    f.close()
+    return dict(n_res=n_res, n_atom=n_atom, n_bead=n_sc, n_donor=n_donor, n_acceptor=n_acceptor)
+
+
+def read_pos(path):
+    with h5lite.open_file(path) as f:
+        return f.read('input/pos', 'f4')[:, :, 0]
+
+
+def read_last_frame(path):
+    """last frame of /output/pos (frame,1,n_atom,3) written by the reference's H5Logger
+    (/root/reference/src/main.cpp:526-531)."""
+    with h5lite.open_file(path) as f:
+        p = f.read('output/pos', 'f4')
+    return p[-1, 0]
