@@ -1,0 +1,106 @@
+/* Drop-in boundary of the MI355X-native Upside engine (libupside_hip.so).
+ *
+ * Part 1 repeats, symbol for symbol, the reference's C-ABI
+ *     /root/reference/src/engine_c_library.h:12-32   (+ upside_main, /root/reference/src/main.h:1-3)
+ * so that `py/upside_engine.py:19-64` (ctypes) binds to this library unchanged.  Semantics kept:
+ *   - construct_deriv_engine opens `potential_file` read-only and builds the DerivComputation graph from
+ *     group /input/potential (engine_c_library.cpp:9-20); returns NULL on failure, never throws.
+ *   - all other calls return 0 on success, 1 on failure after printing "ERROR: ..." to stderr
+ *     (engine_c_library.cpp:37-45); get_param_deriv returns -1 (built without PARAM_DERIV, :101-102).
+ *   - pos / deriv are dense row-major (n_atom,3) fp32 HOST buffers owned by the caller (:30-33,57-60);
+ *     node outputs are dense (n_elem, elem_width) (:146-149); potential nodes report (1,1).
+ *   - evaluate_* always run PotentialAndDerivMode and leave node output/sens inspectable (:34,55).
+ * The force pass itself runs as HIP kernels on the current device; if no GPU / kernel image is usable the
+ * calls FAIL (return NULL / 1) -- there is no CPU fallback in this library.
+ *
+ * Part 2 is the batched / device-resident extension the reference has no single call for: its MD loop
+ * lives in upside_main (/root/reference/src/main.cpp:616-667).  These entry points keep S independent
+ * systems (replicas / ensemble members) of one topology resident in HBM and step them together.
+ */
+#ifndef UPSIDE_ENGINE_C_H
+#define UPSIDE_ENGINE_C_H
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct DerivEngine;
+typedef struct DerivEngine DerivEngine;
+
+/* ---- Part 1: engine_c_library.h:12-32 ------------------------------------------------------ */
+DerivEngine* construct_deriv_engine(int n_atom, const char* potential_file, bool quiet); /* engine_c_library.h:12  */
+void free_deriv_engine(DerivEngine* engine);                                             /* :13 */
+int evaluate_energy(float* energy, DerivEngine* engine, const float* pos);               /* :15 */
+int evaluate_deriv(float* deriv, DerivEngine* engine, const float* pos);                 /* :16 */
+int set_param(int n_param, const float* param, DerivEngine* engine, const char* node_name);        /* :18 */
+int get_param_deriv(int n_param, float* deriv, DerivEngine* engine, const char* node_name);        /* :20 */
+int get_param(int n_param, float* param, DerivEngine* engine, const char* node_name);              /* :21 */
+int get_output_dims(int* n_elem, int* elem_width, DerivEngine* engine, const char* node_name);     /* :22 */
+int get_output(int n_output, float* output, DerivEngine* engine, const char* node_name);           /* :23 */
+int get_sens(int n_output, float* output, DerivEngine* engine, const char* node_name);             /* :24 */
+int get_value_by_name(int n_output, float* output, DerivEngine* engine,
+                      const char* node_name, const char* log_name);                                /* :26-27 */
+int clamped_spline_solve(int N, float* bspline_coeff, const float* values);                        /* :29 */
+int clamped_spline_value(int N, float* result, const float* bspline_coeff, int nx, float* x);      /* :30 */
+int get_clamped_value_and_deriv(int N, float* result, const float* bspline_coeff, int nx, float* x); /* :31 */
+int get_clamped_coeff_deriv(int N, float* result, const float* bspline_coeff, float x);            /* :32 */
+int upside_main(int argc, const char* const* argv, int verbose);                                   /* main.h:1-3 */
+
+/* ---- Part 2: batched device-resident extension ---------------------------------------------- */
+
+/* Same as construct_deriv_engine but with n_system independent copies (replicas / ensemble members) of
+ * the topology, all resident on the current HIP device.  construct_deriv_engine == n_system 1. */
+DerivEngine* upside_hip_construct(int n_atom, const char* potential_file, int n_system, bool quiet);
+int upside_hip_n_system(DerivEngine* engine);
+
+/* host (n_system, n_atom, 3) <-> device positions / momenta */
+int upside_hip_set_pos(DerivEngine* engine, const float* pos);
+int upside_hip_get_pos(DerivEngine* engine, float* pos);
+int upside_hip_set_mom(DerivEngine* engine, const float* mom);
+int upside_hip_get_mom(DerivEngine* engine, float* mom);
+
+/* force pass on all systems from the device-resident positions: energy (n_system) may be NULL
+ * (DerivMode, deriv_engine.h:42-45); deriv (n_system,n_atom,3) may be NULL. */
+int upside_hip_compute(DerivEngine* engine, float* energy, float* deriv);
+
+/* Thermostat set-up of upside_main (main.cpp:515-523): per-system temperature and seed
+ * (seed_s = base_seed + s, main.cpp:459), momenta fully resampled, n_invocations reset. */
+int upside_hip_init_md(DerivEngine* engine, const float* temperature, uint32_t base_seed,
+                       float thermostat_timescale, float dt, int thermostat_interval_rounds);
+
+/* n_round integration cycles (3 leapfrog stages each, deriv_engine.cpp:172-192) with the
+ * Ornstein-Uhlenbeck thermostat (thermostat.cpp:9-18) every thermostat_interval rounds; everything
+ * stays on the device, the call returns after the stream has drained. */
+int upside_hip_run_md(DerivEngine* engine, int n_round);
+
+/* recenter (deriv_engine.cpp:37-48) all systems */
+int upside_hip_recenter(DerivEngine* engine);
+
+/* Replica-exchange swap attempt among the systems of THIS engine (main.cpp:227-275): pairs (n_pair,2) are
+ * one swap set; energies are evaluated, Metropolis tested with the REPLICA_EXCHANGE random stream
+ * (random.h:26, keyed by round) and accepted pairs exchange coordinates.  accepted (n_pair) out. */
+int upside_hip_replica_swap(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
+                            uint64_t round, int* accepted);
+
+/* Parity/diagnostic access: the in-range pair list of an interaction-graph node of system `sys` after the
+ * last force pass, canonical order of interaction_graph.h:122-157.  Returns n_edge or -1. */
+int upside_hip_get_pairlist(DerivEngine* engine, const char* node_name, int sys, int max_edge, int* i1, int* i2);
+
+/* number of BP sweeps of the last rotamer solve per system (rotamer.cpp:1038-1051) */
+int upside_hip_rotamer_iterations(DerivEngine* engine, int* iters);
+
+/* last error text of this thread ("" if none) */
+const char* upside_hip_last_error(void);
+
+/* Per-kernel timing hooks used by bench.py: HIP-event time (ms) accumulated on the engine's stream for
+ * the kernel family `which` ("igraph", "bp", "all") since the last reset, and its launch count. */
+int upside_hip_profile_reset(DerivEngine* engine, int enable);
+int upside_hip_profile_get(DerivEngine* engine, const char* which, double* ms, long* launches,
+                           double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

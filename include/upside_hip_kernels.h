@@ -1,0 +1,186 @@
+/* Thin C-ABI between the host-side C++ engine (DerivEngine / DerivComputation nodes) and the hand-written
+ * HIP kernels for gfx950.  Plain pointers, ints and floats only; every pointer is a DEVICE pointer unless
+ * marked host.  All launchers are asynchronous on `L->stream` and return the hipError_t of the launch
+ * (0 = success).  Arrays carry a leading system dimension S = L->n_system ("[S]" below): S independent
+ * replicas / ensemble members of one topology are processed by one launch (grid.y = system).
+ *
+ * Each launcher names the reference loop it replaces (paths relative to /root/reference/).
+ */
+#ifndef UPSIDE_HIP_KERNELS_H
+#define UPSIDE_HIP_KERNELS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int n_system; void* stream; } upk_launch_t;
+
+/* A CoordNode's storage (src/deriv_engine.h:83-96): out/sens are [S][n_elem][stride] */
+typedef struct { float* out; float* sens; int n_elem; int width; int stride; } upk_coord_t;
+
+/* ---- generic ---------------------------------------------------------------------------------- */
+/* out[s] (+)= sum_i in[s][i]; one workgroup per system, fixed tree order (deterministic).            */
+int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate);
+/* deterministic gather of deferred derivative contributions into a node's sens:
+ * sens[s][t][c] += sum_{e in csr[t]} arena[s][entry[e] + c], c < width  (replaces the scatter-adds of
+ * e.g. src/bonds.cpp:315-316, src/placement.cpp:304-305, src/eig.cpp:467)                               */
+int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_stride, const int* csr_start,
+                       const int* csr_entry, upk_coord_t target, int width, int comp_offset);
+
+/* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
+int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
+                          float max_force);
+/* n_invocations is common to all systems (they are thermalised at the same rounds); mom is [S][n_atom][4] */
+int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, uint64_t n_invocations,
+                   const float* mom_scale, const float* noise_scale);
+int upk_recenter(const upk_launch_t* L, upk_coord_t pos, int xy_only);
+int upk_kinetic(const upk_launch_t* L, const float* mom, int n_atom, float* kin);
+
+/* ---- backbone coordinate nodes ------------------------------------------------------------------ */
+/* affine_alignment (src/eig.cpp:317-470): eig is [S][n_res][20] (4 eigenvalues + 4x4 eigenvectors) */
+int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, const float* ref_geom, int n_res,
+                   upk_coord_t out, float* eig);
+/* writes per-residue 3 atoms x 3 comps into contrib[s][res*9 ...] */
+int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
+                   float* contrib, long contrib_stride);
+/* rama_coord (src/bonds.cpp:205-247): jac [S][n_res][2][5][3] */
+int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
+                 float* jac);
+int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride);
+/* infer_H_O (src/hbond.cpp:59-119): dfd [S][n_virtual][12] */
+int upk_infer_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const float* bond_length, int n_virtual,
+                  upk_coord_t out, float* dfd);
+int upk_infer_bwd(const upk_launch_t* L, upk_coord_t infer, const float* bond_length, const float* dfd, int n_virtual,
+                  float* contrib, long contrib_stride);
+
+/* ---- bonded potentials (src/bonds.cpp:297-318, 457-487, 519-545, 350-372) -------------------------- */
+/* kind: 2 dist, 3 angle, 4 dihedral.  contrib: [term][kind][3]; pot_terms [S][n] (may be NULL)         */
+int upk_spring(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* equil, const float* k, int n,
+               float* contrib, long contrib_stride, float* pot_terms);
+int upk_cavity_radial(const upk_launch_t* L, upk_coord_t pos, const int* id, const float* radius, const float* k, int n,
+                      float* contrib, long contrib_stride, float* pot_terms);
+
+/* ---- placement (src/placement.cpp:264-307) ------------------------------------------------------- */
+typedef struct {
+    int n_elem, n_pos_dim, n_sig; int sig[3];              /* 0 scalar, 1 vector, 2 point */
+    const int* affine_residue; const int* layer; const int* rama_residue;
+    int is_rama; const float* fixed_data;                  /* (n_layer, n_pos_dim) */
+    const float* spline_coeff; int nx, ny;                 /* (n_layer,nx,ny,n_pos_dim,16) */
+} upk_placement_t;
+int upk_placement_fwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out,
+                      float* rama_deriv);
+/* aff_contrib [elem][6] (com, torque); rama_contrib [elem][2] (NULL unless is_rama) */
+int upk_placement_bwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out,
+                      const float* rama_deriv, float* aff_contrib, long aff_stride, float* rama_contrib, long rama_stride);
+
+/* ---- simple per-element nodes ---------------------------------------------------------------------- */
+/* rama_map_pot (src/rama_map_pot.cpp:57-82): adds into rama.sens directly (residue ids are distinct) */
+int upk_rama_map_pot(const upk_launch_t* L, upk_coord_t rama, const int* residue, const int* map_id, int n,
+                     const float* coeff, int nx, float* pot_terms);
+/* weighted_pos (src/environment.cpp:132-154) */
+int upk_weighted_pos_fwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
+                         const int* index_weight, upk_coord_t out);
+int upk_weighted_pos_bwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
+                         const int* index_weight, upk_coord_t self);
+/* nonlinear_coupling (src/environment.cpp:358-369) */
+int upk_nonlinear_coupling(const upk_launch_t* L, upk_coord_t input, const int* types, const float* coeff, int n_coeff,
+                           float offset, float inv_dx, float* pot_terms);
+/* hbond_energy (src/hbond.cpp:430-444) */
+int upk_hbond_energy(const upk_launch_t* L, upk_coord_t protein_hbond, float E_protein, float* pot_terms);
+/* backbone_pairs (src/backbone_steric.cpp:81-145): brute force over residue pairs, gather form;
+ * aff_contrib [res][6]; pot_terms [S][n_res] (each pair counted once) */
+int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
+                       const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
+                       float* pot_terms);
+
+/* ---- interaction graph (src/interaction_graph.h) ---------------------------------------------------- */
+enum { UPK_IT_ROTAMER = 0, UPK_IT_HBOND_COVERAGE = 1, UPK_IT_ENVIRONMENT = 2, UPK_IT_PROTEIN_HBOND = 3 };
+
+typedef struct {
+    int itype, symmetric;
+    int n1, n2;                          /* elements on each side */
+    int dim1, dim2;                      /* components used (6/6, 7/6, 6/4) */
+    upk_coord_t node1, node2;            /* source CoordNodes */
+    const int *loc1, *loc2, *type1, *type2, *id1, *id2;
+    const float* param; int n_type1, n_type2, n_param;
+    int n_knot, n_knot_angular; float inv_dx, inv_dtheta;
+    float cutoff, cache_cutoff;          /* cache_cutoff = cutoff + skin (interaction_graph.h:97,395-396) */
+    /* cached Verlet lists: for side-1 rows nbr1[s][i][k] (neighbours on side 2, ascending) and count;
+       for asymmetric graphs the transposed list nbr2 as well; symmetric graphs keep the full list in nbr1. */
+    int cap1, cap2;
+    int *nbr1, *cnt1, *nbr2, *cnt2;
+    float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from */
+    int* rebuild_flag;                   /* [S] */
+    int* error_flag;                     /* [1] set to non-zero on capacity overflow */
+} upk_igraph_t;
+
+/* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build
+ * (interaction_graph.h:57-90) */
+int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G);
+/* K2: where flag[s] is set rebuild the row lists with d < cache_cutoff and acceptable_id_pair
+ * (interaction_graph.h:116-158); clears the flag */
+int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G);
+/* K3 forward: rowsum over in-range neighbours of the pair value.
+ *   side = 1: out[s][i1] = sum_{i2} value   (environment_coverage, protein_hbond donors)
+ *   side = 2: out[s][i2] = sum_{i1} value   (hbond_coverage, protein_hbond acceptors)
+ * out has element stride out_stride, component out_comp, row offset out_row0. */
+int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
+                      int out_stride, int out_comp, int out_row0);
+/* K8 backward: for every row of `side`, sum over in-range neighbours of sens(pair) * d(value)/d(row coords),
+ * added to the source node's sens at loc[row] (interaction_graph.h:525-555 in gather form).
+ * Pair sensitivity: sens_mode 1: sens1[s][i1*sens_stride]; 2: sens2[s][i2*sens_stride]; 3: sens1[i1]+sens2[i2]. */
+int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
+                    const float* sens2, long sens_sys_stride, int sens_stride);
+/* parity/diagnostic: flags[s][i][k] = 1 where cached neighbour k of row i is in range this step */
+int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags);
+
+/* ---- rotamer (src/rotamer.cpp) ------------------------------------------------------------------- */
+typedef struct {
+    upk_igraph_t G;                      /* symmetric bead graph */
+    int n_node, n_node1, n_node3;        /* global node ids: class 1, then 3, then 6 */
+    const int* node_nrot;                /* [n_node] */
+    const int *bead_node, *bead_rot;     /* [n_bead] */
+    const int *node_bead_start, *node_bead_list;   /* CSR (node*6+rot) -> beads of that rotamer state */
+    int n_prob; const float* const* prob_out; float* const* prob_sens; const int* prob_stride;   /* 1-body parents (device arrays of device ptrs) */
+    const long* prob_sys_stride;
+    /* per system state */
+    float *node_prob, *node_off, *nb_cur, *nb_old;      /* [S][n_node][6], off [S][n_node] */
+    int slot_cap, adj_cap;
+    int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
+    int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
+    float *P, *msg_cur, *msg_old, *marg; /* [S][cap][36], [S][cap][12], [S][cap][12], [S][cap][36] */
+    float damping, tol; int max_iter, chunk;
+    int* iters;                          /* [S] sweeps of the last solve */
+    float* energy;                       /* [S] Bethe free energy (only when want_energy) */
+} upk_rotamer_t;
+
+/* after a pair-list rebuild: residue-pair slots and node adjacency (replaces EdgeLocator, rotamer.cpp:134-206) */
+int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R);
+/* 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256) */
+int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t* R);
+/* bead-pair energies accumulated into the residue-pair matrices (rotamer.cpp:829-846, interaction_graph.h:470-503) */
+int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R);
+/* damped belief propagation + marginals (+ Bethe free energy): rotamer.cpp:1005-1061, 453-522, 283-302, 405-451, 854-866 */
+int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy);
+/* derivative push: pair marginal x pair gradient gathered per bead, node marginals to the 1-body parents
+ * (rotamer.cpp:956-985, interaction_graph.h:525-555) */
+int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R);
+
+/* protein_hbond finish (src/hbond.cpp:320-335): copy the 6 infer components, out[6] = 1 - exp(-sum) */
+int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out);
+/* protein_hbond backward prologue/epilogue (src/hbond.cpp:343-365): sens_scaled and pass-through */
+int upk_protein_hbond_bwd_pre(const upk_launch_t* L, upk_coord_t self, float* sens_scaled);
+int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_coord_t infer, const int* loc1, int n1,
+                                  const int* loc2, int n2);
+
+/* device-side Metropolis for one swap set of replica exchange (src/main.cpp:251-273).  draw0 = number of
+ * uniform 4-vectors already consumed from this round's generator; accepted has n_pair+1 entries, the last
+ * one receives the generator position after this set. */
+int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const float* energy, const float* beta, int n_pair,
+                     const int* pairs, uint32_t seed, uint64_t round, int draw0, int* accepted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

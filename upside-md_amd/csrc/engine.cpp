@@ -1,0 +1,280 @@
+// Host-side engine core: graph construction from HDF5 (deriv_engine.cpp:195-270), the forward/backward
+// schedule (deriv_engine.cpp:124-169) and the integration cycle (deriv_engine.cpp:172-192).  Everything here
+// only enqueues work on the engine's HIP stream; data stays in HBM.
+#include "engine.h"
+#include "h5util.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace std;
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw string("HIP error in ") + what + ": " + hipGetErrorString(e);
+}
+void upk_check(int code, const char* what) {
+    if (code == 0) return;
+    if (code >= 9000) throw string("kernel launcher ") + what + " rejected its arguments (code " + to_string(code) + ")";
+    throw string("HIP launch failure in ") + what + ": " + hipGetErrorString((hipError_t)code);
+}
+
+// ---- DeviceCtx profiling --------------------------------------------------------------------------
+void DeviceCtx::begin(const char* fam) {
+    if (!profile) return;
+    hipEvent_t a, b;
+    hip_check(hipEventCreate(&a), "hipEventCreate"); hip_check(hipEventCreate(&b), "hipEventCreate");
+    hip_check(hipEventRecord(a, stream), "hipEventRecord");
+    families[fam].pending.emplace_back(a, b);
+}
+void DeviceCtx::end(const char* fam, double algorithmic_bytes) {
+    if (!profile) return;
+    auto& f = families[fam];
+    hip_check(hipEventRecord(f.pending.back().second, stream), "hipEventRecord");
+    f.launches += 1; f.bytes += algorithmic_bytes;
+}
+void DeviceCtx::flush_profile() {
+    for (auto& kv : families) {
+        for (auto& ev : kv.second.pending) {
+            hip_check(hipEventSynchronize(ev.second), "hipEventSynchronize");
+            float ms = 0.f;
+            hip_check(hipEventElapsedTime(&ms, ev.first, ev.second), "hipEventElapsedTime");
+            kv.second.ms += ms;
+            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ---- ScatterPlan -----------------------------------------------------------------------------------
+int ScatterPlan::add_source(int n_term, int n_slot, int w, const vector<int>& targets) {
+    if (finalized) throw string("scatter plan already finalized");
+    if ((int)targets.size() != n_term * n_slot) throw string("scatter source: wrong target table size");
+    if (width && width != w) throw string("scatter sources of one node must share a width");
+    width = w;
+    Source s; s.n_term = n_term; s.n_slot = n_slot; s.width = w; s.targets = targets; s.offset = arena_size;
+    arena_size += (long)n_term * n_slot * w;
+    sources.push_back(move(s));
+    return (int)sources.size() - 1;
+}
+void ScatterPlan::finalize(int n_target, int n_system) {
+    vector<int> count(n_target + 1, 0);
+    for (auto& s : sources) for (int t : s.targets) if (t >= 0) { if (t >= n_target) throw string("scatter target out of range"); count[t + 1]++; }
+    for (int t = 0; t < n_target; ++t) count[t + 1] += count[t];
+    vector<int> fill(count.begin(), count.end() - 1), entry(count[n_target]);
+    for (auto& s : sources)
+        for (int i = 0; i < (int)s.targets.size(); ++i) {
+            int t = s.targets[i];
+            if (t >= 0) entry[fill[t]++] = (int)(s.offset + (long)i * s.width);
+        }
+    csr_start.upload(count); csr_entry.upload(entry);
+    arena.alloc((size_t)n_system * (size_t)max(arena_size, 1L));
+    // source offsets become per-system-relative pointers: source_ptr(id) + s*arena_size
+    finalized = true;
+}
+
+CoordNode::CoordNode(DeviceCtx* c, int n_elem_, int elem_width_)
+    : DerivComputation(false), n_elem(n_elem_), elem_width(elem_width_), stride(ru(elem_width_)) {
+    ctx = c;
+    output.alloc((size_t)c->n_system * n_elem * stride);
+    sens.alloc((size_t)c->n_system * n_elem * stride);
+}
+void CoordNode::gather_contributions() {
+    if (scatter.sources.empty()) return;
+    upk_check(upk_gather_contrib(&ctx->L, scatter.arena.p, scatter.arena_size, scatter.csr_start.p, scatter.csr_entry.p, coord(),
+                                 scatter.width, 0), "gather_contrib");
+}
+
+// ---- registry (deriv_engine.cpp:50-92, 272-281) ------------------------------------------------------
+NodeCreationMap& node_creation_map() {
+    static NodeCreationMap m;
+    if (!m.size())
+        m[string("pos")] = NodeCreationFunction([](DeviceCtx*, hid_t_compat, const ArgList&) -> DerivComputation* {
+            throw string("Cannot create pos-type node"); });
+    return m;
+}
+bool is_prefix(const string& s1, const string& s2) { return s1 == s2.substr(0, s1.size()); }
+void add_node_creation_function(string name_prefix, NodeCreationFunction fcn) {
+    auto& m = node_creation_map();
+    for (const auto& kv : m) {
+        if (is_prefix(kv.first, name_prefix)) throw string("Internal error.  Type name ") + kv.first + " is a prefix of " + name_prefix + ".";
+        if (is_prefix(name_prefix, kv.first)) throw string("Internal error.  Type name ") + name_prefix + " is a prefix of " + kv.first + ".";
+    }
+    m[name_prefix] = fcn;
+}
+void check_elem_width_lower_bound(const CoordNode& node, int lb) {
+    if (node.elem_width < lb) throw string("expected argument with width at least ") + to_string(lb) + " but received argument with width " + to_string(node.elem_width);
+}
+void check_elem_width(const CoordNode& node, int w) {
+    if (node.elem_width != w) throw string("expected argument with width ") + to_string(w) + " but received argument with width " + to_string(node.elem_width);
+}
+void check_arguments_length(const ArgList& a, int n) {
+    if ((int)a.size() != n) throw string("expected ") + to_string(n) + " arguments but got " + to_string(a.size());
+}
+
+// ---- DerivEngine -----------------------------------------------------------------------------------
+DerivEngine::DerivEngine(int n_atom, int n_system) {
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev < 1) throw string("no HIP device available (this library has no CPU fallback)");
+    ctx.n_system = n_system;
+    hip_check(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking), "hipStreamCreate");
+    ctx.L.n_system = n_system; ctx.L.stream = (void*)ctx.stream;
+    ctx.error_flag.alloc(1);
+    potential.assign(n_system, 0.f);
+    Node n; n.name = "pos"; n.computation.reset(new Pos(&ctx, n_atom));
+    nodes.push_back(move(n));
+    pos = dynamic_cast<Pos*>(nodes[0].computation.get());
+    mom.alloc((size_t)n_system * n_atom * 4);
+    seeds.assign(n_system, 0u); temperature.assign(n_system, 1.f);
+}
+DerivEngine::~DerivEngine() {
+    if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); }
+    nodes.clear();
+    if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
+}
+void DerivEngine::add_node(const string& name, unique_ptr<DerivComputation> fcn, vector<string> argument_names) {
+    if (any_of(nodes.begin(), nodes.end(), [&](const Node& n) { return n.name == name; })) throw string("name conflict in DerivEngine");
+    Node node; node.name = name; node.computation = move(fcn);
+    nodes.push_back(move(node));
+    for (auto& nm : argument_names) {
+        int parent_idx = get_idx(nm);
+        nodes.back().parents.push_back(parent_idx);
+        nodes[parent_idx].children.push_back(nodes.size() - 1);
+    }
+}
+DerivEngine::Node& DerivEngine::get(const string& name) {
+    auto loc = find_if(begin(nodes), end(nodes), [&](const Node& n) { return n.name == name; });
+    if (loc == nodes.end()) throw string("name not found");
+    return *loc;
+}
+int DerivEngine::get_idx(const string& name, bool must_exist) {
+    auto loc = find_if(begin(nodes), end(nodes), [&](const Node& n) { return n.name == name; });
+    if (must_exist && loc == nodes.end()) throw string("name not found");
+    return loc != nodes.end() ? int(loc - begin(nodes)) : -1;
+}
+
+void DerivEngine::finalize() {
+    for (auto& n : nodes) n.computation->finalize();
+    // Unroll the level-synchronous sweep of deriv_engine.cpp:124-169 once; the order of events is static.
+    schedule.clear();
+    for (auto& n : nodes) n.germ_exec_level = n.deriv_exec_level = -1;
+    for (int lvl = 0, not_finished = 1;; ++lvl, not_finished = 0) {
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            auto& n = nodes[i];
+            if (n.germ_exec_level == -1) {
+                not_finished = 1;
+                bool all_parents = all_of(begin(n.parents), end(n.parents), [&](size_t ip) {
+                    int l = nodes[ip].germ_exec_level; return l != -1 && l != lvl; });
+                if (all_parents) { schedule.push_back(Step{(int)i, false}); n.germ_exec_level = lvl; }
+            }
+            if (n.deriv_exec_level == -1 && n.germ_exec_level != -1) {
+                not_finished = 1;
+                bool all_children = all_of(begin(n.children), end(n.children), [&](size_t ip) {
+                    int l = nodes[ip].deriv_exec_level; return l != -1 && l != lvl; });
+                if (all_children) { schedule.push_back(Step{(int)i, true}); n.deriv_exec_level = lvl; }
+            }
+        }
+        if (!not_finished) break;
+    }
+}
+
+void DerivEngine::compute(ComputeMode mode) {
+    for (auto& st : schedule) {
+        auto* c = nodes[st.node].computation.get();
+        if (!st.backward) {
+            c->compute_value(mode);
+            if (!c->potential_term) {
+                auto* cn = static_cast<CoordNode*>(c);   // zero sensitivity for later derivative writing (:147-151)
+                hip_check(hipMemsetAsync(cn->sens.p, 0, cn->sens.n * sizeof(float), ctx.stream), "hipMemsetAsync");
+            }
+        } else if (!c->potential_term) {
+            auto* cn = static_cast<CoordNode*>(c);
+            cn->gather_contributions();
+            c->propagate_deriv();
+        }
+    }
+}
+
+void DerivEngine::fetch_potentials() {
+    sync();
+    fill(potential.begin(), potential.end(), 0.f);
+    for (auto& n : nodes) {
+        if (!n.computation->potential_term) continue;
+        auto* p = static_cast<PotentialNode*>(n.computation.get());
+        p->potential = p->potential_dev.download();
+        for (int s = 0; s < ctx.n_system; ++s) potential[s] += p->potential[s];   // node order, deriv_engine.cpp:143-146
+    }
+}
+
+void DerivEngine::integration_cycle(float dt_, float max_force) {
+    const float a = 1.f / 6.f, b = 1.f / 3.f;   // Verlet
+    const float mom_update[] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
+    const float pos_update[] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
+    for (int stage = 0; stage < 3; ++stage) {
+        compute(DerivMode);
+        upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force), "integration_stage");
+    }
+}
+
+void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
+
+void DerivEngine::check_device_errors() {
+    sync();
+    auto f = ctx.error_flag.download();
+    if (f[0]) {
+        ctx.error_flag.fill_bytes(0);
+        throw string("device capacity overflow (code ") + to_string(f[0]) +
+            "): raise UPSIDE_HIP_NBR_CAP / UPSIDE_HIP_SLOT_FACTOR (1 = neighbour list, 2 = residue-pair slots, 3 = node adjacency)";
+    }
+}
+
+// ---- graph construction (deriv_engine.cpp:195-270) ---------------------------------------------------
+DerivEngine* initialize_engine_from_hdf5(int n_atom, int n_system, hid_t_compat potential_group_, bool quiet) {
+    (void)quiet;
+    hid_t potential_group = (hid_t)potential_group_;
+    unique_ptr<DerivEngine> engine(new DerivEngine(n_atom, n_system));
+    auto& m = node_creation_map();
+
+    map<string, pair<bool, vector<string>>> dep_graph;
+    dep_graph["pos"] = make_pair(true, vector<string>());
+    for (const auto& name : h5u::node_names_in_group(potential_group))
+        dep_graph[name] = make_pair(true, h5u::attr_strings(potential_group, name, "arguments"));
+    for (auto& kv : dep_graph)
+        for (auto& dep_name : kv.second.second)
+            if (dep_graph.find(dep_name) == end(dep_graph))
+                throw string("Node ") + kv.first + " takes " + dep_name + " as an argument, but no node of that name can be found.";
+
+    vector<string> topo_order;
+    auto in_topo = [&](const string& name) { return find(begin(topo_order), end(topo_order), name) != end(topo_order); };
+    int graph_size = dep_graph.size();
+    for (int round_num = 0; round_num < graph_size; ++round_num)
+        for (auto it = begin(dep_graph); it != end(dep_graph); ++it) {
+            if (!it->second.first) continue;
+            if (all_of(begin(it->second.second), end(it->second.second), in_topo)) { topo_order.push_back(it->first); it->second.first = false; }
+        }
+    for (auto& kv : dep_graph) if (kv.second.first) throw string("Unsatisfiable dependency ") + kv.first + " in potential computation";
+
+    for (auto& nm : topo_order) {
+        if (nm == "pos") continue;
+        string node_type_name = "";
+        for (auto& kv : m) if (is_prefix(kv.first, nm)) node_type_name = kv.first;
+        if (node_type_name == "") throw string("No node type found for name '") + nm + "'";
+        NodeCreationFunction& node_func = m[node_type_name];
+        auto argument_names = dep_graph[nm].second;
+        ArgList arguments;
+        for (const auto& arg_name : argument_names) {
+            arguments.push_back(dynamic_cast<CoordNode*>(engine->get(arg_name).computation.get()));
+            if (!arguments.back()) throw arg_name + " is not an intermediate value, but it is an argument of " + nm;
+        }
+        try {
+            auto grp = h5u::open_group(potential_group, nm);
+            auto computation = unique_ptr<DerivComputation>(node_func(&engine->ctx, (hid_t_compat)(hid_t)grp, arguments));
+            engine->add_node(nm, move(computation), argument_names);
+        } catch (const string& e) {
+            throw "while adding '" + nm + "', " + e;
+        }
+    }
+    engine->finalize();
+    return engine.release();
+}

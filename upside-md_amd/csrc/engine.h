@@ -1,0 +1,207 @@
+// Host-side engine: the reference's differentiable-graph contract re-hosted for device-resident data.
+//
+// The class names and the plug-in contract follow /root/reference/src/deriv_engine.h:48-335 so that a node
+// written for the reference maps one-to-one: DerivComputation (compute_value / propagate_deriv / get_param /
+// set_param / get_value_by_name), CoordNode (n_elem, elem_width, output, sens), PotentialNode (potential),
+// DerivEngine (nodes, pos, potential, compute, integration_cycle) and the name-prefix registry
+// (node_creation_map / add_node_creation_function / RegisterNodeType<T,N>).
+// What differs is WHERE data lives: output/sens are device buffers holding n_system independent systems, and a
+// node's methods enqueue HIP kernels (through the C launchers of include/upside_hip_kernels.h) on the engine's
+// stream instead of computing on the host.  There is no host fallback for any node.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/upside_hip_kernels.h"
+
+typedef long long hid_t_compat;
+
+inline int round_up(int i, int a) { return ((i + a - 1) / a) * a; }
+inline int ru(int i) { return i == 1 ? i : round_up(i, 4); }   // vector_math.h:23-25
+
+void hip_check(hipError_t e, const char* what);
+void upk_check(int code, const char* what);
+
+// ---- device memory ----------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t n_) { alloc(n_); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t n_) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = n_;
+        if (n) { hip_check(hipMalloc((void**)&p, n * sizeof(T)), "hipMalloc"); hip_check(hipMemset(p, 0, n * sizeof(T)), "hipMemset"); }
+    }
+    void upload(const std::vector<T>& v) { alloc(v.size()); if (n) hip_check(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice), "H2D"); }
+    std::vector<T> download() const {
+        std::vector<T> v(n);
+        if (n) hip_check(hipMemcpy(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost), "D2H");
+        return v;
+    }
+    void fill_bytes(int byte) { if (n) hip_check(hipMemset(p, byte, n * sizeof(T)), "hipMemset"); }
+};
+
+enum ComputeMode { DerivMode = 0, PotentialAndDerivMode = 1 };   // deriv_engine.h:42-45
+
+struct DerivEngine;
+
+// per-engine launch context shared by all nodes
+struct DeviceCtx {
+    int n_system = 1;
+    hipStream_t stream = nullptr;
+    upk_launch_t L{};
+    DevBuf<int> error_flag;          // [1]: pair-list / slot capacity overflow
+    // profiling (bench.py): HIP-event timing of kernel families on `stream`
+    bool profile = false;
+    struct Family { double ms = 0; long launches = 0; double bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+    std::map<std::string, Family> families;
+    void begin(const char* fam);
+    void end(const char* fam, double algorithmic_bytes);
+    void flush_profile();
+};
+
+// deferred derivative contributions gathered into a CoordNode's sens (see upk_gather_contrib)
+struct ScatterPlan {
+    struct Source { int n_term, n_slot, width; std::vector<int> targets; long offset; };
+    std::vector<Source> sources;
+    long arena_size = 0;
+    int width = 0;
+    DevBuf<float> arena; DevBuf<int> csr_start, csr_entry;
+    bool finalized = false;
+    // targets[term*n_slot+slot] = element of the owning node (or -1); returns the source id
+    int add_source(int n_term, int n_slot, int width, const std::vector<int>& targets);
+    float* source_ptr(int id) const { return arena.p + sources[id].offset; }
+    void finalize(int n_target, int n_system);
+};
+
+struct DerivComputation {   // deriv_engine.h:48-80
+    const bool potential_term;
+    DeviceCtx* ctx = nullptr;
+    explicit DerivComputation(bool potential_term_) : potential_term(potential_term_) {}
+    virtual ~DerivComputation() {}
+    virtual void compute_value(ComputeMode mode) = 0;
+    virtual void propagate_deriv() = 0;
+    virtual std::vector<float> get_param() const { return std::vector<float>(); }
+    virtual void set_param(const std::vector<float>&) {}
+    virtual std::vector<float> get_value_by_name(const char*) { throw std::string("No values implemented"); }
+    virtual void finalize() {}   // called once after the whole graph exists (scatter plans, device pointer tables)
+};
+
+struct CoordNode : public DerivComputation {   // deriv_engine.h:83-96
+    int n_elem, elem_width, stride;
+    DevBuf<float> output, sens;   // [S][n_elem][stride]
+    ScatterPlan scatter;
+    CoordNode(DeviceCtx* c, int n_elem_, int elem_width_);
+    upk_coord_t coord() const { upk_coord_t r; r.out = output.p; r.sens = sens.p; r.n_elem = n_elem; r.width = elem_width; r.stride = stride; return r; }
+    long sys_stride() const { return (long)n_elem * stride; }
+    void gather_contributions();
+    void finalize() override { if (!scatter.sources.empty()) scatter.finalize(n_elem, ctx->n_system); }
+};
+
+struct PotentialNode : public DerivComputation {   // deriv_engine.h:100-110
+    DevBuf<float> potential_dev;      // [S]
+    DevBuf<float> pot_terms;          // [S][n_term] scratch for the deterministic reduction
+    int n_pot_term = 0;
+    std::vector<float> potential;     // host copy, valid after DerivEngine::fetch_potentials
+    explicit PotentialNode(DeviceCtx* c) : DerivComputation(true) { ctx = c; potential_dev.alloc(c->n_system); potential.assign(c->n_system, 0.f); }
+    void alloc_terms(int n) { n_pot_term = n; pot_terms.alloc((size_t)ctx->n_system * n); }
+    void reduce_terms() { upk_check(upk_reduce_sum(&ctx->L, pot_terms.p, n_pot_term, potential_dev.p, 0), "reduce_sum"); }
+    void propagate_deriv() override {}
+};
+
+struct HBondCounter : public PotentialNode {   // deriv_engine.h:114-118
+    using PotentialNode::PotentialNode;
+};
+
+struct Pos : public CoordNode {   // deriv_engine.h:122-141
+    int n_atom;
+    Pos(DeviceCtx* c, int n_atom_) : CoordNode(c, n_atom_, 3), n_atom(n_atom_) {}
+    void compute_value(ComputeMode) override {}
+    void propagate_deriv() override {}
+};
+
+struct DerivEngine {   // deriv_engine.h:145-237
+    struct Node {
+        std::string name;
+        std::unique_ptr<DerivComputation> computation;
+        std::vector<size_t> parents, children;
+        int germ_exec_level = -1, deriv_exec_level = -1;
+    };
+    DeviceCtx ctx;
+    std::vector<Node> nodes;
+    Pos* pos = nullptr;
+    std::vector<float> potential;   // [S]
+
+    // MD state (System of main.cpp:93-111, one entry per system)
+    DevBuf<float> mom;              // [S][n_atom][4]
+    DevBuf<uint32_t> seed; DevBuf<float> mom_scale, noise_scale;
+    std::vector<float> temperature; std::vector<uint32_t> seeds;
+    float thermostat_timescale = 5.f, dt = 0.009f; int thermostat_interval = 1;
+    uint64_t n_invocations = 0, round_num = 0;
+
+    // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
+    struct Step { int node; bool backward; };
+    std::vector<Step> schedule;
+
+    DerivEngine(int n_atom, int n_system);
+    ~DerivEngine();
+    void add_node(const std::string& name, std::unique_ptr<DerivComputation> fcn, std::vector<std::string> argument_names);
+    Node& get(const std::string& name);
+    int get_idx(const std::string& name, bool must_exist = true);
+    template <typename T> T& get_computation(const std::string& name) {
+        auto c = get(name).computation.get();
+        if (!c) throw std::string("impossible pointer value");
+        return dynamic_cast<T&>(*c);
+    }
+    void finalize();
+    void compute(ComputeMode mode);            // enqueue; no synchronisation
+    void fetch_potentials();                   // D2H of every PotentialNode::potential + engine total
+    void integration_cycle(float dt, float max_force = 0.f);   // deriv_engine.cpp:172-192 (Verlet weights)
+    void check_device_errors();                // throws if a capacity overflow was flagged
+    void sync();
+};
+
+DerivEngine* initialize_engine_from_hdf5(int n_atom, int n_system, hid_t_compat potential_group, bool quiet = false);
+
+typedef std::vector<CoordNode*> ArgList;
+typedef std::function<DerivComputation*(DeviceCtx*, hid_t_compat, const ArgList&)> NodeCreationFunction;
+typedef std::map<std::string, NodeCreationFunction> NodeCreationMap;
+NodeCreationMap& node_creation_map();
+bool is_prefix(const std::string& s1, const std::string& s2);
+void add_node_creation_function(std::string name_prefix, NodeCreationFunction fcn);
+void check_elem_width(const CoordNode& node, int expected);
+void check_elem_width_lower_bound(const CoordNode& node, int lower_bound);
+void check_arguments_length(const ArgList& arguments, int n_expected);
+
+template <typename NodeClass, int n_args>
+struct RegisterNodeType { RegisterNodeType(std::string name_prefix); };
+template <typename NodeClass>
+struct RegisterNodeType<NodeClass, -1> {
+    RegisterNodeType(std::string name_prefix) {
+        add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
+            if (!args.size()) throw std::string("Expected at least 1 arg");
+            return new NodeClass(c, grp, args); });
+    }
+};
+template <typename NodeClass>
+struct RegisterNodeType<NodeClass, 1> {
+    RegisterNodeType(std::string name_prefix) {
+        add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
+            check_arguments_length(args, 1); return new NodeClass(c, grp, *args[0]); });
+    }
+};
+template <typename NodeClass>
+struct RegisterNodeType<NodeClass, 2> {
+    RegisterNodeType(std::string name_prefix) {
+        add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
+            check_arguments_length(args, 2); return new NodeClass(c, grp, *args[0], *args[1]); });
+    }
+};

@@ -1,0 +1,307 @@
+// C-ABI of libupside_hip.so: the reference's engine_c_library entry points
+// (/root/reference/src/engine_c_library.cpp) over the device engine, plus the batched extension declared in
+// include/upside_engine_c.h.  No exception crosses the boundary: failures print "ERROR: ..." to stderr and
+// return NULL / 1 exactly like engine_c_library.cpp:15-20,37-45.
+#include "../../include/upside_engine_c.h"
+#include "engine.h"
+#include "h5util.h"
+#include "spline_fit.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace std;
+
+int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pair<int, int>>& out);
+int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters);
+double engine_igraph_bytes(DerivEngine& e);
+int upside_main_impl(int argc, const char* const* argv, int verbose);
+
+static thread_local string g_last_error;
+static int fail(const string& s) { g_last_error = s; fprintf(stderr, "ERROR: %s\n", s.c_str()); return 1; }
+#define API_TRY try {
+#define API_CATCH(ret) } catch (const string& s) { fail(s); return ret; } catch (const char* s) { fail(s); return ret; } \
+    catch (const std::exception& e) { fail(e.what()); return ret; } catch (...) { fail("unknown error"); return ret; }
+
+extern "C" const char* upside_hip_last_error(void) { return g_last_error.c_str(); }
+
+// ---- construction ----------------------------------------------------------------------------------
+extern "C" DerivEngine* upside_hip_construct(int n_atom, const char* potential_file, int n_system, bool quiet) {
+    API_TRY
+    if (n_system < 1) throw string("n_system must be positive");
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t f = H5Fopen(potential_file, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f < 0) throw string("unable to open ") + potential_file;
+    h5u::Handle config(f, H5Fclose);
+    auto potential_group = h5u::open_group(config, "/input/potential");
+    return initialize_engine_from_hdf5(n_atom, n_system, (hid_t_compat)(hid_t)potential_group, quiet);
+    API_CATCH(nullptr)
+}
+extern "C" DerivEngine* construct_deriv_engine(int n_atom, const char* potential_file, bool quiet) {
+    return upside_hip_construct(n_atom, potential_file, 1, quiet);
+}
+extern "C" void free_deriv_engine(DerivEngine* engine) { delete engine; }
+extern "C" int upside_hip_n_system(DerivEngine* engine) { return engine ? engine->ctx.n_system : 0; }
+
+// ---- positions / momenta ----------------------------------------------------------------------------
+static void upload_pos(DerivEngine* e, const float* pos, int n_sys_in) {
+    const int S = e->ctx.n_system, na = e->pos->n_atom, st = e->pos->stride;
+    vector<float> buf((size_t)S * na * st, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float* p = pos + (size_t)(n_sys_in == 1 ? 0 : s) * na * 3;
+        for (int a = 0; a < na; ++a) for (int d = 0; d < 3; ++d) buf[((size_t)s * na + a) * st + d] = p[a * 3 + d];
+    }
+    hip_check(hipMemcpyAsync(e->pos->output.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, e->ctx.stream), "H2D pos");
+    e->sync();
+}
+static void download_rows(DerivEngine* e, const float* dev, int n_elem, int stride, int width, float* out, int n_sys_out) {
+    const int S = e->ctx.n_system;
+    vector<float> buf((size_t)S * n_elem * stride);
+    e->sync();
+    hip_check(hipMemcpy(buf.data(), dev, buf.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+    for (int s = 0; s < n_sys_out; ++s) for (int i = 0; i < n_elem; ++i) for (int d = 0; d < width; ++d)
+        out[((size_t)s * n_elem + i) * width + d] = buf[((size_t)s * n_elem + i) * stride + d];
+}
+
+extern "C" int upside_hip_set_pos(DerivEngine* e, const float* pos) { API_TRY upload_pos(e, pos, e->ctx.n_system); return 0; API_CATCH(1) }
+extern "C" int upside_hip_get_pos(DerivEngine* e, float* pos) {
+    API_TRY download_rows(e, e->pos->output.p, e->pos->n_atom, e->pos->stride, 3, pos, e->ctx.n_system); return 0; API_CATCH(1) }
+extern "C" int upside_hip_set_mom(DerivEngine* e, const float* mom) {
+    API_TRY
+    const int S = e->ctx.n_system, na = e->pos->n_atom;
+    vector<float> buf((size_t)S * na * 4, 0.f);
+    for (size_t i = 0; i < (size_t)S * na; ++i) for (int d = 0; d < 3; ++d) buf[i * 4 + d] = mom[i * 3 + d];
+    hip_check(hipMemcpy(e->mom.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice), "H2D mom");
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_get_mom(DerivEngine* e, float* mom) {
+    API_TRY download_rows(e, e->mom.p, e->pos->n_atom, 4, 3, mom, e->ctx.n_system); return 0; API_CATCH(1) }
+
+// ---- evaluation (engine_c_library.cpp:29-64) ----------------------------------------------------------
+extern "C" int upside_hip_compute(DerivEngine* e, float* energy, float* deriv) {
+    API_TRY
+    e->compute(energy ? PotentialAndDerivMode : DerivMode);
+    e->check_device_errors();
+    if (energy) { e->fetch_potentials(); for (int s = 0; s < e->ctx.n_system; ++s) energy[s] = e->potential[s]; }
+    if (deriv) download_rows(e, e->pos->sens.p, e->pos->n_atom, e->pos->stride, 3, deriv, e->ctx.n_system);
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int evaluate_energy(float* energy, DerivEngine* e, const float* pos) {
+    API_TRY
+    upload_pos(e, pos, 1);
+    e->compute(PotentialAndDerivMode);
+    e->check_device_errors();
+    e->fetch_potentials();
+    *energy = e->potential[0];
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int evaluate_deriv(float* deriv, DerivEngine* e, const float* pos) {
+    API_TRY
+    upload_pos(e, pos, 1);
+    e->compute(PotentialAndDerivMode);
+    e->check_device_errors();
+    e->fetch_potentials();
+    download_rows(e, e->pos->sens.p, e->pos->n_atom, e->pos->stride, 3, deriv, 1);
+    return 0;
+    API_CATCH(1)
+}
+
+// ---- parameters and node inspection (engine_c_library.cpp:67-193) ---------------------------------------
+extern "C" int set_param(int n_param, const float* param, DerivEngine* e, const char* node_name) {
+    API_TRY e->get(string(node_name)).computation->set_param(vector<float>(param, param + n_param)); return 0; API_CATCH(1) }
+extern "C" int get_param(int n_param, float* param, DerivEngine* e, const char* node_name) {
+    API_TRY
+    auto v = e->get(string(node_name)).computation->get_param();
+    if (v.size() != size_t(n_param)) throw string("Wrong number of parameters, expected ") + to_string(v.size()) + " but got " + to_string(n_param);
+    copy(begin(v), end(v), param);
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int get_param_deriv(int, float*, DerivEngine*, const char*) { return -1; }   // built without PARAM_DERIV (:101-102)
+
+extern "C" int get_output_dims(int* n_elem, int* elem_width, DerivEngine* e, const char* node_name) {
+    API_TRY
+    auto& dc = *e->get(string(node_name)).computation;
+    if (dc.potential_term) { *n_elem = 1; *elem_width = 1; }
+    else { auto& c = dynamic_cast<CoordNode&>(dc); *n_elem = c.n_elem; *elem_width = c.elem_width; }
+    return 0;
+    API_CATCH(1)
+}
+static int get_array(int n_output, float* out, DerivEngine* e, const char* node_name, bool want_sens) {
+    API_TRY
+    auto& dc = *e->get(string(node_name)).computation;
+    if (dc.potential_term) {
+        if (n_output != 1) throw string("wrong size for potential node");
+        auto& p = dynamic_cast<PotentialNode&>(dc);
+        e->sync();
+        *out = p.potential_dev.download()[0];
+    } else {
+        auto& c = dynamic_cast<CoordNode&>(dc);
+        if (n_output != c.n_elem * c.elem_width) throw string("wrong size for CoordNode");
+        download_rows(e, want_sens ? c.sens.p : c.output.p, c.n_elem, c.stride, c.elem_width, out, 1);
+    }
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int get_output(int n_output, float* output, DerivEngine* e, const char* node_name) { return get_array(n_output, output, e, node_name, false); }
+extern "C" int get_sens(int n_output, float* output, DerivEngine* e, const char* node_name) { return get_array(n_output, output, e, node_name, true); }
+extern "C" int get_value_by_name(int n_output, float* output, DerivEngine* e, const char* node_name, const char* log_name) {
+    API_TRY
+    auto value = e->get(string(node_name)).computation->get_value_by_name(log_name);
+    if (n_output != int(value.size()))
+        throw string("expected size (") + to_string(n_output) + " elements) inconsistent with actual size (" + to_string(value.size()) + ")";
+    copy(begin(value), end(value), output);
+    return 0;
+    API_CATCH(1)
+}
+
+// ---- engine-free spline helpers (engine_c_library.cpp:196-276); host arithmetic as in the reference -------
+namespace {
+void de_boor(float& val, float& der, const float* c, float x) {   // spline.h:136-174 on the window starting at c[int(x)-1]
+    int x_bin = (int)x; float e = x - x_bin; const float* p = c + (x_bin - 1);
+    float yu1 = e + 2.f, yu2 = e + 1.f, yu3 = e, f13 = 1.f / 3.f;
+    float a11 = f13 * yu1, a12 = f13 * yu2, a13 = f13 * yu3;
+    float c11 = (1.f - a11) * p[0] + a11 * p[1], d11 = p[1] - p[0];
+    float c12 = (1.f - a12) * p[1] + a12 * p[2], d12 = p[2] - p[1];
+    float c13 = (1.f - a13) * p[2] + a13 * p[3], d13 = p[3] - p[2];
+    float a22 = 0.5f * yu2, a23 = 0.5f * yu3;
+    float c22 = (1.f - a22) * c11 + a22 * c12, d22 = (1.f - a22) * d11 + a22 * d12;
+    float c23 = (1.f - a23) * c12 + a23 * c13, d23 = (1.f - a23) * d12 + a23 * d13;
+    val = (1.f - yu3) * c22 + yu3 * c23; der = (1.f - yu3) * d22 + yu3 * d23;
+}
+void clamped_de_boor(float& val, float& der, const float* c, float x, int n, bool strict) {
+    bool lo = strict ? x < 1.f : x <= 1.f, hi = (float)(n - 2) <= x;
+    if (lo) { val = (1.f / 6.f) * c[0] + (2.f / 3.f) * c[1] + (1.f / 6.f) * c[2]; der = 0.f; return; }
+    if (hi) { val = (1.f / 6.f) * c[n - 3] + (2.f / 3.f) * c[n - 2] + (1.f / 6.f) * c[n - 1]; der = 0.f; return; }
+    de_boor(val, der, c, x);
+}
+}  // namespace
+extern "C" int clamped_spline_solve(int N, float* bspline_coeff, const float* values) {
+    vector<double> temp(3 * N), c(N), v(values, values + (N - 2));
+    splinefit::solve_clamped_1d_spline_for_bsplines(N, c.data(), v.data(), temp.data());
+    for (int i = 0; i < N; ++i) bspline_coeff[i] = (float)c[i];
+    return 0;
+}
+extern "C" int clamped_spline_value(int N, float* result, const float* bspline_coeff, int nx, float* x) {
+    for (int i = 0; i < nx; ++i) { float d; clamped_de_boor(result[i], d, bspline_coeff, x[i], N, true); }
+    return 0;
+}
+extern "C" int get_clamped_value_and_deriv(int N, float* result, const float* bspline_coeff, int nx, float* x) {
+    for (int i = 0; i < nx; ++i) clamped_de_boor(result[i * 2], result[i * 2 + 1], bspline_coeff, x[i], N, false);
+    return 0;
+}
+extern "C" int get_clamped_coeff_deriv(int N, float* result, const float*, float x) {
+    for (int i = 0; i < N; ++i) result[i] = 0.f;
+    int start; float data[4];
+    if (x <= 1.f) { start = 0; data[0] = 1.f / 6.f; data[1] = 2.f / 3.f; data[2] = 1.f / 6.f; data[3] = 0.f; }
+    else if (x >= N - 2) { start = N - 4; data[0] = 0.f; data[1] = 1.f / 6.f; data[2] = 2.f / 3.f; data[3] = 1.f / 6.f; }
+    else {
+        int x_bin = (int)x; start = x_bin - 1; float y = x - x_bin + 1.f;
+        for (int i = 0; i < 4; ++i) { float dc[4] = {0.f, 0.f, 0.f, 0.f}; dc[i] = 1.f; float d; de_boor(data[i], d, dc, y); }
+    }
+    for (int i = 0; i < 4; ++i) result[start + i] = data[i];
+    return 0;
+}
+
+// ---- MD on the device (main.cpp:515-523, 616-667; thermostat.h:9-12) -------------------------------------
+static void thermostat_params(DerivEngine* e, float delta_t) {
+    const int S = e->ctx.n_system;
+    vector<float> ms(S), ns(S);
+    for (int s = 0; s < S; ++s) {
+        ms[s] = (float)exp(-delta_t / e->thermostat_timescale);
+        ns[s] = sqrtf(e->temperature[s] * (1 - ms[s] * ms[s]));
+    }
+    e->mom_scale.upload(ms); e->noise_scale.upload(ns);
+}
+extern "C" int upside_hip_init_md(DerivEngine* e, const float* temperature, uint32_t base_seed, float thermostat_timescale, float dt,
+                                  int thermostat_interval_rounds) {
+    API_TRY
+    const int S = e->ctx.n_system;
+    if (thermostat_interval_rounds < 1) throw string("thermostat interval must be at least one round");
+    e->thermostat_timescale = thermostat_timescale; e->dt = dt; e->thermostat_interval = thermostat_interval_rounds;
+    for (int s = 0; s < S; ++s) { e->temperature[s] = temperature[s]; e->seeds[s] = base_seed + (uint32_t)s; }   // main.cpp:459
+    e->seed.upload(e->seeds);
+    e->mom.fill_bytes(0);
+    e->n_invocations = 0; e->round_num = 0;
+    thermostat_params(e, 1e8f);                     // mom_scale = 0: momenta fully resampled (main.cpp:515-522)
+    upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
+    e->n_invocations++;
+    e->sync();
+    thermostat_params(e, thermostat_interval_rounds * 3 * dt);   // main.cpp:523
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
+    API_TRY
+    for (int r = 0; r < n_round; ++r, ++e->round_num) {
+        if (!(e->round_num % e->thermostat_interval)) {   // main.cpp:657-662
+            upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
+            e->n_invocations++;
+        }
+        e->integration_cycle(e->dt, 0.f);                  // main.cpp:663
+    }
+    e->check_device_errors();
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_recenter(DerivEngine* e) {
+    API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
+
+extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int* accepted) {
+    API_TRY
+    const int S = e->ctx.n_system;
+    for (int i = 0; i < 2 * n_pair; ++i) if (pairs[i] < 0 || pairs[i] >= S) throw string("invalid system");
+    e->compute(PotentialAndDerivMode);
+    e->fetch_potentials();
+    vector<float> beta(S);
+    for (int s = 0; s < S; ++s) beta[s] = 1.f / e->temperature[s];
+    DevBuf<float> d_en, d_beta; d_en.upload(e->potential); d_beta.upload(beta);
+    DevBuf<int> d_pairs, d_acc; d_pairs.upload(vector<int>(pairs, pairs + 2 * n_pair)); d_acc.alloc(n_pair + 1);
+    upk_check(upk_replica_swap(&e->ctx.L, e->pos->coord(), d_en.p, d_beta.p, n_pair, d_pairs.p, base_seed, round, 0, d_acc.p), "replica_swap");
+    e->sync();
+    auto acc = d_acc.download();
+    for (int i = 0; i < n_pair; ++i) accepted[i] = acc[i];
+    return 0;
+    API_CATCH(1)
+}
+
+extern "C" int upside_hip_get_pairlist(DerivEngine* e, const char* node_name, int sys, int max_edge, int* i1, int* i2) {
+    API_TRY
+    vector<pair<int, int>> pl;
+    int n = engine_pairlist(*e, node_name, sys, pl);
+    if (n < 0) throw string("node has no interaction graph");
+    for (int k = 0; k < n && k < max_edge; ++k) { i1[k] = pl[k].first; i2[k] = pl[k].second; }
+    return n;
+    API_CATCH(-1)
+}
+extern "C" int upside_hip_rotamer_iterations(DerivEngine* e, int* iters) {
+    API_TRY
+    vector<int> it;
+    if (engine_rotamer_iterations(*e, it)) throw string("no rotamer node");
+    copy(it.begin(), it.end(), iters);
+    return 0;
+    API_CATCH(1)
+}
+
+extern "C" int upside_hip_profile_reset(DerivEngine* e, int enable) {
+    API_TRY e->sync(); e->ctx.flush_profile(); e->ctx.families.clear(); e->ctx.profile = enable != 0; return 0; API_CATCH(1) }
+extern "C" int upside_hip_profile_get(DerivEngine* e, const char* which, double* ms, long* launches, double* algorithmic_bytes) {
+    API_TRY
+    e->sync(); e->ctx.flush_profile();
+    auto it = e->ctx.families.find(which);
+    *ms = it == e->ctx.families.end() ? 0. : it->second.ms;
+    *launches = it == e->ctx.families.end() ? 0 : it->second.launches;
+    if (algorithmic_bytes) *algorithmic_bytes = !strcmp(which, "igraph") ? engine_igraph_bytes(*e) : 0.;
+    return 0;
+    API_CATCH(1)
+}
+
+extern "C" int upside_main(int argc, const char* const* argv, int verbose) {
+    API_TRY return upside_main_impl(argc, argv, verbose); API_CATCH(1)
+}

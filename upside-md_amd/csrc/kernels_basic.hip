@@ -1,0 +1,827 @@
+// gfx950 kernels for the per-element nodes of the Upside force pass and for the integrator.
+// One lane owns one element (atom / residue / virtual site / placed bead); grid.y is the system index.
+// Scatter-adds of the reference are replaced by per-term contribution buffers that the parent node
+// gathers deterministically (upk_gather_contrib) -- no float atomics anywhere in the force pass.
+#include "device_math.h"
+#include "../../include/upside_hip_kernels.h"
+
+using namespace up;
+
+#define UPK_BLOCK 256
+#define ST(L) ((hipStream_t)(L)->stream)
+static inline dim3 grid1(int n, int S) { return dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)S, 1); }
+static inline int launch_status() { return (int)hipGetLastError(); }
+
+#define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
+#define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
+
+// ------------------------------------------------------------------------------------------------
+// generic
+__global__ void k_reduce_sum(const float* __restrict__ in, int n, float* __restrict__ out, int accumulate) {
+    __shared__ float part[UPK_BLOCK / UP_WAVE];
+    const int s = blockIdx.y;
+    const float* p = in + (size_t)s * n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += p[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[w];
+        out[s] = accumulate ? out[s] + t : t;
+    }
+}
+extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate) {
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, n, out, accumulate);
+    return launch_status();
+}
+
+__global__ void k_gather_contrib(const float* __restrict__ arena, long arena_stride, const int* __restrict__ csr_start,
+                                 const int* __restrict__ csr_entry, upk_coord_t target, int width, int comp_offset) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= target.n_elem) return;
+    const int s = blockIdx.y;
+    const float* a = arena + (size_t)s * arena_stride;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    const int e0 = csr_start[t], e1 = csr_start[t + 1];
+    for (int e = e0; e < e1; ++e) {
+        const float* p = a + csr_entry[e];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < width) acc[c] += p[c];
+    }
+    float* sens = C_SENS(target, s) + (size_t)t * target.stride + comp_offset;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < width) sens[c] += acc[c];
+}
+extern "C" int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_stride, const int* csr_start,
+                                  const int* csr_entry, upk_coord_t target, int width, int comp_offset) {
+    hipLaunchKernelGGL(k_gather_contrib, grid1(target.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), arena, arena_stride,
+                       csr_start, csr_entry, target, width, comp_offset);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// integrator (deriv_engine.cpp:11-35), thermostat (thermostat.cpp:9-18), recenter (deriv_engine.cpp:37-48)
+__global__ void k_integration_stage(float* __restrict__ mom, upk_coord_t pos, float vel_factor, float pos_factor, float max_force) {
+    const int na = blockIdx.x * blockDim.x + threadIdx.x;
+    if (na >= pos.n_elem) return;
+    const int s = blockIdx.y;
+    const float* d_ = C_SENS(pos, s) + (size_t)na * pos.stride;
+    float* x = C_OUT(pos, s) + (size_t)na * pos.stride;
+    float* m = mom + ((size_t)s * pos.n_elem + na) * 4;
+    f3 d = ld3(d_);
+    if (max_force != 0.f) {
+        const float f_mag = sqrtf(mag2(d)) + 1e-6f;
+        const float scale = atanf(f_mag * ((0.5f * UP_PI_F) / max_force)) * (max_force / f_mag * (2.f / UP_PI_F));
+        d = scale * d;
+    }
+    const f3 p = ld3(m) - vel_factor * d;
+    m[0] = p.x; m[1] = p.y; m[2] = p.z;
+    x[0] += pos_factor * p.x; x[1] += pos_factor * p.y; x[2] += pos_factor * p.z;
+}
+extern "C" int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
+                                     float max_force) {
+    hipLaunchKernelGGL(k_integration_stage, grid1(pos.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, pos, vel_factor,
+                       pos_factor, max_force);
+    return launch_status();
+}
+
+__global__ void k_thermostat(float* __restrict__ mom, int n_atom, const uint32_t* __restrict__ seed,
+                             uint64_t n_inv, const float* __restrict__ mom_scale,
+                             const float* __restrict__ noise_scale) {
+    const int na = blockIdx.x * blockDim.x + threadIdx.x;
+    if (na >= n_atom) return;
+    const int s = blockIdx.y;
+    const uint64_t t = n_inv;
+    const uint32_t key[4] = {seed[s], 0u /* THERMOSTAT_RANDOM_STREAM, random.h:25 */, 0u, 0u};
+    uint32_t X[4] = {(uint32_t)(t & 0xffffffffu), (uint32_t)(t >> 32), (uint32_t)na, 0u};
+    threefry4x32_20(X, key);
+    float n0, n1, n2, n3;
+    boxmuller(n0, n1, X[0], X[1]);
+    boxmuller(n2, n3, X[2], X[3]);   // 4th normal discarded (random.h:62-66)
+    float* m = mom + ((size_t)s * n_atom + na) * 4;
+    const float ms = mom_scale[s], ns = noise_scale[s];
+    m[0] = ms * m[0] + ns * n0; m[1] = ms * m[1] + ns * n1; m[2] = ms * m[2] + ns * n2;
+}
+extern "C" int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, uint64_t n_invocations,
+                              const float* mom_scale, const float* noise_scale) {
+    hipLaunchKernelGGL(k_thermostat, grid1(n_atom, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, n_atom, seed, n_invocations,
+                       mom_scale, noise_scale);
+    return launch_status();
+}
+
+__global__ void k_recenter(upk_coord_t pos, int xy_only) {
+    __shared__ float part[3][UPK_BLOCK / UP_WAVE];
+    __shared__ float center[3];
+    const int s = blockIdx.y;
+    float* x = C_OUT(pos, s);
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < pos.n_elem; i += blockDim.x) for (int c = 0; c < 3; ++c) a[c] += x[(size_t)i * pos.stride + c];
+    for (int c = 0; c < 3; ++c) { a[c] = wave_sum(a[c]); if ((threadIdx.x & 63) == 0) part[c][threadIdx.x >> 6] = a[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[threadIdx.x][w];
+        center[threadIdx.x] = (xy_only && threadIdx.x == 2) ? 0.f : t / (float)pos.n_elem;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pos.n_elem; i += blockDim.x) for (int c = 0; c < 3; ++c) x[(size_t)i * pos.stride + c] -= center[c];
+}
+extern "C" int upk_recenter(const upk_launch_t* L, upk_coord_t pos, int xy_only) {
+    hipLaunchKernelGGL(k_recenter, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, xy_only);
+    return launch_status();
+}
+
+__global__ void k_kinetic(const float* __restrict__ mom, int n_atom, float* __restrict__ kin) {
+    __shared__ float part[UPK_BLOCK / UP_WAVE];
+    const int s = blockIdx.y;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n_atom; i += blockDim.x) { const float* m = mom + ((size_t)s * n_atom + i) * 4; a += m[0] * m[0] + m[1] * m[1] + m[2] * m[2]; }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[w]; kin[s] = 0.5f * t / (float)n_atom; }
+}
+extern "C" int upk_kinetic(const upk_launch_t* L, const float* mom, int n_atom, float* kin) {
+    hipLaunchKernelGGL(k_kinetic, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, n_atom, kin);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// affine_alignment (eig.cpp).  The reference solves the 4x4 symmetric eigenproblem for 4 residues at a time
+// and decides the QR control flow with any()/none() over those 4 SIMD lanes (eig.cpp:255-267).  Here one
+// lane owns one residue; groups of 4 consecutive lanes take the same decisions through a wavefront ballot, so
+// every residue receives exactly the sweeps it receives in the reference.
+__device__ __forceinline__ int r_idx(int i, int j) {
+    const int ii = i < j ? i : j, jj = i < j ? j : i;
+    return (ii == 0 ? 0 : (ii == 1 ? 3 : (ii == 2 ? 5 : 6))) + jj;
+}
+__device__ __forceinline__ bool group_any(bool p) {
+    const unsigned long long b = __ballot(p);
+    const int lane = threadIdx.x & 63;
+    return ((b >> (lane & ~3)) & 0xFull) != 0ull;
+}
+
+__device__ void house(int n, float* x, float& beta) {   // eig.cpp:56-73
+    float sigma2 = 1e-20f;
+    for (int i = 1; i < n; ++i) sigma2 += x[i] * x[i];
+    const float mu = sqrtf(x[0] * x[0] + sigma2);
+    const float s = (0.f < x[0]) ? -sigma2 * rcp(x[0] + mu) : x[0] - mu;
+    beta = 2.f * s * s * rcp(sigma2 + s * s);
+    x[0] = mu;
+    for (int i = 1; i < n; ++i) x[i] *= rcp(s);
+}
+
+__device__ void qr_step(int n, float* d, float* u, float* rot) {   // eig.cpp:183-228; rot points at row p
+    const float dval = 0.5f * (d[n - 2] - d[n - 1]) + 1e-20f;
+    const float un = u[n - 2];
+    const float mu = d[n - 1] - un * un * rcp(dval + copysignf(sqrtf(dval * dval + un * un), dval));
+    float x = d[0] - mu, z = u[0];
+    for (int k = 0; k < n - 1; ++k) {
+        const float inv_r = rsqrt_(x * x + z * z);
+        const bool trivial = (z == 0.f);
+        const float c = trivial ? 1.f : x * inv_r;
+        const float s = trivial ? 0.f : -z * inv_r;
+        for (int j = 0; j < 4; ++j) {
+            const float t1 = rot[k * 4 + j], t2 = rot[(k + 1) * 4 + j];
+            rot[k * 4 + j] = c * t1 - s * t2;
+            rot[(k + 1) * 4 + j] = s * t1 + c * t2;
+        }
+        if (k > 0) u[k - 1] = c * x - s * z;
+        const float T00 = d[k], T11 = d[k + 1], T01 = u[k];
+        d[k] = T00 * c * c - T01 * 2.f * c * s + T11 * s * s;
+        d[k + 1] = T00 * s * s + T01 * 2.f * c * s + T11 * c * c;
+        u[k] = (T00 - T11) * c * s + T01 * (c * c - s * s);
+        x = u[k];
+        if (k < n - 2) { z = -u[k + 1] * s; u[k + 1] *= c; }
+    }
+}
+
+__global__ void k_affine_fwd(upk_coord_t pos, const int* __restrict__ atoms, const float* __restrict__ ref_geom, int n_res,
+                             upk_coord_t out, float* __restrict__ eig) {
+    const int lane_res = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    const int n_pad = (n_res + 3) & ~3;
+    // every lane of a wave must reach the ballots; lanes beyond n_pad replay residue 0 and are discarded
+    const bool in_pad = lane_res < n_pad;
+    int nr = lane_res;
+    if (lane_res >= n_res) nr = in_pad ? (lane_res & ~3) : 0;   // padding duplicates lane 0 of its group (eig.cpp:307-314)
+    const float* x = C_OUT(pos, s);
+    f3 a1 = ld3(x + (size_t)atoms[nr * 3 + 0] * pos.stride), a2 = ld3(x + (size_t)atoms[nr * 3 + 1] * pos.stride),
+       a3 = ld3(x + (size_t)atoms[nr * 3 + 2] * pos.stride);
+    const f3 center = (1.f / 3.f) * (a1 + a2 + a3);
+    a1 = a1 - center; a2 = a2 - center; a3 = a3 - center;
+    const float* g = ref_geom + nr * 9;
+    const float A1[3] = {a1.x, a1.y, a1.z}, A2[3] = {a2.x, a2.y, a2.z}, A3[3] = {a3.x, a3.y, a3.z};
+    float R[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = A1[j] * g[i] + A2[j] * g[3 + i] + A3[j] * g[6 + i];
+    float A[10] = {R[0][0] + R[1][1] + R[2][2], R[1][2] - R[2][1], R[2][0] - R[0][2], R[0][1] - R[1][0],
+                   R[0][0] - R[1][1] - R[2][2], R[0][1] + R[1][0], R[0][2] + R[2][0],
+                   -R[0][0] + R[1][1] - R[2][2], R[1][2] + R[2][1], -R[0][0] - R[1][1] + R[2][2]};
+    // --- symmetric_tridiagonalize_4x4 (eig.cpp:105-134)
+    float beta[2];
+    for (int k = 0; k < 2; ++k) {
+        const int m = 4 - (k + 1);
+        house(m, A + r_idx(k, k + 1), beta[k]);
+        float p[3], w[3];
+#define VV(j) ((j) == 0 ? 1.f : A[r_idx(k, k + 1 + (j))])
+        for (int i = 0; i < m; ++i) {
+            p[i] = 0.f;
+            for (int j = 0; j < m; ++j) p[i] += A[r_idx(i + k + 1, j + k + 1)] * VV(j);
+            p[i] *= beta[k];
+        }
+        float pdv = 0.f;
+        for (int i = 0; i < m; ++i) pdv += p[i] * VV(i);
+        for (int i = 0; i < m; ++i) w[i] = p[i] - (0.5f * beta[k] * pdv) * VV(i);
+        for (int i = 0; i < m; ++i) for (int j = i; j < m; ++j) A[r_idx(i + k + 1, j + k + 1)] -= VV(i) * w[j] + VV(j) * w[i];
+#undef VV
+    }
+    // --- unpack_tridiagonalize_4x4 (eig.cpp:137-178)
+    float d[4], u[3], rot[16];
+    for (int i = 0; i < 4; ++i) d[i] = A[r_idx(i, i)];
+    for (int i = 0; i < 3; ++i) u[i] = A[r_idx(i, i + 1)];
+    for (int i = 0; i < 16; ++i) rot[i] = 0.f;
+    for (int i = 0; i < 4; ++i) rot[i * 4 + i] = 1.f;
+#define V0(j) ((j) == 0 ? 1.f : A[r_idx(0, 1 + (j))])
+#define V1(j) ((j) == 0 ? 1.f : A[r_idx(1, 2 + (j))])
+    for (int i = 1; i < 4; ++i) for (int j = i; j < 4; ++j) rot[i * 4 + j] -= beta[0] * (V0(i - 1) * V0(j - 1));
+    for (int i = 2; i < 4; ++i) for (int j = i; j < 4; ++j) rot[i * 4 + j] -= beta[1] * (V1(i - 2) * V1(j - 2));
+    for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) rot[j * 4 + i] = rot[i * 4 + j];
+    const float coeff = beta[0] * beta[1] * (V0(1) * V1(0) + V0(2) * V1(1));
+    for (int i = 2; i < 4; ++i) for (int j = 1; j < 4; ++j) rot[i * 4 + j] += coeff * V1(i - 2) * V0(j - 1);
+#undef V0
+#undef V1
+    // --- symm_QR_4x4 main loop (eig.cpp:248-272) with 4-lane group decisions
+    bool done = false;
+    for (int k = 0; k < 100; ++k) {
+        if (!done)
+            for (int i = 0; i < 3; ++i) if (fabsf(u[i]) <= 1e-5f * (fabsf(d[i]) + fabsf(d[i + 1]))) u[i] = 0.f;
+        const bool any2 = group_any(!done && u[2] != 0.f), any1 = group_any(!done && u[1] != 0.f), any0 = group_any(!done && u[0] != 0.f);
+        if (!done) {
+            int q;
+            if (any2) q = 0; else if (any1) q = 1; else if (any0) q = 2; else { q = 3; done = true; }
+            if (!done) {
+                const bool anyu[3] = {any0, any1, any2};
+                int p;
+                for (p = 4 - q - 1; p > 0; --p) if (!anyu[p - 1]) break;
+                qr_step(4 - q - p, d + p, u + p, rot + 4 * p);
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+    }
+    // --- largest eigenvalue to row 0 (eig.cpp:359-374)
+    for (int i = 1; i < 4; ++i) if (d[0] < d[i]) {
+        const float t = d[0]; d[0] = d[i]; d[i] = t;
+        for (int c = 0; c < 4; ++c) { const float tt = rot[c]; rot[c] = rot[i * 4 + c]; rot[i * 4 + c] = tt; }
+    }
+    if (lane_res < n_res) {
+        float* o = C_OUT(out, s) + (size_t)lane_res * out.stride;
+        o[0] = center.x; o[1] = center.y; o[2] = center.z;
+        o[3] = rot[0]; o[4] = rot[1]; o[5] = rot[2]; o[6] = rot[3];
+        float* e = eig + ((size_t)s * n_res + lane_res) * 20;
+        for (int i = 0; i < 4; ++i) e[i] = d[i];
+        for (int i = 0; i < 16; ++i) e[4 + i] = rot[i];
+    }
+}
+extern "C" int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, const float* ref_geom, int n_res,
+                              upk_coord_t out, float* eig) {
+    hipLaunchKernelGGL(k_affine_fwd, grid1((n_res + 3) & ~3, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atoms, ref_geom, n_res, out, eig);
+    return launch_status();
+}
+
+__global__ void k_affine_bwd(upk_coord_t aff, const float* __restrict__ ref_geom, const float* __restrict__ eig, int n_res,
+                             float* __restrict__ contrib, long contrib_stride) {   // eig.cpp:388-470
+    const int nr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nr >= n_res) return;
+    const int s = blockIdx.y;
+    const float* e = eig + ((size_t)s * n_res + nr) * 20;
+    const float* evals = e; const float* ev = e + 4;
+#define EV(k, i) ev[(k) * 4 + (i)]
+    float inv_evals[4];
+    for (int j = 1; j < 4; ++j) inv_evals[j] = rcp(evals[0] - evals[j]);
+    const float* sn = C_SENS(aff, s) + (size_t)nr * aff.stride;
+    const float sens3[3] = {sn[0], sn[1], sn[2]}, tq[3] = {sn[3], sn[4], sn[5]};
+    const float quat_sens[4] = {
+        2.f * (-tq[0] * EV(0, 1) - tq[1] * EV(0, 2) - tq[2] * EV(0, 3)),
+        2.f * (tq[0] * EV(0, 0) + tq[1] * EV(0, 3) - tq[2] * EV(0, 2)),
+        2.f * (tq[1] * EV(0, 0) + tq[2] * EV(0, 1) - tq[0] * EV(0, 3)),
+        2.f * (tq[2] * EV(0, 0) + tq[0] * EV(0, 2) - tq[1] * EV(0, 1))};
+    float qsdb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int dd = 0; dd < 4; ++dd) for (int i = 0; i < 4; ++i) qsdb[dd] += quat_sens[i] * EV(dd, i);
+    float* out = contrib + (size_t)s * contrib_stride + (size_t)nr * 9;
+    for (int na = 0; na < 3; ++na) {
+        const float* g = ref_geom + nr * 9 + na * 3;
+        const float f[3][10] = {
+            {g[0], 0.f, g[2], -g[1], g[0], g[1], g[2], -g[0], 0.f, -g[0]},
+            {g[1], -g[2], 0.f, g[0], -g[1], g[0], 0.f, g[1], g[2], -g[1]},
+            {g[2], g[1], -g[0], 0.f, -g[2], 0.f, g[0], -g[2], g[1], g[2]}};
+        for (int c = 0; c < 3; ++c) {
+            float deriv = (1.f / 3.f) * sens3[c];
+            for (int k = 1; k < 4; ++k) {
+                float acc = 0.f;
+                for (int i = 0; i < 4; ++i) for (int j = i; j < 4; ++j) {
+                    const float t = (i == j) ? EV(k, i) * EV(0, j) : EV(k, i) * EV(0, j) + EV(k, j) * EV(0, i);
+                    acc += f[c][r_idx(i, j)] * t;
+                }
+                deriv += (inv_evals[k] * acc) * qsdb[k];
+            }
+            out[na * 3 + c] = deriv;
+        }
+    }
+#undef EV
+}
+extern "C" int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
+                              float* contrib, long contrib_stride) {
+    hipLaunchKernelGGL(k_affine_bwd, grid1(n_res, L->n_system), dim3(UPK_BLOCK), 0, ST(L), aff, ref_geom, eig, n_res, contrib, contrib_stride);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// rama_coord (bonds.cpp:205-247)
+__global__ void k_rama_fwd(upk_coord_t pos, const int* __restrict__ atom, const int* __restrict__ dummy, int n_res,
+                           upk_coord_t out, float* __restrict__ jac) {
+    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt >= n_res) return;
+    const int s = blockIdx.y;
+    const float* x = C_OUT(pos, s);
+    f3 p[5];
+    for (int a = 0; a < 5; ++a) p[a] = ld3(x + (size_t)atom[nt * 5 + a] * pos.stride);
+    float* o = C_OUT(out, s) + (size_t)nt * out.stride;
+    float* j = jac + ((size_t)s * n_res + nt) * 30;
+    for (int pp = 0; pp < 2; ++pp) {
+        f3 d[5];
+        for (int a = 0; a < 5; ++a) d[a] = mk3(0.f, 0.f, 0.f);
+        if (dummy[nt * 2 + pp]) o[pp] = -1.3963f;
+        else o[pp] = dihedral_germ(p[0 + pp], p[1 + pp], p[2 + pp], p[3 + pp], d[0 + pp], d[1 + pp], d[2 + pp], d[3 + pp]);
+        for (int a = 0; a < 5; ++a) { j[(pp * 5 + a) * 3 + 0] = d[a].x; j[(pp * 5 + a) * 3 + 1] = d[a].y; j[(pp * 5 + a) * 3 + 2] = d[a].z; }
+    }
+}
+extern "C" int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
+                            float* jac) {
+    hipLaunchKernelGGL(k_rama_fwd, grid1(n_res, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atom, dummy, n_res, out, jac);
+    return launch_status();
+}
+__global__ void k_rama_bwd(upk_coord_t rama, const float* __restrict__ jac, int n_res, float* __restrict__ contrib, long contrib_stride) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (residue, atom slot)
+    if (idx >= n_res * 5) return;
+    const int s = blockIdx.y, nt = idx / 5, a = idx % 5;
+    const float* sn = C_SENS(rama, s) + (size_t)nt * rama.stride;
+    const float* j = jac + ((size_t)s * n_res + nt) * 30;
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)idx * 3;
+    for (int c = 0; c < 3; ++c) o[c] = sn[0] * j[(0 * 5 + a) * 3 + c] + sn[1] * j[(1 * 5 + a) * 3 + c];
+}
+extern "C" int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride) {
+    hipLaunchKernelGGL(k_rama_bwd, grid1(n_res * 5, L->n_system), dim3(UPK_BLOCK), 0, ST(L), rama, jac, n_res, contrib, contrib_stride);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// infer_H_O (hbond.cpp:59-119)
+__global__ void k_infer_fwd(upk_coord_t pos, const int* __restrict__ atom, const float* __restrict__ bond_length, int n_virtual,
+                            upk_coord_t out, float* __restrict__ dfd) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= n_virtual) return;
+    const int s = blockIdx.y;
+    const float* x = C_OUT(pos, s);
+    const f3 prev_c = ld3(x + (size_t)atom[nv * 3] * pos.stride), curr_c = ld3(x + (size_t)atom[nv * 3 + 1] * pos.stride),
+             next_c = ld3(x + (size_t)atom[nv * 3 + 2] * pos.stride);
+    f3 prev = prev_c - curr_c; const float prev_im = rsqrt_(mag2(prev)); prev = prev_im * prev;
+    f3 next = next_c - curr_c; const float next_im = rsqrt_(mag2(next)); next = next_im * next;
+    f3 disp = prev + next; const float disp_im = rsqrt_(mag2(disp)); disp = disp_im * disp;
+    const f3 dir = -disp;
+    const f3 hp = bond_length[nv] * dir + curr_c;
+    float* sd = dfd + ((size_t)s * n_virtual + nv) * 12;
+    sd[0] = prev.x; sd[1] = prev.y; sd[2] = prev.z; sd[3] = prev_im;
+    sd[4] = next.x; sd[5] = next.y; sd[6] = next.z; sd[7] = next_im;
+    sd[8] = disp.x; sd[9] = disp.y; sd[10] = disp.z; sd[11] = disp_im;
+    float* o = C_OUT(out, s) + (size_t)nv * out.stride;
+    o[0] = hp.x; o[1] = hp.y; o[2] = hp.z; o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
+}
+extern "C" int upk_infer_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const float* bond_length, int n_virtual,
+                             upk_coord_t out, float* dfd) {
+    hipLaunchKernelGGL(k_infer_fwd, grid1(n_virtual, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atom, bond_length, n_virtual, out, dfd);
+    return launch_status();
+}
+__global__ void k_infer_bwd(upk_coord_t infer, const float* __restrict__ bond_length, const float* __restrict__ dfd, int n_virtual,
+                            float* __restrict__ contrib, long contrib_stride) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= n_virtual) return;
+    const int s = blockIdx.y;
+    const float* sn = C_SENS(infer, s) + (size_t)nv * infer.stride;
+    const f3 sens_pos = ld3(sn), sens_dir = ld3(sn + 3);
+    const f3 snu = sens_dir + bond_length[nv] * sens_pos;
+    const float* sd = dfd + ((size_t)s * n_virtual + nv) * 12;
+    const f3 prev = ld3(sd), next = ld3(sd + 4), disp = ld3(sd + 8);
+    const float prev_im = sd[3], next_im = sd[7], disp_im = sd[11];
+    const f3 sn_disp = disp_im * (dot(disp, snu) * disp - snu);
+    const f3 sn_prev = (-prev_im) * (dot(prev, sn_disp) * prev - sn_disp);
+    const f3 sn_next = (-next_im) * (dot(next, sn_disp) * next - sn_disp);
+    const f3 mid = sens_pos - sn_prev - sn_next;
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)nv * 9;
+    o[0] = sn_prev.x; o[1] = sn_prev.y; o[2] = sn_prev.z;
+    o[3] = mid.x; o[4] = mid.y; o[5] = mid.z;
+    o[6] = sn_next.x; o[7] = sn_next.y; o[8] = sn_next.z;
+}
+extern "C" int upk_infer_bwd(const upk_launch_t* L, upk_coord_t infer, const float* bond_length, const float* dfd, int n_virtual,
+                             float* contrib, long contrib_stride) {
+    hipLaunchKernelGGL(k_infer_bwd, grid1(n_virtual, L->n_system), dim3(UPK_BLOCK), 0, ST(L), infer, bond_length, dfd, n_virtual, contrib, contrib_stride);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bonded springs (bonds.cpp:297-318, 457-487, 519-545)
+__global__ void k_spring(int kind, upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ equil,
+                         const float* __restrict__ kk, int n, float* __restrict__ contrib, long contrib_stride,
+                         float* __restrict__ pot_terms) {
+    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt >= n) return;
+    const int s = blockIdx.y;
+    const float* x = C_OUT(pos, s);
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)nt * kind * 3;
+    float pot;
+    if (kind == 2) {
+        const f3 x1 = ld3(x + (size_t)id[nt * 2] * pos.stride), x2 = ld3(x + (size_t)id[nt * 2 + 1] * pos.stride);
+        const f3 disp = x1 - x2;
+        const float m2 = mag2(disp);
+        const f3 deriv = (kk[nt] * (1.f - equil[nt] * rsqrt_(m2))) * disp;
+        pot = 0.5f * kk[nt] * sqr(sqrtf(m2) - equil[nt]);
+        o[0] = deriv.x; o[1] = deriv.y; o[2] = deriv.z; o[3] = -deriv.x; o[4] = -deriv.y; o[5] = -deriv.z;
+    } else if (kind == 3) {
+        const f3 a1 = ld3(x + (size_t)id[nt * 3] * pos.stride), a2 = ld3(x + (size_t)id[nt * 3 + 1] * pos.stride),
+                 a3 = ld3(x + (size_t)id[nt * 3 + 2] * pos.stride);
+        const f3 x1 = a1 - a3; const float inv_d1 = rsqrt_(mag2(x1)); const f3 x1h = inv_d1 * x1;
+        const f3 x2 = a2 - a3; const float inv_d2 = rsqrt_(mag2(x2)); const f3 x2h = inv_d2 * x2;
+        const float dp = dot(x1h, x2h);
+        const float pref = kk[nt] * (dp - equil[nt]);
+        const f3 d1 = (pref * inv_d1) * (x2h - dp * x1h);
+        const f3 d2 = (pref * inv_d2) * (x1h - dp * x2h);
+        const f3 d3 = -(d1 + d2);
+        pot = 0.5f * kk[nt] * sqr(dp - equil[nt]);
+        o[0] = d1.x; o[1] = d1.y; o[2] = d1.z; o[3] = d2.x; o[4] = d2.y; o[5] = d2.z; o[6] = d3.x; o[7] = d3.y; o[8] = d3.z;
+    } else {
+        f3 p[4], d[4];
+        for (int a = 0; a < 4; ++a) p[a] = ld3(x + (size_t)id[nt * 4 + a] * pos.stride);
+        const float dihedral = dihedral_germ(p[0], p[1], p[2], p[3], d[0], d[1], d[2], d[3]);
+        float disp = dihedral - equil[nt];
+        disp = (disp > UP_PI_F) ? disp - 2.f * UP_PI_F : disp;
+        disp = (disp < -UP_PI_F) ? disp + 2.f * UP_PI_F : disp;
+        const float sc = kk[nt] * disp;
+        pot = 0.5f * kk[nt] * sqr(disp);
+        for (int a = 0; a < 4; ++a) { o[a * 3] = sc * d[a].x; o[a * 3 + 1] = sc * d[a].y; o[a * 3 + 2] = sc * d[a].z; }
+    }
+    if (pot_terms) pot_terms[(size_t)s * n + nt] = pot;
+}
+extern "C" int upk_spring(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* equil, const float* k, int n,
+                          float* contrib, long contrib_stride, float* pot_terms) {
+    hipLaunchKernelGGL(k_spring, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), kind, pos, id, equil, k, n, contrib, contrib_stride, pot_terms);
+    return launch_status();
+}
+
+__global__ void k_cavity(upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ radius, const float* __restrict__ kk,
+                         int n, float* __restrict__ contrib, long contrib_stride, float* __restrict__ pot_terms) {   // bonds.cpp:350-372
+    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt >= n) return;
+    const int s = blockIdx.y;
+    const f3 x = ld3(C_OUT(pos, s) + (size_t)id[nt] * pos.stride);
+    const float r2 = mag2(x);
+    float pot = 0.f; f3 d = mk3(0.f, 0.f, 0.f);
+    if (r2 > sqr(radius[nt])) {
+        const float inv_r = rsqrt_(r2), r = r2 * inv_r, excess = r - radius[nt];
+        pot = 0.5f * kk[nt] * sqr(excess);
+        d = (kk[nt] * excess * inv_r) * x;
+    }
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)nt * 3;
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    if (pot_terms) pot_terms[(size_t)s * n + nt] = pot;
+}
+extern "C" int upk_cavity_radial(const upk_launch_t* L, upk_coord_t pos, const int* id, const float* radius, const float* k, int n,
+                                 float* contrib, long contrib_stride, float* pot_terms) {
+    hipLaunchKernelGGL(k_cavity, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, id, radius, k, n, contrib, contrib_stride, pot_terms);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// placement (placement.cpp:264-307; RamaPlacement 60-92; FixedPlacement 139-141)
+__global__ void k_placement_fwd(upk_placement_t P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out, float* __restrict__ rama_deriv) {
+    const int ne = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ne >= P.n_elem) return;
+    const int s = blockIdx.y;
+    const int ar = P.affine_residue[ne];
+    const float* a = C_OUT(aff, s) + (size_t)ar * aff.stride;
+    const f3 t = ld3(a);
+    float U[9]; quat_to_rot(U, a[3], a[4], a[5], a[6]);
+    float val[8];
+    if (P.is_rama) {
+        const float scale_x = P.nx * (0.5f / UP_PI_F - 1e-7f), scale_y = P.ny * (0.5f / UP_PI_F - 1e-7f);
+        const float* r = C_OUT(rama, s) + (size_t)P.rama_residue[ne] * rama.stride;
+        const float xx = (r[0] + UP_PI_F) * scale_x, yy = (r[1] + UP_PI_F) * scale_y;
+        const int x_bin = (int)xx, y_bin = (int)yy;
+        const float fx = xx - x_bin, fy = yy - y_bin;
+        const float* c = P.spline_coeff + ((size_t)P.layer[ne] * P.nx * P.ny + (size_t)x_bin * P.ny + y_bin) * 16 * P.n_pos_dim;
+        float* rd = rama_deriv + ((size_t)s * P.n_elem + ne) * 2 * P.n_pos_dim;
+        for (int id = 0; id < P.n_pos_dim; ++id) bicubic_vd(val[id], rd[id], rd[P.n_pos_dim + id], c + id * 16, fx, fy);
+    } else {
+        for (int c = 0; c < P.n_pos_dim; ++c) val[c] = P.fixed_data[P.layer[ne] * P.n_pos_dim + c];
+    }
+    float* o = C_OUT(out, s) + (size_t)ne * out.stride;
+    int off = 0;
+    for (int k = 0; k < P.n_sig; ++k) {
+        if (P.sig[k] == 0) { o[off] = val[off]; off += 1; }
+        else {
+            const f3 v = mk3(val[off], val[off + 1], val[off + 2]);
+            const f3 r = P.sig[k] == 1 ? apply_rotation(U, v) : apply_affine(U, t, v);
+            o[off] = r.x; o[off + 1] = r.y; o[off + 2] = r.z; off += 3;
+        }
+    }
+}
+extern "C" int upk_placement_fwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out,
+                                 float* rama_deriv) {
+    hipLaunchKernelGGL(k_placement_fwd, grid1(P->n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *P, aff, rama, out, rama_deriv);
+    return launch_status();
+}
+
+__global__ void k_placement_bwd(upk_placement_t P, upk_coord_t aff, upk_coord_t out, const float* __restrict__ rama_deriv,
+                                float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ rama_contrib, long rama_stride) {
+    const int ne = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ne >= P.n_elem) return;
+    const int s = blockIdx.y;
+    const int ar = P.affine_residue[ne];
+    const float* a = C_OUT(aff, s) + (size_t)ar * aff.stride;
+    const f3 t = ld3(a);
+    float U[9]; quat_to_rot(U, a[3], a[4], a[5], a[6]);
+    const float* sn = C_SENS(out, s) + (size_t)ne * out.stride;
+    const float* xo = C_OUT(out, s) + (size_t)ne * out.stride;
+    float ref_sens[8];
+    f3 com = mk3(0.f, 0.f, 0.f), torque = mk3(0.f, 0.f, 0.f);
+    int off = 0;
+    for (int k = 0; k < P.n_sig; ++k) {
+        if (P.sig[k] == 0) { ref_sens[off] = sn[off]; off += 1; }
+        else {
+            const f3 sv = ld3(sn + off), xv = ld3(xo + off);
+            const f3 rs = apply_inverse_rotation(U, sv);
+            ref_sens[off] = rs.x; ref_sens[off + 1] = rs.y; ref_sens[off + 2] = rs.z;
+            if (P.sig[k] == 2) { com = com + sv; torque = torque + cross(xv - t, sv); }
+            else torque = torque + cross(xv, sv);
+            off += 3;
+        }
+    }
+    if (P.is_rama && rama_contrib) {
+        const float scale_x = P.nx * (0.5f / UP_PI_F - 1e-7f), scale_y = P.ny * (0.5f / UP_PI_F - 1e-7f);
+        const float* rd = rama_deriv + ((size_t)s * P.n_elem + ne) * 2 * P.n_pos_dim;
+        float ax = 0.f, bx = 0.f;
+        for (int c = 0; c < P.n_pos_dim; ++c) { ax += ref_sens[c] * rd[c]; bx += ref_sens[c] * rd[P.n_pos_dim + c]; }
+        float* ro = rama_contrib + (size_t)s * rama_stride + (size_t)ne * 2;
+        ro[0] = scale_x * ax; ro[1] = scale_y * bx;
+    }
+    float* ao = aff_contrib + (size_t)s * aff_stride + (size_t)ne * 6;
+    ao[0] = com.x; ao[1] = com.y; ao[2] = com.z; ao[3] = torque.x; ao[4] = torque.y; ao[5] = torque.z;
+}
+extern "C" int upk_placement_bwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out,
+                                 const float* rama_deriv, float* aff_contrib, long aff_stride, float* rama_contrib, long rama_stride) {
+    hipLaunchKernelGGL(k_placement_bwd, grid1(P->n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *P, aff, out, rama_deriv, aff_contrib,
+                       aff_stride, rama_contrib, rama_stride);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// rama_map_pot (rama_map_pot.cpp:57-82)
+__global__ void k_rama_map_pot(upk_coord_t rama, const int* __restrict__ residue, const int* __restrict__ map_id, int n,
+                               const float* __restrict__ coeff, int nx, float* __restrict__ pot_terms) {
+    const int nr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nr >= n) return;
+    const int s = blockIdx.y;
+    const float scale = nx * (0.5f / UP_PI_F - 1e-7f);
+    const int r = residue[nr];
+    const float* rc = C_OUT(rama, s) + (size_t)r * rama.stride;
+    const float xx = (rc[0] + UP_PI_F) * scale, yy = (rc[1] + UP_PI_F) * scale;
+    const int x_bin = (int)xx, y_bin = (int)yy;
+    float value, dx, dy;
+    bicubic_vd(value, dx, dy, coeff + ((size_t)map_id[nr] * nx * nx + (size_t)x_bin * nx + y_bin) * 16, xx - x_bin, yy - y_bin);
+    float* rs = C_SENS(rama, s) + (size_t)r * rama.stride;
+    rs[0] += dx * scale; rs[1] += dy * scale;
+    if (pot_terms) pot_terms[(size_t)s * n + nr] = value;
+}
+extern "C" int upk_rama_map_pot(const upk_launch_t* L, upk_coord_t rama, const int* residue, const int* map_id, int n,
+                                const float* coeff, int nx, float* pot_terms) {
+    hipLaunchKernelGGL(k_rama_map_pot, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), rama, residue, map_id, n, coeff, nx, pot_terms);
+    return launch_status();
+}
+
+// weighted_pos (environment.cpp:132-154)
+__global__ void k_weighted_pos_fwd(upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
+                                   const int* __restrict__ index_weight, upk_coord_t out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out.n_elem) return;
+    const int s = blockIdx.y;
+    const float* p = C_OUT(pos, s) + (size_t)index_pos[i] * pos.stride;
+    float* o = C_OUT(out, s) + (size_t)i * out.stride;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+    o[3] = expf(-C_OUT(energy, s)[(size_t)index_weight[i] * energy.stride]);
+}
+extern "C" int upk_weighted_pos_fwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
+                                    const int* index_weight, upk_coord_t out) {
+    hipLaunchKernelGGL(k_weighted_pos_fwd, grid1(out.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, energy, index_pos, index_weight, out);
+    return launch_status();
+}
+__global__ void k_weighted_pos_bwd(upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
+                                   const int* __restrict__ index_weight, upk_coord_t self) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= self.n_elem) return;
+    const int s = blockIdx.y;
+    const float* sn = C_SENS(self, s) + (size_t)i * self.stride;
+    const float* o = C_OUT(self, s) + (size_t)i * self.stride;
+    float* ps = C_SENS(pos, s) + (size_t)index_pos[i] * pos.stride;      // index_pos / index_weight are injective (checked on the host)
+    ps[0] += sn[0]; ps[1] += sn[1]; ps[2] += sn[2];
+    C_SENS(energy, s)[(size_t)index_weight[i] * energy.stride] -= o[3] * sn[3];
+}
+extern "C" int upk_weighted_pos_bwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
+                                    const int* index_weight, upk_coord_t self) {
+    hipLaunchKernelGGL(k_weighted_pos_bwd, grid1(self.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, energy, index_pos, index_weight, self);
+    return launch_status();
+}
+
+// nonlinear_coupling (environment.cpp:358-369)
+__global__ void k_nonlinear_coupling(upk_coord_t input, const int* __restrict__ types, const float* __restrict__ coeff, int n_coeff,
+                                     float offset, float inv_dx, float* __restrict__ pot_terms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= input.n_elem) return;
+    const int s = blockIdx.y;
+    const float coord = (C_OUT(input, s)[(size_t)i * input.stride] - offset) * inv_dx;
+    float v, dv;
+    clamped_deBoor_vd_scalar(v, dv, coeff + types[i] * n_coeff, coord, n_coeff);
+    C_SENS(input, s)[(size_t)i * input.stride] += dv * inv_dx;
+    if (pot_terms) pot_terms[(size_t)s * input.n_elem + i] = v;
+}
+extern "C" int upk_nonlinear_coupling(const upk_launch_t* L, upk_coord_t input, const int* types, const float* coeff, int n_coeff,
+                                      float offset, float inv_dx, float* pot_terms) {
+    hipLaunchKernelGGL(k_nonlinear_coupling, grid1(input.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), input, types, coeff, n_coeff, offset, inv_dx, pot_terms);
+    return launch_status();
+}
+
+// hbond_energy (hbond.cpp:430-444)
+__global__ void k_hbond_energy(upk_coord_t ph, float Ep, float* __restrict__ pot_terms) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= ph.n_elem) return;
+    const int s = blockIdx.y;
+    C_SENS(ph, s)[(size_t)nv * ph.stride + 6] += Ep;
+    if (pot_terms) pot_terms[(size_t)s * ph.n_elem + nv] = C_OUT(ph, s)[(size_t)nv * ph.stride + 6] * Ep;
+}
+extern "C" int upk_hbond_energy(const upk_launch_t* L, upk_coord_t protein_hbond, float E_protein, float* pot_terms) {
+    hipLaunchKernelGGL(k_hbond_energy, grid1(protein_hbond.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), protein_hbond, E_protein, pot_terms);
+    return launch_status();
+}
+
+// protein_hbond helpers (hbond.cpp:320-335, 343-365)
+__global__ void k_protein_hbond_finish(upk_coord_t infer, upk_coord_t out) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= out.n_elem) return;
+    const int s = blockIdx.y;
+    const float* h = C_OUT(infer, s) + (size_t)nv * infer.stride;
+    float* o = C_OUT(out, s) + (size_t)nv * out.stride;
+    for (int c = 0; c < 6; ++c) o[c] = h[c];
+    o[6] = 1.f - expf(-o[6]);
+}
+extern "C" int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out) {
+    hipLaunchKernelGGL(k_protein_hbond_finish, grid1(out.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), infer, out);
+    return launch_status();
+}
+__global__ void k_protein_hbond_bwd_pre(upk_coord_t self, float* __restrict__ sens_scaled) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= self.n_elem) return;
+    const int s = blockIdx.y;
+    sens_scaled[(size_t)s * self.n_elem + nv] = C_SENS(self, s)[(size_t)nv * self.stride + 6] * (1.f - C_OUT(self, s)[(size_t)nv * self.stride + 6]);
+}
+extern "C" int upk_protein_hbond_bwd_pre(const upk_launch_t* L, upk_coord_t self, float* sens_scaled) {
+    hipLaunchKernelGGL(k_protein_hbond_bwd_pre, grid1(self.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, sens_scaled);
+    return launch_status();
+}
+__global__ void k_protein_hbond_passthrough(upk_coord_t self, upk_coord_t infer, const int* __restrict__ loc1, int n1,
+                                            const int* __restrict__ loc2, int n2) {
+    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nv >= n1 + n2) return;
+    const int s = blockIdx.y;
+    const int tgt = nv < n1 ? loc1[nv] : loc2[nv - n1];
+    const float* sn = C_SENS(self, s) + (size_t)nv * self.stride;
+    float* t = C_SENS(infer, s) + (size_t)tgt * infer.stride;
+    for (int c = 0; c < 6; ++c) t[c] += sn[c];
+}
+extern "C" int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_coord_t infer, const int* loc1, int n1,
+                                             const int* loc2, int n2) {
+    hipLaunchKernelGGL(k_protein_hbond_passthrough, grid1(n1 + n2, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, infer, loc1, n1, loc2, n2);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backbone_pairs (backbone_steric.cpp:81-145).  Residue counts are a few hundred, so instead of a cached pair
+// list every residue scans all others each step (LDS-staged centres) and accumulates its OWN force and
+// torque: each pair is visited from both ends, nothing is scattered.
+__device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, float r_mag2) {   // backbone_steric.cpp:18-30
+    const float wall = 3.0f, width = 0.10f, sharpness = 1.f / (wall * width);
+    float cs, dcs; compact_sigmoid(cs, dcs, r_mag2 - wall * wall, sharpness);
+    v = 4.f * cs; dv_over_r = 2.f * (4.f * dcs);
+}
+__global__ void k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residue, const int* __restrict__ id,
+                                 const int* __restrict__ n_atom, const float* __restrict__ ref_pos, int n_res, float dist_cutoff,
+                                 float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ pot_terms) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // per residue: 4 atoms x 3 + centre 3 + (n_atom,id) as float bits
+    const int s = blockIdx.y;
+    float* atoms = lds;                       // [n_res][12]
+    float* ctr = lds + (size_t)n_res * 12;    // [n_res][3]
+    int* meta = (int*)(ctr + (size_t)n_res * 3);   // [n_res][2]
+    for (int nr = threadIdx.x; nr < n_res; nr += blockDim.x) {
+        const float* a = C_OUT(aff, s) + (size_t)residue[nr] * aff.stride;
+        float U[9]; quat_to_rot(U, a[3], a[4], a[5], a[6]);
+        const f3 t = ld3(a);
+        ctr[nr * 3] = t.x; ctr[nr * 3 + 1] = t.y; ctr[nr * 3 + 2] = t.z;
+        for (int na = 0; na < 4; ++na) {
+            const f3 r = apply_affine(U, t, ld3(ref_pos + (nr * 4 + na) * 3));
+            atoms[nr * 12 + na * 3] = r.x; atoms[nr * 12 + na * 3 + 1] = r.y; atoms[nr * 12 + na * 3 + 2] = r.z;
+        }
+        meta[nr * 2] = n_atom[nr]; meta[nr * 2 + 1] = id[nr];
+    }
+    __syncthreads();
+    const float cutoff2_atom = 3.f * 3.f + 0.1f * 3.f;
+    const float cut2 = dist_cutoff * dist_cutoff;
+    for (int nr1 = blockIdx.x * blockDim.x + threadIdx.x; nr1 < n_res; nr1 += gridDim.x * blockDim.x) {
+        const f3 t1 = ld3(ctr + nr1 * 3);
+        const int na1 = meta[nr1 * 2], id1 = meta[nr1 * 2 + 1];
+        f3 d1 = mk3(0.f, 0.f, 0.f), tq1 = mk3(0.f, 0.f, 0.f);
+        float pot = 0.f;
+        for (int nr2 = 0; nr2 < n_res; ++nr2) {
+            const int id2 = meta[nr2 * 2 + 1];
+            if (!((1 < id1 - id2) || (1 < id2 - id1))) continue;                 // backbone_steric.cpp:32-35
+            const f3 t2 = ld3(ctr + nr2 * 3);
+            if (!(dist2_exact(t1.x, t1.y, t1.z, t2.x, t2.y, t2.z) < cut2)) continue;
+            const int na2 = meta[nr2 * 2];
+            for (int i1 = 0; i1 < na1; ++i1) {
+                const f3 x1 = ld3(atoms + nr1 * 12 + i1 * 3);
+                for (int i2 = 0; i2 < na2; ++i2) {
+                    const f3 r = x1 - ld3(atoms + nr2 * 12 + i2 * 3);
+                    const float r2 = mag2(r);
+                    if (r2 > cutoff2_atom) continue;
+                    float v, dor; nonbonded_kernel(v, dor, r2);
+                    const f3 g = dor * r;
+                    d1 = d1 + g; tq1 = tq1 + cross(x1 - t1, g);
+                    if (nr1 < nr2) pot += v;                                     // each pair's energy once
+                }
+            }
+        }
+        float* o = aff_contrib + (size_t)s * aff_stride + (size_t)nr1 * 6;
+        o[0] = d1.x; o[1] = d1.y; o[2] = d1.z; o[3] = tq1.x; o[4] = tq1.y; o[5] = tq1.z;
+        if (pot_terms) pot_terms[(size_t)s * n_res + nr1] = pot;
+    }
+}
+extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
+                                  const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
+                                  float* pot_terms) {
+    const size_t lds = (size_t)n_res * (12 + 3 + 2) * sizeof(float);
+    if (lds > 150 * 1024) return 9001;   // > ~2200 residues: needs the tiled variant
+    const int blocks = (n_res + UPK_BLOCK - 1) / UPK_BLOCK;
+    hipLaunchKernelGGL(k_backbone_pairs, dim3(blocks, L->n_system), dim3(UPK_BLOCK), lds, ST(L), aff, residue, id, n_atom, ref_pos, n_res,
+                       dist_cutoff, aff_contrib, aff_stride, pot_terms);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// replica exchange Metropolis on the device (main.cpp:251-273); one lane per swap pair, pairs are disjoint.
+__global__ void k_replica_swap(upk_coord_t pos, const float* __restrict__ energy, const float* __restrict__ beta, int n_pair,
+                               const int* __restrict__ pairs, uint32_t seed, uint64_t round, int draw0, int* __restrict__ accepted) {
+    // uniforms are drawn sequentially from one generator, one 4-vector per REJECTABLE pair (main.cpp:268:
+    // `expf(lboltz_diff) < random.uniform_open_closed().x()` is only evaluated when lboltz_diff < 0)
+    __shared__ int draw_index[1024];
+    __shared__ int acc[1024];
+    if (threadIdx.x == 0) {
+        int draw = draw0;
+        for (int p = 0; p < n_pair; ++p) {
+            const int s1 = pairs[p * 2], s2 = pairs[p * 2 + 1];
+            // temperature exchange of one Hamiltonian: new_lboltz - old_lboltz = (beta1-beta2)(E1-E2)
+            const float lb = (-beta[s1] * energy[s2] + -beta[s2] * energy[s1]) - (-beta[s1] * energy[s1] + -beta[s2] * energy[s2]);
+            int ok = 1;
+            if (lb < 0.f) {
+                const uint32_t key[4] = {seed, 1u /* REPLICA_EXCHANGE_RANDOM_STREAM */, 0u, 0u};
+                uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, (uint32_t)draw};
+                threefry4x32_20(X, key);
+                ++draw;
+                if (expf(lb) < u01f(X[0])) ok = 0;
+            }
+            acc[p] = ok; accepted[p] = ok; draw_index[p] = draw;
+        }
+        accepted[n_pair] = draw;   // generator position for the next swap set of this round
+    }
+    __syncthreads();
+    const int n = pos.n_elem * pos.stride;
+    for (int p = 0; p < n_pair; ++p) {
+        if (!acc[p]) continue;
+        float* a = C_OUT(pos, pairs[p * 2]); float* b = C_OUT(pos, pairs[p * 2 + 1]);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const float t = a[i]; a[i] = b[i]; b[i] = t; }
+    }
+}
+extern "C" int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const float* energy, const float* beta, int n_pair,
+                                const int* pairs, uint32_t seed, uint64_t round, int draw0, int* accepted) {
+    if (n_pair > 1024) return 9002;
+    hipLaunchKernelGGL(k_replica_swap, dim3(1), dim3(UPK_BLOCK), 0, ST(L), pos, energy, beta, n_pair, pairs, seed, round, draw0, accepted);
+    return launch_status();
+}

@@ -1,0 +1,775 @@
+// DerivComputation nodes of the README force field, hosted on the device.  Each class mirrors the reference
+// node of the same registry prefix (cited per class); constructors read the same HDF5 datasets, methods only
+// enqueue the kernels of include/upside_hip_kernels.h.
+#include "engine.h"
+#include "h5util.h"
+#include "spline_fit.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+using namespace std;
+using namespace h5u;
+
+namespace {
+
+inline hid_t H(hid_t_compat g) { return (hid_t)g; }
+
+vector<int> iota_targets(int n) { vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = i; return v; }
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+float env_float(const char* name, float dflt) { const char* e = getenv(name); return e ? (float)atof(e) : dflt; }
+
+void require_injective(const vector<int>& loc, int n_target, const char* what) {
+    vector<char> seen(n_target, 0);
+    for (int x : loc) {
+        if (x < 0 || x >= n_target) throw string(what) + ": index out of range";
+        if (seen[x]) throw string(what) + ": repeated index (the device gather path needs distinct elements)";
+        seen[x] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bonded springs: bonds.cpp:252-320 (dist_spring), 430-489 (angle_spring), 492-547 (dihedral_spring)
+struct SpringNode : public PotentialNode {
+    int kind, n_elem;
+    CoordNode& pos;
+    DevBuf<int> id; DevBuf<float> equil, k;
+    int src = -1;
+    SpringNode(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_, int kind_) : PotentialNode(c), kind(kind_), pos(pos_) {
+        vector<hsize_t> dims;
+        auto ids = read<int>(H(grp), "id", 2, &dims);
+        n_elem = (int)dims[0];
+        if ((int)dims[1] != kind) throw string("wrong width for id");
+        check_size(H(grp), "equil_dist", {(size_t)n_elem});
+        check_size(H(grp), "spring_const", {(size_t)n_elem});
+        if (kind == 2) check_size(H(grp), "bonded_atoms", {(size_t)n_elem});
+        for (int x : ids) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
+        id.upload(ids);
+        equil.upload(read<float>(H(grp), "equil_dist", 1));
+        k.upload(read<float>(H(grp), "spring_const", 1));
+        src = pos.scatter.add_source(n_elem, kind, 3, ids);
+        alloc_terms(n_elem);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_spring(&ctx->L, kind, pos.coord(), id.p, equil.p, k.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size,
+                             mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "spring");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+struct DistSpring : SpringNode { DistSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 2) {} };
+struct AngleSpring : SpringNode { AngleSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 3) {} };
+struct DihedralSpring : SpringNode { DihedralSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 4) {} };
+RegisterNodeType<DistSpring, 1> dist_spring_node("dist_spring");
+RegisterNodeType<AngleSpring, 1> angle_spring_node("angle_spring");
+RegisterNodeType<DihedralSpring, 1> dihedral_spring_node("dihedral_spring");
+
+// cavity_radial: bonds.cpp:323-374 (used to compact synthetic chains)
+struct CavityRadial : public PotentialNode {
+    int n_term; CoordNode& pos;
+    DevBuf<int> id; DevBuf<float> radius, k; int src;
+    CavityRadial(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_) : PotentialNode(c), pos(pos_) {
+        auto ids = read<int>(H(grp), "id", 1);
+        n_term = (int)ids.size();
+        check_size(H(grp), "radius", {(size_t)n_term}); check_size(H(grp), "spring_constant", {(size_t)n_term});
+        id.upload(ids); radius.upload(read<float>(H(grp), "radius", 1)); k.upload(read<float>(H(grp), "spring_constant", 1));
+        src = pos.scatter.add_source(n_term, 1, 3, ids);
+        alloc_terms(n_term);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_cavity_radial(&ctx->L, pos.coord(), id.p, radius.p, k.p, n_term, pos.scatter.source_ptr(src), pos.scatter.arena_size,
+                                    mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "cavity_radial");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+RegisterNodeType<CavityRadial, 1> cavity_radial_node("cavity_radial");
+
+// ---------------------------------------------------------------------------------------------------
+// rama_coord: bonds.cpp:171-249
+struct RamaCoord : public CoordNode {
+    CoordNode& pos;
+    DevBuf<int> atom, dummy; DevBuf<float> jac; int src;
+    RamaCoord(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_) : CoordNode(c, (int)dset_size(2, H(grp), "id")[0], 2), pos(pos_) {
+        check_size(H(grp), "id", {(size_t)n_elem, 5});
+        auto a = read<int>(H(grp), "id", 2);
+        vector<int> dm(n_elem * 2);
+        for (int i = 0; i < n_elem; ++i) {
+            dm[i * 2] = a[i * 5] == -1; dm[i * 2 + 1] = a[i * 5 + 4] == -1;
+            if (dm[i * 2]) a[i * 5] = 0;
+            if (dm[i * 2 + 1]) a[i * 5 + 4] = 0;
+        }
+        for (int x : a) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
+        atom.upload(a); dummy.upload(dm);
+        jac.alloc((size_t)c->n_system * n_elem * 30);
+        src = pos.scatter.add_source(n_elem, 5, 3, a);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_rama_fwd(&ctx->L, pos.coord(), atom.p, dummy.p, n_elem, coord(), jac.p), "rama_fwd"); }
+    void propagate_deriv() override {
+        upk_check(upk_rama_bwd(&ctx->L, coord(), jac.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size), "rama_bwd"); }
+};
+RegisterNodeType<RamaCoord, 1> rama_coord_node("rama_coord");
+
+// affine_alignment: eig.cpp:277-473
+struct AffineAlignment : public CoordNode {
+    CoordNode& pos;
+    DevBuf<int> atoms; DevBuf<float> ref_geom, eig; int src;
+    AffineAlignment(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_) : CoordNode(c, (int)dset_size(2, H(grp), "atoms")[0], 7), pos(pos_) {
+        check_size(H(grp), "atoms", {(size_t)n_elem, 3});
+        check_size(H(grp), "ref_geom", {(size_t)n_elem, 3, 3});
+        auto a = read<int>(H(grp), "atoms", 2);
+        for (int x : a) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
+        atoms.upload(a); ref_geom.upload(read<float>(H(grp), "ref_geom", 3));
+        eig.alloc((size_t)c->n_system * n_elem * 20);
+        src = pos.scatter.add_source(n_elem, 3, 3, a);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_affine_fwd(&ctx->L, pos.coord(), atoms.p, ref_geom.p, n_elem, coord(), eig.p), "affine_fwd"); }
+    void propagate_deriv() override {
+        upk_check(upk_affine_bwd(&ctx->L, coord(), ref_geom.p, eig.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size), "affine_bwd"); }
+};
+RegisterNodeType<AffineAlignment, 1> affine_alignment_node("affine_alignment");
+
+// infer_H_O: hbond.cpp:14-121
+struct Infer_H_O : public CoordNode {
+    CoordNode& pos; int n_donor, n_acceptor, n_virtual;
+    DevBuf<int> atom; DevBuf<float> bond_length, dfd; int src;
+    Infer_H_O(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_)
+        : CoordNode(c, (int)(dset_size(2, H(grp), "donors/id")[0] + dset_size(2, H(grp), "acceptors/id")[0]), 6), pos(pos_) {
+        n_donor = (int)dset_size(2, H(grp), "donors/id")[0]; n_acceptor = (int)dset_size(2, H(grp), "acceptors/id")[0];
+        n_virtual = n_donor + n_acceptor;
+        check_size(H(grp), "donors/id", {(size_t)n_donor, 3}); check_size(H(grp), "acceptors/id", {(size_t)n_acceptor, 3});
+        check_size(H(grp), "donors/bond_length", {(size_t)n_donor}); check_size(H(grp), "acceptors/bond_length", {(size_t)n_acceptor});
+        auto a = read<int>(H(grp), "donors/id", 2); auto a2 = read<int>(H(grp), "acceptors/id", 2);
+        a.insert(a.end(), a2.begin(), a2.end());
+        auto b = read<float>(H(grp), "donors/bond_length", 1); auto b2 = read<float>(H(grp), "acceptors/bond_length", 1);
+        b.insert(b.end(), b2.begin(), b2.end());
+        for (int x : a) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
+        atom.upload(a); bond_length.upload(b);
+        dfd.alloc((size_t)c->n_system * n_virtual * 12);
+        src = pos.scatter.add_source(n_virtual, 3, 3, a);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_infer_fwd(&ctx->L, pos.coord(), atom.p, bond_length.p, n_virtual, coord(), dfd.p), "infer_fwd"); }
+    void propagate_deriv() override {
+        upk_check(upk_infer_bwd(&ctx->L, coord(), bond_length.p, dfd.p, n_virtual, pos.scatter.source_ptr(src), pos.scatter.arena_size), "infer_bwd"); }
+};
+RegisterNodeType<Infer_H_O, 1> infer_node("infer_H_O");
+
+// ---------------------------------------------------------------------------------------------------
+// placement: placement.cpp:233-325.  signature: 0 scalar, 1 vector, 2 point
+struct PlacementNode : public CoordNode {
+    CoordNode& alignment; CoordNode* rama;
+    upk_placement_t P;
+    DevBuf<int> affine_residue, layer, rama_residue; DevBuf<float> fixed_data, spline_coeff, rama_deriv;
+    vector<float> host_fixed; int n_layer = 0;
+    int src_aff = -1, src_rama = -1;
+    bool has_geometry;
+    static int sig_dim(const vector<int>& sig) { int d = 0; for (int s : sig) d += s == 0 ? 1 : 3; return d; }
+    PlacementNode(DeviceCtx* c, hid_t_compat grp, CoordNode& alignment_, CoordNode* rama_, vector<int> sig)
+        : CoordNode(c, (int)dset_size(1, H(grp), "layer_index")[0], sig_dim(sig)), alignment(alignment_), rama(rama_) {
+        memset(&P, 0, sizeof(P));
+        check_elem_width(alignment, 7);
+        P.n_elem = n_elem; P.n_pos_dim = elem_width; P.n_sig = (int)sig.size();
+        for (size_t i = 0; i < sig.size(); ++i) P.sig[i] = sig[i];
+        has_geometry = false; for (int s : sig) if (s != 0) has_geometry = true;
+        check_size(H(grp), "affine_residue", {(size_t)n_elem});
+        auto ar = read<int>(H(grp), "affine_residue", 1);
+        for (int x : ar) if (x < 0 || x >= alignment.n_elem) throw string("affine_residue out of range");
+        auto ly = read<int>(H(grp), "layer_index", 1);
+        affine_residue.upload(ar);
+        if (rama) {
+            check_elem_width(*rama, 2);
+            check_size(H(grp), "rama_residue", {(size_t)n_elem});
+            auto rr = read<int>(H(grp), "rama_residue", 1);
+            for (int x : rr) if (x < 0 || x >= rama->n_elem) throw string("rama_residue out of range");
+            rama_residue.upload(rr);
+            vector<hsize_t> dims;
+            auto raw = read<double>(H(grp), "placement_data", 4, &dims);
+            if ((int)dims[3] != elem_width) throw string("placement_data has the wrong width");
+            n_layer = (int)dims[0]; P.nx = (int)dims[1]; P.ny = (int)dims[2];
+            spline_coeff.upload(fit_layered_periodic_spline2d(raw, n_layer, P.nx, P.ny, elem_width));   // placement.cpp:50-55
+            rama_deriv.alloc((size_t)c->n_system * n_elem * 2 * elem_width);
+            P.is_rama = 1;
+            src_rama = rama->scatter.add_source(n_elem, 1, 2, rr);
+        } else {
+            vector<hsize_t> dims;
+            host_fixed = read<float>(H(grp), "placement_data", 2, &dims);
+            if ((int)dims[1] != elem_width) throw string("placement_data has the wrong width");
+            n_layer = (int)dims[0];
+            fixed_data.upload(host_fixed);
+        }
+        for (int x : ly) if (x < 0 || x >= n_layer) throw string("layer_index out of range");
+        layer.upload(ly);
+        if (has_geometry) src_aff = alignment.scatter.add_source(n_elem, 1, 6, ar);
+        P.affine_residue = affine_residue.p; P.layer = layer.p; P.rama_residue = rama_residue.p;
+        P.fixed_data = fixed_data.p; P.spline_coeff = spline_coeff.p;
+    }
+    void compute_value(ComputeMode) override {
+        upk_coord_t rc; memset(&rc, 0, sizeof(rc));
+        if (rama) rc = rama->coord();
+        upk_check(upk_placement_fwd(&ctx->L, &P, alignment.coord(), rc, coord(), rama_deriv.p), "placement_fwd");
+    }
+    void propagate_deriv() override {
+        // a pure scalar placement has no force/torque on the frame; its affine contribution slot is not registered
+        static DevBuf<float>* dummy = nullptr;
+        float* aff_ptr; long aff_stride;
+        if (has_geometry) { aff_ptr = alignment.scatter.source_ptr(src_aff); aff_stride = alignment.scatter.arena_size; }
+        else {
+            if (!scalar_sink.p) scalar_sink.alloc((size_t)ctx->n_system * n_elem * 6);
+            aff_ptr = scalar_sink.p; aff_stride = (long)n_elem * 6;
+        }
+        (void)dummy;
+        upk_check(upk_placement_bwd(&ctx->L, &P, alignment.coord(), coord(), rama_deriv.p, aff_ptr, aff_stride,
+                                    rama ? rama->scatter.source_ptr(src_rama) : nullptr, rama ? rama->scatter.arena_size : 0), "placement_bwd");
+    }
+    DevBuf<float> scalar_sink;
+    vector<float> get_param() const override { return host_fixed; }
+    void set_param(const vector<float>& p) override {
+        if (rama) return;
+        if (p.size() != host_fixed.size()) throw string("wrong param size");
+        host_fixed = p;
+        hip_check(hipMemcpy(fixed_data.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    }
+};
+struct PlScalar : PlacementNode { PlScalar(DeviceCtx* c, hid_t_compat g, CoordNode& a, CoordNode& r) : PlacementNode(c, g, a, &r, {0}) {} };
+struct PlFixedScalar : PlacementNode { PlFixedScalar(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {0}) {} };
+struct PlPointOnly : PlacementNode { PlPointOnly(DeviceCtx* c, hid_t_compat g, CoordNode& a, CoordNode& r) : PlacementNode(c, g, a, &r, {2}) {} };
+struct PlFixedPointOnly : PlacementNode { PlFixedPointOnly(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {2}) {} };
+struct PlPointVector : PlacementNode { PlPointVector(DeviceCtx* c, hid_t_compat g, CoordNode& a, CoordNode& r) : PlacementNode(c, g, a, &r, {2, 1}) {} };
+struct PlFixedPointVector : PlacementNode { PlFixedPointVector(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {2, 1}) {} };
+struct PlFixedPointVectorScalar : PlacementNode { PlFixedPointVectorScalar(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {2, 1, 0}) {} };
+// same seven registrations as placement.cpp:319-325
+RegisterNodeType<PlScalar, 2> pl1("placement_scalar");
+RegisterNodeType<PlFixedScalar, 1> pl2("placement_fixed_scalar");
+RegisterNodeType<PlPointOnly, 2> pl3("placement_point_only");
+RegisterNodeType<PlFixedPointOnly, 1> pl4("placement_fixed_point_only");
+RegisterNodeType<PlPointVector, 2> pl5("placement_point_vector_only");
+RegisterNodeType<PlFixedPointVector, 1> pl6("placement_fixed_point_vector_only");
+RegisterNodeType<PlFixedPointVectorScalar, 1> pl7("placement_fixed_point_vector_scalar");
+
+// ---------------------------------------------------------------------------------------------------
+// rama_map_pot: rama_map_pot.cpp:15-93
+struct RamaMapPot : public PotentialNode {
+    int n_residue; CoordNode& rama; int nx;
+    DevBuf<int> residue, map_id; DevBuf<float> coeff;
+    RamaMapPot(DeviceCtx* c, hid_t_compat grp, CoordNode& rama_) : PotentialNode(c), rama(rama_) {
+        check_elem_width(rama, 2);
+        auto res = read<int>(H(grp), "residue_id", 1);
+        n_residue = (int)res.size();
+        check_size(H(grp), "rama_map_id", {(size_t)n_residue});
+        auto mid = read<int>(H(grp), "rama_map_id", 1);
+        vector<hsize_t> dims;
+        auto raw = read<double>(H(grp), "rama_pot", 3, &dims);
+        if (dims[1] != dims[2]) throw string("must have same x and y grid spacing for Rama maps");
+        nx = (int)dims[1];
+        require_injective(res, rama.n_elem, "rama_map_pot residue_id");
+        for (int x : mid) if (x < 0 || x >= (int)dims[0]) throw string("rama_map_id out of range");
+        residue.upload(res); map_id.upload(mid);
+        coeff.upload(fit_layered_periodic_spline2d(raw, (int)dims[0], nx, nx, 1));
+        alloc_terms(n_residue);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_rama_map_pot(&ctx->L, rama.coord(), residue.p, map_id.p, n_residue, coeff.p, nx,
+                                   mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "rama_map_pot");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+RegisterNodeType<RamaMapPot, 1> rama_map_pot_node("rama_map_pot");
+
+// ---------------------------------------------------------------------------------------------------
+// backbone_pairs: backbone_steric.cpp:38-147
+struct BackbonePairs : public PotentialNode {
+    int n_residue; CoordNode& alignment;
+    DevBuf<int> id, n_atom; DevBuf<float> ref_pos; float dist_cutoff; int src;
+    BackbonePairs(DeviceCtx* c, hid_t_compat grp, CoordNode& alignment_) : PotentialNode(c), alignment(alignment_) {
+        check_elem_width(alignment, 7);
+        auto ids = read<int>(H(grp), "id", 1);
+        n_residue = (int)ids.size();
+        check_size(H(grp), "n_atom", {(size_t)n_residue}); check_size(H(grp), "ref_pos", {(size_t)n_residue, 4, 3});
+        auto na = read<int>(H(grp), "n_atom", 1); auto rp = read<float>(H(grp), "ref_pos", 3);
+        for (int x : ids) if (x < 0 || x >= alignment.n_elem) throw string("residue id out of range");
+        float max_dev = 0.f;
+        for (int nr = 0; nr < n_residue; ++nr) for (int a = 0; a < na[nr]; ++a) {
+            const float* p = &rp[(nr * 4 + a) * 3];
+            max_dev = max(max_dev, sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+        }
+        for (auto& x : rp) if (!(x == x)) x = 0.f;   // NaN padding of absent CB atoms is never read (n_atom) but keep it finite
+        dist_cutoff = 2 * max_dev + sqrtf(3.f * 3.f + 0.1f * 3.f);
+        id.upload(ids); n_atom.upload(na); ref_pos.upload(rp);
+        src = alignment.scatter.add_source(n_residue, 1, 6, ids);
+        alloc_terms(n_residue);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_backbone_pairs(&ctx->L, alignment.coord(), id.p, id.p, n_atom.p, ref_pos.p, n_residue, dist_cutoff,
+                                     alignment.scatter.source_ptr(src), alignment.scatter.arena_size,
+                                     mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "backbone_pairs");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+RegisterNodeType<BackbonePairs, 1> backbone_pairs_node("backbone_pairs");
+
+// ---------------------------------------------------------------------------------------------------
+// interaction graph host side: interaction_graph.h:261-398
+struct IGraphHost {
+    DeviceCtx* ctx;
+    upk_igraph_t G;
+    CoordNode *node1, *node2;
+    vector<int> loc1, loc2, type1, type2, id1, id2;
+    vector<float> param;
+    DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag;
+    DevBuf<float> d_param, cache_pos1, cache_pos2;
+
+    float type_cutoff(const float* p) const {
+        switch (G.itype) {
+            case UPK_IT_ROTAMER: case UPK_IT_HBOND_COVERAGE: return (float)((G.n_knot - 2 - 1e-6) / G.inv_dx);
+            case UPK_IT_ENVIRONMENT: return p[0] + 1.f / p[1];
+            default: return sqrtf(3.5f * 3.5f);
+        }
+    }
+    void update_cutoffs() {   // interaction_graph.h:383-398
+        float cutoff = 0.f;
+        for (int t1 = 0; t1 < G.n_type1; ++t1) for (int t2 = 0; t2 < G.n_type2; ++t2)
+            cutoff = max(cutoff, type_cutoff(&param[(size_t)(t1 * G.n_type2 + t2) * G.n_param]));
+        if (G.itype == UPK_IT_ROTAMER)   // is_compatible, bead_interaction.h:209-218
+            for (int t1 = 0; t1 < G.n_type1; ++t1) for (int t2 = 0; t2 < G.n_type2; ++t2) {
+                const float* p1 = &param[(size_t)(t1 * G.n_type2 + t2) * G.n_param];
+                const float* p2 = &param[(size_t)(t2 * G.n_type2 + t1) * G.n_param];
+                for (int k = 0; k < G.n_knot_angular; ++k)
+                    if (p1[k] != p2[k + G.n_knot_angular] || p1[k + G.n_knot_angular] != p2[k]) throw string("bad angular match");
+                for (int k = 0; k < 2 * G.n_knot; ++k)
+                    if (p1[2 * G.n_knot_angular + k] != p2[2 * G.n_knot_angular + k]) throw string("incompatible parameters");
+            }
+        G.cutoff = cutoff;
+        G.cache_cutoff = cutoff + (1.0f + 0.2f * cutoff);
+    }
+
+    IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
+        memset(&G, 0, sizeof(G));
+        G.itype = itype; G.symmetric = itype == UPK_IT_ROTAMER;
+        if (!(G.symmetric ^ bool(n2))) throw string("second node must be null iff symmetric interaction");
+        switch (itype) {
+            case UPK_IT_ROTAMER: G.dim1 = 6; G.dim2 = 6; break;
+            case UPK_IT_HBOND_COVERAGE: G.dim1 = 7; G.dim2 = 6; break;
+            case UPK_IT_ENVIRONMENT: G.dim1 = 6; G.dim2 = 4; break;
+            default: G.dim1 = 6; G.dim2 = 6; break;
+        }
+        check_elem_width_lower_bound(*node1, G.dim1);
+        check_elem_width_lower_bound(*node2, G.dim2);
+        vector<hsize_t> dims;
+        param = read<float>(grp, "interaction_param", 3, &dims);
+        G.n_type1 = (int)dims[0]; G.n_type2 = (int)dims[1]; G.n_param = (int)dims[2];
+        // the reference fixes the knot counts at compile time (bead_interaction.h:12-27); here they follow from
+        // the shape of interaction_param: n_param = 2*n_knot_angular + 2*n_knot
+        if (itype == UPK_IT_ROTAMER) {
+            if (G.n_param == 34) { G.n_knot_angular = 8; G.n_knot = 9; G.inv_dx = 1.f; }
+            else if (G.n_param == 40) { G.n_knot_angular = 8; G.n_knot = 12; G.inv_dx = 1.f; }
+            else if (G.n_param == 62) { G.n_knot_angular = 15; G.n_knot = 16; G.inv_dx = 2.f; }
+            else throw string("unsupported interaction_param width ") + to_string(G.n_param) + " for the rotamer pair interaction";
+        } else if (itype == UPK_IT_HBOND_COVERAGE) {
+            if (G.n_param == 30) { G.n_knot_angular = 8; G.n_knot = 7; G.inv_dx = 1.f; }
+            else if (G.n_param == 40) { G.n_knot_angular = 8; G.n_knot = 12; G.inv_dx = 1.f; }
+            else if (G.n_param == 54) { G.n_knot_angular = 15; G.n_knot = 12; G.inv_dx = 2.f; }
+            else throw string("unsupported interaction_param width ") + to_string(G.n_param) + " for hbond_coverage";
+        } else if (itype == UPK_IT_ENVIRONMENT) { if (G.n_param != 4) throw string("environment_coverage expects 4 parameters");
+        } else if (G.n_param != 8) throw string("protein_hbond expects 8 parameters");
+        G.inv_dtheta = (G.n_knot_angular - 3) / 2.f;
+        update_cutoffs();
+
+        const string s1 = G.symmetric ? "" : "1";
+        loc1 = read<int>(grp, "index" + s1, 1); G.n1 = (int)loc1.size();
+        check_size(grp, "type" + s1, {(size_t)G.n1}); check_size(grp, "id" + s1, {(size_t)G.n1});
+        type1 = read<int>(grp, "type" + s1, 1); id1 = read<int>(grp, "id" + s1, 1);
+        if (!G.symmetric) {
+            loc2 = read<int>(grp, "index2", 1); G.n2 = (int)loc2.size();
+            check_size(grp, "type2", {(size_t)G.n2}); check_size(grp, "id2", {(size_t)G.n2});
+            type2 = read<int>(grp, "type2", 1); id2 = read<int>(grp, "id2", 1);
+        } else { loc2 = loc1; type2 = type1; id2 = id1; G.n2 = G.n1; }
+        for (int t : type1) if (t < 0 || t >= G.n_type1) throw string("type1 out of range");
+        for (int t : type2) if (t < 0 || t >= G.n_type2) throw string("type2 out of range");
+        require_injective(loc1, node1->n_elem, "interaction graph index1");
+        require_injective(loc2, node2->n_elem, "interaction graph index2");
+
+        const int cap_max = env_int("UPSIDE_HIP_NBR_CAP", 512);
+        G.cap1 = min(round_up(G.n2, 4), cap_max);
+        G.cap2 = min(round_up(G.n1, 4), cap_max);
+        const int S = c->n_system;
+        d_loc1.upload(loc1); d_type1.upload(type1); d_id1.upload(id1);
+        d_param.upload(param);
+        nbr1.alloc((size_t)S * G.n1 * G.cap1); cnt1.alloc((size_t)S * G.n1);
+        cache_pos1.upload(vector<float>((size_t)S * G.n1 * 4, 1e10f));   // forces the first rebuild (interaction_graph.h:194-198)
+        if (!G.symmetric) {
+            d_loc2.upload(loc2); d_type2.upload(type2); d_id2.upload(id2);
+            nbr2.alloc((size_t)S * G.n2 * G.cap2); cnt2.alloc((size_t)S * G.n2);
+            cache_pos2.upload(vector<float>((size_t)S * G.n2 * 4, 1e10f));
+        }
+        rebuild_flag.alloc(S);
+        G.loc1 = d_loc1.p; G.type1 = d_type1.p; G.id1 = d_id1.p;
+        G.loc2 = G.symmetric ? d_loc1.p : d_loc2.p; G.type2 = G.symmetric ? d_type1.p : d_type2.p; G.id2 = G.symmetric ? d_id1.p : d_id2.p;
+        G.param = d_param.p;
+        G.nbr1 = nbr1.p; G.cnt1 = cnt1.p; G.nbr2 = nbr2.p; G.cnt2 = cnt2.p;
+        G.cache_pos1 = cache_pos1.p; G.cache_pos2 = G.symmetric ? cache_pos1.p : cache_pos2.p;
+        G.rebuild_flag = rebuild_flag.p; G.error_flag = c->error_flag.p;
+        G.node1 = node1->coord(); G.node2 = node2->coord();
+    }
+    void update_lists() {   // K1 + K2
+        upk_check(upk_pairlist_check(&ctx->L, &G), "pairlist_check");
+        upk_check(upk_pairlist_build(&ctx->L, &G), "pairlist_build");
+    }
+    void set_param(const vector<float>& p) {
+        if (p.size() != param.size()) throw string("Bad param size, got ") + to_string(p.size()) + " params, but expected " + to_string(param.size());
+        param = p; update_cutoffs();
+        hip_check(hipMemcpy(d_param.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+        cache_pos1.upload(vector<float>(cache_pos1.n, 1e10f)); G.cache_pos1 = cache_pos1.p;
+        if (G.symmetric) G.cache_pos2 = cache_pos1.p;
+    }
+    // algorithmic bytes of one forward+backward use of this graph:
+    // 8*(n1*d1 + n2*d2) + 16*E + 4*n_type1*n_type2*n_param, E taken as the in-range pair count
+    double algorithmic_bytes(double n_edge) const {
+        return 8. * (G.n1 * (double)G.dim1 + (G.symmetric ? 0. : G.n2 * (double)G.dim2)) + 16. * n_edge + 4. * G.n_type1 * G.n_type2 * G.n_param;
+    }
+    // canonical in-range pair list of one system (parity/diagnostics)
+    vector<pair<int, int>> pairlist(int sys) {
+        DevBuf<unsigned char> flags((size_t)ctx->n_system * G.n1 * G.cap1);
+        upk_check(upk_igraph_inrange(&ctx->L, &G, flags.p), "igraph_inrange");
+        hip_check(hipStreamSynchronize(ctx->stream), "sync");
+        auto f = flags.download(); auto nb = nbr1.download(); auto ct = cnt1.download();
+        vector<pair<int, int>> out;
+        for (int i = 0; i < G.n1; ++i)
+            for (int k = 0; k < ct[(size_t)sys * G.n1 + i]; ++k) {
+                size_t idx = ((size_t)sys * G.n1 + i) * G.cap1 + k;
+                int j = nb[idx];
+                if (!f[idx]) continue;
+                if (G.symmetric && j <= i) continue;
+                out.emplace_back(i, j);
+            }
+        sort(out.begin(), out.end(), [](const pair<int, int>& a, const pair<int, int>& b) {   // (i1>>2, i2, i1&3)
+            if ((a.first >> 2) != (b.first >> 2)) return (a.first >> 2) < (b.first >> 2);
+            if (a.second != b.second) return a.second < b.second;
+            return (a.first & 3) < (b.first & 3); });
+        return out;
+    }
+    vector<float> count_edges_by_type(int sys) {   // interaction_graph.h:427-441
+        vector<float> r((size_t)G.n_type1 * G.n_type2, 0.f);
+        for (auto& e : pairlist(sys)) r[(size_t)type1[e.first] * G.n_type2 + type2[e.second]] += 1.f;
+        return r;
+    }
+};
+
+// protein_hbond: hbond.cpp:290-368
+struct ProteinHBond : public CoordNode {
+    CoordNode& infer; IGraphHost ig; int n_donor, n_acceptor; DevBuf<float> sens_scaled;
+    ProteinHBond(DeviceCtx* c, hid_t_compat grp, CoordNode& infer_)
+        : CoordNode(c, (int)(dset_size(1, H(grp), "index1")[0] + dset_size(1, H(grp), "index2")[0]), 7), infer(infer_),
+          ig(c, H(grp), UPK_IT_PROTEIN_HBOND, &infer_, &infer_), n_donor(ig.G.n1), n_acceptor(ig.G.n2) {
+        // this node mirrors infer_H_O element for element (hbond.cpp:320-323 copies row nv to row nv)
+        if (n_donor + n_acceptor != infer.n_elem) throw string("protein_hbond expects one row per infer_H_O site");
+        sens_scaled.alloc((size_t)c->n_system * n_elem);
+    }
+    void compute_value(ComputeMode) override {
+        ig.update_lists();
+        ctx->begin("igraph");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0), "protein_hbond rowsum donors");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor), "protein_hbond rowsum acceptors");
+        ctx->end("igraph", 0.);
+        upk_check(upk_protein_hbond_finish(&ctx->L, infer.coord(), coord()), "protein_hbond_finish");
+    }
+    void propagate_deriv() override {
+        upk_check(upk_protein_hbond_bwd_pre(&ctx->L, coord(), sens_scaled.p), "protein_hbond_bwd_pre");
+        ctx->begin("igraph");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad donors");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad acceptors");
+        ctx->end("igraph", 0.);
+        upk_check(upk_protein_hbond_passthrough(&ctx->L, coord(), infer.coord(), ig.G.loc1, n_donor, ig.G.loc2, n_acceptor), "protein_hbond_passthrough");
+    }
+    vector<float> get_param() const override { return ig.param; }
+    void set_param(const vector<float>& p) override { ig.set_param(p); }
+};
+RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
+
+// hbond_coverage: hbond.cpp:371-414
+struct HBondCoverage : public CoordNode {
+    IGraphHost ig;
+    HBondCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& infer_, CoordNode& sidechains_)
+        : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {}
+    void compute_value(ComputeMode) override {
+        ig.update_lists();
+        ctx->begin("igraph");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0), "hbond_coverage rowsum");
+        ctx->end("igraph", 0.);
+    }
+    void propagate_deriv() override {
+        ctx->begin("igraph");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad beads");
+        ctx->end("igraph", 0.);
+    }
+    vector<float> get_param() const override { return ig.param; }
+    void set_param(const vector<float>& p) override { ig.set_param(p); }
+    vector<float> get_value_by_name(const char* log_name) override {
+        if (!strcmp(log_name, "count_edges_by_type")) return ig.count_edges_by_type(0);
+        throw string("Value ") + log_name + string(" not implemented");
+    }
+};
+RegisterNodeType<HBondCoverage, 2> coverage_node("hbond_coverage");
+
+// environment_coverage: environment.cpp:71-109
+struct EnvironmentCoverage : public CoordNode {
+    IGraphHost ig;
+    EnvironmentCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& cb_pos_, CoordNode& weighted_sidechains_)
+        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {}
+    void compute_value(ComputeMode) override {
+        ig.update_lists();
+        ctx->begin("igraph");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0), "environment_coverage rowsum");
+        ctx->end("igraph", 0.);
+    }
+    void propagate_deriv() override {
+        ctx->begin("igraph");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad cb");
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc");
+        ctx->end("igraph", 0.);
+    }
+    vector<float> get_param() const override { return ig.param; }
+    void set_param(const vector<float>& p) override { ig.set_param(p); }
+};
+RegisterNodeType<EnvironmentCoverage, 2> environment_coverage_node("environment_coverage");
+
+// hbond_energy: hbond.cpp:417-456
+struct HBondEnergy : public HBondCounter {
+    CoordNode& protein_hbond; float E_protein;
+    HBondEnergy(DeviceCtx* c, hid_t_compat grp, CoordNode& ph) : HBondCounter(c), protein_hbond(ph), E_protein(attr<float>(H(grp), ".", "protein_hbond_energy")) {
+        check_elem_width(ph, 7);
+        alloc_terms(ph.n_elem);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_hbond_energy(&ctx->L, protein_hbond.coord(), E_protein, mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "hbond_energy");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+    vector<float> get_param() const override { return vector<float>(1, E_protein); }
+    void set_param(const vector<float>& p) override {
+        if (p.size() != 1u) throw string("expected 1 param to hbond_energy but got " + to_string(p.size()));
+        E_protein = p[0];
+    }
+};
+RegisterNodeType<HBondEnergy, 1> hbond_energy_node("hbond_energy");
+
+// weighted_pos: environment.cpp:112-156
+struct WeightedPos : public CoordNode {
+    CoordNode &pos, &energy; DevBuf<int> index_pos, index_weight;
+    WeightedPos(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_, CoordNode& energy_)
+        : CoordNode(c, (int)dset_size(1, H(grp), "index_pos")[0], 4), pos(pos_), energy(energy_) {
+        check_elem_width_lower_bound(pos, 3);
+        auto ip = read<int>(H(grp), "index_pos", 1); auto iw = read<int>(H(grp), "index_weight", 1);
+        if ((int)iw.size() != n_elem) throw string("index_weight has the wrong size");
+        require_injective(ip, pos.n_elem, "weighted_pos index_pos");
+        require_injective(iw, energy.n_elem, "weighted_pos index_weight");
+        index_pos.upload(ip); index_weight.upload(iw);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_weighted_pos_fwd(&ctx->L, pos.coord(), energy.coord(), index_pos.p, index_weight.p, coord()), "weighted_pos_fwd"); }
+    void propagate_deriv() override { upk_check(upk_weighted_pos_bwd(&ctx->L, pos.coord(), energy.coord(), index_pos.p, index_weight.p, coord()), "weighted_pos_bwd"); }
+};
+RegisterNodeType<WeightedPos, 2> weighted_pos_node("weighted_pos");
+
+// nonlinear_coupling: environment.cpp:324-397
+struct NonlinearCoupling : public PotentialNode {
+    CoordNode& input; int n_restype, n_coeff; float spline_offset, spline_inv_dx;
+    vector<float> coeff; DevBuf<float> d_coeff; DevBuf<int> types;
+    NonlinearCoupling(DeviceCtx* c, hid_t_compat grp, CoordNode& input_) : PotentialNode(c), input(input_) {
+        check_elem_width(input, 1);
+        vector<hsize_t> dims;
+        coeff = read<float>(H(grp), "coeff", 2, &dims);
+        n_restype = (int)dims[0]; n_coeff = (int)dims[1];
+        spline_offset = attr<float>(H(grp), "coeff", "spline_offset"); spline_inv_dx = attr<float>(H(grp), "coeff", "spline_inv_dx");
+        check_size(H(grp), "coupling_types", {(size_t)input.n_elem});
+        auto t = read<int>(H(grp), "coupling_types", 1);
+        for (int i : t) if (i < 0 || i >= n_restype) throw string("invalid coupling type");
+        d_coeff.upload(coeff); types.upload(t);
+        alloc_terms(input.n_elem);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_nonlinear_coupling(&ctx->L, input.coord(), types.p, d_coeff.p, n_coeff, spline_offset, spline_inv_dx,
+                                         mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "nonlinear_coupling");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+    vector<float> get_param() const override { return coeff; }
+    void set_param(const vector<float>& p) override {
+        if (p.size() != coeff.size()) throw string("attempting to change size of coeff vector on set_param");
+        coeff = p; hip_check(hipMemcpy(d_coeff.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    }
+};
+RegisterNodeType<NonlinearCoupling, 1> nonlinear_coupling_node("nonlinear_coupling");
+
+// ---------------------------------------------------------------------------------------------------
+// rotamer: rotamer.cpp:581-1082
+struct RotamerSidechain : public PotentialNode {
+    vector<CoordNode*> prob_nodes;
+    IGraphHost ig;
+    upk_rotamer_t R;
+    int n_node, n1, n3, n6;
+    vector<int> node_nrot, bead_node, bead_rot;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters;
+    DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
+    DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
+    long n_bad_solve = 0;
+
+    RotamerSidechain(DeviceCtx* c, hid_t_compat grp, const ArgList& args)
+        : PotentialNode(c), prob_nodes(args.begin() + 1, args.end()),
+          ig(c, h5u::open_group(H(grp), "pair_interaction"), UPK_IT_ROTAMER, args[0], nullptr) {
+        memset(&R, 0, sizeof(R));
+        for (size_t i = 0; i < prob_nodes.size(); ++i)
+            if (ig.node1->n_elem != prob_nodes[i]->n_elem)
+                throw string("rotamer positions have " + to_string(ig.node1->n_elem) + " elements but the " + to_string(i) +
+                             "-th (0-indexed) probability node has only " + to_string(prob_nodes[i]->n_elem) + " elements.");
+        R.damping = attr<float>(H(grp), ".", "damping"); R.max_iter = attr<int>(H(grp), ".", "max_iter");
+        R.tol = attr<float>(H(grp), ".", "tol"); R.chunk = attr<int>(H(grp), ".", "iteration_chunk_size");
+        if (R.chunk < 1) throw string("iteration_chunk_size must be positive");
+        // calculate_n_elem (rotamer.cpp:559-578) + the id bit-field (rotamer.cpp:812-816)
+        const unsigned selector = 15u;
+        int n_elem_rot[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int id_ : ig.id1) {
+            unsigned id = (unsigned)id_; unsigned rot = id & selector; id >>= 4; unsigned n_rot = id & selector; id >>= 4;
+            if (rot >= n_rot) throw string("invalid rotamer number");
+            if (n_rot != 1 && n_rot != 3 && n_rot != 6) throw string("invalid rotamer count ") + to_string(n_rot);
+            n_elem_rot[n_rot] = max(n_elem_rot[n_rot], (int)id + 1);
+        }
+        n1 = n_elem_rot[1]; n3 = n_elem_rot[3]; n6 = n_elem_rot[6]; n_node = n1 + n3 + n6;
+        const int start[7] = {0, 0, 0, n1, 0, 0, n1 + n3};
+        node_nrot.assign(n_node, 0);
+        for (int g = 0; g < n_node; ++g) node_nrot[g] = g < n1 ? 1 : (g < n1 + n3 ? 3 : 6);
+        int n_bead = ig.G.n1;
+        bead_node.resize(n_bead); bead_rot.resize(n_bead);
+        vector<vector<int>> beads_of(n_node * 6);
+        for (int i = 0; i < n_bead; ++i) {
+            unsigned id = (unsigned)ig.id1[i]; unsigned rot = id & selector; id >>= 4; unsigned n_rot = id & selector; id >>= 4;
+            bead_node[i] = start[n_rot] + (int)id; bead_rot[i] = (int)rot;
+            beads_of[bead_node[i] * 6 + rot].push_back(i);
+        }
+        vector<int> nb_start(n_node * 6 + 1, 0), nb_list;
+        for (int k = 0; k < n_node * 6; ++k) { nb_start[k] = (int)nb_list.size(); nb_list.insert(nb_list.end(), beads_of[k].begin(), beads_of[k].end()); }
+        nb_start[n_node * 6] = (int)nb_list.size();
+        const int S = c->n_system;
+        d_node_nrot.upload(node_nrot); d_bead_node.upload(bead_node); d_bead_rot.upload(bead_rot); d_nb_start.upload(nb_start); d_nb_list.upload(nb_list);
+        const float slot_factor = env_float("UPSIDE_HIP_SLOT_FACTOR", 96.f);
+        long full = (long)n_node * (n_node - 1) / 2;
+        R.slot_cap = (int)max(1L, min(full, (long)(n_node * slot_factor)));
+        R.adj_cap = min(max(n_node, 1), env_int("UPSIDE_HIP_ADJ_CAP", 256));
+        n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
+        slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
+        iters.alloc(S); energy.alloc(S);
+        node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6); nb_old.alloc((size_t)S * n_node * 6);
+        P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
+        msg_cur.alloc((size_t)S * R.slot_cap * 12); msg_old.alloc((size_t)S * R.slot_cap * 12);
+    }
+    void finalize() override {
+        vector<const float*> po; vector<float*> ps; vector<int> st; vector<long> ss;
+        for (auto* p : prob_nodes) { po.push_back(p->output.p); ps.push_back(p->sens.p); st.push_back(p->stride); ss.push_back(p->sys_stride()); }
+        if (po.empty()) { po.push_back(nullptr); ps.push_back(nullptr); st.push_back(0); ss.push_back(0); }
+        d_prob_out.upload(po); d_prob_sens.upload(ps); d_prob_stride.upload(st); d_prob_sys_stride.upload(ss);
+        fill_struct();
+    }
+    void fill_struct() {
+        R.G = ig.G;
+        R.n_node = n_node; R.n_node1 = n1; R.n_node3 = n3;
+        R.node_nrot = d_node_nrot.p; R.bead_node = d_bead_node.p; R.bead_rot = d_bead_rot.p;
+        R.node_bead_start = d_nb_start.p; R.node_bead_list = d_nb_list.p;
+        R.n_prob = (int)prob_nodes.size(); R.prob_out = d_prob_out.p; R.prob_sens = d_prob_sens.p; R.prob_stride = d_prob_stride.p;
+        R.prob_sys_stride = d_prob_sys_stride.p;
+        R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p; R.nb_old = nb_old.p;
+        R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p;
+        R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p;
+        R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
+        R.iters = iters.p; R.energy = energy.p;
+    }
+    void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
+        R.G = ig.G;
+        ig.update_lists();
+        upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
+        upk_check(upk_rotamer_node_prob(&ctx->L, &R), "rotamer_node_prob");
+        ctx->begin("igraph");
+        upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
+        ctx->end("igraph", 0.);
+        ctx->begin("bp");
+        upk_check(upk_rotamer_bp(&ctx->L, &R, mode == PotentialAndDerivMode), "rotamer_bp");
+        ctx->end("bp", 0.);
+        ctx->begin("igraph");
+        upk_check(upk_rotamer_grad(&ctx->L, &R), "rotamer_grad");
+        ctx->end("igraph", 0.);
+        if (mode == PotentialAndDerivMode)
+            hip_check(hipMemcpyAsync(potential_dev.p, energy.p, ctx->n_system * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream), "D2D");
+    }
+    vector<float> get_param() const override { return ig.param; }
+    void set_param(const vector<float>& p) override { ig.set_param(p); R.G = ig.G; }
+
+    vector<float> get_value_by_name(const char* log_name) override {   // rotamer.cpp:675-773 (system 0)
+        hip_check(hipStreamSynchronize(ctx->stream), "sync");
+        if (!strcmp(log_name, "n_node")) return vector<float>(1, (float)n_node);
+        if (!strcmp(log_name, "count_edges_by_type")) return ig.count_edges_by_type(0);
+        if (!strcmp(log_name, "node_energy")) {
+            // before folding of 1-state partners this is exactly -log(prob); the reference reports the folded prob,
+            // which is what the BP kernel keeps in LDS only.  Report the unfolded 1-body part plus folded partners.
+            throw string("Value node_energy not implemented on the device engine");
+        }
+        if (!strcmp(log_name, "edge_marginal_in_graph_order")) {
+            auto nb = nb_cur.download(); auto mg = marg.download(); auto sa = slot_a.download(); auto sb = slot_b.download();
+            auto act = slot_active.download(); int ns = n_slot.download()[0];
+            vector<float> ev((size_t)n_node * n_node * 36, 0.f);
+            for (int i1 = 0; i1 < n_node; ++i1) for (int i2 = 0; i2 < n_node; ++i2) for (int r1 = 0; r1 < 6; ++r1) for (int r2 = 0; r2 < 6; ++r2)
+                ev[(((size_t)i1 * n_node + i2) * 6 + r1) * 6 + r2] = (i1 == i2) ? nb[i1 * 6 + r1] * (r1 == r2) : nb[i1 * 6 + r1] * nb[i2 * 6 + r2];
+            for (int sl = 0; sl < ns; ++sl) {
+                if (!act[sl]) continue;
+                int a = sa[sl], b = sb[sl];
+                if (node_nrot[a] == 1 && node_nrot[b] != 1) continue;   // 1-3 / 1-6 edges are not listed (rotamer.cpp:745)
+                for (int r1 = 0; r1 < node_nrot[a]; ++r1) for (int r2 = 0; r2 < node_nrot[b]; ++r2) {
+                    float v = node_nrot[b] == 1 ? 1.f : mg[(size_t)sl * 36 + r1 * 6 + r2];
+                    ev[(((size_t)a * n_node + b) * 6 + r1) * 6 + r2] = v;
+                    ev[(((size_t)b * n_node + a) * 6 + r2) * 6 + r1] = v;
+                }
+            }
+            return ev;
+        }
+        if (!strcmp(log_name, "read n_bad_solve")) return vector<float>(1, float(n_bad_solve));
+        throw string("Value ") + log_name + string(" not implemented");
+    }
+};
+struct RegisterRotamer {
+    RegisterRotamer(string name_prefix) {
+        add_node_creation_function(name_prefix, [name_prefix](DeviceCtx* c, hid_t_compat grp, const ArgList& args) -> DerivComputation* {
+            if (args.size() < 1u) throw string("node " + name_prefix + " needs at least 1 arg");
+            return new RotamerSidechain(c, grp, args); });
+    }
+};
+RegisterRotamer rotamer_node("rotamer");
+
+}  // namespace
+
+// accessors used by the C-ABI layer (engine_c_api.cpp)
+int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pair<int, int>>& out) {
+    auto* c = e.get(node_name).computation.get();
+    IGraphHost* ig = nullptr;
+    if (auto* r = dynamic_cast<RotamerSidechain*>(c)) ig = &r->ig;
+    else if (auto* h = dynamic_cast<HBondCoverage*>(c)) ig = &h->ig;
+    else if (auto* en = dynamic_cast<EnvironmentCoverage*>(c)) ig = &en->ig;
+    else if (auto* p = dynamic_cast<ProteinHBond*>(c)) ig = &p->ig;
+    if (!ig) return -1;
+    out = ig->pairlist(sys);
+    return (int)out.size();
+}
+int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters) {
+    for (auto& n : e.nodes)
+        if (auto* r = dynamic_cast<RotamerSidechain*>(n.computation.get())) { e.sync(); iters = r->iters.download(); return 0; }
+    return -1;
+}
+double engine_igraph_bytes(DerivEngine& e) {
+    // algorithmic bytes of all interaction graphs for one force pass of ONE system
+    double b = 0.;
+    for (auto& n : e.nodes) {
+        auto* c = n.computation.get();
+        IGraphHost* ig = nullptr;
+        if (auto* r = dynamic_cast<RotamerSidechain*>(c)) ig = &r->ig;
+        else if (auto* h = dynamic_cast<HBondCoverage*>(c)) ig = &h->ig;
+        else if (auto* en = dynamic_cast<EnvironmentCoverage*>(c)) ig = &en->ig;
+        else if (auto* p = dynamic_cast<ProteinHBond*>(c)) ig = &p->ig;
+        if (ig) b += ig->algorithmic_bytes((double)ig->pairlist(0).size());
+    }
+    return b;
+}
