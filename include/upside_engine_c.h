@@ -50,6 +50,9 @@ int upside_main(int argc, const char* const* argv, int verbose);                
 
 /* ---- Part 2: batched device-resident extension ---------------------------------------------- */
 
+/* select the HIP device used by engines constructed afterwards on this thread (one process per GPU) */
+int upside_hip_set_device(int device);
+
 /* Same as construct_deriv_engine but with n_system independent copies (replicas / ensemble members) of
  * the topology, all resident on the current HIP device.  construct_deriv_engine == n_system 1. */
 DerivEngine* upside_hip_construct(int n_atom, const char* potential_file, int n_system, bool quiet);
@@ -94,11 +97,13 @@ int upside_hip_rotamer_iterations(DerivEngine* engine, int* iters);
 /* last error text of this thread ("" if none) */
 const char* upside_hip_last_error(void);
 
-/* Per-kernel timing hooks used by bench.py: HIP-event time (ms) accumulated on the engine's stream for
- * the kernel family `which` ("igraph", "bp", "all") since the last reset, and its launch count. */
+/* Per-kernel timing hooks used by bench.py.  With profiling enabled every interaction-graph / BP kernel
+ * launch is bracketed by HIP events on the engine's stream.  upside_hip_profile_dump writes one text line per
+ * kernel: "<kind>:<node> <total ms> <launches> <total algorithmic bytes>" (bytes as defined in DESIGN.md). */
 int upside_hip_profile_reset(DerivEngine* engine, int enable);
-int upside_hip_profile_get(DerivEngine* engine, const char* which, double* ms, long* launches,
-                           double* algorithmic_bytes);
+int upside_hip_profile_dump(DerivEngine* engine, char* buf, int buflen);
+/* algorithmic bytes of all interaction graphs for one force evaluation of one system */
+double upside_hip_igraph_bytes_per_system(DerivEngine* engine);
 
 #ifdef __cplusplus
 }

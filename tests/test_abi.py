@@ -1,0 +1,71 @@
+"""CPU tests: the C-ABI shared library loads and exports every symbol include/*.h declares; without a GPU the
+product fails loudly (no CPU fallback)."""
+import ctypes as ct
+import os
+import re
+import pytest
+import parity_util as P
+
+INCLUDE = os.path.join(P.ROOT, 'include')
+
+
+def declared_functions(header):
+    txt = open(os.path.join(INCLUDE, header)).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = re.findall(r'\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;', txt)
+    return sorted(set(n for n in names if n not in ('defined',)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(P.pkg.PRODUCT_LIB):
+        pytest.skip('libupside_hip.so not built (run __graft_entry__.build())')
+    return ct.CDLL(P.pkg.PRODUCT_LIB)
+
+
+@pytest.mark.parametrize('header', ['upside_engine_c.h', 'upside_hip_kernels.h'])
+def test_every_declared_symbol_is_exported(lib, header):
+    names = declared_functions(header)
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, 'declared in %s but not exported: %s' % (header, missing)
+
+
+def test_reference_abi_names_present(lib):
+    # /root/reference/src/engine_c_library.h:12-32 + main.h
+    for n in ['construct_deriv_engine', 'free_deriv_engine', 'evaluate_energy', 'evaluate_deriv', 'set_param',
+              'get_param_deriv', 'get_param', 'get_output_dims', 'get_output', 'get_sens', 'get_value_by_name',
+              'clamped_spline_solve', 'clamped_spline_value', 'get_clamped_value_and_deriv',
+              'get_clamped_coeff_deriv', 'upside_main']:
+        assert hasattr(lib, n), n
+
+
+def test_engine_free_spline_helpers_match_oracle(lib):
+    import numpy as np
+    if not os.path.exists(P.ORACLE_LIB):
+        pytest.skip('oracle not built')
+    prod = P.pkg.UpsideLibrary(P.pkg.PRODUCT_LIB)
+    orc = P.oracle_library()
+    rs = np.random.RandomState(3)
+    vals = rs.normal(size=14).astype('f4')
+    c1, c2 = prod.clamped_spline_solve(vals), orc.clamped_spline_solve(vals)
+    assert np.array_equal(c1, c2)
+    x = np.linspace(-0.5, 15.5, 101).astype('f4')
+    assert np.array_equal(prod.clamped_spline_value(c1, x), orc.clamped_spline_value(c1, x))
+    assert np.array_equal(prod.clamped_value_and_deriv(c1, x), orc.clamped_value_and_deriv(c1, x))
+    assert np.array_equal(prod.clamped_coeff_deriv(c1, x), orc.clamped_coeff_deriv(c1, x))
+
+
+def test_no_cpu_fallback(lib):
+    """without a GPU, construction must fail (NULL) with an explicit message instead of computing on the host"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    lib.construct_deriv_engine.restype = ct.c_void_p
+    lib.construct_deriv_engine.argtypes = [ct.c_int, ct.c_char_p, ct.c_bool]
+    lib.upside_hip_last_error.restype = ct.c_char_p
+    e = lib.construct_deriv_engine(60, P.fixture('trpcage20_7A').encode(), True)
+    assert not e
+    assert b'no HIP device' in lib.upside_hip_last_error()
+    with pytest.raises(RuntimeError):
+        P.pkg.Upside(P.fixture('trpcage20_7A'))

@@ -20,14 +20,14 @@ void upk_check(int code, const char* what) {
 }
 
 // ---- DeviceCtx profiling --------------------------------------------------------------------------
-void DeviceCtx::begin(const char* fam) {
+void DeviceCtx::begin(const std::string& fam) {
     if (!profile) return;
     hipEvent_t a, b;
     hip_check(hipEventCreate(&a), "hipEventCreate"); hip_check(hipEventCreate(&b), "hipEventCreate");
     hip_check(hipEventRecord(a, stream), "hipEventRecord");
     families[fam].pending.emplace_back(a, b);
 }
-void DeviceCtx::end(const char* fam, double algorithmic_bytes) {
+void DeviceCtx::end(const std::string& fam, double algorithmic_bytes) {
     if (!profile) return;
     auto& f = families[fam];
     hip_check(hipEventRecord(f.pending.back().second, stream), "hipEventRecord");
@@ -135,7 +135,7 @@ DerivEngine::~DerivEngine() {
 }
 void DerivEngine::add_node(const string& name, unique_ptr<DerivComputation> fcn, vector<string> argument_names) {
     if (any_of(nodes.begin(), nodes.end(), [&](const Node& n) { return n.name == name; })) throw string("name conflict in DerivEngine");
-    Node node; node.name = name; node.computation = move(fcn);
+    Node node; node.name = name; node.computation = move(fcn); node.computation->name = name;
     nodes.push_back(move(node));
     for (auto& nm : argument_names) {
         int parent_idx = get_idx(nm);

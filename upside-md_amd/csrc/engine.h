@@ -61,10 +61,10 @@ struct DeviceCtx {
     DevBuf<int> error_flag;          // [1]: pair-list / slot capacity overflow
     // profiling (bench.py): HIP-event timing of kernel families on `stream`
     bool profile = false;
-    struct Family { double ms = 0; long launches = 0; double bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+    struct Family { double ms = 0; long launches = 0; double bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };   // one family = one kernel of one node
     std::map<std::string, Family> families;
-    void begin(const char* fam);
-    void end(const char* fam, double algorithmic_bytes);
+    void begin(const std::string& fam);
+    void end(const std::string& fam, double algorithmic_bytes);
     void flush_profile();
 };
 
@@ -85,6 +85,7 @@ struct ScatterPlan {
 struct DerivComputation {   // deriv_engine.h:48-80
     const bool potential_term;
     DeviceCtx* ctx = nullptr;
+    std::string name;   // graph name, set by DerivEngine::add_node (used for profiling labels)
     explicit DerivComputation(bool potential_term_) : potential_term(potential_term_) {}
     virtual ~DerivComputation() {}
     virtual void compute_value(ComputeMode mode) = 0;

@@ -29,6 +29,8 @@ static int fail(const string& s) { g_last_error = s; fprintf(stderr, "ERROR: %s\
 extern "C" const char* upside_hip_last_error(void) { return g_last_error.c_str(); }
 
 // ---- construction ----------------------------------------------------------------------------------
+extern "C" int upside_hip_set_device(int device) {
+    API_TRY hip_check(hipSetDevice(device), "hipSetDevice"); return 0; API_CATCH(1) }
 extern "C" DerivEngine* upside_hip_construct(int n_atom, const char* potential_file, int n_system, bool quiet) {
     API_TRY
     if (n_system < 1) throw string("n_system must be positive");
@@ -291,15 +293,22 @@ extern "C" int upside_hip_rotamer_iterations(DerivEngine* e, int* iters) {
 
 extern "C" int upside_hip_profile_reset(DerivEngine* e, int enable) {
     API_TRY e->sync(); e->ctx.flush_profile(); e->ctx.families.clear(); e->ctx.profile = enable != 0; return 0; API_CATCH(1) }
-extern "C" int upside_hip_profile_get(DerivEngine* e, const char* which, double* ms, long* launches, double* algorithmic_bytes) {
+extern "C" int upside_hip_profile_dump(DerivEngine* e, char* buf, int buflen) {
     API_TRY
     e->sync(); e->ctx.flush_profile();
-    auto it = e->ctx.families.find(which);
-    *ms = it == e->ctx.families.end() ? 0. : it->second.ms;
-    *launches = it == e->ctx.families.end() ? 0 : it->second.launches;
-    if (algorithmic_bytes) *algorithmic_bytes = !strcmp(which, "igraph") ? engine_igraph_bytes(*e) : 0.;
+    string out;
+    char line[512];
+    for (auto& kv : e->ctx.families) {
+        snprintf(line, sizeof(line), "%s %.6f %ld %.1f\n", kv.first.c_str(), kv.second.ms, kv.second.launches, kv.second.bytes);
+        out += line;
+    }
+    if ((int)out.size() + 1 > buflen) throw string("profile buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
     API_CATCH(1)
+}
+extern "C" double upside_hip_igraph_bytes_per_system(DerivEngine* e) {
+    API_TRY return engine_igraph_bytes(*e); API_CATCH(-1.)
 }
 
 extern "C" int upside_main(int argc, const char* const* argv, int verbose) {

@@ -422,11 +422,26 @@ struct IGraphHost {
         cache_pos1.upload(vector<float>(cache_pos1.n, 1e10f)); G.cache_pos1 = cache_pos1.p;
         if (G.symmetric) G.cache_pos2 = cache_pos1.p;
     }
-    // algorithmic bytes of one forward+backward use of this graph:
-    // 8*(n1*d1 + n2*d2) + 16*E + 4*n_type1*n_type2*n_param, E taken as the in-range pair count
-    double algorithmic_bytes(double n_edge) const {
-        return 8. * (G.n1 * (double)G.dim1 + (G.symmetric ? 0. : G.n2 * (double)G.dim2)) + 16. * n_edge + 4. * G.n_type1 * G.n_type2 * G.n_param;
-    }
+    // Algorithmic bytes: one force evaluation of one graph moves
+    //   8*(n1*d1 + n2*d2) + 16*E + 4*n_type1*n_type2*n_param   bytes
+    // (coordinates read + gradients written, two indices + value + sensitivity per in-range pair, the table
+    // once).  The forward launch accounts for the coordinate read, the index pair and the table; the backward
+    // launches share the gradient write and the per-pair value/sensitivity.  E = in-range pairs of system 0.
+    double edge_count = -1.;
+    double coord_bytes() const { return 4. * (G.n1 * (double)G.dim1 + (G.symmetric ? 0. : G.n2 * (double)G.dim2)); }
+    double edges() { if (edge_count < 0.) edge_count = (double)pairlist(0).size(); return edge_count; }
+    double bytes_fwd() { return ctx->n_system * (coord_bytes() + 8. * edges() + 4. * G.n_type1 * G.n_type2 * G.n_param); }
+    double bytes_bwd(int n_launch) { return ctx->n_system * (coord_bytes() + 8. * edges()) / n_launch; }
+    double algorithmic_bytes() { return bytes_fwd() + bytes_bwd(1); }
+    struct Prof {   // brackets ONE kernel launch with HIP events when profiling is on
+        DeviceCtx* c; std::string nm; double bytes;
+        Prof(IGraphHost& ig, const std::string& owner, const char* kind, int bwd_launches) : c(ig.ctx) {
+            if (!c->profile) return;
+            nm = std::string(kind) + ":" + owner; bytes = bwd_launches ? ig.bytes_bwd(bwd_launches) : ig.bytes_fwd();
+            c->begin(nm);
+        }
+        ~Prof() { if (c->profile) c->end(nm, bytes); }
+    };
     // canonical in-range pair list of one system (parity/diagnostics)
     vector<pair<int, int>> pairlist(int sys) {
         DevBuf<unsigned char> flags((size_t)ctx->n_system * G.n1 * G.cap1);
@@ -467,18 +482,18 @@ struct ProteinHBond : public CoordNode {
     }
     void compute_value(ComputeMode) override {
         ig.update_lists();
-        ctx->begin("igraph");
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0), "protein_hbond rowsum donors");
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor), "protein_hbond rowsum acceptors");
-        ctx->end("igraph", 0.);
+        { IGraphHost::Prof pr(ig, name, "igraph_fwd1", 0);
+          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0), "protein_hbond rowsum donors"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_fwd2", 0);
+          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor), "protein_hbond rowsum acceptors"); }
         upk_check(upk_protein_hbond_finish(&ctx->L, infer.coord(), coord()), "protein_hbond_finish");
     }
     void propagate_deriv() override {
         upk_check(upk_protein_hbond_bwd_pre(&ctx->L, coord(), sens_scaled.p), "protein_hbond_bwd_pre");
-        ctx->begin("igraph");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad donors");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad acceptors");
-        ctx->end("igraph", 0.);
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad donors"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad acceptors"); }
         upk_check(upk_protein_hbond_passthrough(&ctx->L, coord(), infer.coord(), ig.G.loc1, n_donor, ig.G.loc2, n_acceptor), "protein_hbond_passthrough");
     }
     vector<float> get_param() const override { return ig.param; }
@@ -493,15 +508,14 @@ struct HBondCoverage : public CoordNode {
         : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {}
     void compute_value(ComputeMode) override {
         ig.update_lists();
-        ctx->begin("igraph");
+        IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
         upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0), "hbond_coverage rowsum");
-        ctx->end("igraph", 0.);
     }
     void propagate_deriv() override {
-        ctx->begin("igraph");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad beads");
-        ctx->end("igraph", 0.);
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad beads"); }
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
@@ -519,15 +533,14 @@ struct EnvironmentCoverage : public CoordNode {
         : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {}
     void compute_value(ComputeMode) override {
         ig.update_lists();
-        ctx->begin("igraph");
+        IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
         upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0), "environment_coverage rowsum");
-        ctx->end("igraph", 0.);
     }
     void propagate_deriv() override {
-        ctx->begin("igraph");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad cb");
-        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc");
-        ctx->end("igraph", 0.);
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad cb"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
+          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc"); }
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
@@ -685,15 +698,13 @@ struct RotamerSidechain : public PotentialNode {
         ig.update_lists();
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
         upk_check(upk_rotamer_node_prob(&ctx->L, &R), "rotamer_node_prob");
-        ctx->begin("igraph");
-        upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
-        ctx->end("igraph", 0.);
-        ctx->begin("bp");
+        { IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
+          upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy"); }
+        if (ctx->profile) ctx->begin("bp:" + name);
         upk_check(upk_rotamer_bp(&ctx->L, &R, mode == PotentialAndDerivMode), "rotamer_bp");
-        ctx->end("bp", 0.);
-        ctx->begin("igraph");
-        upk_check(upk_rotamer_grad(&ctx->L, &R), "rotamer_grad");
-        ctx->end("igraph", 0.);
+        if (ctx->profile) ctx->end("bp:" + name, 0.);
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);
+          upk_check(upk_rotamer_grad(&ctx->L, &R), "rotamer_grad"); }
         if (mode == PotentialAndDerivMode)
             hip_check(hipMemcpyAsync(potential_dev.p, energy.p, ctx->n_system * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream), "D2D");
     }
@@ -769,7 +780,7 @@ double engine_igraph_bytes(DerivEngine& e) {
         else if (auto* h = dynamic_cast<HBondCoverage*>(c)) ig = &h->ig;
         else if (auto* en = dynamic_cast<EnvironmentCoverage*>(c)) ig = &en->ig;
         else if (auto* p = dynamic_cast<ProteinHBond*>(c)) ig = &p->ig;
-        if (ig) b += ig->algorithmic_bytes((double)ig->pairlist(0).size());
+        if (ig) b += ig->algorithmic_bytes() / e.ctx.n_system;
     }
     return b;
 }
