@@ -149,7 +149,8 @@ typedef struct {
     int slot_cap, adj_cap;
     int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
-    float *P, *msg_cur, *msg_old, *marg; /* [S][cap][36], [S][cap][12], [S][cap][12], [S][cap][36] */
+    int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
+    float *P, *msg_cur, *msg_old, *marg; /* [S][cap][36], inbox [S][cap][12] (messages grouped by receiving node), unused, [S][cap][36] */
     float damping, tol; int max_iter, chunk;
     int* iters;                          /* [S] sweeps of the last solve */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */

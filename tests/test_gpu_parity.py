@@ -1,0 +1,256 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP product, driven through its C-ABI, against the CPU
+oracle on the same seeded inputs, plus size-independent properties at the benchmark size.
+
+Tolerance (BASELINE.json north_star): pair-list indices bit-exact; forces / energies / node values within 1e-5
+relative fp32, where "relative" for an array is the reference's own relative RMS deviation
+(/root/reference/src/deriv_engine.h:345-357) and for the total energy is relative to the sum of the magnitudes of
+the per-node potentials (the total is a difference of large terms)."""
+import ctypes as ct
+import os
+import numpy as np
+import pytest
+import parity_util as P
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+FIXTURES = ['trpcage20_7A', 'proteinG56_7A', 'syn150_10A', 'syn300_10A', 'syn300_7A']
+IGRAPH_NODES = ['rotamer', 'hbond_coverage', 'hbond_coverage_hydrophobe', 'environment_coverage', 'protein_hbond']
+
+
+@pytest.fixture(scope='module')
+def hip():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need a GPU'
+    lib = P.pkg.default_library()     # raises when the HIP extension is missing: no fallback
+    c = lib.calc
+    c.upside_hip_construct.restype = ct.c_void_p
+    c.upside_hip_construct.argtypes = [ct.c_int, ct.c_char_p, ct.c_int, ct.c_bool]
+    c.upside_hip_get_pairlist.restype = ct.c_int
+    c.upside_hip_get_pairlist.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p]
+    c.upside_hip_rotamer_iterations.argtypes = [ct.c_void_p, ct.c_void_p]
+    c.upside_hip_set_pos.argtypes = [ct.c_void_p, ct.c_void_p]
+    c.upside_hip_get_pos.argtypes = [ct.c_void_p, ct.c_void_p]
+    c.upside_hip_get_mom.argtypes = [ct.c_void_p, ct.c_void_p]
+    c.upside_hip_set_mom.argtypes = [ct.c_void_p, ct.c_void_p]
+    c.upside_hip_compute.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    c.upside_hip_init_md.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint32, ct.c_float, ct.c_float, ct.c_int]
+    c.upside_hip_run_md.argtypes = [ct.c_void_p, ct.c_int]
+    c.upside_hip_replica_swap.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_void_p]
+    c.upside_hip_last_error.restype = ct.c_char_p
+    return lib
+
+
+def hip_pairlist(up, node, sys=0, cap=400000):
+    i1 = np.zeros(cap, 'i4'); i2 = np.zeros(cap, 'i4')
+    n = up.calc.upside_hip_get_pairlist(up.engine, node.encode(), sys, cap, i1.ctypes.data, i2.ctypes.data)
+    assert 0 <= n <= cap
+    return np.column_stack((i1[:n], i2[:n]))
+
+
+def assert_close(ref, act, keys=None):
+    bad = P.compare(ref, act, keys=keys, rtol=RTOL)
+    assert not bad, 'outside 1e-5 relative: %r' % (bad,)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_force_pass_matches_oracle(hip, name):
+    """every node output / sensitivity, per-node potentials, total energy and forces; first call (pair list
+    built) and a second, perturbed call through the cached pair list."""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    for tag in ('pos', 'pos2'):
+        ref = P.evaluate_all(orc, g[tag])
+        act = P.evaluate_all(up, g[tag])
+        keys = [k for k in ref if k != 'energy']
+        assert_close(ref, act, keys)
+        scale = sum(abs(float(ref['pot/' + k])) for k in P.POTENTIAL_NODES)
+        assert abs(float(ref['energy']) - float(act['energy'])) <= RTOL * scale
+        # pair-list indices: bit-exact, canonical order
+        for node in IGRAPH_NODES:
+            po = P.oracle_pairlist(orc, node)
+            ph = hip_pairlist(up, node)
+            assert ph.shape == po.shape and np.array_equal(ph, po), (node, tag, ph.shape, po.shape)
+        it = np.zeros(1, 'i4')
+        up.calc.upside_hip_rotamer_iterations(up.engine, it.ctypes.data)
+        assert int(it[0]) == orc.calc.oracle_rotamer_iterations(orc.engine)
+        # marginals (what predict_chi1.py reads): node and pair marginals in graph order
+        n = int(g['rotamer/n_node'])
+        if n <= 60:
+            em_h = up.get_value_by_name((n, n, 6, 6), 'rotamer', 'edge_marginal_in_graph_order')
+            em_o = orc.get_value_by_name((n, n, 6, 6), 'rotamer', 'edge_marginal_in_graph_order')
+            assert np.abs(em_h - em_o).max() < 2e-6
+    up.close(); orc.close()
+
+
+@pytest.mark.parametrize('name', ['proteinG56_7A', 'syn300_10A'])
+def test_forces_match_reference_golden(hip, name):
+    """the committed golden vectors of the unmodified reference; tolerance = the reference's own build-to-build
+    spread (profiles/r01_reference_noise_floor.txt), see tests/test_oracle_pinning.py"""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    act = P.evaluate_all(up, g['pos'])
+    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4
+    for k in g:
+        if k.startswith('out/'):
+            assert P.rel_rms(g[k], act[k]) < 1e-5, k
+    assert np.array_equal(hip_pairlist(up, 'rotamer'), g['pairlist/edges'][:, :2])
+    up.close()
+
+
+def test_empty_and_degenerate_requests(hip):
+    """error behaviour of the C-ABI mirrors engine_c_library.cpp: wrong sizes and unknown names return 1"""
+    up = P.pkg.Upside(P.fixture('trpcage20_7A'))
+    up.energy(up.initial_pos)
+    buf = np.zeros(5, 'f4')
+    assert up.calc.get_output(5, buf.ctypes.data, up.engine, b'rama_coord') == 1        # wrong size
+    assert up.calc.get_output(1, buf.ctypes.data, up.engine, b'no_such_node') == 1
+    assert up.calc.get_param_deriv(1, buf.ctypes.data, up.engine, b'rotamer') == -1     # built without PARAM_DERIV
+    assert up.calc.get_output(1, buf.ctypes.data, up.engine, b'rotamer') == 0           # potential node -> (1,1)
+    with pytest.raises((RuntimeError, OSError)):
+        P.pkg.Upside('/nonexistent/file.up')
+    up.close()
+
+
+def test_batched_systems_are_independent_and_identical(hip):
+    """S copies of one system in one engine give S times the single-system answer (replica independence)."""
+    name = 'proteinG56_7A'
+    c = hip.calc
+    g = P.golden(name)
+    n_atom = g['pos'].shape[0]
+    S = 5
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), S, True)
+    assert eng
+    pos = np.stack([g['pos'], g['pos2'], g['pos'], g['pos2'], g['pos']]).astype('f4')
+    assert c.upside_hip_set_pos(eng, pos.ctypes.data) == 0
+    en = np.zeros(S, 'f4'); der = np.zeros((S, n_atom, 3), 'f4')
+    assert c.upside_hip_compute(eng, en.ctypes.data, der.ctypes.data) == 0
+    assert en[0] == en[2] == en[4] and en[1] == en[3]
+    assert np.array_equal(der[0], der[2]) and np.array_equal(der[1], der[3])
+    # a fresh single-system engine per structure reproduces the batched result bit for bit (same pair-list
+    # build, same summation order); an engine that reaches pos2 through the cached list of pos only to rounding
+    for tag, s in (('pos', 0), ('pos2', 1)):
+        single = P.pkg.Upside(P.fixture(name))
+        assert np.array_equal(single.deriv(g[tag]), der[s])
+        single.close()
+    single = P.pkg.Upside(P.fixture(name))
+    single.deriv(g['pos'])
+    assert P.rel_rms(der[1], single.deriv(g['pos2'])) < 1e-6
+    c.free_deriv_engine(ct.c_void_p(eng)); single.close()
+
+
+def test_thermostat_and_integrator_match_oracle(hip):
+    """Threefry/Box-Muller momenta and a short leapfrog trajectory against the oracle's MD loop
+    (main.cpp:515-523,616-667).  Momenta after initialisation agree to rounding of sinf/cosf/logf; positions are
+    compared after few enough steps that chaotic growth stays below 1e-4."""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    pos0 = orc.initial_pos.copy(); n_atom = pos0.shape[0]
+    T, seed, dt = 0.8, 12345, 0.009
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 2, True)
+    both = np.stack([pos0, pos0]).astype('f4')
+    assert c.upside_hip_set_pos(eng, both.ctypes.data) == 0
+    temps = np.array([T, T], 'f4')
+    assert c.upside_hip_init_md(eng, temps.ctypes.data, seed, 5.0, dt, 1) == 0
+    mom_h = np.zeros((2, n_atom, 3), 'f4')
+    assert c.upside_hip_get_mom(eng, mom_h.ctypes.data) == 0
+    for s in range(2):      # system s uses seed + s (main.cpp:459)
+        p = pos0.copy(); m = np.zeros_like(p)
+        orc.calc.oracle_run_md(orc.engine, p.ctypes.data, m.ctypes.data, 0, dt, T, seed + s, 5.0, 1)
+        assert np.abs(m - mom_h[s]).max() < 2e-6 * np.abs(m).max()
+    n_round = 8
+    assert c.upside_hip_run_md(eng, n_round) == 0
+    pos_h = np.zeros((2, n_atom, 3), 'f4'); c.upside_hip_get_pos(eng, pos_h.ctypes.data)
+    c.upside_hip_get_mom(eng, mom_h.ctypes.data)
+    for s in range(2):
+        p = pos0.copy(); m = np.zeros_like(p)
+        orc.calc.oracle_run_md(orc.engine, p.ctypes.data, m.ctypes.data, n_round, dt, T, seed + s, 5.0, 1)
+        assert P.rel_rms(p, pos_h[s]) < 1e-5
+        assert P.rel_rms(m, mom_h[s]) < 1e-3
+    assert not np.array_equal(pos_h[0], pos_h[1])
+    c.free_deriv_engine(ct.c_void_p(eng))
+
+
+def test_cached_pairlist_path_after_md(hip):
+    """after MD steps (cached Verlet lists, some rebuilds) the device's in-range pair lists and forces still equal
+    the oracle's evaluated at the device's current coordinates"""
+    name = 'proteinG56_7A'
+    c = hip.calc
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 1, True)
+    pos = g['pos'][None].astype('f4').copy()
+    c.upside_hip_set_pos(eng, pos.ctypes.data)
+    temps = np.array([0.9], 'f4')
+    c.upside_hip_init_md(eng, temps.ctypes.data, 7, 5.0, 0.009, 1)
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    for chunk in range(3):
+        assert c.upside_hip_run_md(eng, 15) == 0
+        x = np.zeros((1, n_atom, 3), 'f4'); c.upside_hip_get_pos(eng, x.ctypes.data)
+        en = np.zeros(1, 'f4'); der = np.zeros((1, n_atom, 3), 'f4')
+        assert c.upside_hip_compute(eng, en.ctypes.data, der.ctypes.data) == 0
+        d_ref = orc.deriv(x[0])
+        assert P.rel_rms(d_ref, der[0]) < RTOL
+        up_view = type('V', (), {'calc': c, 'engine': ct.c_void_p(eng)})
+        for node in IGRAPH_NODES:
+            assert np.array_equal(hip_pairlist(up_view, node), P.oracle_pairlist(orc, node)), node
+    c.free_deriv_engine(ct.c_void_p(eng))
+
+
+def test_benchmark_size_properties(hip):
+    """BASELINE-size checks that need no oracle run: translation invariance (sum of forces ~ 0), rigid-rotation
+    invariance of the energy, energy conservation trend of the leapfrog integrator without thermostat noise,
+    and finite-difference agreement of the analytic force along a random direction."""
+    name = 'syn300_10A'
+    up = P.pkg.Upside(P.fixture(name))
+    x = up.initial_pos.copy()
+    e0 = up.energy(x); f = up.deriv(x)
+    assert np.abs(f.sum(axis=0)).max() < 5e-3 * np.abs(f).max()
+    # rigid rotation + translation
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], 'f4')
+    x2 = (x.dot(R.T) + np.array([1.5, -2., 0.5], 'f4')).astype('f4')
+    e1 = up.energy(x2); f2 = up.deriv(x2)
+    scale = sum(abs(float(up.get_output(k)[0, 0])) for k in P.POTENTIAL_NODES)
+    assert abs(e1 - e0) < 2e-5 * scale
+    assert P.rel_rms(f.dot(R.T), f2) < 1e-4
+    # directional finite difference (deriv_engine.cpp:291-342 in one direction)
+    rs = np.random.RandomState(0)
+    d = rs.normal(size=x.shape).astype('f4'); d /= np.sqrt((d ** 2).sum())
+    eps = 2e-2
+    fd = (float(up.energy((x + eps * d).astype('f4'))) - float(up.energy((x - eps * d).astype('f4')))) / (2 * eps)
+    an = float((f * d).sum())
+    assert abs(fd - an) < 3e-2 * max(1., abs(an))
+    up.close()
+
+
+def test_replica_exchange_swap(hip):
+    """Metropolis swap of main.cpp:251-273 on the device: with equal temperatures every proposed swap is
+    accepted (lboltz_diff = 0 is not < 0) and coordinates are exchanged; with a huge temperature gap favouring
+    the current assignment the swap is rejected."""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 4, True)
+    pos = np.stack([g['pos'], g['pos2'], g['pos'], g['pos2']]).astype('f4')
+    c.upside_hip_set_pos(eng, pos.ctypes.data)
+    temps = np.array([0.8, 0.8, 0.8, 0.8], 'f4')
+    c.upside_hip_init_md(eng, temps.ctypes.data, 5, 5.0, 0.009, 1)
+    pairs = np.array([[0, 1], [2, 3]], 'i4'); acc = np.zeros(3, 'i4')
+    assert c.upside_hip_replica_swap(eng, 2, pairs.ctypes.data, 99, 3, acc.ctypes.data) == 0
+    assert list(acc[:2]) == [1, 1]
+    out = np.zeros_like(pos); c.upside_hip_get_pos(eng, out.ctypes.data)
+    assert np.array_equal(out[0], pos[1]) and np.array_equal(out[1], pos[0])
+    # E(pos) < E(pos2) here; system 0 cold holding the low-energy structure, system 1 hot: swapping is uphill
+    c.upside_hip_set_pos(eng, pos.ctypes.data)
+    temps = np.array([0.01, 100.0, 0.8, 0.8], 'f4')
+    c.upside_hip_init_md(eng, temps.ctypes.data, 5, 5.0, 0.009, 1)
+    pairs = np.array([[0, 1]], 'i4')
+    assert c.upside_hip_replica_swap(eng, 1, pairs.ctypes.data, 99, 4, acc.ctypes.data) == 0
+    e = [float(P.golden(name)['energy']), float(P.golden(name)['energy2'])]
+    expect_reject = (1 / 0.01 - 1 / 100.0) * (e[0] - e[1]) < -50
+    if expect_reject:
+        assert acc[0] == 0
+        c.upside_hip_get_pos(eng, out.ctypes.data)
+        assert np.array_equal(out[0], pos[0])
+    c.free_deriv_engine(ct.c_void_p(eng))

@@ -38,7 +38,9 @@ struct DevBuf {
     void alloc(size_t n_) {
         if (p) { (void)hipFree(p); p = nullptr; }
         n = n_;
-        if (n) { hip_check(hipMalloc((void**)&p, n * sizeof(T)), "hipMalloc"); hip_check(hipMemset(p, 0, n * sizeof(T)), "hipMemset"); }
+        // hipMemset runs on the NULL stream and may still be in flight when the call returns; engine streams are
+        // non-blocking (they do not order against the NULL stream), so drain it before anyone can touch the buffer
+        if (n) { hip_check(hipMalloc((void**)&p, n * sizeof(T)), "hipMalloc"); hip_check(hipMemset(p, 0, n * sizeof(T)), "hipMemset"); hip_check(hipStreamSynchronize(nullptr), "sync"); }
     }
     void upload(const std::vector<T>& v) { alloc(v.size()); if (n) hip_check(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice), "H2D"); }
     std::vector<T> download() const {
@@ -46,7 +48,7 @@ struct DevBuf {
         if (n) hip_check(hipMemcpy(v.data(), p, n * sizeof(T), hipMemcpyDeviceToHost), "D2H");
         return v;
     }
-    void fill_bytes(int byte) { if (n) hip_check(hipMemset(p, byte, n * sizeof(T)), "hipMemset"); }
+    void fill_bytes(int byte) { if (n) { hip_check(hipMemset(p, byte, n * sizeof(T)), "hipMemset"); hip_check(hipStreamSynchronize(nullptr), "sync"); } }
 };
 
 enum ComputeMode { DerivMode = 0, PotentialAndDerivMode = 1 };   // deriv_engine.h:42-45

@@ -122,10 +122,14 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
         }
     }
     __syncthreads();
-    // adjacency: slots touching each node, ascending partner id
+    // adjacency: slots touching each node, ascending partner id.  BP slots (both nodes with >1 state) also get
+    // an "inbox" position: messages TO node g are stored contiguously at inbox[(bp_start[g]+k)*6 ...], so the node
+    // update streams them without index indirection; slot_off[2*slot+side] remembers where each slot writes.
+    const int* nrot = R.node_nrot;
     for (int g = wave; g < NN; g += n_wave) {
         int* adj = R.adj_slot + ((size_t)s * NN + g) * R.adj_cap;
-        int count = 0;
+        int count = 0, count_bp = 0;
+        const bool g_multi = nrot[g] > 1;
         for (int b0 = 0; b0 < NN; b0 += 64) {
             const int b = b0 + lane;
             const int sl = b < NN ? slot_of[g * NN + b] : -1;
@@ -134,8 +138,34 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
             const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
             if (hit && pos < R.adj_cap) adj[pos] = sl;
             count += __popcll(m);
+            count_bp += __popcll(__ballot(hit && g_multi && nrot[b] > 1));
         }
-        if (lane == 0) { R.adj_cnt[(size_t)s * NN + g] = count < R.adj_cap ? count : R.adj_cap; if (count > R.adj_cap) *G.error_flag = 3; }
+        if (lane == 0) {
+            R.adj_cnt[(size_t)s * NN + g] = count < R.adj_cap ? count : R.adj_cap;
+            if (count > R.adj_cap) *G.error_flag = 3;
+            row_count[g] = count_bp;
+        }
+    }
+    __syncthreads();
+    int* bp_start = R.bp_start + (size_t)s * (NN + 1);
+    if (tid == 0) {
+        int acc = 0;
+        for (int g = 0; g < NN; ++g) { bp_start[g] = acc; row_start[g] = acc; acc += row_count[g]; }
+        bp_start[NN] = acc;
+    }
+    __syncthreads();
+    int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
+    for (int g = wave; g < NN; g += n_wave) {
+        if (nrot[g] == 1) continue;
+        int base = row_start[g];
+        for (int b0 = 0; b0 < NN; b0 += 64) {
+            const int b = b0 + lane;
+            const int sl = b < NN ? slot_of[g * NN + b] : -1;
+            const bool hit = sl >= 0 && nrot[b] > 1;
+            const unsigned long long m = __ballot(hit);
+            if (hit) slot_off[sl * 2 + (g < b ? 0 : 1)] = (base + __popcll(m & ((1ull << lane) - 1ull))) * 6;
+            base += __popcll(m);
+        }
     }
 }
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
@@ -238,6 +268,67 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
+// one residue-pair edge with compile-time state counts: new messages from the old beliefs
+// (update_beliefs, rotamer.cpp:468-499 and the L1 normalisation of 506-521), written in place
+template <int NA, int NB>
+__device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, const float* __restrict__ nba, const float* __restrict__ nbb,
+                                        float* __restrict__ ma, float* __restrict__ mb) {
+    float va[NA], vb[NB], P[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) va[i] = nba[i] * rcp(1e-10f + ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) vb[j] = nbb[j] * rcp(1e-10f + mb[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) P[i][j] = Ps[i * 6 + j];
+    float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) t += P[i][j] * vb[j];
+        ta[i] = t; sa += t; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
+        tb[j] = t; sb += t; }
+    const float ra = rcp(sa), rb = rcp(sb);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+}
+
+// pair marginal and (optionally) its Bethe free-energy term (rotamer.cpp:405-451)
+template <int NA, int NB>
+__device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, const float* __restrict__ nba, const float* __restrict__ nbb,
+                                             const float* __restrict__ ma, const float* __restrict__ mb, float* __restrict__ mg_out,
+                                             bool want_energy) {
+    float bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bc1[i] = nba[i] * rcp(1e-10f + ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bc2[j] = nbb[j] * rcp(1e-10f + mb[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { mg[i][j] = Ps[i * 6 + j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
+    const float rs = rcp(sum);
+    float en = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float pm = mg[i][j] * rs;
+            mg_out[i * 6 + j] = pm;
+            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + Ps[i * 6 + j] * nba[i] * nbb[j]));
+        }
+    return en;
+}
+
+#define BP_GROUP 16   // lanes cooperating on one node in the node phase
+
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -252,18 +343,21 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     const int* active = R.slot_active + (size_t)s * R.slot_cap;
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
+    const int* bp_start = R.bp_start + (size_t)s * (NN + 1);
+    const int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
     float* P = R.P + (size_t)s * R.slot_cap * 36;
-    float* m0 = R.msg_cur + (size_t)s * R.slot_cap * 12;
-    float* m1 = R.msg_old + (size_t)s * R.slot_cap * 12;
+    float* inbox = R.msg_cur + (size_t)s * R.slot_cap * 12;
     float* marg = R.marg + (size_t)s * R.slot_cap * 36;
     const int* nrot = R.node_nrot;
 
-    // energies -> probabilities (rotamer.cpp:835)
+    // energies -> probabilities (rotamer.cpp:835); old edge beliefs = 1 (rotamer.cpp:1015-1032), also for the
+    // slots without an in-range bead pair this step, whose (unit) message then multiplies as an exact 1
     for (int i = tid; i < n_slot * 36; i += nt) {
         const int sl = i / 36, e = i % 36, ra = e / 6, rb = e % 6;
         const bool used = ra < nrot[slot_a[sl]] && rb < nrot[slot_b[sl]];
         P[i] = used ? expf(-P[i]) : 0.f;
     }
+    for (int i = tid; i < bp_start[NN] * 6; i += nt) inbox[i] = 1.f;
     for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
@@ -273,70 +367,74 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         for (int k = 0; k < adj_cnt[g]; ++k) {
             const int sl = adj_slot[g * R.adj_cap + k];
             const int a = slot_a[sl];
-            if (a == g || nrot[a] != 1 || !active[sl]) continue;     // partner is `a` (lower id) when it has one state
+            if (a == g || nrot[a] != 1 || !active[sl]) continue;     // a 1-state partner always has the lower id
             for (int r = 0; r < n; ++r) prob[g * 6 + r] *= P[(size_t)sl * 36 + r];
         }
     }
     __syncthreads();
-    // old node belief = prob, old edge beliefs = 1 (rotamer.cpp:1009-1032)
-    for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }
-    for (int i = tid; i < n_slot * 12; i += nt) m1[i] = 1.f;
+    for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
 
     float* nb_old = nb0; float* nb_cur = nb1;
-    float* m_old = m1; float* m_cur = m0;
     int iter = 0;
     float maxdev = 1e10f;
+    const int grp = tid / BP_GROUP, gl = tid % BP_GROUP, n_grp = nt / BP_GROUP;
     // sweep -1 is calculate_new_beliefs(0.f, true): only its messages survive and the "old" node belief becomes
     // prob / max(prob) (rotamer.cpp:1034 with the swap at 995-1001)
     for (int sweep = -1;; ++sweep) {
-        // ---- edge phase: messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 + 506-521)
+        // ---- edge phase: every residue pair rewrites its two messages in place from the old node beliefs
         for (int sl = tid; sl < n_slot; sl += nt) {
             const int a = slot_a[sl], b = slot_b[sl];
-            const int na = nrot[a], nb = nrot[b];
+            const int na = nrot[a];
             if (na == 1 || !active[sl]) continue;
+            const int nb = nrot[b];
             const float* Ps = P + (size_t)sl * 36;
-            float va[6], vb[6];
-            for (int i = 0; i < 6; ++i) va[i] = i < na ? nb_old[a * 6 + i] * rcp(1e-10f + m_old[sl * 12 + i]) : 0.f;
-            for (int j = 0; j < 6; ++j) vb[j] = j < nb ? nb_old[b * 6 + j] * rcp(1e-10f + m_old[sl * 12 + 6 + j]) : 0.f;
-            float ta[6], tb[6], sa = 0.f, sb = 0.f;
-            for (int i = 0; i < 6; ++i) { float t = 0.f; if (i < na) for (int j = 0; j < nb; ++j) t += Ps[i * 6 + j] * vb[j]; ta[i] = t; sa += t; }
-            for (int j = 0; j < 6; ++j) { float t = 0.f; if (j < nb) for (int i = 0; i < na; ++i) t += va[i] * Ps[i * 6 + j]; tb[j] = t; sb += t; }
-            const float ra = rcp(sa), rb = rcp(sb);
-            for (int i = 0; i < 6; ++i) m_cur[sl * 12 + i] = ta[i] * ra;
-            for (int j = 0; j < 6; ++j) m_cur[sl * 12 + 6 + j] = tb[j] * rb;
+            float* ma = inbox + slot_off[sl * 2];
+            float* mb = inbox + slot_off[sl * 2 + 1];
+            if (na == 3 && nb == 3) bp_edge<3, 3>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
+            else if (na == 3) bp_edge<3, 6>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
+            else bp_edge<6, 6>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
         }
         __syncthreads();
-        // ---- node phase
+        // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
         float dev = 0.f;
-        for (int g = tid; g < NN; g += nt) {
-            const int n = nrot[g];
-            if (n == 1) continue;
-            float bsum = 0.f, bb[6];
-            if (sweep < 0) {
-                for (int r = 0; r < n; ++r) bb[r] = prob[g * 6 + r];
-            } else {
-                for (int r = 0; r < n; ++r) bb[r] = prob[g * 6 + r];
-                for (int k = 0; k < adj_cnt[g]; ++k) {
-                    const int sl = adj_slot[g * R.adj_cap + k];
-                    const int a = slot_a[sl];
-                    if (nrot[a] == 1 || !active[sl]) continue;
-                    const float* m = m_cur + sl * 12 + (a == g ? 0 : 6);
-                    bsum = 0.f;
-                    for (int r = 0; r < n; ++r) { bb[r] *= m[r]; bsum += bb[r]; }
-                    const float rs = rcp(bsum);
-                    for (int r = 0; r < n; ++r) bb[r] *= rs;       // node normalisation, rotamer.cpp:489-493
+        for (int g0 = 0; g0 < NN; g0 += n_grp) {
+            const int g = g0 + grp;
+            const bool live = g < NN && nrot[g] > 1;
+            const int n = live ? nrot[g] : 0;
+            float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (live && sweep >= 0) {
+                const int k0 = bp_start[g], k1 = bp_start[g + 1];
+                for (int k = k0 + gl; k < k1; k += BP_GROUP) {
+                    const float* m = inbox + (size_t)k * 6;
+                    float mx = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) { bb[r] *= (r < n ? m[r] : 1.f); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                    const float rm = rcp(mx);           // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) bb[r] *= rm;
                 }
             }
-            float mx = bb[0];
-            for (int r = 1; r < n; ++r) mx = fmaxf(bb[r], mx);
-            const float rm = rcp(mx);
-            const float damp = sweep < 0 ? 0.f : R.damping;
-            for (int r = 0; r < n; ++r) {
-                const float o = nb_old[g * 6 + r];
-                const float v = damp != 0.f ? (1.f - damp) * rm * bb[r] + damp * o : rm * bb[r];   // rotamer.cpp:258-273
-                nb_cur[g * 6 + r] = v;
-                dev = fmaxf(v - o, dev);                           // signed, rotamer.cpp:275-281
+            // product over the lanes of the group
+#pragma unroll
+            for (int off = BP_GROUP / 2; off > 0; off >>= 1) {
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { bb[r] *= __shfl_xor(bb[r], off, UP_WAVE); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                const float rm = mx > 0.f ? rcp(mx) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+            }
+            if (live && gl < n) {
+                // lane r of the group finishes rotamer state r: b = prob * product, then standardize (rotamer.cpp:258-273)
+                float mine = 0.f, mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) if (r < n) { const float v = prob[g * 6 + r] * bb[r]; mx = fmaxf(mx, v); if (r == gl) mine = v; }
+                const float o = nb_old[g * 6 + gl];
+                const float damp = sweep < 0 ? 0.f : R.damping;
+                const float v = damp != 0.f ? (1.f - damp) * rcp(mx) * mine + damp * o : rcp(mx) * mine;
+                nb_cur[g * 6 + gl] = v;
+                dev = fmaxf(v - o, dev);                               // signed, rotamer.cpp:275-281
             }
         }
         __syncthreads();
@@ -344,16 +442,11 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
             ++iter;
             if (iter % R.chunk == 0) {
                 maxdev = block_max(dev, scratch);
-                if (!(maxdev > R.tol && iter < R.max_iter)) break;   // rotamer.cpp:1038
+                if (!(maxdev > R.tol && iter < R.max_iter)) break;     // rotamer.cpp:1038
             }
         }
-        // swap for the next sweep (rotamer.cpp:1040-1044)
-        float* t = nb_old; nb_old = nb_cur; nb_cur = t;
-        t = m_old; m_old = m_cur; m_cur = t;
-        __syncthreads();
+        float* t = nb_old; nb_old = nb_cur; nb_cur = t;                // rotamer.cpp:1040-1044
     }
-    // the reference tests the loop condition before the first chunk only with max_deviation = 1e10, so at least
-    // one chunk always runs; iter counts sweeps exactly as `iter` in rotamer.cpp:1036-1051
     if (tid == 0) R.iters[s] = iter;
 
     // ---- marginals (rotamer.cpp:1053-1059)
@@ -374,17 +467,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         const float* Ps = P + (size_t)sl * 36;
         if (nb == 1) { if (want_energy) en += -logf(Ps[0]); continue; }   // 1-1 edge (rotamer.cpp:861)
         if (na == 1) continue;                                            // folded into node b
-        float bc1[6], bc2[6], mg[36], sum = 0.f;
-        for (int i = 0; i < na; ++i) bc1[i] = nb_cur[a * 6 + i] * rcp(1e-10f + m_cur[sl * 12 + i]);
-        for (int j = 0; j < nb; ++j) bc2[j] = nb_cur[b * 6 + j] * rcp(1e-10f + m_cur[sl * 12 + 6 + j]);
-        for (int i = 0; i < na; ++i) for (int j = 0; j < nb; ++j) { const float v = Ps[i * 6 + j] * bc1[i] * bc2[j]; mg[i * 6 + j] = v; sum += v; }
-        const float rs = rcp(sum);
-        for (int i = 0; i < na; ++i) for (int j = 0; j < nb; ++j) {
-            const float pm = mg[i * 6 + j] * rs;
-            marg[(size_t)sl * 36 + i * 6 + j] = pm;
-            if (want_energy)   // edge_free_energy, rotamer.cpp:431-451
-                en += pm * logf((1e-10f + pm) * rcp(1e-10f + Ps[i * 6 + j] * nb_cur[a * 6 + i] * nb_cur[b * 6 + j]));
-        }
+        const float* ma = inbox + slot_off[sl * 2];
+        const float* mb = inbox + slot_off[sl * 2 + 1];
+        float* mo = marg + (size_t)sl * 36;
+        if (na == 3 && nb == 3) en += bp_marginal<3, 3>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
+        else if (na == 3) en += bp_marginal<3, 6>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
+        else en += bp_marginal<6, 6>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
     }
     if (want_energy) {
         for (int g = tid; g < NN; g += nt) {   // node_free_energy, rotamer.cpp:292-302

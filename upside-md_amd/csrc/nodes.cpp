@@ -620,7 +620,7 @@ struct RotamerSidechain : public PotentialNode {
     upk_rotamer_t R;
     int n_node, n1, n3, n6;
     vector<int> node_nrot, bead_node, bead_rot;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off;
     DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     long n_bad_solve = 0;
@@ -668,10 +668,10 @@ struct RotamerSidechain : public PotentialNode {
         R.adj_cap = min(max(n_node, 1), env_int("UPSIDE_HIP_ADJ_CAP", 256));
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
-        iters.alloc(S); energy.alloc(S);
+        iters.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6); nb_old.alloc((size_t)S * n_node * 6);
         P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
-        msg_cur.alloc((size_t)S * R.slot_cap * 12); msg_old.alloc((size_t)S * R.slot_cap * 12);
+        msg_cur.alloc((size_t)S * R.slot_cap * 12);
     }
     void finalize() override {
         vector<const float*> po; vector<float*> ps; vector<int> st; vector<long> ss;
@@ -689,7 +689,7 @@ struct RotamerSidechain : public PotentialNode {
         R.prob_sys_stride = d_prob_sys_stride.p;
         R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p; R.nb_old = nb_old.p;
         R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p;
-        R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p;
+        R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
         R.iters = iters.p; R.energy = energy.p;
     }
