@@ -1,0 +1,159 @@
+// Device-side building blocks shared by the interaction-graph kernels (kernels_igraph.hip, kernels_rotamer.hip).
+//
+// Work decomposition on gfx950:
+//   * one workgroup (up to 16 wavefronts) serves ONE system at a time; it first stages into LDS
+//       - the whole spline/parameter table of the graph (6-99 KB), and
+//       - the packed coordinates of every element of both sides (8 floats per element, <= ~60 KB),
+//     so the per-pair gathers (4 coefficient windows + neighbour coordinates) hit LDS instead of issuing
+//     64-line scattered global loads per wave instruction;
+//   * one wavefront owns one row of the cached Verlet list; candidates are distance-tested 64 at a time and the
+//     survivors are compacted (ballot + popcount) into a small per-wave LDS queue so that the expensive pair
+//     functor always runs with (nearly) all 64 lanes busy;
+//   * row results are reduced with wavefront shuffles; nothing is scattered.
+#pragma once
+#include "device_math.h"
+#include "../../include/upside_hip_kernels.h"
+
+namespace up {
+
+#define IG_MAX_WAVES 16
+#define IG_QUEUE 128            // per-wave compaction queue (ints)
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront execute in order; this only stops the compiler from reordering them and
+    // makes the data written by other lanes of the SAME wave visible to subsequent reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// uniform cubic B-spline in basis form: value and derivative from the 4-coefficient window starting at c[bin-1]
+// (same interpolant as spline.h:136-174; de Boor's recurrence re-associated into the 4 basis polynomials)
+__device__ __forceinline__ void bspline_basis(float y, float b[4], float d[4]) {
+    const float y2 = y * y, y3 = y2 * y, omy = 1.f - y, omy2 = omy * omy;
+    const float s = 1.f / 6.f;
+    b[0] = s * omy2 * omy;
+    b[1] = s * (3.f * y3 - 6.f * y2 + 4.f);
+    b[2] = s * (-3.f * y3 + 3.f * y2 + 3.f * y + 1.f);
+    b[3] = s * y3;
+    d[0] = -0.5f * omy2;
+    d[1] = 0.5f * (3.f * y2 - 4.f * y);
+    d[2] = 0.5f * (-3.f * y2 + 2.f * y + 1.f);
+    d[3] = 0.5f * y2;
+}
+template <typename P>
+__device__ __forceinline__ void bspline_vd(float& val, float& der, P c, int bin, const float b[4], const float d[4]) {
+    const float c0 = c[bin - 1], c1 = c[bin], c2 = c[bin + 1], c3 = c[bin + 2];
+    val = c0 * b[0] + c1 * b[1] + c2 * b[2] + c3 * b[3];
+    der = c0 * d[0] + c1 * d[1] + c2 * d[2] + c3 * d[3];
+}
+
+struct QuadShape { int ka, k; float inv_dx, inv_dtheta; };
+
+// bead_interaction.h:30-84 with the B-splines in basis form and hardware rsqrt (1 ulp).
+// WANT_D: 0 value only, 1 derivative w.r.t. the first element, 2 w.r.t. the second.
+template <int WANT_D, typename P>
+__device__ __forceinline__ float quadspline2(const QuadShape& Q, P p, const float* x1, const float* x2, float* d) {
+    const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
+    const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
+    const float dist2 = mag2(displace), inv_dist = rsqrtf(dist2);
+    const float dist_coord = dist2 * (inv_dist * Q.inv_dx);
+    const f3 u = inv_dist * displace;
+    const float cos1 = dot(rvec1, u), cos2 = -dot(rvec2, u);
+    float b[4], db[4];
+    // angular splines (unclamped, spline.h:228-242)
+    float a1, da1, a2, da2;
+    {
+        const float x = (cos1 + 1.f) * Q.inv_dtheta + 1.f; const int bin = (int)x;
+        bspline_basis(x - (float)bin, b, db); bspline_vd(a1, da1, p, bin, b, db);
+    }
+    {
+        const float x = (cos2 + 1.f) * Q.inv_dtheta + 1.f; const int bin = (int)x;
+        bspline_basis(x - (float)bin, b, db); bspline_vd(a2, da2, p + Q.ka, bin, b, db);
+    }
+    // radial splines share one coordinate; clamped ends (spline.h:275-310)
+    float wide, dwide, narrow, dnarrow;
+    {
+        const bool too_small = dist_coord < 1.f, too_big = (float)(Q.k - 2) <= dist_coord;
+        const float xc = (too_small || too_big) ? 1.f : dist_coord;
+        const int bin = (int)xc;
+        bspline_basis(xc - (float)bin, b, db);
+        bspline_vd(wide, dwide, p + 2 * Q.ka, bin, b, db);
+        bspline_vd(narrow, dnarrow, p + 2 * Q.ka + Q.k, bin, b, db);
+        if (too_small || too_big) {
+            dwide = 0.f; dnarrow = 0.f;
+            const int o = too_small ? 0 : Q.k - 3;
+            P pw = p + 2 * Q.ka, pn = p + 2 * Q.ka + Q.k;
+            wide = (1.f / 6.f) * pw[o] + (2.f / 3.f) * pw[o + 1] + (1.f / 6.f) * pw[o + 2];
+            narrow = (1.f / 6.f) * pn[o] + (2.f / 3.f) * pn[o + 1] + (1.f / 6.f) * pn[o + 2];
+        }
+    }
+    const float angular_weight = a1 * a2;
+    if (WANT_D) {
+        const float radial_deriv = Q.inv_dx * (dwide + angular_weight * dnarrow);
+        const float angular_deriv1 = Q.inv_dtheta * da1 * a2 * narrow;
+        const float angular_deriv2 = Q.inv_dtheta * a1 * da2 * narrow;
+        const f3 rXX = angular_deriv1 * rvec1 - angular_deriv2 * rvec2;
+        const f3 deriv_dir = inv_dist * (rXX - dot(u, rXX) * u);
+        const f3 dd = radial_deriv * u + deriv_dir;
+        if (WANT_D == 1) {
+            d[0] = -dd.x; d[1] = -dd.y; d[2] = -dd.z;
+            d[3] = angular_deriv1 * u.x; d[4] = angular_deriv1 * u.y; d[5] = angular_deriv1 * u.z;
+        } else {
+            d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+            d[3] = -angular_deriv2 * u.x; d[4] = -angular_deriv2 * u.y; d[5] = -angular_deriv2 * u.z;
+        }
+    }
+    return wide + angular_weight * narrow;
+}
+
+// cooperative staging of one system's packed coordinates: elements [0,n) of `node` gathered through `loc`
+// into lds[i*8 .. i*8+dim)
+__device__ __forceinline__ void stage_coords(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim) {
+    const float* base = node.out + (size_t)s * node.n_elem * node.stride;
+    for (int t = threadIdx.x; t < n * 8; t += blockDim.x) {
+        const int i = t >> 3, c = t & 7;
+        lds[t] = c < dim ? base[(size_t)loc[i] * node.stride + c] : 0.f;
+    }
+}
+__device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
+}
+
+// Iterate over the in-range neighbours of one row with dense lanes.
+//   nbr/cnt: the row's cached list; xr: row coordinates; other: LDS coordinates [n][8] of the other side
+//   q: this wave's LDS queue (IG_QUEUE ints).  f(j, valid) is called with ALL lanes converged.
+template <typename F>
+__device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, int cnt, const float* xr, const float* other, float cut2,
+                                                 int* q, int lane, int skip_le /* symmetric energy pass: ignore j <= skip_le */, F f) {
+    int nq = 0;
+    for (int k0 = 0; k0 < cnt; k0 += 64) {
+        const int k = k0 + lane;
+        int j = -1; bool hit = false;
+        if (k < cnt) {
+            j = nbr[k];
+            const float* y = other + j * 8;
+            hit = (j > skip_le) && (dist2_exact(xr[0], xr[1], xr[2], y[0], y[1], y[2]) < cut2);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        nq += __popcll(m);
+        wave_lds_fence();
+        if (nq >= 64) {
+            const int jj = q[lane];
+            const int keep = lane + 64 < nq ? q[lane + 64] : 0;
+            wave_lds_fence();
+            f(jj, true);
+            if (lane + 64 < nq) q[lane] = keep;
+            nq -= 64;
+            wave_lds_fence();
+        }
+    }
+    if (nq > 0) {
+        const int jj = lane < nq ? q[lane] : 0;
+        wave_lds_fence();
+        f(jj, lane < nq);
+    }
+}
+
+}  // namespace up

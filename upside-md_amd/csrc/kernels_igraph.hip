@@ -11,6 +11,7 @@
 //     pair-list membership is bit-identical to the CPU oracle on identical coordinates.
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
+#include <cstring>
 
 using namespace up;
 
@@ -260,7 +261,7 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
         if (lane == 0) out[(size_t)s * out_sys_stride + (size_t)(out_row0 + row) * out_stride + out_comp] = acc;
     }
 }
-extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
+static int igraph_rowsum_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
                                  int out_stride, int out_comp, int out_row0) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_rowsum, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
@@ -320,12 +321,176 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
         }
     }
 }
-extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
+static int igraph_grad_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                                const float* sens2, long sens_sys_stride, int sens_stride) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_grad, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
                        sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
     return launch_status();
+}
+
+
+// ================================================================================================
+// LDS-staged kernels (the normal path): see igraph_device.h for the decomposition
+#include "igraph_device.h"
+
+__device__ __forceinline__ QuadShape quad_shape(const upk_igraph_t& G) { QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta; return Q; }
+
+// value and (optionally) the derivative w.r.t. the ROW element; x1 is always the side-1 element.
+// ROW_SIDE: 1 or 2.  GRAD: derivative wanted.  d has 8 entries.
+template <int IT, int ROW_SIDE, bool GRAD>
+__device__ __forceinline__ float pair_eval2(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
+                                            const float* x1, const float* x2, float* d) {
+    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
+    if (IT == UPK_IT_HBOND_COVERAGE) {
+        const float coverage = quadspline2<GRAD ? ROW_SIDE : 0>(Q, p, x1, x2, d);
+        const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
+        if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d[c] *= prefactor;
+            if (ROW_SIDE == 1) d[6] = -coverage * one_m * 2.f;
+        }
+        return prefactor * coverage;
+    } else if (IT == UPK_IT_ENVIRONMENT) {
+        float d1[8], d2[8];
+        const float v = environment_edge(p, x1, x2, d1, d2);
+        if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) d[c] = ROW_SIDE == 1 ? (c < 6 ? d1[c] : 0.f) : (c < 4 ? d2[c] : 0.f);
+        }
+        return v;
+    } else {
+        float d1[8], d2[8];
+        const float v = protein_hbond_edge(p, x1, x2, d1, d2);
+        if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) d[c] = c < 6 ? (ROW_SIDE == 1 ? d1[c] : d2[c]) : 0.f;
+        }
+        return v;
+    }
+}
+
+struct Ig2Args {
+    float* out; long out_sys_stride; int out_stride, out_comp, out_row0;      // rowsum
+    int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // grad
+    int tab_floats;
+};
+
+template <int IT, int ROW_SIDE, bool GRAD>
+__global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    float* tab = lds;
+    float* c1 = lds + ((A.tab_floats + 3) & ~3);
+    float* c2 = c1 + G.n1 * 8;
+    int* q = (int*)(c2 + G.n2 * 8) + wave * IG_QUEUE;
+    stage_table(tab, G.param, A.tab_floats);
+    stage_coords(c1, G.node1, s, G.loc1, G.n1, G.dim1);
+    stage_coords(c2, G.node2, s, G.loc2, G.n2, G.dim2);
+    __syncthreads();
+    const QuadShape Q = quad_shape(G);
+    const int n_rows = ROW_SIDE == 1 ? G.n1 : G.n2;
+    const float cut2 = G.cutoff * G.cutoff;
+    const float* crow = ROW_SIDE == 1 ? c1 : c2;
+    const float* coth = ROW_SIDE == 1 ? c2 : c1;
+    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
+    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
+    for (int row = blockIdx.x * n_wave + wave; row < n_rows; row += gridDim.x * n_wave) {
+        const int cap = ROW_SIDE == 1 ? G.cap1 : G.cap2;
+        const int* nbr = (ROW_SIDE == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)row * cap;
+        const int cnt = (ROW_SIDE == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[row];
+        float xr[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[c] = crow[row * 8 + c];
+        const int tr = ROW_SIDE == 1 ? G.type1[row] : G.type2[row];
+        float srow = 0.f;
+        if (GRAD) {
+            if (A.sens_mode == 1 && ROW_SIDE == 1) srow = S1[(size_t)row * A.sens_stride];
+            if (A.sens_mode == 2 && ROW_SIDE == 2) srow = S2[(size_t)row * A.sens_stride];
+            if (A.sens_mode == 3) srow = ROW_SIDE == 1 ? S1[(size_t)row * A.sens_stride] : S2[(size_t)row * A.sens_stride];
+        }
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        for_each_inrange(nbr, cnt, xr, coth, cut2, q, lane, -1, [&](int j, bool valid) {
+            if (!valid) return;
+            float xo[8], d[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { xo[c] = coth[j * 8 + c]; d[c] = 0.f; }
+            const int to = ROW_SIDE == 1 ? G.type2[j] : G.type1[j];
+            const float v = ROW_SIDE == 1 ? pair_eval2<IT, 1, GRAD>(G, Q, tab, tr, to, xr, xo, d)
+                                          : pair_eval2<IT, 2, GRAD>(G, Q, tab, to, tr, xo, xr, d);
+            if (!GRAD) { acc[0] += v; return; }
+            float ps;
+            if (A.sens_mode == 1) ps = ROW_SIDE == 1 ? srow : S1[(size_t)j * A.sens_stride];
+            else if (A.sens_mode == 2) ps = ROW_SIDE == 2 ? srow : S2[(size_t)j * A.sens_stride];
+            else ps = srow + (ROW_SIDE == 1 ? S2[(size_t)j * A.sens_stride] : S1[(size_t)j * A.sens_stride]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] += ps * d[c];
+        });
+        if (!GRAD) {
+            const float t = wave_sum(acc[0]);
+            if (lane == 0) A.out[(size_t)s * A.out_sys_stride + (size_t)(A.out_row0 + row) * A.out_stride + A.out_comp] = t;
+        } else {
+            const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = wave_sum(acc[c]);
+            if (lane == 0) {
+                const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
+                float* t = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1[row] : G.loc2[row]) * node.stride;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c < dim_row) t[c] += acc[c];
+            }
+        }
+    }
+}
+
+static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+    tab_floats = G->n_type1 * G->n_type2 * G->n_param;
+    const int waves = 16;
+    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
+    if (lds_bytes > 158 * 1024) return false;
+    int bps = (1024 + L->n_system - 1) / L->n_system;            // aim at >= 1024 workgroups in flight across systems
+    const int max_bps = (n_rows + waves - 1) / waves;
+    if (bps > max_bps) bps = max_bps;
+    if (bps < 1) bps = 1;
+    grid = dim3(bps, L->n_system); block = dim3(waves * 64);
+    return true;
+}
+
+template <int IT>
+static int ig2_launch(const upk_launch_t* L, const upk_igraph_t* G, int side, bool grad, const Ig2Args& A0) {
+    Ig2Args A = A0; size_t lds; dim3 grid, block;
+    if (!ig2_geometry(L, G, side == 1 ? G->n1 : G->n2, A.tab_floats, lds, grid, block)) return -1;
+    if (side == 1) { if (grad) hipLaunchKernelGGL((k_ig2<IT, 1, true>), grid, block, lds, ST(L), *G, A); else hipLaunchKernelGGL((k_ig2<IT, 1, false>), grid, block, lds, ST(L), *G, A); }
+    else           { if (grad) hipLaunchKernelGGL((k_ig2<IT, 2, true>), grid, block, lds, ST(L), *G, A); else hipLaunchKernelGGL((k_ig2<IT, 2, false>), grid, block, lds, ST(L), *G, A); }
+    return launch_status();
+}
+static int ig2_dispatch(const upk_launch_t* L, const upk_igraph_t* G, int side, bool grad, const Ig2Args& A) {
+    switch (G->itype) {
+        case UPK_IT_HBOND_COVERAGE: return ig2_launch<UPK_IT_HBOND_COVERAGE>(L, G, side, grad, A);
+        case UPK_IT_ENVIRONMENT: return ig2_launch<UPK_IT_ENVIRONMENT>(L, G, side, grad, A);
+        case UPK_IT_PROTEIN_HBOND: return ig2_launch<UPK_IT_PROTEIN_HBOND>(L, G, side, grad, A);
+        default: return -1;
+    }
+}
+
+extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
+                                 int out_stride, int out_comp, int out_row0) {
+    Ig2Args A; memset(&A, 0, sizeof(A));
+    A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp; A.out_row0 = out_row0;
+    const int r = ig2_dispatch(L, G, side, false, A);
+    if (r >= 0) return r;
+    return igraph_rowsum_v1(L, G, side, out, out_sys_stride, out_stride, out_comp, out_row0);   // system too large for LDS staging
+}
+extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
+                               const float* sens2, long sens_sys_stride, int sens_stride) {
+    Ig2Args A; memset(&A, 0, sizeof(A));
+    A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
+    const int r = ig2_dispatch(L, G, side, true, A);
+    if (r >= 0) return r;
+    return igraph_grad_v1(L, G, side, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
 }
 
 // parity / diagnostics: which cached neighbours of the side-1 rows are in range this step

@@ -12,6 +12,7 @@
 //     pair gradient per bead row and reduces it with wavefront shuffles.
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
+#include "igraph_device.h"
 
 using namespace up;
 
@@ -53,6 +54,10 @@ __device__ __forceinline__ float quadspline_r(const upk_igraph_t& G, const float
     }
     return wide + angular_weight * narrow;
 }
+
+// slot matrices are stored structure-of-arrays: entry e (= ra*6+rb) of slot sl lives at [e*slot_cap + sl], so that
+// consecutive lanes working on consecutive slots read consecutive addresses
+#define PIDX(R, sl, e) ((size_t)(e) * (R).slot_cap + (sl))
 
 __device__ __forceinline__ void load6(float* x, const upk_coord_t& node, int s, int loc) {
     const float* p = C_OUT(node, s) + (size_t)loc * node.stride;
@@ -181,7 +186,7 @@ __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
     const int s = blockIdx.y;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_slot = R.n_slot[s];
-    if (tid < n_slot * 36) R.P[(size_t)s * R.slot_cap * 36 + tid] = 0.f;
+    if (tid < R.slot_cap * 36 && (tid % R.slot_cap) < n_slot) R.P[(size_t)s * R.slot_cap * 36 + tid] = 0.f;
     if (tid < n_slot) R.slot_active[(size_t)s * R.slot_cap + tid] = 0;
     if (tid >= R.n_node) return;
     const int g = tid, n_rot = R.node_nrot[g];
@@ -211,39 +216,71 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 }
 
 // bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
-__global__ void k_rotamer_pair_energy(upk_rotamer_t R) {
+struct RotLds { float* tab; float* coords; int* q; };
+__device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
+    RotLds r;
+    r.tab = lds; r.coords = lds + ((tab_floats + 3) & ~3);
+    r.q = (int*)(r.coords + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
+    stage_table(r.tab, R.G.param, tab_floats);
+    stage_coords(r.coords, R.G.node1, s, R.G.loc1, R.G.n1, 6);
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const RotLds L = rot_stage(R, lds, s, tab_floats);
     const int NN = R.n_node;
     const float cut2 = G.cutoff * G.cutoff;
     const int* slot_of = R.slot_of + (size_t)s * NN * NN;
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active = R.slot_active + (size_t)s * R.slot_cap;
-    for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * ROWS_PER_BLOCK) {
+    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
+    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
         const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[6]; load6(xr, G.node1, s, G.loc1[row]);
+        float xr[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xr[c] = L.coords[row * 8 + c];
         const int tr = G.type1[row], a = R.bead_node[row], ra = R.bead_rot[row];
-        for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
-            if (j <= row) continue;                       // each pair once, i1 < i2 as in the reference
-            float xo[6]; load6(xo, G.node1, s, G.loc1[j]);
-            if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
-            const float* p = G.param + (size_t)(tr * G.n_type2 + G.type1[j]) * G.n_param;
-            const float E = quadspline_r(G, p, xr, xo, nullptr);
+        // each pair once: only partners with a larger bead index (i1 < i2 as in the reference)
+        for_each_inrange(nbr, cnt, xr, L.coords, cut2, L.q, lane, row, [&](int j, bool valid) {
+            if (!valid) return;
+            float xo[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) xo[c] = L.coords[j * 8 + c];
+            const float* p = L.tab + (tr * G.n_type2 + G.type1[j]) * G.n_param;
+            const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
             const int b = R.bead_node[j], rb = R.bead_rot[j];
             const int sl = slot_of[a * NN + b];
-            if (sl < 0) continue;                         // only after a capacity overflow (error flag is set)
+            if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
             const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
-            atomicAdd(&P[(size_t)sl * 36 + idx], E);      // one bead per rotamer state => a single contributor
+            atomicAdd(&P[PIDX(R, sl, idx)], E);           // one bead per rotamer state => a single contributor
             active[sl] = 1;
-        }
+        });
     }
 }
 
+static bool rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+    tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
+    const int waves = 16;
+    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)R->G.n1 * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
+    if (lds_bytes > 158 * 1024) return false;
+    int bps = (1024 + L->n_system - 1) / L->n_system;
+    const int max_bps = (R->G.n1 + waves - 1) / waves;
+    if (bps > max_bps) bps = max_bps;
+    if (bps < 1) bps = 1;
+    grid = dim3(bps, L->n_system); block = dim3(waves * 64);
+    return true;
+}
+
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
-    hipLaunchKernelGGL(k_rotamer_pair_energy, dim3((R->G.n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *R);
+    int tab_floats; size_t lds; dim3 grid, block;
+    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;   // more beads than LDS can stage
+    hipLaunchKernelGGL(k_rotamer_pair_energy, grid, block, lds, ST(L), *R, tab_floats);
     return launch_status();
 }
 
@@ -271,7 +308,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 // one residue-pair edge with compile-time state counts: new messages from the old beliefs
 // (update_beliefs, rotamer.cpp:468-499 and the L1 normalisation of 506-521), written in place
 template <int NA, int NB>
-__device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, const float* __restrict__ nba, const float* __restrict__ nbb,
+__device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, int pstride, const float* __restrict__ nba, const float* __restrict__ nbb,
                                         float* __restrict__ ma, float* __restrict__ mb) {
     float va[NA], vb[NB], P[NA][NB];
 #pragma unroll
@@ -281,7 +318,7 @@ __device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, const floa
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) P[i][j] = Ps[i * 6 + j];
+        for (int j = 0; j < NB; ++j) P[i][j] = Ps[(size_t)(i * 6 + j) * pstride];
     float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) { float t = 0.f;
@@ -302,9 +339,14 @@ __device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, const floa
 
 // pair marginal and (optionally) its Bethe free-energy term (rotamer.cpp:405-451)
 template <int NA, int NB>
-__device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, const float* __restrict__ nba, const float* __restrict__ nbb,
+__device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, int pstride, const float* __restrict__ nba, const float* __restrict__ nbb,
                                              const float* __restrict__ ma, const float* __restrict__ mb, float* __restrict__ mg_out,
                                              bool want_energy) {
+    float Pl[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Pl[i][j] = Ps[(size_t)(i * 6 + j) * pstride];
     float bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) bc1[i] = nba[i] * rcp(1e-10f + ma[i]);
@@ -313,7 +355,7 @@ __device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, const
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { mg[i][j] = Ps[i * 6 + j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
+        for (int j = 0; j < NB; ++j) { mg[i][j] = Pl[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
     const float rs = rcp(sum);
     float en = 0.f;
 #pragma unroll
@@ -321,8 +363,8 @@ __device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, const
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float pm = mg[i][j] * rs;
-            mg_out[i * 6 + j] = pm;
-            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + Ps[i * 6 + j] * nba[i] * nbb[j]));
+            mg_out[(size_t)(i * 6 + j) * pstride] = pm;
+            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + Pl[i][j] * nba[i] * nbb[j]));
         }
     return en;
 }
@@ -336,26 +378,31 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
     float* nb0 = lds + NN * 6;         // [NN][6]
     float* nb1 = lds + NN * 12;        // [NN][6]
-    float* scratch = lds + NN * 18;    // [16]
+    float* scratch = lds + NN * 18;    // [32]
+    int* nrot = (int*)(lds + NN * 18 + 32);      // [NN]   state counts
+    int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
     const int n_slot = R.n_slot[s];
+    const int cap = R.slot_cap;
     const int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
     const int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
     const int* active = R.slot_active + (size_t)s * R.slot_cap;
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
-    const int* bp_start = R.bp_start + (size_t)s * (NN + 1);
+    for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
+    for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
+    __syncthreads();
     const int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     float* inbox = R.msg_cur + (size_t)s * R.slot_cap * 12;
     float* marg = R.marg + (size_t)s * R.slot_cap * 36;
-    const int* nrot = R.node_nrot;
 
     // energies -> probabilities (rotamer.cpp:835); old edge beliefs = 1 (rotamer.cpp:1015-1032), also for the
     // slots without an in-range bead pair this step, whose (unit) message then multiplies as an exact 1
     for (int i = tid; i < n_slot * 36; i += nt) {
-        const int sl = i / 36, e = i % 36, ra = e / 6, rb = e % 6;
+        const int e = i / n_slot, sl = i % n_slot, ra = e / 6, rb = e % 6;
         const bool used = ra < nrot[slot_a[sl]] && rb < nrot[slot_b[sl]];
-        P[i] = used ? expf(-P[i]) : 0.f;
+        const size_t pi = (size_t)e * cap + sl;
+        P[pi] = used ? expf(-P[pi]) : 0.f;
     }
     for (int i = tid; i < bp_start[NN] * 6; i += nt) inbox[i] = 1.f;
     for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
@@ -368,7 +415,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
             const int sl = adj_slot[g * R.adj_cap + k];
             const int a = slot_a[sl];
             if (a == g || nrot[a] != 1 || !active[sl]) continue;     // a 1-state partner always has the lower id
-            for (int r = 0; r < n; ++r) prob[g * 6 + r] *= P[(size_t)sl * 36 + r];
+            for (int r = 0; r < n; ++r) prob[g * 6 + r] *= P[(size_t)r * cap + sl];
         }
     }
     __syncthreads();
@@ -388,12 +435,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
             const int na = nrot[a];
             if (na == 1 || !active[sl]) continue;
             const int nb = nrot[b];
-            const float* Ps = P + (size_t)sl * 36;
+            const float* Ps = P + sl;
             float* ma = inbox + slot_off[sl * 2];
             float* mb = inbox + slot_off[sl * 2 + 1];
-            if (na == 3 && nb == 3) bp_edge<3, 3>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
-            else if (na == 3) bp_edge<3, 6>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
-            else bp_edge<6, 6>(Ps, nb_old + a * 6, nb_old + b * 6, ma, mb);
+            if (na == 3 && nb == 3) bp_edge<3, 3>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
+            else if (na == 3) bp_edge<3, 6>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
+            else bp_edge<6, 6>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
         }
         __syncthreads();
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
@@ -464,15 +511,15 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         const int a = slot_a[sl], b = slot_b[sl];
         const int na = nrot[a], nb = nrot[b];
         if (!active[sl]) continue;
-        const float* Ps = P + (size_t)sl * 36;
+        const float* Ps = P + sl;
         if (nb == 1) { if (want_energy) en += -logf(Ps[0]); continue; }   // 1-1 edge (rotamer.cpp:861)
         if (na == 1) continue;                                            // folded into node b
         const float* ma = inbox + slot_off[sl * 2];
         const float* mb = inbox + slot_off[sl * 2 + 1];
-        float* mo = marg + (size_t)sl * 36;
-        if (na == 3 && nb == 3) en += bp_marginal<3, 3>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
-        else if (na == 3) en += bp_marginal<3, 6>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
-        else en += bp_marginal<6, 6>(Ps, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
+        float* mo = marg + sl;
+        if (na == 3 && nb == 3) en += bp_marginal<3, 3>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
+        else if (na == 3) en += bp_marginal<3, 6>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
+        else en += bp_marginal<6, 6>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
     }
     if (want_energy) {
         for (int g = tid; g < NN; g += nt) {   // node_free_energy, rotamer.cpp:292-302
@@ -488,7 +535,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
 }
 
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
-    const size_t lds = ((size_t)R->n_node * 18 + 32) * sizeof(float);
+    const size_t lds = ((size_t)R->n_node * 20 + 40) * sizeof(float);
     if (lds > 155 * 1024) return 9004;
     hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy);
     return launch_status();
@@ -496,30 +543,35 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
 
 // ------------------------------------------------------------------------------------------------
 // derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
-__global__ void k_rotamer_grad(upk_rotamer_t R) {
+__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const RotLds L = rot_stage(R, lds, s, tab_floats);
     const int NN = R.n_node;
     const float cut2 = G.cutoff * G.cutoff;
     const int* slot_of = R.slot_of + (size_t)s * NN * NN;
     const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
     const float* nbm = R.nb_cur + (size_t)s * NN * 6;
-    for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * ROWS_PER_BLOCK) {
+    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
+    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
         const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[6]; load6(xr, G.node1, s, G.loc1[row]);
+        float xr[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xr[c] = L.coords[row * 8 + c];
         const int tr = G.type1[row], a = R.bead_node[row], ra = R.bead_rot[row], na = R.node_nrot[a];
         float acc[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc[c] = 0.f;
-        for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
-            float xo[6]; load6(xo, G.node1, s, G.loc1[j]);
-            if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
-            const float* p = G.param + (size_t)(tr * G.n_type2 + G.type1[j]) * G.n_param;
-            float d1[6];
-            quadspline_r(G, p, xr, xo, d1);
+        for_each_inrange(nbr, cnt, xr, L.coords, cut2, L.q, lane, -1, [&](int j, bool valid) {
+            if (!valid) return;
+            float xo[6], d1[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) xo[c] = L.coords[j * 8 + c];
+            const float* p = L.tab + (tr * G.n_type2 + G.type1[j]) * G.n_param;
+            quadspline2<1>(Q, p, xr, xo, d1);
             const int b = R.bead_node[j], rb = R.bead_rot[j], nb = R.node_nrot[b];
             float ps;
             if (na == 1 && nb == 1) ps = 1.f;
@@ -527,11 +579,11 @@ __global__ void k_rotamer_grad(upk_rotamer_t R) {
             else if (nb == 1) ps = nbm[a * 6 + ra];
             else {
                 const int sl = slot_of[a * NN + b];
-                ps = sl < 0 ? 0.f : marg[(size_t)sl * 36 + (a < b ? ra * 6 + rb : rb * 6 + ra)];
+                ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) acc[c] += ps * d1[c];
-        }
+        });
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
         if (lane == 0) {
@@ -545,6 +597,8 @@ __global__ void k_rotamer_grad(upk_rotamer_t R) {
     }
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
-    hipLaunchKernelGGL(k_rotamer_grad, dim3((R->G.n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *R);
+    int tab_floats; size_t lds; dim3 grid, block;
+    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;
+    hipLaunchKernelGGL(k_rotamer_grad, grid, block, lds, ST(L), *R, tab_floats);
     return launch_status();
 }

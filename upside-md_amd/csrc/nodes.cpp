@@ -731,7 +731,7 @@ struct RotamerSidechain : public PotentialNode {
                 int a = sa[sl], b = sb[sl];
                 if (node_nrot[a] == 1 && node_nrot[b] != 1) continue;   // 1-3 / 1-6 edges are not listed (rotamer.cpp:745)
                 for (int r1 = 0; r1 < node_nrot[a]; ++r1) for (int r2 = 0; r2 < node_nrot[b]; ++r2) {
-                    float v = node_nrot[b] == 1 ? 1.f : mg[(size_t)sl * 36 + r1 * 6 + r2];
+                    float v = node_nrot[b] == 1 ? 1.f : mg[(size_t)(r1 * 6 + r2) * R.slot_cap + sl];
                     ev[(((size_t)a * n_node + b) * 6 + r1) * 6 + r2] = v;
                     ev[(((size_t)b * n_node + a) * 6 + r2) * 6 + r1] = v;
                 }
