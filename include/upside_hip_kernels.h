@@ -113,6 +113,9 @@ typedef struct {
     float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from */
     int* rebuild_flag;                   /* [S] */
     int* error_flag;                     /* [1] set to non-zero on capacity overflow */
+    /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
+       (mark_n x mark_n ints, pre-cleared to -1 by upk_rotamer_clear_slots) is set to -2 for every cached pair */
+    int* mark_table; const int* mark_node; int mark_n;
 } upk_igraph_t;
 
 /* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build
@@ -141,6 +144,7 @@ typedef struct {
     int n_node, n_node1, n_node3;        /* global node ids: class 1, then 3, then 6 */
     const int* node_nrot;                /* [n_node] */
     const int *bead_node, *bead_rot;     /* [n_bead] */
+    const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     const int *node_bead_start, *node_bead_list;   /* CSR (node*6+rot) -> beads of that rotamer state */
     int n_prob; const float* const* prob_out; float* const* prob_sens; const int* prob_stride;   /* 1-body parents (device arrays of device ptrs) */
     const long* prob_sys_stride;
@@ -150,14 +154,22 @@ typedef struct {
     int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
-    float *P, *msg_cur, *msg_old, *marg; /* [S][cap][36], inbox [S][cap][12] (messages grouped by receiving node), unused, [S][cap][36] */
+    int *class_start;                    /* [S][6] slot ranges by class: 3x3, 3x6, 6x6, 1x1, 1xN */
+    int *nbr_slot;                       /* [S][n_bead][cap1] slot of every cached bead pair */
+    int *slot_active_last;               /* [S][cap] activity flags of the last solve (diagnostics) */
+    float *P, *msg_cur, *msg_old, *marg; /* P, marg: SoA [S][36][cap]; msg_cur: inbox [S][cap][16] (8-float message rows grouped by receiving node); msg_old unused */
     float damping, tol; int max_iter, chunk;
     int* iters;                          /* [S] sweeps of the last solve */
+    long long* bp_trace;                 /* [S][16] 100 MHz phase clocks of the last solve, or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
 } upk_rotamer_t;
 
-/* after a pair-list rebuild: residue-pair slots and node adjacency (replaces EdgeLocator, rotamer.cpp:134-206) */
+/* pair-list rebuild of flagged systems (replaces EdgeLocator, rotamer.cpp:134-206): clear the node x node table,
+ * [upk_pairlist_build marks it through G.mark_table], number the slots by class + adjacency + inbox layout, and
+ * record the slot of every cached bead pair */
+int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R);
 int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R);
+int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R);
 /* 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256) */
 int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t* R);
 /* bead-pair energies accumulated into the residue-pair matrices (rotamer.cpp:829-846, interaction_graph.h:470-503) */

@@ -107,22 +107,37 @@ __device__ __forceinline__ float quadspline2(const QuadShape& Q, P p, const floa
     return wide + angular_weight * narrow;
 }
 
-// cooperative staging of one system's packed coordinates: elements [0,n) of `node` gathered through `loc`
-// into lds[i*8 .. i*8+dim)
-__device__ __forceinline__ void stage_coords(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim) {
+// cooperative staging of one system's packed elements: element i of `node` (gathered through `loc`) becomes the
+// 8-float LDS row  [0,dim) coordinates | [6] aux0 | [7] aux1  where the aux words carry per-element metadata so
+// that the pair loop never touches global memory for them:
+//   aux1 = integer `meta1[i]` (e.g. the element type) as raw bits,
+//   aux0 = sens[i*sens_stride] (a per-element pair sensitivity) when dim <= 6 and sens != nullptr,
+//          else integer `meta0[i]` as raw bits when meta0 != nullptr.
+__device__ __forceinline__ void stage_rows(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim,
+                                           const int* __restrict__ meta1, const int* __restrict__ meta0,
+                                           const float* __restrict__ sens, int sens_stride) {
     const float* base = node.out + (size_t)s * node.n_elem * node.stride;
     for (int t = threadIdx.x; t < n * 8; t += blockDim.x) {
         const int i = t >> 3, c = t & 7;
-        lds[t] = c < dim ? base[(size_t)loc[i] * node.stride + c] : 0.f;
+        float v = 0.f;
+        if (c < dim) v = base[(size_t)loc[i] * node.stride + c];
+        else if (c == 7 && meta1) v = __int_as_float(meta1[i]);
+        else if (c == 6 && sens) v = sens[(size_t)i * sens_stride];
+        else if (c == 6 && meta0) v = __int_as_float(meta0[i]);
+        lds[t] = v;
     }
+}
+__device__ __forceinline__ void stage_coords(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim) {
+    stage_rows(lds, node, s, loc, n, dim, nullptr, nullptr, nullptr, 0);
 }
 __device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
 }
 
 // Iterate over the in-range neighbours of one row with dense lanes.
-//   nbr/cnt: the row's cached list; xr: row coordinates; other: LDS coordinates [n][8] of the other side
-//   q: this wave's LDS queue (IG_QUEUE ints).  f(j, valid) is called with ALL lanes converged.
+//   nbr/cnt: the row's cached list; xr: row coordinates; other: LDS rows [n][8] of the other side
+//   q: this wave's LDS queue (IG_QUEUE ints).  f(j, k, valid) is called with ALL lanes converged; k is the position
+//   of neighbour j in the row's cached list (j < 2^20, k < 2^12 are packed into one queue word).
 template <typename F>
 __device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, int cnt, const float* xr, const float* other, float cut2,
                                                  int* q, int lane, int skip_le /* symmetric energy pass: ignore j <= skip_le */, F f) {
@@ -136,24 +151,26 @@ __device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, in
             hit = (j > skip_le) && (dist2_exact(xr[0], xr[1], xr[2], y[0], y[1], y[2]) < cut2);
         }
         const unsigned long long m = __ballot(hit);
-        if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = j | (k << 20);
         nq += __popcll(m);
         wave_lds_fence();
         if (nq >= 64) {
-            const int jj = q[lane];
+            const int w = q[lane];
             const int keep = lane + 64 < nq ? q[lane + 64] : 0;
             wave_lds_fence();
-            f(jj, true);
+            f(w & 0xFFFFF, (int)((unsigned)w >> 20), true);
             if (lane + 64 < nq) q[lane] = keep;
             nq -= 64;
             wave_lds_fence();
         }
     }
     if (nq > 0) {
-        const int jj = lane < nq ? q[lane] : 0;
+        const int w = lane < nq ? q[lane] : 0;
         wave_lds_fence();
-        f(jj, lane < nq);
+        f(w & 0xFFFFF, (int)((unsigned)w >> 20), lane < nq);
     }
 }
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 
 }  // namespace up

@@ -218,6 +218,11 @@ __global__ void k_pairlist_build(upk_igraph_t G) {
             const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
             if (hit && pos < cap) nbr[pos] = j;
             count += __popcll(b);
+            if (G.mark_table && hit && j > i) {   // residue pairs owning a cached bead pair (rotamer slots); benign race
+                int* mt = G.mark_table + (size_t)s * G.mark_n * G.mark_n;
+                const int a = G.mark_node[i], bb = G.mark_node[j];
+                mt[a * G.mark_n + bb] = -2; mt[bb * G.mark_n + a] = -2;
+            }
         }
         if (lane == 0) {
             (side1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[i] = count < cap ? count : cap;
@@ -385,17 +390,18 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     float* c1 = lds + ((A.tab_floats + 3) & ~3);
     float* c2 = c1 + G.n1 * 8;
     int* q = (int*)(c2 + G.n2 * 8) + wave * IG_QUEUE;
+    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
+    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(tab, G.param, A.tab_floats);
-    stage_coords(c1, G.node1, s, G.loc1, G.n1, G.dim1);
-    stage_coords(c2, G.node2, s, G.loc2, G.n2, G.dim2);
+    // rows: [0,dim) coordinates, [6] per-element pair sensitivity (sides with dim <= 6), [7] element type
+    stage_rows(c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (GRAD && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
+    stage_rows(c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (GRAD && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
     __syncthreads();
     const QuadShape Q = quad_shape(G);
     const int n_rows = ROW_SIDE == 1 ? G.n1 : G.n2;
     const float cut2 = G.cutoff * G.cutoff;
     const float* crow = ROW_SIDE == 1 ? c1 : c2;
     const float* coth = ROW_SIDE == 1 ? c2 : c1;
-    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
-    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     for (int row = blockIdx.x * n_wave + wave; row < n_rows; row += gridDim.x * n_wave) {
         const int cap = ROW_SIDE == 1 ? G.cap1 : G.cap2;
         const int* nbr = (ROW_SIDE == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)row * cap;
@@ -403,29 +409,24 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
         float xr[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) xr[c] = crow[row * 8 + c];
-        const int tr = ROW_SIDE == 1 ? G.type1[row] : G.type2[row];
-        float srow = 0.f;
-        if (GRAD) {
-            if (A.sens_mode == 1 && ROW_SIDE == 1) srow = S1[(size_t)row * A.sens_stride];
-            if (A.sens_mode == 2 && ROW_SIDE == 2) srow = S2[(size_t)row * A.sens_stride];
-            if (A.sens_mode == 3) srow = ROW_SIDE == 1 ? S1[(size_t)row * A.sens_stride] : S2[(size_t)row * A.sens_stride];
-        }
+        const int tr = __float_as_int(xr[7]);
+        // pair sensitivity = (row part) + (other part); a part is 0 when that side does not contribute
+        const bool row_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == ROW_SIDE));
+        const bool oth_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == 3 - ROW_SIDE));
+        const float srow = row_has ? xr[6] : 0.f;
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-        for_each_inrange(nbr, cnt, xr, coth, cut2, q, lane, -1, [&](int j, bool valid) {
+        for_each_inrange(nbr, cnt, xr, coth, cut2, q, lane, -1, [&](int j, int, bool valid) {
             if (!valid) return;
             float xo[8], d[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) { xo[c] = coth[j * 8 + c]; d[c] = 0.f; }
-            const int to = ROW_SIDE == 1 ? G.type2[j] : G.type1[j];
+            const int to = __float_as_int(xo[7]);
             const float v = ROW_SIDE == 1 ? pair_eval2<IT, 1, GRAD>(G, Q, tab, tr, to, xr, xo, d)
                                           : pair_eval2<IT, 2, GRAD>(G, Q, tab, to, tr, xo, xr, d);
             if (!GRAD) { acc[0] += v; return; }
-            float ps;
-            if (A.sens_mode == 1) ps = ROW_SIDE == 1 ? srow : S1[(size_t)j * A.sens_stride];
-            else if (A.sens_mode == 2) ps = ROW_SIDE == 2 ? srow : S2[(size_t)j * A.sens_stride];
-            else ps = srow + (ROW_SIDE == 1 ? S2[(size_t)j * A.sens_stride] : S1[(size_t)j * A.sens_stride]);
+            const float ps = srow + (oth_has ? xo[6] : 0.f);
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += ps * d[c];
         });

@@ -4,12 +4,15 @@
 //   * side-chain "nodes" (one per residue with 1/3/6 rotamer states) get global ids sorted by state count
 //     (1-state, then 3, then 6), so the reference's canonical edge orientation n_rot1 <= n_rot2
 //     (rotamer.cpp:837) is simply a < b;
-//   * residue-pair "slots" (the BP edges) are assigned on the device when the bead pair list is rebuilt:
-//     a dense node x node table replaces the EdgeLocator hash (rotamer.cpp:134-206) and per-node adjacency
-//     lists make the belief update a gather (no in-place multiply through a shared node belief);
-//   * bead-pair energies are accumulated straight into the 6x6 slot matrices, belief propagation runs as ONE
-//     persistent workgroup per system with the node beliefs in LDS, and the derivative pass re-evaluates the
-//     pair gradient per bead row and reduces it with wavefront shuffles.
+//   * residue-pair "slots" (the BP edges) are assigned on the device when the bead pair list is rebuilt: the list
+//     build marks a dense node x node table (replaces the EdgeLocator hash, rotamer.cpp:134-206), one workgroup
+//     per system then numbers the slots GROUPED BY CLASS (3x3, 3x6, 6x6, 1x1, 1xN) so that belief propagation
+//     runs divergence-free template instances over contiguous ranges, and every cached bead pair remembers its
+//     slot (nbr_slot) so the pair kernels need no table lookup;
+//   * slot matrices are structure-of-arrays ([36][slot_cap]); BP messages live in an "inbox" grouped by receiving
+//     node so the node update streams them;
+//   * belief propagation is ONE persistent workgroup per system with node beliefs in LDS; the bead-pair kernels
+//     stage the spline table and every bead (coordinates + packed metadata) of the system in LDS.
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
 #include "igraph_device.h"
@@ -17,95 +20,77 @@
 using namespace up;
 
 #define ST(L) ((hipStream_t)(L)->stream)
-#define ROWS_PER_BLOCK 4
-#define IG_BLOCK (ROWS_PER_BLOCK * UP_WAVE)
 #define BP_BLOCK 1024
 static inline int launch_status() { return (int)hipGetLastError(); }
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
-
-// defined in kernels_igraph.hip; duplicated as a static inline copy would be error-prone, so the quadspline is
-// re-declared here through a small header-less contract: same translation unit layout, separate copy.
-__device__ __forceinline__ float quadspline_r(const upk_igraph_t& G, const float* __restrict__ p, const float* x1, const float* x2,
-                                              float* d1) {
-    const int ka = G.n_knot_angular, k = G.n_knot;
-    const float inv_dx = G.inv_dx, inv_dtheta = G.inv_dtheta;
-    const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
-    const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
-    const float dist2 = mag2(displace), inv_dist = rsqrt_(dist2);
-    const float dist_coord = dist2 * (inv_dist * inv_dx);
-    const f3 u = inv_dist * displace;
-    const float cos1 = dot(rvec1, u), cos2 = -dot(rvec2, u);
-    float a1, da1, a2, da2, wide, dwide, narrow, dnarrow;
-    deBoor_vd(a1, da1, p, (cos1 + 1.f) * inv_dtheta + 1.f);
-    deBoor_vd(a2, da2, p + ka, (cos2 + 1.f) * inv_dtheta + 1.f);
-    clamped_deBoor_vd(wide, dwide, p + 2 * ka, dist_coord, k);
-    clamped_deBoor_vd(narrow, dnarrow, p + 2 * ka + k, dist_coord, k);
-    const float angular_weight = a1 * a2;
-    if (d1) {
-        const float radial_deriv = inv_dx * (dwide + angular_weight * dnarrow);
-        const float angular_deriv1 = inv_dtheta * da1 * a2 * narrow;
-        const float angular_deriv2 = inv_dtheta * a1 * da2 * narrow;
-        const f3 rXX = angular_deriv1 * rvec1 - angular_deriv2 * rvec2;
-        const f3 deriv_dir = inv_dist * (rXX - dot(u, rXX) * u);
-        const f3 dd = radial_deriv * u + deriv_dir;
-        d1[0] = -dd.x; d1[1] = -dd.y; d1[2] = -dd.z;
-        d1[3] = angular_deriv1 * u.x; d1[4] = angular_deriv1 * u.y; d1[5] = angular_deriv1 * u.z;
-    }
-    return wide + angular_weight * narrow;
-}
-
-// slot matrices are stored structure-of-arrays: entry e (= ra*6+rb) of slot sl lives at [e*slot_cap + sl], so that
-// consecutive lanes working on consecutive slots read consecutive addresses
 #define PIDX(R, sl, e) ((size_t)(e) * (R).slot_cap + (sl))
 
-__device__ __forceinline__ void load6(float* x, const upk_coord_t& node, int s, int loc) {
-    const float* p = C_OUT(node, s) + (size_t)loc * node.stride;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) x[c] = p[c];
+// slot classes in storage order
+enum { CL33 = 0, CL36 = 1, CL66 = 2, CL11 = 3, CL1X = 4, N_CLASS = 5 };
+__device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
+    if (na == 1) return nb == 1 ? CL11 : CL1X;
+    if (na == 3) return nb == 3 ? CL33 : CL36;
+    return CL66;
 }
 
 // ------------------------------------------------------------------------------------------------
-// slots + adjacency, one workgroup per flagged system
+// rebuild step 0: clear the node x node table of flagged systems (before the list build marks it)
+__global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
+    const int s = blockIdx.y;
+    if (!R.G.rebuild_flag[s]) return;
+    const int n = R.n_node * R.n_node;
+    int* slot_of = R.slot_of + (size_t)s * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slot_of[i] = -1;
+}
+extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    const int n = R->n_node * R->n_node;
+    int blocks = (n + 1023) / 1024; if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, L->n_system), dim3(1024), 0, ST(L), *R);
+    return launch_status();
+}
+
+// rebuild step 2 (after the list build has marked the table): number the slots by class, build the adjacency and
+// the message inbox layout; one workgroup per flagged system
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t R) {
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
     if (!G.rebuild_flag[s]) return;
-    __shared__ int row_count[2048];
-    __shared__ int row_start[2048];
-    __shared__ int total;
+    __shared__ int row_cnt[2][1024];      // per row a: hits in its lower / higher class (a row feeds at most two classes)
+    __shared__ int row_pos[2][1024];
+    __shared__ int class_base[N_CLASS + 1];
+    __shared__ int deg_bp[1024];
     const int NN = R.n_node;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_wave = blockDim.x >> 6;
     int* slot_of = R.slot_of + (size_t)s * NN * NN;
-    for (int i = tid; i < NN * NN; i += blockDim.x) slot_of[i] = -1;
-    __syncthreads();
-    // mark residue pairs that own at least one cached bead pair
-    for (int row = wave; row < G.n1; row += n_wave) {
-        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
-        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        const int a = R.bead_node[row];
-        for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
-            if (j <= row) continue;
-            const int b = R.bead_node[j];
-            slot_of[a * NN + b] = -2; slot_of[b * NN + a] = -2;    // benign race: all writers store -2
-        }
-    }
-    __syncthreads();
-    // count canonical (a<b) marked pairs per row a
+    const int* nrot = R.node_nrot;
+    // a row's partners b > a come in ascending class: row class 1 -> (1,1) then (1,x); 3 -> (3,3) then (3,6); 6 -> (6,6)
     for (int a = wave; a < NN; a += n_wave) {
-        int c = 0;
+        const int na = nrot[a];
+        int c_lo = 0, c_hi = 0;
         for (int b0 = a + 1; b0 < NN; b0 += 64) {
             const int b = b0 + lane;
-            c += __popcll(__ballot(b < NN && slot_of[a * NN + b] == -2));
+            const bool hit = b < NN && slot_of[a * NN + b] == -2;
+            const bool lo = hit && nrot[b] == na;
+            c_lo += __popcll(__ballot(lo));
+            c_hi += __popcll(__ballot(hit && !lo));
         }
-        if (lane == 0) row_count[a] = c;
+        if (lane == 0) { row_cnt[0][a] = c_lo; row_cnt[1][a] = c_hi; }
     }
     __syncthreads();
-    if (tid == 0) {   // NN is a few hundred: a serial scan is cheaper than another two barriers
+    if (tid == 0) {
+        int cnt[N_CLASS] = {0, 0, 0, 0, 0};
+        for (int a = 0; a < NN; ++a) {
+            const int na = nrot[a];
+            const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
+            row_pos[0][a] = cnt[cl_lo]; cnt[cl_lo] += row_cnt[0][a];
+            row_pos[1][a] = cnt[cl_hi]; cnt[cl_hi] += row_cnt[1][a];
+        }
         int acc = 0;
-        for (int a = 0; a < NN; ++a) { row_start[a] = acc; acc += row_count[a]; }
-        total = acc;
+        for (int c = 0; c < N_CLASS; ++c) { class_base[c] = acc; acc += cnt[c]; }
+        class_base[N_CLASS] = acc;
+        int* cs = R.class_start + (size_t)s * (N_CLASS + 1);
+        for (int c = 0; c <= N_CLASS; ++c) cs[c] = class_base[c] < R.slot_cap ? class_base[c] : R.slot_cap;
         R.n_slot[s] = acc < R.slot_cap ? acc : R.slot_cap;
         if (acc > R.slot_cap) *G.error_flag = 2;
     }
@@ -113,24 +98,31 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
     int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
     int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
     for (int a = wave; a < NN; a += n_wave) {
-        int base = row_start[a];
+        const int na = nrot[a];
+        const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
+        int p_lo = class_base[cl_lo] + row_pos[0][a], p_hi = class_base[cl_hi] + row_pos[1][a];
         for (int b0 = a + 1; b0 < NN; b0 += 64) {
             const int b = b0 + lane;
             const bool hit = b < NN && slot_of[a * NN + b] == -2;
-            const unsigned long long m = __ballot(hit);
-            const int sl = base + __popcll(m & ((1ull << lane) - 1ull));
+            const bool lo = hit && nrot[b] == na;
+            const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hit && !lo);
+            const unsigned long long below = (1ull << lane) - 1ull;
             if (hit) {
+                const int sl = lo ? p_lo + __popcll(m_lo & below) : p_hi + __popcll(m_hi & below);
                 if (sl < R.slot_cap) { slot_a[sl] = a; slot_b[sl] = b; slot_of[a * NN + b] = sl; slot_of[b * NN + a] = sl; }
                 else { slot_of[a * NN + b] = -1; slot_of[b * NN + a] = -1; }
             }
-            base += __popcll(m);
+            p_lo += __popcll(m_lo); p_hi += __popcll(m_hi);
         }
     }
     __syncthreads();
-    // adjacency: slots touching each node, ascending partner id.  BP slots (both nodes with >1 state) also get
-    // an "inbox" position: messages TO node g are stored contiguously at inbox[(bp_start[g]+k)*6 ...], so the node
-    // update streams them without index indirection; slot_off[2*slot+side] remembers where each slot writes.
-    const int* nrot = R.node_nrot;
+    // zero the energy accumulators and the activity flags of the new slots
+    const int n_slot = class_base[N_CLASS] < R.slot_cap ? class_base[N_CLASS] : R.slot_cap;
+    float* P = R.P + (size_t)s * R.slot_cap * 36;
+    for (int i = tid; i < n_slot * 36; i += blockDim.x) P[(size_t)(i / n_slot) * R.slot_cap + (i % n_slot)] = 0.f;
+    int* active = R.slot_active + (size_t)s * R.slot_cap;
+    for (int i = tid; i < n_slot; i += blockDim.x) active[i] = 0;
+    // adjacency of 1-state partners (for folding, rotamer.cpp:378-385) and BP inbox sizes
     for (int g = wave; g < NN; g += n_wave) {
         int* adj = R.adj_slot + ((size_t)s * NN + g) * R.adj_cap;
         int count = 0, count_bp = 0;
@@ -138,66 +130,84 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
         for (int b0 = 0; b0 < NN; b0 += 64) {
             const int b = b0 + lane;
             const int sl = b < NN ? slot_of[g * NN + b] : -1;
-            const bool hit = sl >= 0;
-            const unsigned long long m = __ballot(hit);
+            const bool fold = sl >= 0 && g_multi && nrot[b] == 1;        // partner with a single state
+            const unsigned long long m = __ballot(fold);
             const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (hit && pos < R.adj_cap) adj[pos] = sl;
+            if (fold && pos < R.adj_cap) adj[pos] = sl;
             count += __popcll(m);
-            count_bp += __popcll(__ballot(hit && g_multi && nrot[b] > 1));
+            count_bp += __popcll(__ballot(sl >= 0 && g_multi && nrot[b] > 1));
         }
         if (lane == 0) {
             R.adj_cnt[(size_t)s * NN + g] = count < R.adj_cap ? count : R.adj_cap;
             if (count > R.adj_cap) *G.error_flag = 3;
-            row_count[g] = count_bp;
+            deg_bp[g] = count_bp;
         }
     }
     __syncthreads();
     int* bp_start = R.bp_start + (size_t)s * (NN + 1);
     if (tid == 0) {
         int acc = 0;
-        for (int g = 0; g < NN; ++g) { bp_start[g] = acc; row_start[g] = acc; acc += row_count[g]; }
+        for (int g = 0; g < NN; ++g) { bp_start[g] = acc; row_pos[0][g] = acc; acc += deg_bp[g]; }
         bp_start[NN] = acc;
     }
     __syncthreads();
+    // messages TO node g are stored contiguously at inbox[(bp_start[g]+k)*8 ...] (8-float rows, 6 used)
     int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
     for (int g = wave; g < NN; g += n_wave) {
         if (nrot[g] == 1) continue;
-        int base = row_start[g];
+        int base = row_pos[0][g];
         for (int b0 = 0; b0 < NN; b0 += 64) {
             const int b = b0 + lane;
             const int sl = b < NN ? slot_of[g * NN + b] : -1;
             const bool hit = sl >= 0 && nrot[b] > 1;
             const unsigned long long m = __ballot(hit);
-            if (hit) slot_off[sl * 2 + (g < b ? 0 : 1)] = (base + __popcll(m & ((1ull << lane) - 1ull))) * 6;
+            if (hit) slot_off[sl * 2 + (g < b ? 0 : 1)] = (base + __popcll(m & ((1ull << lane) - 1ull))) * 8;
             base += __popcll(m);
         }
     }
 }
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    if (R->n_node > 2048) return 9003;
+    if (R->n_node > 1024) return 9003;
     hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system), dim3(BP_BLOCK), 0, ST(L), *R);
     return launch_status();
 }
 
+// rebuild step 3: every cached bead pair remembers its slot
+__global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
+    const int s = blockIdx.y;
+    const upk_igraph_t& G = R.G;
+    if (!G.rebuild_flag[s]) return;
+    const int NN = R.n_node;
+    const int* slot_of = R.slot_of + (size_t)s * NN * NN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
+        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+        const int a = R.bead_node[row];
+        for (int k = lane; k < cnt; k += 64) R.nbr_slot[base + k] = slot_of[a * NN + R.bead_node[G.nbr1[base + k]]];
+    }
+}
+extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    int blocks = (R->G.n1 + 3) / 4;
+    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, L->n_system), dim3(256), 0, ST(L), *R);
+    return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
-// 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256); also clears the slot accumulators
+// 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256)
 __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
     const int* __restrict__ nb_start = R.node_bead_start; const int* __restrict__ nb_list = R.node_bead_list;
     const int s = blockIdx.y;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_slot = R.n_slot[s];
-    if (tid < R.slot_cap * 36 && (tid % R.slot_cap) < n_slot) R.P[(size_t)s * R.slot_cap * 36 + tid] = 0.f;
-    if (tid < n_slot) R.slot_active[(size_t)s * R.slot_cap + tid] = 0;
-    if (tid >= R.n_node) return;
-    const int g = tid, n_rot = R.node_nrot[g];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= R.n_node) return;
+    const int n_rot = R.node_nrot[g];
     float e[6];
     float off = 0.f;
     for (int r = 0; r < 6; ++r) {
         e[r] = 0.f;
         if (r >= n_rot) continue;
         for (int q = nb_start[g * 6 + r]; q < nb_start[g * 6 + r + 1]; ++q) {
-            const int bead = nb_list[q];
-            const int loc = R.G.loc1[bead];
+            const int loc = R.G.loc1[nb_list[q]];
             float en = 0.f;
             for (int k = 0; k < R.n_prob; ++k) en += R.prob_out[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]];
             e[r] += en;
@@ -208,55 +218,58 @@ __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
     for (int r = 0; r < 6; ++r) pr[r] = r < n_rot ? expf(off - e[r]) : 0.f;
     R.node_off[(size_t)s * R.n_node + g] = off;
 }
-
 extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int n = R->slot_cap * 36; if (R->n_node > n) n = R->n_node;
-    hipLaunchKernelGGL(k_rotamer_node_prob, dim3((n + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_node_prob, dim3((R->n_node + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
     return launch_status();
 }
 
-// bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
-struct RotLds { float* tab; float* coords; int* q; };
+// ------------------------------------------------------------------------------------------------
+// bead-pair kernels: table + all beads of the system in LDS.  Bead row: [0,6) pos+dir, [6] type | rot<<8 |
+// nrot<<12, [7] node id (raw int bits).
+struct RotLds { float* tab; float* rows; int* q; };
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
     RotLds r;
-    r.tab = lds; r.coords = lds + ((tab_floats + 3) & ~3);
-    r.q = (int*)(r.coords + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
+    r.tab = lds; r.rows = lds + ((tab_floats + 3) & ~3);
+    r.q = (int*)(r.rows + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
     stage_table(r.tab, R.G.param, tab_floats);
-    stage_coords(r.coords, R.G.node1, s, R.G.loc1, R.G.n1, 6);
+    stage_rows(r.rows, R.G.node1, s, R.G.loc1, R.G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
     __syncthreads();
     return r;
 }
 
+// bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
 __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
     const RotLds L = rot_stage(R, lds, s, tab_floats);
-    const int NN = R.n_node;
     const float cut2 = G.cutoff * G.cutoff;
-    const int* slot_of = R.slot_of + (size_t)s * NN * NN;
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active = R.slot_active + (size_t)s * R.slot_cap;
     QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
     for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
+        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+        const int* nbr = G.nbr1 + base;
+        const int* nsl = R.nbr_slot + base;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[6];
+        float xr[8];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) xr[c] = L.coords[row * 8 + c];
-        const int tr = G.type1[row], a = R.bead_node[row], ra = R.bead_rot[row];
+        for (int c = 0; c < 8; ++c) xr[c] = L.rows[row * 8 + c];
+        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+        const int tr = mr & 0xFF, ra = (mr >> 8) & 0xF;
         // each pair once: only partners with a larger bead index (i1 < i2 as in the reference)
-        for_each_inrange(nbr, cnt, xr, L.coords, cut2, L.q, lane, row, [&](int j, bool valid) {
+        for_each_inrange(nbr, cnt, xr, L.rows, cut2, L.q, lane, row, [&](int j, int k, bool valid) {
             if (!valid) return;
-            float xo[6];
+            float xo[8];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) xo[c] = L.coords[j * 8 + c];
-            const float* p = L.tab + (tr * G.n_type2 + G.type1[j]) * G.n_param;
+            for (int c = 0; c < 8; ++c) xo[c] = L.rows[j * 8 + c];
+            const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+            const float* p = L.tab + (tr * G.n_type2 + (mo & 0xFF)) * G.n_param;
             const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
-            const int b = R.bead_node[j], rb = R.bead_rot[j];
-            const int sl = slot_of[a * NN + b];
+            const int sl = nsl[k];
             if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
+            const int rb = (mo >> 8) & 0xF;
             const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
             atomicAdd(&P[PIDX(R, sl, idx)], E);           // one bead per rotamer state => a single contributor
             active[sl] = 1;
@@ -276,11 +289,74 @@ static bool rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab
     grid = dim3(bps, L->n_system); block = dim3(waves * 64);
     return true;
 }
-
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
     if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;   // more beads than LDS can stage
     hipLaunchKernelGGL(k_rotamer_pair_energy, grid, block, lds, ST(L), *R, tab_floats);
+    return launch_status();
+}
+
+// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
+__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const upk_igraph_t& G = R.G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const RotLds L = rot_stage(R, lds, s, tab_floats);
+    const int NN = R.n_node;
+    const float cut2 = G.cutoff * G.cutoff;
+    const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
+    const float* nbm = R.nb_cur + (size_t)s * NN * 6;
+    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
+    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
+        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+        const int* nbr = G.nbr1 + base;
+        const int* nsl = R.nbr_slot + base;
+        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+        float xr[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xr[c] = L.rows[row * 8 + c];
+        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+        const int tr = mr & 0xFF, ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF;
+        float acc[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] = 0.f;
+        for_each_inrange(nbr, cnt, xr, L.rows, cut2, L.q, lane, -1, [&](int j, int k, bool valid) {
+            if (!valid) return;
+            float xo[8], d1[6];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xo[c] = L.rows[j * 8 + c];
+            const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+            const float* p = L.tab + (tr * G.n_type2 + (mo & 0xFF)) * G.n_param;
+            quadspline2<1>(Q, p, xr, xo, d1);
+            const int rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
+            float ps;
+            if (na == 1 && nb == 1) ps = 1.f;
+            else if (na == 1) ps = nbm[b * 6 + rb];
+            else if (nb == 1) ps = nbm[a * 6 + ra];
+            else {
+                const int sl = nsl[k];
+                ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[c] += ps * d1[c];
+        });
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
+        if (lane == 0) {
+            const int loc = G.loc1[row];
+            float* t = C_SENS(G.node1, s) + (size_t)loc * G.node1.stride;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t[c] += acc[c];
+            const float mg = nbm[a * 6 + ra];
+            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+        }
+    }
+}
+extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
+    int tab_floats; size_t lds; dim3 grid, block;
+    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;
+    hipLaunchKernelGGL(k_rotamer_grad, grid, block, lds, ST(L), *R, tab_floats);
     return launch_status();
 }
 
@@ -305,71 +381,87 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
-// one residue-pair edge with compile-time state counts: new messages from the old beliefs
-// (update_beliefs, rotamer.cpp:468-499 and the L1 normalisation of 506-521), written in place
+struct BpCtx {
+    const int *slot_a, *slot_b, *active, *slot_off;
+    float *P, *inbox, *marg;
+    int cap;
+};
+
+// edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
+// L1 normalisation of 506-521), rewritten in place.  1-ulp hardware reciprocals: the reference itself uses the
+// 12-bit rcpps here (Float4.h:199-212).
 template <int NA, int NB>
-__device__ __forceinline__ void bp_edge(const float* __restrict__ Ps, int pstride, const float* __restrict__ nba, const float* __restrict__ nbb,
-                                        float* __restrict__ ma, float* __restrict__ mb) {
-    float va[NA], vb[NB], P[NA][NB];
+__device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
+    for (int sl = lo + tid; sl < hi; sl += nt) {
+        if (!C.active[sl]) continue;
+        const int a = C.slot_a[sl], b = C.slot_b[sl];
+        float* ma = C.inbox + C.slot_off[sl * 2];
+        float* mb = C.inbox + C.slot_off[sl * 2 + 1];
+        float P[NA][NB], va[NA], vb[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = nba[i] * rcp(1e-10f + ma[i]);
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) vb[j] = nbb[j] * rcp(1e-10f + mb[j]);
+            for (int j = 0; j < NB; ++j) P[i][j] = C.P[(size_t)(i * 6 + j) * C.cap + sl];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+        for (int i = 0; i < NA; ++i) va[i] = nb_old[a * 6 + i] * fast_rcp(1e-10f + ma[i]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) P[i][j] = Ps[(size_t)(i * 6 + j) * pstride];
-    float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
+        for (int j = 0; j < NB; ++j) vb[j] = nb_old[b * 6 + j] * fast_rcp(1e-10f + mb[j]);
+        float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) { float t = 0.f;
+        for (int i = 0; i < NA; ++i) { float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) t += P[i][j] * vb[j];
-        ta[i] = t; sa += t; }
+            for (int j = 0; j < NB; ++j) t += P[i][j] * vb[j];
+            ta[i] = t; sa += t; }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { float t = 0.f;
+        for (int j = 0; j < NB; ++j) { float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
-        tb[j] = t; sb += t; }
-    const float ra = rcp(sa), rb = rcp(sb);
+            for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
+            tb[j] = t; sb += t; }
+        const float ra = fast_rcp(sa), rb = fast_rcp(sb);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+        for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+        for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+    }
 }
 
-// pair marginal and (optionally) its Bethe free-energy term (rotamer.cpp:405-451)
+// pair marginals and (optionally) their Bethe free-energy terms (rotamer.cpp:405-451)
 template <int NA, int NB>
-__device__ __forceinline__ float bp_marginal(const float* __restrict__ Ps, int pstride, const float* __restrict__ nba, const float* __restrict__ nbb,
-                                             const float* __restrict__ ma, const float* __restrict__ mb, float* __restrict__ mg_out,
-                                             bool want_energy) {
-    float Pl[NA][NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Pl[i][j] = Ps[(size_t)(i * 6 + j) * pstride];
-    float bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) bc1[i] = nba[i] * rcp(1e-10f + ma[i]);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bc2[j] = nbb[j] * rcp(1e-10f + mb[j]);
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { mg[i][j] = Pl[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
-    const float rs = rcp(sum);
+__device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nbm, int tid, int nt,
+                                                   bool want_energy) {
     float en = 0.f;
+    for (int sl = lo + tid; sl < hi; sl += nt) {
+        if (!C.active[sl]) continue;
+        const int a = C.slot_a[sl], b = C.slot_b[sl];
+        const float* ma = C.inbox + C.slot_off[sl * 2];
+        const float* mb = C.inbox + C.slot_off[sl * 2 + 1];
+        float P[NA][NB], bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const float pm = mg[i][j] * rs;
-            mg_out[(size_t)(i * 6 + j) * pstride] = pm;
-            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + Pl[i][j] * nba[i] * nbb[j]));
-        }
+            for (int j = 0; j < NB; ++j) P[i][j] = C.P[(size_t)(i * 6 + j) * C.cap + sl];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) bc1[i] = nbm[a * 6 + i] * rcp(1e-10f + ma[i]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bc2[j] = nbm[b * 6 + j] * rcp(1e-10f + mb[j]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { mg[i][j] = P[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
+        const float rs = rcp(sum);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float pm = mg[i][j] * rs;
+                C.marg[(size_t)(i * 6 + j) * C.cap + sl] = pm;
+                if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i][j] * nbm[a * 6 + i] * nbm[b * 6 + j]));
+            }
+    }
     return en;
 }
 
-#define BP_GROUP 16   // lanes cooperating on one node in the node phase
+#define BP_GROUP 4   // lanes cooperating on one node in the node phase
 
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -381,31 +473,39 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     float* scratch = lds + NN * 18;    // [32]
     int* nrot = (int*)(lds + NN * 18 + 32);      // [NN]   state counts
     int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
+    int* cls = bp_start + NN + 1;                // [N_CLASS+1]
     const int n_slot = R.n_slot[s];
-    const int cap = R.slot_cap;
-    const int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
-    const int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
-    const int* active = R.slot_active + (size_t)s * R.slot_cap;
+    long long tr_t0 = 0, tr_edge = 0, tr_node = 0, tr_pro = 0, tr_loop = 0;
+    const bool trace = R.bp_trace != nullptr && tid == 0;
+    if (trace) tr_t0 = wall_clock64();
+    BpCtx C;
+    C.cap = R.slot_cap;
+    C.slot_a = R.slot_a + (size_t)s * R.slot_cap;
+    C.slot_b = R.slot_b + (size_t)s * R.slot_cap;
+    C.active = R.slot_active + (size_t)s * R.slot_cap;
+    C.slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
+    C.P = R.P + (size_t)s * R.slot_cap * 36;
+    C.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
+    C.marg = R.marg + (size_t)s * R.slot_cap * 36;
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
     for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
+    if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
+    for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
-    const int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
-    float* P = R.P + (size_t)s * R.slot_cap * 36;
-    float* inbox = R.msg_cur + (size_t)s * R.slot_cap * 12;
-    float* marg = R.marg + (size_t)s * R.slot_cap * 36;
 
-    // energies -> probabilities (rotamer.cpp:835); old edge beliefs = 1 (rotamer.cpp:1015-1032), also for the
-    // slots without an in-range bead pair this step, whose (unit) message then multiplies as an exact 1
+    // energies -> probabilities for the entries each class uses (rotamer.cpp:835)
     for (int i = tid; i < n_slot * 36; i += nt) {
         const int e = i / n_slot, sl = i % n_slot, ra = e / 6, rb = e % 6;
-        const bool used = ra < nrot[slot_a[sl]] && rb < nrot[slot_b[sl]];
-        const size_t pi = (size_t)e * cap + sl;
-        P[pi] = used ? expf(-P[pi]) : 0.f;
+        const int c = sl < cls[1] ? CL33 : (sl < cls[2] ? CL36 : (sl < cls[3] ? CL66 : (sl < cls[4] ? CL11 : CL1X)));
+        const int na = c == CL66 ? 6 : (c == CL33 || c == CL36 ? 3 : 1);
+        const int nb = c == CL33 ? 3 : (c == CL11 ? 1 : 6);       // 1xN: up to 6 columns (unused ones stay exp(0) = 1, never read)
+        if (ra < na && rb < nb) { const size_t pi = (size_t)e * C.cap + sl; C.P[pi] = expf(-C.P[pi]); }
     }
-    for (int i = tid; i < bp_start[NN] * 6; i += nt) inbox[i] = 1.f;
-    for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
+    // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
+    // whose unit message then multiplies as an exact 1
+    for (int i = tid; i < bp_start[NN] * 8; i += nt) C.inbox[i] = 1.f;
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     for (int g = tid; g < NN; g += nt) {
@@ -413,9 +513,8 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         if (n == 1) continue;
         for (int k = 0; k < adj_cnt[g]; ++k) {
             const int sl = adj_slot[g * R.adj_cap + k];
-            const int a = slot_a[sl];
-            if (a == g || nrot[a] != 1 || !active[sl]) continue;     // a 1-state partner always has the lower id
-            for (int r = 0; r < n; ++r) prob[g * 6 + r] *= P[(size_t)r * cap + sl];
+            if (!C.active[sl]) continue;
+            for (int r = 0; r < n; ++r) prob[g * 6 + r] *= C.P[(size_t)r * C.cap + sl];
         }
     }
     __syncthreads();
@@ -425,66 +524,72 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     float* nb_old = nb0; float* nb_cur = nb1;
     int iter = 0;
     float maxdev = 1e10f;
-    const int grp = tid / BP_GROUP, gl = tid % BP_GROUP, n_grp = nt / BP_GROUP;
+    const int gl = tid % BP_GROUP, n_grp = nt / BP_GROUP;
     // sweep -1 is calculate_new_beliefs(0.f, true): only its messages survive and the "old" node belief becomes
     // prob / max(prob) (rotamer.cpp:1034 with the swap at 995-1001)
+    if (trace) tr_pro = wall_clock64();
     for (int sweep = -1;; ++sweep) {
+        long long tr_a = 0, tr_b = 0;
+        if (trace) tr_a = wall_clock64();
         // ---- edge phase: every residue pair rewrites its two messages in place from the old node beliefs
-        for (int sl = tid; sl < n_slot; sl += nt) {
-            const int a = slot_a[sl], b = slot_b[sl];
-            const int na = nrot[a];
-            if (na == 1 || !active[sl]) continue;
-            const int nb = nrot[b];
-            const float* Ps = P + sl;
-            float* ma = inbox + slot_off[sl * 2];
-            float* mb = inbox + slot_off[sl * 2 + 1];
-            if (na == 3 && nb == 3) bp_edge<3, 3>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
-            else if (na == 3) bp_edge<3, 6>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
-            else bp_edge<6, 6>(Ps, cap, nb_old + a * 6, nb_old + b * 6, ma, mb);
-        }
+        bp_edge_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
+        bp_edge_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_old, tid, nt);
+        bp_edge_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_old, tid, nt);
         __syncthreads();
+        if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
         float dev = 0.f;
         for (int g0 = 0; g0 < NN; g0 += n_grp) {
-            const int g = g0 + grp;
+            const int g = g0 + tid / BP_GROUP;
             const bool live = g < NN && nrot[g] > 1;
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int k0 = bp_start[g], k1 = bp_start[g + 1];
-                for (int k = k0 + gl; k < k1; k += BP_GROUP) {
-                    const float* m = inbox + (size_t)k * 6;
-                    float mx = 0.f;
+                const int k1 = bp_start[g + 1];
+                int parity = 0;
+                for (int k = bp_start[g] + gl; k < k1; k += BP_GROUP) {
+                    const float4 m0 = *(const float4*)(C.inbox + (size_t)k * 8);
+                    const float2 m1 = *(const float2*)(C.inbox + (size_t)k * 8 + 4);
+                    bb[0] *= m0.x; bb[1] *= m0.y; bb[2] *= m0.z;
+                    if (n == 6) { bb[3] *= m0.w; bb[4] *= m1.x; bb[5] *= m1.y; }
+                    if ((++parity & 1) == 0) {          // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
+                        float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
+                        if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
+                        const float rm = fast_rcp(mx);
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) { bb[r] *= (r < n ? m[r] : 1.f); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
-                    const float rm = rcp(mx);           // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                        for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                    }
                 }
             }
-            // product over the lanes of the group
 #pragma unroll
             for (int off = BP_GROUP / 2; off > 0; off >>= 1) {
                 float mx = 0.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) { bb[r] *= __shfl_xor(bb[r], off, UP_WAVE); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
-                const float rm = mx > 0.f ? rcp(mx) : 1.f;
+                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
             }
-            if (live && gl < n) {
-                // lane r of the group finishes rotamer state r: b = prob * product, then standardize (rotamer.cpp:258-273)
-                float mine = 0.f, mx = 0.f;
+            if (live) {
+                // b = prob * product, then standardize (rotamer.cpp:258-273); lane gl finishes states gl and gl+4
+                float v[6], mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) if (r < n) { const float v = prob[g * 6 + r] * bb[r]; mx = fmaxf(mx, v); if (r == gl) mine = v; }
-                const float o = nb_old[g * 6 + gl];
+                for (int r = 0; r < 6; ++r) { v[r] = r < n ? prob[g * 6 + r] * bb[r] : 0.f; mx = fmaxf(mx, v[r]); }
+                const float rm = rcp(mx);
                 const float damp = sweep < 0 ? 0.f : R.damping;
-                const float v = damp != 0.f ? (1.f - damp) * rcp(mx) * mine + damp * o : rcp(mx) * mine;
-                nb_cur[g * 6 + gl] = v;
-                dev = fmaxf(v - o, dev);                               // signed, rotamer.cpp:275-281
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    if (r < n && (r % BP_GROUP) == gl) {
+                        const float o = nb_old[g * 6 + r];
+                        const float nv = damp != 0.f ? (1.f - damp) * rm * v[r] + damp * o : rm * v[r];
+                        nb_cur[g * 6 + r] = nv;
+                        dev = fmaxf(nv - o, dev);                      // signed, rotamer.cpp:275-281
+                    }
+                }
             }
         }
         __syncthreads();
+        if (trace) tr_node += wall_clock64() - tr_b;
         if (sweep >= 0) {
             ++iter;
             if (iter % R.chunk == 0) {
@@ -495,6 +600,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         float* t = nb_old; nb_old = nb_cur; nb_cur = t;                // rotamer.cpp:1040-1044
     }
     if (tid == 0) R.iters[s] = iter;
+    if (trace) tr_loop = wall_clock64();
 
     // ---- marginals (rotamer.cpp:1053-1059)
     for (int g = tid; g < NN; g += nt) {
@@ -507,21 +613,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     }
     __syncthreads();
     float en = 0.f;
-    for (int sl = tid; sl < n_slot; sl += nt) {
-        const int a = slot_a[sl], b = slot_b[sl];
-        const int na = nrot[a], nb = nrot[b];
-        if (!active[sl]) continue;
-        const float* Ps = P + sl;
-        if (nb == 1) { if (want_energy) en += -logf(Ps[0]); continue; }   // 1-1 edge (rotamer.cpp:861)
-        if (na == 1) continue;                                            // folded into node b
-        const float* ma = inbox + slot_off[sl * 2];
-        const float* mb = inbox + slot_off[sl * 2 + 1];
-        float* mo = marg + sl;
-        if (na == 3 && nb == 3) en += bp_marginal<3, 3>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
-        else if (na == 3) en += bp_marginal<3, 6>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
-        else en += bp_marginal<6, 6>(Ps, cap, nb_cur + a * 6, nb_cur + b * 6, ma, mb, mo, want_energy);
-    }
+    en += bp_marginal_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_cur, tid, nt, want_energy);
+    en += bp_marginal_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
+    en += bp_marginal_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
     if (want_energy) {
+        for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
+            if (C.active[sl]) en += -logf(C.P[sl]);
         for (int g = tid; g < NN; g += nt) {   // node_free_energy, rotamer.cpp:292-302
             const int n = nrot[g];
             float e = R.node_off[(size_t)s * NN + g];
@@ -532,73 +629,23 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         if (tid == 0) R.energy[s] = tot;
     }
     for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[i];
+    __syncthreads();
+    // leave the accumulators clean for the next force evaluation
+    for (int i = tid; i < n_slot * 36; i += nt) C.P[(size_t)(i / n_slot) * C.cap + (i % n_slot)] = 0.f;
+    int* active_w = R.slot_active + (size_t)s * R.slot_cap;
+    int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
+    for (int i = tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
+    if (trace) {
+        long long* T = R.bp_trace + (size_t)s * 16;
+        T[0] = tr_pro - tr_t0; T[1] = tr_loop - tr_pro; T[2] = wall_clock64() - tr_loop; T[3] = tr_edge; T[4] = tr_node;
+        T[5] = iter; T[6] = n_slot; T[7] = bp_start[NN];
+        for (int c = 0; c <= N_CLASS; ++c) T[8 + c] = cls[c];
+    }
 }
 
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
-    const size_t lds = ((size_t)R->n_node * 20 + 40) * sizeof(float);
+    const size_t lds = ((size_t)R->n_node * 20 + 64) * sizeof(float);
     if (lds > 155 * 1024) return 9004;
     hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy);
-    return launch_status();
-}
-
-// ------------------------------------------------------------------------------------------------
-// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
-__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = blockIdx.y;
-    const upk_igraph_t& G = R.G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    const RotLds L = rot_stage(R, lds, s, tab_floats);
-    const int NN = R.n_node;
-    const float cut2 = G.cutoff * G.cutoff;
-    const int* slot_of = R.slot_of + (size_t)s * NN * NN;
-    const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
-    const float* nbm = R.nb_cur + (size_t)s * NN * 6;
-    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
-    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
-        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) xr[c] = L.coords[row * 8 + c];
-        const int tr = G.type1[row], a = R.bead_node[row], ra = R.bead_rot[row], na = R.node_nrot[a];
-        float acc[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] = 0.f;
-        for_each_inrange(nbr, cnt, xr, L.coords, cut2, L.q, lane, -1, [&](int j, bool valid) {
-            if (!valid) return;
-            float xo[6], d1[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) xo[c] = L.coords[j * 8 + c];
-            const float* p = L.tab + (tr * G.n_type2 + G.type1[j]) * G.n_param;
-            quadspline2<1>(Q, p, xr, xo, d1);
-            const int b = R.bead_node[j], rb = R.bead_rot[j], nb = R.node_nrot[b];
-            float ps;
-            if (na == 1 && nb == 1) ps = 1.f;
-            else if (na == 1) ps = nbm[b * 6 + rb];
-            else if (nb == 1) ps = nbm[a * 6 + ra];
-            else {
-                const int sl = slot_of[a * NN + b];
-                ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[c] += ps * d1[c];
-        });
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
-        if (lane == 0) {
-            const int loc = G.loc1[row];
-            float* t = C_SENS(G.node1, s) + (size_t)loc * G.node1.stride;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) t[c] += acc[c];
-            const float mg = nbm[a * 6 + ra];
-            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
-        }
-    }
-}
-extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int tab_floats; size_t lds; dim3 grid, block;
-    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;
-    hipLaunchKernelGGL(k_rotamer_grad, grid, block, lds, ST(L), *R, tab_floats);
     return launch_status();
 }

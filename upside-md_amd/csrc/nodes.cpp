@@ -620,7 +620,8 @@ struct RotamerSidechain : public PotentialNode {
     upk_rotamer_t R;
     int n_node, n1, n3, n6;
     vector<int> node_nrot, bead_node, bead_rot;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off;
+    DevBuf<long long> bp_trace;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
     DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     long n_bad_solve = 0;
@@ -662,6 +663,12 @@ struct RotamerSidechain : public PotentialNode {
         nb_start[n_node * 6] = (int)nb_list.size();
         const int S = c->n_system;
         d_node_nrot.upload(node_nrot); d_bead_node.upload(bead_node); d_bead_rot.upload(bead_rot); d_nb_start.upload(nb_start); d_nb_list.upload(nb_list);
+        vector<int> bead_meta(n_bead);
+        for (int i = 0; i < n_bead; ++i) {
+            if (ig.type1[i] > 255) throw string("more than 256 bead types");
+            bead_meta[i] = ig.type1[i] | (bead_rot[i] << 8) | (node_nrot[bead_node[i]] << 12);
+        }
+        d_bead_meta.upload(bead_meta);
         const float slot_factor = env_float("UPSIDE_HIP_SLOT_FACTOR", 96.f);
         long full = (long)n_node * (n_node - 1) / 2;
         R.slot_cap = (int)max(1L, min(full, (long)(n_node * slot_factor)));
@@ -669,9 +676,11 @@ struct RotamerSidechain : public PotentialNode {
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
         iters.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
+        class_start.alloc((size_t)S * 6); nbr_slot.alloc((size_t)S * ig.G.n1 * ig.G.cap1); slot_active_last.alloc((size_t)S * R.slot_cap);
+        ig.G.mark_table = slot_of.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
         node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6); nb_old.alloc((size_t)S * n_node * 6);
         P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
-        msg_cur.alloc((size_t)S * R.slot_cap * 12);
+        msg_cur.alloc((size_t)S * R.slot_cap * 16);
     }
     void finalize() override {
         vector<const float*> po; vector<float*> ps; vector<int> st; vector<long> ss;
@@ -690,13 +699,19 @@ struct RotamerSidechain : public PotentialNode {
         R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p; R.nb_old = nb_old.p;
         R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
+        R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
         R.iters = iters.p; R.energy = energy.p;
+        R.bp_trace = nullptr;
+        if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
     }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
         R.G = ig.G;
-        ig.update_lists();
+        upk_check(upk_pairlist_check(&ctx->L, &ig.G), "pairlist_check");
+        upk_check(upk_rotamer_clear_slots(&ctx->L, &R), "rotamer_clear_slots");
+        upk_check(upk_pairlist_build(&ctx->L, &ig.G), "pairlist_build");
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
+        upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
         upk_check(upk_rotamer_node_prob(&ctx->L, &R), "rotamer_node_prob");
         { IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
           upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy"); }
@@ -722,7 +737,7 @@ struct RotamerSidechain : public PotentialNode {
         }
         if (!strcmp(log_name, "edge_marginal_in_graph_order")) {
             auto nb = nb_cur.download(); auto mg = marg.download(); auto sa = slot_a.download(); auto sb = slot_b.download();
-            auto act = slot_active.download(); int ns = n_slot.download()[0];
+            auto act = slot_active_last.download(); int ns = n_slot.download()[0];
             vector<float> ev((size_t)n_node * n_node * 36, 0.f);
             for (int i1 = 0; i1 < n_node; ++i1) for (int i2 = 0; i2 < n_node; ++i2) for (int r1 = 0; r1 < 6; ++r1) for (int r2 = 0; r2 < 6; ++r2)
                 ev[(((size_t)i1 * n_node + i2) * 6 + r1) * 6 + r2] = (i1 == i2) ? nb[i1 * 6 + r1] * (r1 == r2) : nb[i1 * 6 + r1] * nb[i2 * 6 + r2];
@@ -737,6 +752,10 @@ struct RotamerSidechain : public PotentialNode {
                 }
             }
             return ev;
+        }
+        if (!strcmp(log_name, "bp_trace")) {   // diagnostics: phase clocks (10 ns units) of system 0's last solve
+            if (!R.bp_trace) throw string("set UPSIDE_HIP_BP_TRACE=1 before constructing the engine");
+            auto t = bp_trace.download(); return vector<float>(t.begin(), t.begin() + 16);
         }
         if (!strcmp(log_name, "read n_bad_solve")) return vector<float>(1, float(n_bad_solve));
         throw string("Value ") + log_name + string(" not implemented");
