@@ -129,7 +129,12 @@ int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G);
  *   side = 2: out[s][i2] = sum_{i1} value   (hbond_coverage, protein_hbond acceptors)
  * out has element stride out_stride, component out_comp, row offset out_row0. */
 int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
-                      int out_stride, int out_comp, int out_row0);
+                      int out_stride, int out_comp, int out_row0, float* own_grad);
+/* own_grad (may be NULL): [S][n_rows][8], receives the unweighted sum over neighbours of d(value)/d(row element).
+ * When the pair sensitivity is the row element's own (coverage nodes), the backward pass of that side is the
+ * per-element product below instead of a third pair pass. */
+int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
+                              const float* sens, long sens_sys_stride, int sens_stride);
 /* K8 backward: for every row of `side`, sum over in-range neighbours of sens(pair) * d(value)/d(row coords),
  * added to the source node's sens at loc[row] (interaction_graph.h:525-555 in gather form).
  * Pair sensitivity: sens_mode 1: sens1[s][i1*sens_stride]; 2: sens2[s][i2*sens_stride]; 3: sens1[i1]+sens2[i2]. */

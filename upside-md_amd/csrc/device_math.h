@@ -39,6 +39,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, UP_WAVE);
     return v;
 }
+// sum 8 per-lane values over the wavefront with 10 shuffles instead of 48: three halving exchanges leave one
+// partial value per lane, three butterflies finish it.  Returns the total of v[(lane >> 3) & 7] (the same in the
+// 8 lanes of a group), i.e. lane 8*c holds the sum of component c.
+__device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
+    float a[4], b[2], c;
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = h32 ? v[i + 4] : v[i], send = h32 ? v[i] : v[i + 4];
+        a[i] = keep + __shfl_xor(send, 32, UP_WAVE);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = h16 ? a[i + 2] : a[i], send = h16 ? a[i] : a[i + 2];
+        b[i] = keep + __shfl_xor(send, 16, UP_WAVE);
+    }
+    {
+        const float keep = h8 ? b[1] : b[0], send = h8 ? b[0] : b[1];
+        c = keep + __shfl_xor(send, 8, UP_WAVE);
+    }
+    c += __shfl_xor(c, 4, UP_WAVE);
+    c += __shfl_xor(c, 2, UP_WAVE);
+    c += __shfl_xor(c, 1, UP_WAVE);
+    return c;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, UP_WAVE));

@@ -14,6 +14,15 @@
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
 
+#include <cstdlib>
+// total workgroups an LDS-staged pair kernel aims at (each re-stages its system, so fewer + fatter is cheaper;
+// 2 x 16-wave workgroups fill a CU)
+static inline int ig_target_wgs() {
+    static int v = 0;
+    if (!v) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); v = e ? atoi(e) : 256; if (v < 1) v = 256; }
+    return v;
+}
+
 namespace up {
 
 #define IG_MAX_WAVES 16

@@ -240,7 +240,7 @@ extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) 
 // ------------------------------------------------------------------------------------------------
 // K3 forward: row sums of the pair value
 __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ out, long out_sys_stride, int out_stride, int out_comp,
-                                int out_row0) {
+                                int out_row0, float* __restrict__ own_grad) {
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int n_rows = side == 1 ? G.n1 : G.n2;
@@ -252,25 +252,40 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
         float xr[8];
         if (side == 1) load_elem(xr, G.node1, s, G.loc1[row], G.dim1); else load_elem(xr, G.node2, s, G.loc2[row], G.dim2);
         const int tr = side == 1 ? G.type1[row] : G.type2[row];
-        float acc = 0.f;
+        float acc = 0.f, og[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) og[c] = 0.f;
         for (int k = lane; k < cnt; k += 64) {
             const int j = nbr[k];
             float xo[8], d1[8], d2[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { d1[c] = 0.f; d2[c] = 0.f; }
             if (side == 1) load_elem(xo, G.node2, s, G.loc2[j], G.dim2); else load_elem(xo, G.node1, s, G.loc1[j], G.dim1);
             if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
             const int t1 = side == 1 ? tr : G.type1[j], t2 = side == 1 ? G.type2[j] : tr;
             const float* p = G.param + (size_t)(t1 * G.n_type2 + t2) * G.n_param;
             acc += side == 1 ? pair_eval(G, p, xr, xo, d1, d2) : pair_eval(G, p, xo, xr, d1, d2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) og[c] += side == 1 ? d1[c] : d2[c];
         }
         acc = wave_sum(acc);
         if (lane == 0) out[(size_t)s * out_sys_stride + (size_t)(out_row0 + row) * out_stride + out_comp] = acc;
+        if (own_grad) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) og[c] = wave_sum(og[c]);
+            if (lane == 0) {
+                float* o = own_grad + ((size_t)s * n_rows + row) * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = og[c];
+            }
+        }
     }
 }
 static int igraph_rowsum_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
-                                 int out_stride, int out_comp, int out_row0) {
+                                 int out_stride, int out_comp, int out_row0, float* own_grad) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_rowsum, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
-                       out, out_sys_stride, out_stride, out_comp, out_row0);
+                       out, out_sys_stride, out_stride, out_comp, out_row0, own_grad);
     return launch_status();
 }
 
@@ -377,12 +392,18 @@ __device__ __forceinline__ float pair_eval2(const upk_igraph_t& G, const QuadSha
 
 struct Ig2Args {
     float* out; long out_sys_stride; int out_stride, out_comp, out_row0;      // rowsum
+    float* own_grad;                                                          // rowsum: [S][n_rows][8] sum of d(value)/d(row element)
     int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // grad
     int tab_floats;
 };
 
-template <int IT, int ROW_SIDE, bool GRAD>
+// MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element) (so that a backward
+// pass whose pair sensitivity depends on the row element only is a per-element product, upk_igraph_apply_own_grad);
+// 2: sum of sens(pair) * d(value)/d(row element)
+template <int IT, int ROW_SIDE, int MODE>
 __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
+    constexpr bool GRAD = MODE == 2;
+    constexpr bool WANT_D = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
@@ -414,34 +435,45 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
         const bool row_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == ROW_SIDE));
         const bool oth_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == 3 - ROW_SIDE));
         const float srow = row_has ? xr[6] : 0.f;
-        float acc[8];
+        float acc[8], vacc = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
         for_each_inrange(nbr, cnt, xr, coth, cut2, q, lane, -1, [&](int j, int, bool valid) {
             if (!valid) return;
             float xo[8], d[8];
+            const float4 lo = *(const float4*)(coth + j * 8), hi = *(const float4*)(coth + j * 8 + 4);
+            xo[0] = lo.x; xo[1] = lo.y; xo[2] = lo.z; xo[3] = lo.w; xo[4] = hi.x; xo[5] = hi.y; xo[6] = hi.z; xo[7] = hi.w;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { xo[c] = coth[j * 8 + c]; d[c] = 0.f; }
+            for (int c = 0; c < 8; ++c) d[c] = 0.f;
             const int to = __float_as_int(xo[7]);
-            const float v = ROW_SIDE == 1 ? pair_eval2<IT, 1, GRAD>(G, Q, tab, tr, to, xr, xo, d)
-                                          : pair_eval2<IT, 2, GRAD>(G, Q, tab, to, tr, xo, xr, d);
-            if (!GRAD) { acc[0] += v; return; }
-            const float ps = srow + (oth_has ? xo[6] : 0.f);
+            const float v = ROW_SIDE == 1 ? pair_eval2<IT, 1, WANT_D>(G, Q, tab, tr, to, xr, xo, d)
+                                          : pair_eval2<IT, 2, WANT_D>(G, Q, tab, to, tr, xo, xr, d);
+            if (MODE != 2) vacc += v;
+            if (MODE == 1) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] += ps * d[c];
+                for (int c = 0; c < 8; ++c) acc[c] += d[c];
+            }
+            if (MODE == 2) {
+                const float ps = srow + (oth_has ? xo[6] : 0.f);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += ps * d[c];
+            }
         });
-        if (!GRAD) {
-            const float t = wave_sum(acc[0]);
+        if (MODE != 2) {
+            const float t = wave_sum(vacc);
             if (lane == 0) A.out[(size_t)s * A.out_sys_stride + (size_t)(A.out_row0 + row) * A.out_stride + A.out_comp] = t;
-        } else {
-            const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = wave_sum(acc[c]);
-            if (lane == 0) {
-                const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
-                float* t = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1[row] : G.loc2[row]) * node.stride;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) if (c < dim_row) t[c] += acc[c];
+        }
+        if (MODE != 0) {
+            const float t = wave_sum8(acc, lane);          // lane 8*c holds component c
+            const int c = lane >> 3;
+            if ((lane & 7) == 0) {
+                if (MODE == 1) A.own_grad[((size_t)s * n_rows + row) * 8 + c] = t;
+                else {
+                    const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
+                    const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
+                    float* o = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1[row] : G.loc2[row]) * node.stride;
+                    if (c < dim_row) o[c] += t;
+                }
             }
         }
     }
@@ -452,7 +484,7 @@ static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_row
     const int waves = 16;
     lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
     if (lds_bytes > 158 * 1024) return false;
-    int bps = (1024 + L->n_system - 1) / L->n_system;            // aim at >= 1024 workgroups in flight across systems
+    int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;   // workgroups in flight across systems
     const int max_bps = (n_rows + waves - 1) / waves;
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
@@ -460,36 +492,60 @@ static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_row
     return true;
 }
 
-template <int IT>
-static int ig2_launch(const upk_launch_t* L, const upk_igraph_t* G, int side, bool grad, const Ig2Args& A0) {
+template <int IT, int SIDE>
+static int ig2_launch(const upk_launch_t* L, const upk_igraph_t* G, int mode, const Ig2Args& A0) {
     Ig2Args A = A0; size_t lds; dim3 grid, block;
-    if (!ig2_geometry(L, G, side == 1 ? G->n1 : G->n2, A.tab_floats, lds, grid, block)) return -1;
-    if (side == 1) { if (grad) hipLaunchKernelGGL((k_ig2<IT, 1, true>), grid, block, lds, ST(L), *G, A); else hipLaunchKernelGGL((k_ig2<IT, 1, false>), grid, block, lds, ST(L), *G, A); }
-    else           { if (grad) hipLaunchKernelGGL((k_ig2<IT, 2, true>), grid, block, lds, ST(L), *G, A); else hipLaunchKernelGGL((k_ig2<IT, 2, false>), grid, block, lds, ST(L), *G, A); }
+    if (!ig2_geometry(L, G, SIDE == 1 ? G->n1 : G->n2, A.tab_floats, lds, grid, block)) return -1;
+    if (mode == 0) hipLaunchKernelGGL((k_ig2<IT, SIDE, 0>), grid, block, lds, ST(L), *G, A);
+    else if (mode == 1) hipLaunchKernelGGL((k_ig2<IT, SIDE, 1>), grid, block, lds, ST(L), *G, A);
+    else hipLaunchKernelGGL((k_ig2<IT, SIDE, 2>), grid, block, lds, ST(L), *G, A);
     return launch_status();
 }
-static int ig2_dispatch(const upk_launch_t* L, const upk_igraph_t* G, int side, bool grad, const Ig2Args& A) {
+static int ig2_dispatch(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, const Ig2Args& A) {
     switch (G->itype) {
-        case UPK_IT_HBOND_COVERAGE: return ig2_launch<UPK_IT_HBOND_COVERAGE>(L, G, side, grad, A);
-        case UPK_IT_ENVIRONMENT: return ig2_launch<UPK_IT_ENVIRONMENT>(L, G, side, grad, A);
-        case UPK_IT_PROTEIN_HBOND: return ig2_launch<UPK_IT_PROTEIN_HBOND>(L, G, side, grad, A);
+        case UPK_IT_HBOND_COVERAGE: return side == 1 ? ig2_launch<UPK_IT_HBOND_COVERAGE, 1>(L, G, mode, A) : ig2_launch<UPK_IT_HBOND_COVERAGE, 2>(L, G, mode, A);
+        case UPK_IT_ENVIRONMENT: return side == 1 ? ig2_launch<UPK_IT_ENVIRONMENT, 1>(L, G, mode, A) : ig2_launch<UPK_IT_ENVIRONMENT, 2>(L, G, mode, A);
+        case UPK_IT_PROTEIN_HBOND: return side == 1 ? ig2_launch<UPK_IT_PROTEIN_HBOND, 1>(L, G, mode, A) : ig2_launch<UPK_IT_PROTEIN_HBOND, 2>(L, G, mode, A);
         default: return -1;
     }
 }
 
 extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
-                                 int out_stride, int out_comp, int out_row0) {
+                                 int out_stride, int out_comp, int out_row0, float* own_grad) {
     Ig2Args A; memset(&A, 0, sizeof(A));
     A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp; A.out_row0 = out_row0;
-    const int r = ig2_dispatch(L, G, side, false, A);
+    A.own_grad = own_grad;
+    const int r = ig2_dispatch(L, G, side, own_grad ? 1 : 0, A);
     if (r >= 0) return r;
-    return igraph_rowsum_v1(L, G, side, out, out_sys_stride, out_stride, out_comp, out_row0);   // system too large for LDS staging
+    return igraph_rowsum_v1(L, G, side, out, out_sys_stride, out_stride, out_comp, out_row0, own_grad);   // system too large for LDS staging
+}
+
+// backward pass of the row side when the pair sensitivity is the row element's own: sens[row] * own_grad[row]
+__global__ void k_igraph_apply_own_grad(upk_igraph_t G, int side, const float* __restrict__ own_grad, const float* __restrict__ sens,
+                                        long sens_sys_stride, int sens_stride) {
+    const int s = blockIdx.y;
+    const int n_rows = side == 1 ? G.n1 : G.n2, dim = side == 1 ? G.dim1 : G.dim2;
+    const upk_coord_t& node = side == 1 ? G.node1 : G.node2;
+    const int* loc = side == 1 ? G.loc1 : G.loc2;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * 8; t += gridDim.x * blockDim.x) {
+        const int row = t >> 3, c = t & 7;
+        if (c >= dim) continue;
+        const float v = sens[(size_t)s * sens_sys_stride + (size_t)row * sens_stride] * own_grad[((size_t)s * n_rows + row) * 8 + c];
+        C_SENS(node, s)[(size_t)loc[row] * node.stride + c] += v;
+    }
+}
+extern "C" int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
+                                         const float* sens, long sens_sys_stride, int sens_stride) {
+    const int n_rows = side == 1 ? G->n1 : G->n2;
+    hipLaunchKernelGGL(k_igraph_apply_own_grad, dim3((n_rows * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side, own_grad,
+                       sens, sens_sys_stride, sens_stride);
+    return launch_status();
 }
 extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                                const float* sens2, long sens_sys_stride, int sens_stride) {
     Ig2Args A; memset(&A, 0, sizeof(A));
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
-    const int r = ig2_dispatch(L, G, side, true, A);
+    const int r = ig2_dispatch(L, G, side, 2, A);
     if (r >= 0) return r;
     return igraph_grad_v1(L, G, side, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
 }

@@ -282,7 +282,7 @@ static bool rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab
     const int waves = 16;
     lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)R->G.n1 * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
     if (lds_bytes > 158 * 1024) return false;
-    int bps = (1024 + L->n_system - 1) / L->n_system;
+    int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;
     const int max_bps = (R->G.n1 + waves - 1) / waves;
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;

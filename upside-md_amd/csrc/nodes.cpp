@@ -483,9 +483,9 @@ struct ProteinHBond : public CoordNode {
     void compute_value(ComputeMode) override {
         ig.update_lists();
         { IGraphHost::Prof pr(ig, name, "igraph_fwd1", 0);
-          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0), "protein_hbond rowsum donors"); }
+          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0, nullptr), "protein_hbond rowsum donors"); }
         { IGraphHost::Prof pr(ig, name, "igraph_fwd2", 0);
-          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor), "protein_hbond rowsum acceptors"); }
+          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor, nullptr), "protein_hbond rowsum acceptors"); }
         upk_check(upk_protein_hbond_finish(&ctx->L, infer.coord(), coord()), "protein_hbond_finish");
     }
     void propagate_deriv() override {
@@ -504,18 +504,20 @@ RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
 // hbond_coverage: hbond.cpp:371-414
 struct HBondCoverage : public CoordNode {
     IGraphHost ig;
+    DevBuf<float> own_grad;   // [S][n_bead][8]: sum over sites of d(coverage)/d(bead), written by the forward pass
     HBondCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& infer_, CoordNode& sidechains_)
-        : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {}
+        : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {
+        own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
+    }
     void compute_value(ComputeMode) override {
         ig.update_lists();
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0), "hbond_coverage rowsum");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0, own_grad.p), "hbond_coverage rowsum");
     }
     void propagate_deriv() override {
         { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
           upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites"); }
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad beads"); }
+        upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 2, own_grad.p, sens.p, sys_stride(), stride), "hbond_coverage grad beads");
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
@@ -529,16 +531,18 @@ RegisterNodeType<HBondCoverage, 2> coverage_node("hbond_coverage");
 // environment_coverage: environment.cpp:71-109
 struct EnvironmentCoverage : public CoordNode {
     IGraphHost ig;
+    DevBuf<float> own_grad;   // [S][n_res][8]: sum over side chains of d(coverage)/d(CB frame)
     EnvironmentCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& cb_pos_, CoordNode& weighted_sidechains_)
-        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {}
+        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {
+        own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
+    }
     void compute_value(ComputeMode) override {
         ig.update_lists();
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0), "environment_coverage rowsum");
+        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0, own_grad.p), "environment_coverage rowsum");
     }
     void propagate_deriv() override {
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad cb"); }
+        upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 1, own_grad.p, sens.p, sys_stride(), stride), "environment_coverage grad cb");
         { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
           upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc"); }
     }
