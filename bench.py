@@ -45,6 +45,7 @@ def bind(lib):
     c.upside_hip_get_pos.argtypes = [ct.c_void_p, ct.c_void_p]
     c.upside_hip_init_md.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint32, ct.c_float, ct.c_float, ct.c_int]
     c.upside_hip_run_md.argtypes = [ct.c_void_p, ct.c_int]
+    c.upside_hip_run_steps.argtypes = [ct.c_void_p, ct.c_int]
     c.upside_hip_compute.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p]
     c.upside_hip_profile_reset.argtypes = [ct.c_void_p, ct.c_int]
     c.upside_hip_profile_dump.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int]
@@ -117,9 +118,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    pkg = load_package()
+    rep = pkg.replicas
+    rank, local_rank, world = rep.world_from_env()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
@@ -131,7 +132,6 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    pkg = load_package()
     lib = pkg.default_library()          # raises if the HIP extension is missing: no fallback
     c = bind(lib)
     check(c, c.upside_hip_set_device(local_rank), 'set_device')
@@ -147,19 +147,16 @@ def main():
     pos = np.ascontiguousarray(np.tile(pos0[None], (R, 1, 1)).astype('f4'))
     check(c, c.upside_hip_set_pos(eng, pos.ctypes.data), 'set_pos')
     temps = np.full(R, TEMPERATURE, dtype='f4')
-    # every replica (and every rank) gets its own thermostat stream: seed = base + replica index
-    check(c, c.upside_hip_init_md(eng, temps.ctypes.data, 1000 + rank * R, 5.0, DT, 1), 'init_md')
+    # every replica of every rank gets its own thermostat stream: seed = base + GLOBAL replica index (main.cpp:459)
+    first, _ = rep.weak_shard(R, world, rank)
+    check(c, c.upside_hip_init_md(eng, temps.ctypes.data, rep.system_seed(1000, first), 5.0, DT, 1), 'init_md')
 
     def run_steps(n):
-        n_round = max(1, (n + 2) // 3)
-        check(c, c.upside_hip_run_md(eng, n_round), 'run_md')     # returns after the stream has drained
-        return 3 * n_round
+        check(c, c.upside_hip_run_steps(eng, n), 'run_steps')     # exactly n force evaluations; returns after the stream has drained
+        return n
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        rep.barrier(dist, torch.cuda.synchronize)
 
     run_steps(args.warmup)
     barrier()
@@ -167,10 +164,7 @@ def main():
     steps_done = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    value, elapsed = rep.job_throughput(dist, R * steps_done, elapsed, device='cuda')   # all ranks' units / slowest rank
 
     # ---- roofline of the dominant kernel: HIP-event timing on the engine's stream, outside the timed region
     roofline = None
@@ -195,7 +189,6 @@ def main():
                         kernels={r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
                                             GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows})
 
-    value = world * R * steps_done / elapsed
     if rank == 0:
         res = dict(metric='MD steps/sec (force evals/sec) per 300-res protein', value=value, unit='system-steps/s',
                    n_gpus=world, steps=steps_done, warmup=args.warmup, ms_per_step=elapsed / steps_done * 1e3,

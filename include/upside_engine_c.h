@@ -77,6 +77,9 @@ int upside_hip_init_md(DerivEngine* engine, const float* temperature, uint32_t b
  * Ornstein-Uhlenbeck thermostat (thermostat.cpp:9-18) every thermostat_interval rounds; everything
  * stays on the device, the call returns after the stream has drained. */
 int upside_hip_run_md(DerivEngine* engine, int n_round);
+/* the same loop counted in MD steps (one force evaluation + one leapfrog stage each, the unit of the reference's
+ * "steps/s", main.cpp:677-682); a cycle left unfinished is resumed by the next call. */
+int upside_hip_run_steps(DerivEngine* engine, int n_step);
 
 /* recenter (deriv_engine.cpp:37-48) all systems */
 int upside_hip_recenter(DerivEngine* engine);

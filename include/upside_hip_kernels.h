@@ -111,7 +111,9 @@ typedef struct {
     int cap1, cap2;
     int *nbr1, *cnt1, *nbr2, *cnt2;
     float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from */
-    int* rebuild_flag;                   /* [S] */
+    int* rebuild_flag;                   /* [S] system moved further than the skin allows */
+    int* any_flag; int parity;           /* [2] or NULL: when set, ALL systems rebuild together as soon as one is flagged
+                                          * (any_flag[parity] is this step's flag, the other entry is cleared for the next step) */
     int* error_flag;                     /* [1] set to non-zero on capacity overflow */
     /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
        (mark_n x mark_n ints, pre-cleared to -1 by upk_rotamer_clear_slots) is set to -2 for every cached pair */
@@ -144,6 +146,8 @@ int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int 
 int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags);
 
 /* ---- rotamer (src/rotamer.cpp) ------------------------------------------------------------------- */
+#define UPK_REBUILD(G, s) ((G).any_flag ? (G).any_flag[(G).parity] : (G).rebuild_flag[s])
+
 typedef struct {
     upk_igraph_t G;                      /* symmetric bead graph */
     int n_node, n_node1, n_node3;        /* global node ids: class 1, then 3, then 6 */

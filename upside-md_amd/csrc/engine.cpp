@@ -207,14 +207,15 @@ void DerivEngine::fetch_potentials() {
     }
 }
 
-void DerivEngine::integration_cycle(float dt_, float max_force) {
+void DerivEngine::integration_stage(int stage, float dt_, float max_force) {
     const float a = 1.f / 6.f, b = 1.f / 3.f;   // Verlet
     const float mom_update[] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
     const float pos_update[] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
-    for (int stage = 0; stage < 3; ++stage) {
-        compute(DerivMode);
-        upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force), "integration_stage");
-    }
+    compute(DerivMode);
+    upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force), "integration_stage");
+}
+void DerivEngine::integration_cycle(float dt_, float max_force) {
+    for (int stage = 0; stage < 3; ++stage) integration_stage(stage, dt_, max_force);
 }
 
 void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }

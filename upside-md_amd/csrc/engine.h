@@ -168,6 +168,8 @@ struct DerivEngine {   // deriv_engine.h:145-237
     void compute(ComputeMode mode);            // enqueue; no synchronisation
     void fetch_potentials();                   // D2H of every PotentialNode::potential + engine total
     void integration_cycle(float dt, float max_force = 0.f);   // deriv_engine.cpp:172-192 (Verlet weights)
+    void integration_stage(int stage, float dt, float max_force);   // one force evaluation + leapfrog sub-step (deriv_engine.cpp:172-192)
+    int stage_num = 0;                                              // sub-step the next upside_hip_run_steps call starts with
     void check_device_errors();                // throws if a capacity overflow was flagged
     void sync();
 };

@@ -252,6 +252,20 @@ extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
     return 0;
     API_CATCH(1)
 }
+extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
+    API_TRY
+    for (int i = 0; i < n_step; ++i) {
+        if (e->stage_num == 0 && !(e->round_num % e->thermostat_interval)) {
+            upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
+            e->n_invocations++;
+        }
+        e->integration_stage(e->stage_num, e->dt, 0.f);
+        if (++e->stage_num == 3) { e->stage_num = 0; ++e->round_num; }
+    }
+    e->check_device_errors();
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_recenter(DerivEngine* e) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 

@@ -170,7 +170,13 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
     }
     if (m) moved = 1;   // benign race: every writer stores 1
     __syncthreads();
-    if (threadIdx.x == 0) G.rebuild_flag[s] = moved;
+    if (threadIdx.x == 0) {
+        G.rebuild_flag[s] = moved;
+        if (G.any_flag) {
+            if (moved) atomicOr(&G.any_flag[G.parity], 1);
+            if (s == 0) G.any_flag[G.parity ^ 1] = 0;
+        }
+    }
 }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
     hipLaunchKernelGGL(k_pairlist_check, dim3(1, L->n_system), dim3(256), 0, ST(L), *G);
@@ -181,7 +187,7 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
 // a time and compact hits with a ballot + popcount prefix, so each row comes out in ascending order.
 __global__ void k_pairlist_build(upk_igraph_t G) {
     const int s = blockIdx.y;
-    if (!G.rebuild_flag[s]) return;
+    if (!UPK_REBUILD(G, s)) return;
     const int lane = threadIdx.x & 63;
     const int n_rows = G.symmetric ? G.n1 : G.n1 + G.n2;
     const float cut2 = G.cache_cutoff * G.cache_cutoff;

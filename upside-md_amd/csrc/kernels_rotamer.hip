@@ -38,7 +38,7 @@ __device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
 // rebuild step 0: clear the node x node table of flagged systems (before the list build marks it)
 __global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
     const int s = blockIdx.y;
-    if (!R.G.rebuild_flag[s]) return;
+    if (!UPK_REBUILD(R.G, s)) return;
     const int n = R.n_node * R.n_node;
     int* slot_of = R.slot_of + (size_t)s * n;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slot_of[i] = -1;
@@ -55,7 +55,7 @@ extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t R) {
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    if (!G.rebuild_flag[s]) return;
+    if (!UPK_REBUILD(G, s)) return;
     __shared__ int row_cnt[2][1024];      // per row a: hits in its lower / higher class (a row feeds at most two classes)
     __shared__ int row_pos[2][1024];
     __shared__ int class_base[N_CLASS + 1];
@@ -176,7 +176,7 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
 __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    if (!G.rebuild_flag[s]) return;
+    if (!UPK_REBUILD(G, s)) return;
     const int NN = R.n_node;
     const int* slot_of = R.slot_of + (size_t)s * NN * NN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;

@@ -316,7 +316,7 @@ struct IGraphHost {
     CoordNode *node1, *node2;
     vector<int> loc1, loc2, type1, type2, id1, id2;
     vector<float> param;
-    DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag;
+    DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag, any_flag;
     DevBuf<float> d_param, cache_pos1, cache_pos2;
 
     float type_cutoff(const float* p) const {
@@ -409,9 +409,16 @@ struct IGraphHost {
         G.nbr1 = nbr1.p; G.cnt1 = cnt1.p; G.nbr2 = nbr2.p; G.cnt2 = cnt2.p;
         G.cache_pos1 = cache_pos1.p; G.cache_pos2 = G.symmetric ? cache_pos1.p : cache_pos2.p;
         G.rebuild_flag = rebuild_flag.p; G.error_flag = c->error_flag.p;
+        // batched engines rebuild the lists of all systems in the same step: a rebuild then runs at full-device
+        // parallelism every few steps instead of a one-system straggler on (nearly) every step
+        G.any_flag = nullptr; G.parity = 0;
+        const char* sync_env = getenv("UPSIDE_HIP_SYNC_REBUILD");
+        if (S > 1 && !(sync_env && atoi(sync_env) == 0)) { any_flag.alloc(2); G.any_flag = any_flag.p; }
         G.node1 = node1->coord(); G.node2 = node2->coord();
     }
+    void begin_step() { G.parity ^= 1; }
     void update_lists() {   // K1 + K2
+        begin_step();
         upk_check(upk_pairlist_check(&ctx->L, &G), "pairlist_check");
         upk_check(upk_pairlist_build(&ctx->L, &G), "pairlist_build");
     }
@@ -710,6 +717,7 @@ struct RotamerSidechain : public PotentialNode {
         if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
     }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
+        ig.begin_step();
         R.G = ig.G;
         upk_check(upk_pairlist_check(&ctx->L, &ig.G), "pairlist_check");
         upk_check(upk_rotamer_clear_slots(&ctx->L, &R), "rotamer_clear_slots");
