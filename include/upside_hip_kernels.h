@@ -22,6 +22,9 @@ typedef struct { float* out; float* sens; int n_elem; int width; int stride; } u
 /* ---- generic ---------------------------------------------------------------------------------- */
 /* out[s] (+)= sum_i in[s][i]; one workgroup per system, fixed tree order (deterministic).            */
 int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate);
+/* zero n_buf device buffers (float counts in sizes[], 16-byte aligned) in one launch:
+ * the per-node "zero sensitivity" of deriv_engine.cpp:147-151 for the whole graph */
+int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf);
 /* deterministic gather of deferred derivative contributions into a node's sens:
  * sens[s][t][c] += sum_{e in csr[t]} arena[s][entry[e] + c], c < width  (replaces the scatter-adds of
  * e.g. src/bonds.cpp:315-316, src/placement.cpp:304-305, src/eig.cpp:467)                               */
@@ -112,8 +115,10 @@ typedef struct {
     int *nbr1, *cnt1, *nbr2, *cnt2;
     float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from */
     int* rebuild_flag;                   /* [S] system moved further than the skin allows */
-    int* any_flag; int parity;           /* [2] or NULL: when set, ALL systems rebuild together as soon as one is flagged
-                                          * (any_flag[parity] is this step's flag, the other entry is cleared for the next step) */
+    int* flagged; int parity, flag_stride; /* [2][flag_stride]: compact list of the systems flagged this step: entry 0 of
+                                          * half `parity` is the count, entries 1.. the system ids; the other half is
+                                          * reset for the next step.  Rebuild kernels loop over this list with a small
+                                          * grid.y instead of launching (and retiring) workgroups for every system. */
     int* error_flag;                     /* [1] set to non-zero on capacity overflow */
     /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
        (mark_n x mark_n ints, pre-cleared to -1 by upk_rotamer_clear_slots) is set to -2 for every cached pair */
@@ -146,7 +151,8 @@ int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int 
 int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags);
 
 /* ---- rotamer (src/rotamer.cpp) ------------------------------------------------------------------- */
-#define UPK_REBUILD(G, s) ((G).any_flag ? (G).any_flag[(G).parity] : (G).rebuild_flag[s])
+#define UPK_FLAG_GRID 16   /* grid.y of the rebuild kernels */
+#define UPK_FLAG_LIST(G) ((G).flagged + (size_t)(G).parity * (G).flag_stride)
 
 typedef struct {
     upk_igraph_t G;                      /* symmetric bead graph */

@@ -130,6 +130,10 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
 }
 DerivEngine::~DerivEngine() {
     if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); }
+    for (auto& kv : side) {
+        (void)hipStreamSynchronize(kv.second.stream);
+        (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); (void)hipStreamDestroy(kv.second.stream);
+    }
     nodes.clear();
     if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
 }
@@ -177,17 +181,80 @@ void DerivEngine::finalize() {
         }
         if (!not_finished) break;
     }
+    // one launch clears every sensitivity buffer at the start of a force pass
+    {
+        vector<float*> ptrs; vector<long> sizes;
+        for (auto& n : nodes) {
+            if (n.computation->potential_term) continue;
+            auto* cn = static_cast<CoordNode*>(n.computation.get());
+            if (!cn->sens.n) continue;
+            ptrs.push_back(cn->sens.p); sizes.push_back((long)cn->sens.n);
+        }
+        n_zero = (int)ptrs.size();
+        zero_ptrs.upload(ptrs); zero_sizes.upload(sizes);
+    }
+    // hoist prepare() of the nodes that have one to just after the forward step of the last parent it reads, on a
+    // side stream
+    const char* env = getenv("UPSIDE_HIP_ASYNC_PREPARE");
+    if (env && atoi(env) == 0) return;
+    std::vector<Step> hoisted;
+    std::vector<int> n_parent_left(nodes.size(), 0);
+    auto is_dep = [&](size_t child, size_t parent) {
+        auto& deps = nodes[child].computation->prepare_deps;
+        return deps.empty() || std::find(begin(deps), end(deps), nodes[parent].computation.get()) != end(deps);
+    };
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        n_parent_left[i] = -1;
+        if (!nodes[i].computation->has_prepare()) continue;
+        n_parent_left[i] = 0;
+        for (size_t ip : nodes[i].parents) if (is_dep(i, ip)) ++n_parent_left[i];
+    }
+    for (auto& st : schedule) {
+        hoisted.push_back(st);
+        if (st.backward) continue;
+        for (size_t c : nodes[st.node].children) {
+            if (n_parent_left[c] <= 0 || !is_dep(c, (size_t)st.node)) continue;
+            // a parent may be listed twice (same node as two arguments)
+            const int mult = (int)std::count(begin(nodes[c].parents), end(nodes[c].parents), (size_t)st.node);
+            n_parent_left[c] -= mult;
+            if (n_parent_left[c] == 0) {
+                Step ps{(int)c, false}; ps.prepare = true; hoisted.push_back(ps);
+                Side sd;
+                hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
+                hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
+                hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
+                side[(int)c] = sd;
+                n_parent_left[c] = -1;
+            }
+        }
+    }
+    schedule.swap(hoisted);
 }
 
 void DerivEngine::compute(ComputeMode mode) {
+    // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
+    // node's sens before that node's own forward step
+    upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
     for (auto& st : schedule) {
         auto* c = nodes[st.node].computation.get();
+        if (st.prepare) {   // fork: side stream waits for everything enqueued so far, runs the upkeep, records `join`
+            Side& sd = side[st.node];
+            hip_check(hipEventRecord(sd.fork, ctx.stream), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(sd.stream, sd.fork, 0), "hipStreamWaitEvent");
+            hipStream_t main_stream = ctx.stream;
+            ctx.stream = sd.stream; ctx.L.stream = (void*)sd.stream;
+            try { c->prepare(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
+            ctx.stream = main_stream; ctx.L.stream = (void*)main_stream;
+            hip_check(hipEventRecord(sd.join, sd.stream), "hipEventRecord");
+            continue;
+        }
         if (!st.backward) {
-            c->compute_value(mode);
-            if (!c->potential_term) {
-                auto* cn = static_cast<CoordNode*>(c);   // zero sensitivity for later derivative writing (:147-151)
-                hip_check(hipMemsetAsync(cn->sens.p, 0, cn->sens.n * sizeof(float), ctx.stream), "hipMemsetAsync");
+            if (c->has_prepare()) {
+                auto it = side.find(st.node);
+                if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent");
+                else c->prepare();
             }
+            c->compute_value(mode);
         } else if (!c->potential_term) {
             auto* cn = static_cast<CoordNode*>(c);
             cn->gather_contributions();

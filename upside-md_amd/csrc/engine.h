@@ -96,6 +96,12 @@ struct DerivComputation {   // deriv_engine.h:48-80
     virtual void set_param(const std::vector<float>&) {}
     virtual std::vector<float> get_value_by_name(const char*) { throw std::string("No values implemented"); }
     virtual void finalize() {}   // called once after the whole graph exists (scatter plans, device pointer tables)
+    // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).
+    // The engine enqueues it on a side stream as soon as the last parent is computed, so a straggling rebuild of a
+    // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).
+    virtual bool has_prepare() const { return false; }
+    virtual void prepare() {}
+    std::vector<const DerivComputation*> prepare_deps;   // parents prepare() reads (empty = all of them)
 };
 
 struct CoordNode : public DerivComputation {   // deriv_engine.h:83-96
@@ -151,8 +157,11 @@ struct DerivEngine {   // deriv_engine.h:145-237
     uint64_t n_invocations = 0, round_num = 0;
 
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
-    struct Step { int node; bool backward; };
+    struct Step { int node; bool backward; bool prepare = false; };
     std::vector<Step> schedule;
+    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    std::map<int, Side> side;                  // node index -> side stream of its prepare() (empty when disabled)
+    DevBuf<float*> zero_ptrs; DevBuf<long> zero_sizes; int n_zero = 0;   // every CoordNode's sens, cleared by one launch per force pass
 
     DerivEngine(int n_atom, int n_system);
     ~DerivEngine();

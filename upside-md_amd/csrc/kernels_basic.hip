@@ -32,6 +32,19 @@ __global__ void k_reduce_sum(const float* __restrict__ in, int n, float* __restr
         out[s] = accumulate ? out[s] + t : t;
     }
 }
+__global__ void k_zero_many(float* const* __restrict__ ptrs, const long* __restrict__ sizes) {
+    float4* p = (float4*)ptrs[blockIdx.y];
+    const long n4 = sizes[blockIdx.y] >> 2;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) p[i] = z;
+    const long tail = sizes[blockIdx.y] & 3;
+    if (blockIdx.x == 0 && threadIdx.x < tail) ptrs[blockIdx.y][(n4 << 2) + threadIdx.x] = 0.f;
+}
+extern "C" int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf) {
+    if (n_buf <= 0) return 0;
+    hipLaunchKernelGGL(k_zero_many, dim3(128, n_buf), dim3(256), 0, ST(L), ptrs, sizes);
+    return launch_status();
+}
 extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate) {
     hipLaunchKernelGGL(k_reduce_sum, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, n, out, accumulate);
     return launch_status();

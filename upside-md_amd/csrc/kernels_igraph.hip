@@ -172,10 +172,9 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
     __syncthreads();
     if (threadIdx.x == 0) {
         G.rebuild_flag[s] = moved;
-        if (G.any_flag) {
-            if (moved) atomicOr(&G.any_flag[G.parity], 1);
-            if (s == 0) G.any_flag[G.parity ^ 1] = 0;
-        }
+        int* fl = UPK_FLAG_LIST(G);
+        if (moved) fl[1 + atomicAdd(&fl[0], 1)] = s;
+        if (s == 0) G.flagged[(size_t)(G.parity ^ 1) * G.flag_stride] = 0;
     }
 }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
@@ -186,11 +185,13 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
 // K2: rebuild the row lists of flagged systems.  One wavefront per row; the 64 lanes test 64 candidates at
 // a time and compact hits with a ballot + popcount prefix, so each row comes out in ascending order.
 __global__ void k_pairlist_build(upk_igraph_t G) {
-    const int s = blockIdx.y;
-    if (!UPK_REBUILD(G, s)) return;
+    const int* fl = UPK_FLAG_LIST(G);
+    const int n_flagged = fl[0];
     const int lane = threadIdx.x & 63;
     const int n_rows = G.symmetric ? G.n1 : G.n1 + G.n2;
     const float cut2 = G.cache_cutoff * G.cache_cutoff;
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    const int s = fl[1 + fi];
     for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * ROWS_PER_BLOCK) {
         const bool side1 = row < G.n1;
         const int i = side1 ? row : row - G.n1;
@@ -235,11 +236,12 @@ __global__ void k_pairlist_build(upk_igraph_t G) {
             if (count > cap) *G.error_flag = 1;
         }
     }
+    }
 }
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
     const int n_rows = G->symmetric ? G->n1 : G->n1 + G->n2;
     int blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_pairlist_build, dim3(blocks, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G);
+    hipLaunchKernelGGL(k_pairlist_build, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(IG_BLOCK), 0, ST(L), *G);
     return launch_status();
 }
 

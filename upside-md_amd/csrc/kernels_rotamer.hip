@@ -37,31 +37,36 @@ __device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
 // ------------------------------------------------------------------------------------------------
 // rebuild step 0: clear the node x node table of flagged systems (before the list build marks it)
 __global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
-    const int s = blockIdx.y;
-    if (!UPK_REBUILD(R.G, s)) return;
+    const int* fl = UPK_FLAG_LIST(R.G);
+    const int n_flagged = fl[0];
     const int n = R.n_node * R.n_node;
-    int* slot_of = R.slot_of + (size_t)s * n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slot_of[i] = -1;
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+        int* slot_of = R.slot_of + (size_t)fl[1 + fi] * n;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slot_of[i] = -1;
+    }
 }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     const int n = R->n_node * R->n_node;
     int blocks = (n + 1023) / 1024; if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, L->n_system), dim3(1024), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(1024), 0, ST(L), *R);
     return launch_status();
 }
 
 // rebuild step 2 (after the list build has marked the table): number the slots by class, build the adjacency and
 // the message inbox layout; one workgroup per flagged system
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t R) {
-    const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    if (!UPK_REBUILD(G, s)) return;
+    const int* fl = UPK_FLAG_LIST(G);
+    const int n_flagged = fl[0];
     __shared__ int row_cnt[2][1024];      // per row a: hits in its lower / higher class (a row feeds at most two classes)
     __shared__ int row_pos[2][1024];
     __shared__ int class_base[N_CLASS + 1];
     __shared__ int deg_bp[1024];
     const int NN = R.n_node;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_wave = blockDim.x >> 6;
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    const int s = fl[1 + fi];
+    __syncthreads();                       // shared scratch of the previous system is no longer read
     int* slot_of = R.slot_of + (size_t)s * NN * NN;
     const int* nrot = R.node_nrot;
     // a row's partners b > a come in ascending class: row class 1 -> (1,1) then (1,x); 3 -> (3,3) then (3,6); 6 -> (6,6)
@@ -165,31 +170,35 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
             base += __popcll(m);
         }
     }
+    }
 }
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     if (R->n_node > 1024) return 9003;
-    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system), dim3(BP_BLOCK), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 64 ? L->n_system : 64), dim3(BP_BLOCK), 0, ST(L), *R);
     return launch_status();
 }
 
 // rebuild step 3: every cached bead pair remembers its slot
 __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
-    const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    if (!UPK_REBUILD(G, s)) return;
+    const int* fl = UPK_FLAG_LIST(G);
+    const int n_flagged = fl[0];
     const int NN = R.n_node;
-    const int* slot_of = R.slot_of + (size_t)s * NN * NN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
-        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        const int a = R.bead_node[row];
-        for (int k = lane; k < cnt; k += 64) R.nbr_slot[base + k] = slot_of[a * NN + R.bead_node[G.nbr1[base + k]]];
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+        const int s = fl[1 + fi];
+        const int* slot_of = R.slot_of + (size_t)s * NN * NN;
+        for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
+            const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+            const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+            const int a = R.bead_node[row];
+            for (int k = lane; k < cnt; k += 64) R.nbr_slot[base + k] = slot_of[a * NN + R.bead_node[G.nbr1[base + k]]];
+        }
     }
 }
 extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     int blocks = (R->G.n1 + 3) / 4;
-    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, L->n_system), dim3(256), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(256), 0, ST(L), *R);
     return launch_status();
 }
 

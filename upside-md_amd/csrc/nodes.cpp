@@ -316,7 +316,7 @@ struct IGraphHost {
     CoordNode *node1, *node2;
     vector<int> loc1, loc2, type1, type2, id1, id2;
     vector<float> param;
-    DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag, any_flag;
+    DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag, flagged;
     DevBuf<float> d_param, cache_pos1, cache_pos2;
 
     float type_cutoff(const float* p) const {
@@ -409,11 +409,7 @@ struct IGraphHost {
         G.nbr1 = nbr1.p; G.cnt1 = cnt1.p; G.nbr2 = nbr2.p; G.cnt2 = cnt2.p;
         G.cache_pos1 = cache_pos1.p; G.cache_pos2 = G.symmetric ? cache_pos1.p : cache_pos2.p;
         G.rebuild_flag = rebuild_flag.p; G.error_flag = c->error_flag.p;
-        // batched engines rebuild the lists of all systems in the same step: a rebuild then runs at full-device
-        // parallelism every few steps instead of a one-system straggler on (nearly) every step
-        G.any_flag = nullptr; G.parity = 0;
-        const char* sync_env = getenv("UPSIDE_HIP_SYNC_REBUILD");
-        if (S > 1 && !(sync_env && atoi(sync_env) == 0)) { any_flag.alloc(2); G.any_flag = any_flag.p; }
+        flagged.alloc(2 * (size_t)(S + 1)); G.flagged = flagged.p; G.flag_stride = S + 1; G.parity = 0;
         G.node1 = node1->coord(); G.node2 = node2->coord();
     }
     void begin_step() { G.parity ^= 1; }
@@ -487,8 +483,9 @@ struct ProteinHBond : public CoordNode {
         if (n_donor + n_acceptor != infer.n_elem) throw string("protein_hbond expects one row per infer_H_O site");
         sens_scaled.alloc((size_t)c->n_system * n_elem);
     }
+    bool has_prepare() const override { return true; }
+    void prepare() override { ig.update_lists(); }
     void compute_value(ComputeMode) override {
-        ig.update_lists();
         { IGraphHost::Prof pr(ig, name, "igraph_fwd1", 0);
           upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0, nullptr), "protein_hbond rowsum donors"); }
         { IGraphHost::Prof pr(ig, name, "igraph_fwd2", 0);
@@ -516,8 +513,9 @@ struct HBondCoverage : public CoordNode {
         : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {
         own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
     }
+    bool has_prepare() const override { return true; }
+    void prepare() override { ig.update_lists(); }
     void compute_value(ComputeMode) override {
-        ig.update_lists();
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
         upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0, own_grad.p), "hbond_coverage rowsum");
     }
@@ -543,8 +541,9 @@ struct EnvironmentCoverage : public CoordNode {
         : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {
         own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
     }
+    bool has_prepare() const override { return true; }
+    void prepare() override { ig.update_lists(); }
     void compute_value(ComputeMode) override {
-        ig.update_lists();
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
         upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0, own_grad.p), "environment_coverage rowsum");
     }
@@ -714,9 +713,11 @@ struct RotamerSidechain : public PotentialNode {
         R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
         R.iters = iters.p; R.energy = energy.p;
         R.bp_trace = nullptr;
+        prepare_deps.push_back(ig.node1);   // the list upkeep reads the bead positions only, not the 1-body energies
         if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
     }
-    void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
+    bool has_prepare() const override { return true; }
+    void prepare() override {   // pair list + residue-pair slots of the systems that moved (depends on the bead positions only)
         ig.begin_step();
         R.G = ig.G;
         upk_check(upk_pairlist_check(&ctx->L, &ig.G), "pairlist_check");
@@ -724,6 +725,8 @@ struct RotamerSidechain : public PotentialNode {
         upk_check(upk_pairlist_build(&ctx->L, &ig.G), "pairlist_build");
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
         upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
+    }
+    void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
         upk_check(upk_rotamer_node_prob(&ctx->L, &R), "rotamer_node_prob");
         { IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
           upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy"); }
