@@ -90,6 +90,8 @@ int upside_hip_recenter(DerivEngine* engine);
 int upside_hip_replica_swap(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
                             uint64_t round, int* accepted);
 
+/* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */
+int upside_hip_rebuild_flags(DerivEngine* engine, const char* node_name, int* flags);
 /* Parity/diagnostic access: the in-range pair list of an interaction-graph node of system `sys` after the
  * last force pass, canonical order of interaction_graph.h:122-157.  Returns n_edge or -1. */
 int upside_hip_get_pairlist(DerivEngine* engine, const char* node_name, int sys, int max_edge, int* i1, int* i2);

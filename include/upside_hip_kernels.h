@@ -113,7 +113,7 @@ typedef struct {
        for asymmetric graphs the transposed list nbr2 as well; symmetric graphs keep the full list in nbr1. */
     int cap1, cap2;
     int *nbr1, *cnt1, *nbr2, *cnt2;
-    float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from */
+    float *cache_pos1, *cache_pos2;      /* [S][n][4] positions the lists were built from; 4th word = element id (raw bits) */
     int* rebuild_flag;                   /* [S] system moved further than the skin allows */
     int* flagged; int parity, flag_stride; /* [2][flag_stride]: compact list of the systems flagged this step: entry 0 of
                                           * half `parity` is the count, entries 1.. the system ids; the other half is
@@ -121,8 +121,8 @@ typedef struct {
                                           * grid.y instead of launching (and retiring) workgroups for every system. */
     int* error_flag;                     /* [1] set to non-zero on capacity overflow */
     /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
-       (mark_n x mark_n ints, pre-cleared to -1 by upk_rotamer_clear_slots) is set to -2 for every cached pair */
-    int* mark_table; const int* mark_node; int mark_n;
+       (mark_n x mark_n bytes, pre-cleared by upk_rotamer_clear_slots) is set to 1 for every cached pair */
+    unsigned char* mark_table; const int* mark_node; int mark_n, mark_stride;   /* mark_stride: bytes per system (multiple of 16) */
 } upk_igraph_t;
 
 /* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build
@@ -167,6 +167,7 @@ typedef struct {
     float *node_prob, *node_off, *nb_cur, *nb_old;      /* [S][n_node][6], off [S][n_node] */
     int slot_cap, adj_cap;
     int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
+    unsigned char* mark;                 /* [S][n_node^2] residue pairs owning a cached bead pair (= G.mark_table) */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
     int *class_start;                    /* [S][6] slot ranges by class: 3x3, 3x6, 6x6, 1x1, 1xN */

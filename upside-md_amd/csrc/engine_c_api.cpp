@@ -17,6 +17,7 @@ using namespace std;
 
 int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pair<int, int>>& out);
 int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters);
+int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags);
 double engine_igraph_bytes(DerivEngine& e);
 int upside_main_impl(int argc, const char* const* argv, int verbose);
 
@@ -287,6 +288,14 @@ extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pa
     API_CATCH(1)
 }
 
+extern "C" int upside_hip_rebuild_flags(DerivEngine* e, const char* node_name, int* flags) {
+    API_TRY
+    vector<int> f;
+    if (engine_rebuild_flags(*e, node_name, f)) throw string("node has no interaction graph");
+    for (size_t i = 0; i < f.size(); ++i) flags[i] = f[i];
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_get_pairlist(DerivEngine* e, const char* node_name, int sys, int max_edge, int* i1, int* i2) {
     API_TRY
     vector<pair<int, int>> pl;

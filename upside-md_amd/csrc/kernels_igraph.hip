@@ -150,7 +150,9 @@ __device__ __forceinline__ void load_elem(float* x, const upk_coord_t& node, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: one workgroup per system decides whether the cached lists are still valid (interaction_graph.h:57-90)
+// K1: one workgroup per system decides whether the cached lists are still valid (interaction_graph.h:57-90).  A
+// system that moved too far is appended to this step's flagged list and its reference positions are refreshed
+// right here (x, y, z and the element id in the 4th word), so the rebuild streams one float4 array per side.
 __global__ void k_pairlist_check(upk_igraph_t G) {
     __shared__ int moved;
     const int s = blockIdx.y;
@@ -170,6 +172,16 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
     }
     if (m) moved = 1;   // benign race: every writer stores 1
     __syncthreads();
+    if (moved) {
+        for (int e = threadIdx.x; e < n_tot; e += blockDim.x) {
+            const bool side1 = e < G.n1;
+            const int i = side1 ? e : e - G.n1;
+            const upk_coord_t& node = side1 ? G.node1 : G.node2;
+            const float* x = C_OUT(node, s) + (size_t)(side1 ? G.loc1[i] : G.loc2[i]) * node.stride;
+            float4* c = (float4*)(side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + i;
+            *c = make_float4(x[0], x[1], x[2], __int_as_float(side1 ? G.id1[i] : G.id2[i]));
+        }
+    }
     if (threadIdx.x == 0) {
         G.rebuild_flag[s] = moved;
         int* fl = UPK_FLAG_LIST(G);
@@ -182,66 +194,73 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
     return launch_status();
 }
 
-// K2: rebuild the row lists of flagged systems.  One wavefront per row; the 64 lanes test 64 candidates at
-// a time and compact hits with a ballot + popcount prefix, so each row comes out in ascending order.
-__global__ void k_pairlist_build(upk_igraph_t G) {
+// K2: rebuild the row lists of the flagged systems from the refreshed reference positions.  A workgroup stages the
+// whole other side (16 bytes per element) in LDS and serves PLB_ROWS rows; one wavefront per row tests 64
+// candidates at a time and compacts hits with a ballot + popcount prefix, so each row comes out in ascending order.
+#define PLB_ROWS 64
+template <bool STAGED>
+__global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1) {
+    extern __shared__ __attribute__((aligned(16))) float plb_lds[];
+    float4* oth = (float4*)plb_lds;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
-    const int lane = threadIdx.x & 63;
-    const int n_rows = G.symmetric ? G.n1 : G.n1 + G.n2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const bool side1 = (int)blockIdx.x < blocks1;             // workgroups [0, blocks1) serve the side-1 rows
+    const int rb = side1 ? blockIdx.x : blockIdx.x - blocks1;
+    const int n_my = side1 ? G.n1 : G.n2, n_other = side1 ? G.n2 : G.n1;
+    const int cap = side1 ? G.cap1 : G.cap2;
     const float cut2 = G.cache_cutoff * G.cache_cutoff;
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
-    const int s = fl[1 + fi];
-    for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * ROWS_PER_BLOCK) {
-        const bool side1 = row < G.n1;
-        const int i = side1 ? row : row - G.n1;
-        const upk_coord_t& my_node = side1 ? G.node1 : G.node2;
-        const upk_coord_t& ot_node = side1 ? G.node2 : G.node1;
-        const int* my_loc = side1 ? G.loc1 : G.loc2;
-        const int* ot_loc = side1 ? G.loc2 : G.loc1;
-        const int* ot_id = side1 ? G.id2 : G.id1;
-        const int n_other = side1 ? G.n2 : G.n1;
-        const int cap = side1 ? G.cap1 : G.cap2;
-        int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
-        const float* x = C_OUT(my_node, s) + (size_t)my_loc[i] * my_node.stride;
-        const float x0 = x[0], x1 = x[1], x2 = x[2];
-        const int my_id = side1 ? G.id1[i] : G.id2[i];
-        if (lane == 0) {
-            float* c = (side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + (size_t)i * 4;
-            c[0] = x0; c[1] = x1; c[2] = x2;
+        const int s = fl[1 + fi];
+        const float4* src = (const float4*)((side1 ? G.cache_pos2 : G.cache_pos1) + (size_t)s * n_other * 4);
+        const float4* mine = (const float4*)((side1 ? G.cache_pos1 : G.cache_pos2) + (size_t)s * n_my * 4);
+        if (STAGED) {
+            __syncthreads();                                   // the previous system's copy is no longer read
+            for (int j = threadIdx.x; j < n_other; j += blockDim.x) oth[j] = src[j];
+            __syncthreads();
         }
-        int count = 0;
-        for (int j0 = 0; j0 < n_other; j0 += 64) {
-            const int j = j0 + lane;
-            bool hit = false;
-            if (j < n_other) {
-                const float* y = C_OUT(ot_node, s) + (size_t)ot_loc[j] * ot_node.stride;
-                const float d2 = dist2_exact(x0, x1, x2, y[0], y[1], y[2]);
-                const int oid = ot_id[j];
-                hit = (d2 < cut2) && (side1 ? acceptable_id_pair(G.itype, my_id, oid) : acceptable_id_pair(G.itype, oid, my_id));
-                if (G.symmetric) hit = hit && (j != i);
+        for (int r = wave; r < PLB_ROWS; r += n_wave) {
+            const int i = rb * PLB_ROWS + r;
+            if (i >= n_my) break;
+            const float4 x = mine[i];
+            const int my_id = __float_as_int(x.w);
+            int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
+            int count = 0;
+            for (int j0 = 0; j0 < n_other; j0 += 64) {
+                const int j = j0 + lane;
+                bool hit = false;
+                if (j < n_other) {
+                    const float4 y = STAGED ? oth[j] : src[j];
+                    const float d2 = dist2_exact(x.x, x.y, x.z, y.x, y.y, y.z);
+                    const int oid = __float_as_int(y.w);
+                    hit = (d2 < cut2) && (side1 ? acceptable_id_pair(G.itype, my_id, oid) : acceptable_id_pair(G.itype, oid, my_id));
+                    if (G.symmetric) hit = hit && (j != i);
+                }
+                const unsigned long long b = __ballot(hit);
+                const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
+                if (hit && pos < cap) nbr[pos] = j;
+                count += __popcll(b);
+                if (G.mark_table && hit && j > i) {   // residue pairs owning a cached bead pair (rotamer slots); benign race
+                    unsigned char* mt = G.mark_table + (size_t)s * G.mark_stride;
+                    const int a = G.mark_node[i], bb = G.mark_node[j];
+                    mt[a * G.mark_n + bb] = 1; mt[bb * G.mark_n + a] = 1;
+                }
             }
-            const unsigned long long b = __ballot(hit);
-            const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
-            if (hit && pos < cap) nbr[pos] = j;
-            count += __popcll(b);
-            if (G.mark_table && hit && j > i) {   // residue pairs owning a cached bead pair (rotamer slots); benign race
-                int* mt = G.mark_table + (size_t)s * G.mark_n * G.mark_n;
-                const int a = G.mark_node[i], bb = G.mark_node[j];
-                mt[a * G.mark_n + bb] = -2; mt[bb * G.mark_n + a] = -2;
+            if (lane == 0) {
+                (side1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[i] = count < cap ? count : cap;
+                if (count > cap) *G.error_flag = 1;
             }
         }
-        if (lane == 0) {
-            (side1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[i] = count < cap ? count : cap;
-            if (count > cap) *G.error_flag = 1;
-        }
-    }
     }
 }
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
-    const int n_rows = G->symmetric ? G->n1 : G->n1 + G->n2;
-    int blocks = (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(k_pairlist_build, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(IG_BLOCK), 0, ST(L), *G);
+    const int blocks1 = (G->n1 + PLB_ROWS - 1) / PLB_ROWS;
+    const int blocks2 = G->symmetric ? 0 : (G->n2 + PLB_ROWS - 1) / PLB_ROWS;
+    const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
+    const size_t lds = (size_t)n_max * 16;
+    const dim3 grid(blocks1 + blocks2, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID);
+    if (lds <= 150 * 1024) hipLaunchKernelGGL((k_pairlist_build<true>), grid, dim3(1024), lds, ST(L), *G, blocks1);
+    else hipLaunchKernelGGL((k_pairlist_build<false>), grid, dim3(1024), 0, ST(L), *G, blocks1);
     return launch_status();
 }
 

@@ -35,146 +35,170 @@ __device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
 }
 
 // ------------------------------------------------------------------------------------------------
-// rebuild step 0: clear the node x node table of flagged systems (before the list build marks it)
+// rebuild step 0: clear the node x node mark table of the flagged systems (before the list build marks it)
 __global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
     const int* fl = UPK_FLAG_LIST(R.G);
     const int n_flagged = fl[0];
-    const int n = R.n_node * R.n_node;
+    const int n16 = (R.n_node * R.n_node + 15) / 16;          // the table is padded to a multiple of 16 bytes
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
-        int* slot_of = R.slot_of + (size_t)fl[1 + fi] * n;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slot_of[i] = -1;
+        uint4* m = (uint4*)(R.mark + (size_t)fl[1 + fi] * R.G.mark_stride);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
     }
 }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    const int n = R->n_node * R->n_node;
-    int blocks = (n + 1023) / 1024; if (blocks > 64) blocks = 64;
+    const int n16 = (R->n_node * R->n_node + 15) / 16;
+    int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(1024), 0, ST(L), *R);
     return launch_status();
 }
 
+// block-wide exclusive prefix sum over blockDim.x = 1024 values (scratch: 17 ints); returns the prefix, *total the sum
+__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, UP_WAVE); if (lane >= off) incl += t; }
+    __syncthreads();                                   // scratch may still be read from a previous call
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { const int t = scratch[w]; scratch[w] = acc; acc += t; } scratch[16] = acc; }
+    __syncthreads();
+    *total = scratch[16];
+    return scratch[wave] + incl - v;
+}
+
 // rebuild step 2 (after the list build has marked the table): number the slots by class, build the adjacency and
-// the message inbox layout; one workgroup per flagged system
+// the message inbox layout.  One workgroup per flagged system; the marks are packed into an LDS bit matrix
+// (one row of 64-bit words per node) and every later pass is one THREAD per node over its row of words.
 __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t R) {
+    extern __shared__ unsigned long long bits[];            // [NN][W]
+    __shared__ int row_lo[1024], row_hi[1024], deg1[1024], bp_s[1025], scratch[17], cls_lds[N_CLASS + 1];
     const upk_igraph_t& G = R.G;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
-    __shared__ int row_cnt[2][1024];      // per row a: hits in its lower / higher class (a row feeds at most two classes)
-    __shared__ int row_pos[2][1024];
-    __shared__ int class_base[N_CLASS + 1];
-    __shared__ int deg_bp[1024];
-    const int NN = R.n_node;
+    const int NN = R.n_node, W = (NN + 63) / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_wave = blockDim.x >> 6;
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
-    const int s = fl[1 + fi];
-    __syncthreads();                       // shared scratch of the previous system is no longer read
-    int* slot_of = R.slot_of + (size_t)s * NN * NN;
     const int* nrot = R.node_nrot;
-    // a row's partners b > a come in ascending class: row class 1 -> (1,1) then (1,x); 3 -> (3,3) then (3,6); 6 -> (6,6)
-    for (int a = wave; a < NN; a += n_wave) {
-        const int na = nrot[a];
-        int c_lo = 0, c_hi = 0;
-        for (int b0 = a + 1; b0 < NN; b0 += 64) {
-            const int b = b0 + lane;
-            const bool hit = b < NN && slot_of[a * NN + b] == -2;
-            const bool lo = hit && nrot[b] == na;
-            c_lo += __popcll(__ballot(lo));
-            c_hi += __popcll(__ballot(hit && !lo));
-        }
-        if (lane == 0) { row_cnt[0][a] = c_lo; row_cnt[1][a] = c_hi; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int cnt[N_CLASS] = {0, 0, 0, 0, 0};
-        for (int a = 0; a < NN; ++a) {
-            const int na = nrot[a];
-            const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
-            row_pos[0][a] = cnt[cl_lo]; cnt[cl_lo] += row_cnt[0][a];
-            row_pos[1][a] = cnt[cl_hi]; cnt[cl_hi] += row_cnt[1][a];
-        }
-        int acc = 0;
-        for (int c = 0; c < N_CLASS; ++c) { class_base[c] = acc; acc += cnt[c]; }
-        class_base[N_CLASS] = acc;
-        int* cs = R.class_start + (size_t)s * (N_CLASS + 1);
-        for (int c = 0; c <= N_CLASS; ++c) cs[c] = class_base[c] < R.slot_cap ? class_base[c] : R.slot_cap;
-        R.n_slot[s] = acc < R.slot_cap ? acc : R.slot_cap;
-        if (acc > R.slot_cap) *G.error_flag = 2;
-    }
-    __syncthreads();
-    int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
-    int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
-    for (int a = wave; a < NN; a += n_wave) {
-        const int na = nrot[a];
-        const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
-        int p_lo = class_base[cl_lo] + row_pos[0][a], p_hi = class_base[cl_hi] + row_pos[1][a];
-        for (int b0 = a + 1; b0 < NN; b0 += 64) {
-            const int b = b0 + lane;
-            const bool hit = b < NN && slot_of[a * NN + b] == -2;
-            const bool lo = hit && nrot[b] == na;
-            const unsigned long long m_lo = __ballot(lo), m_hi = __ballot(hit && !lo);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (hit) {
-                const int sl = lo ? p_lo + __popcll(m_lo & below) : p_hi + __popcll(m_hi & below);
-                if (sl < R.slot_cap) { slot_a[sl] = a; slot_b[sl] = b; slot_of[a * NN + b] = sl; slot_of[b * NN + a] = sl; }
-                else { slot_of[a * NN + b] = -1; slot_of[b * NN + a] = -1; }
+    // nodes are sorted by state count: [0, e1) have 1 state, [e1, e3) 3, [e3, NN) 6
+    const int e1 = R.n_node1, e3 = R.n_node1 + R.n_node3;
+    auto below = [](int x, int c) -> unsigned long long {   // bits of word c whose node id is < x
+        const int r = x - c * 64;
+        return r <= 0 ? 0ull : (r >= 64 ? ~0ull : ((1ull << r) - 1ull));
+    };
+    auto rank_below = [&](int g, int x) {                    // partners of g with id < x
+        int n = 0;
+        for (int c = 0; c * 64 < x && c < W; ++c) n += __popcll(bits[g * W + c] & below(x, c));
+        return n;
+    };
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+        const int s = fl[1 + fi];
+        const unsigned char* mark = R.mark + (size_t)s * G.mark_stride;
+        int* slot_of = R.slot_of + (size_t)s * NN * NN;
+        __syncthreads();                                     // LDS of the previous system is no longer read
+        // ---- pack the marks: wave item = (row, word); 8 loads in flight per lane
+        for (int item0 = wave * 8; item0 < NN * W; item0 += n_wave * 8) {
+            unsigned char v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int item = item0 + u, a = item / W, b = (item % W) * 64 + lane;
+                v[u] = (item < NN * W && b < NN) ? mark[(size_t)a * NN + b] : (unsigned char)0;
             }
-            p_lo += __popcll(m_lo); p_hi += __popcll(m_hi);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned long long m = __ballot(v[u] != 0);
+                if (lane == 0 && item0 + u < NN * W) bits[item0 + u] = m;
+            }
         }
-    }
-    __syncthreads();
-    // zero the energy accumulators and the activity flags of the new slots
-    const int n_slot = class_base[N_CLASS] < R.slot_cap ? class_base[N_CLASS] : R.slot_cap;
-    float* P = R.P + (size_t)s * R.slot_cap * 36;
-    for (int i = tid; i < n_slot * 36; i += blockDim.x) P[(size_t)(i / n_slot) * R.slot_cap + (i % n_slot)] = 0.f;
-    int* active = R.slot_active + (size_t)s * R.slot_cap;
-    for (int i = tid; i < n_slot; i += blockDim.x) active[i] = 0;
-    // adjacency of 1-state partners (for folding, rotamer.cpp:378-385) and BP inbox sizes
-    for (int g = wave; g < NN; g += n_wave) {
-        int* adj = R.adj_slot + ((size_t)s * NN + g) * R.adj_cap;
-        int count = 0, count_bp = 0;
-        const bool g_multi = nrot[g] > 1;
-        for (int b0 = 0; b0 < NN; b0 += 64) {
-            const int b = b0 + lane;
-            const int sl = b < NN ? slot_of[g * NN + b] : -1;
-            const bool fold = sl >= 0 && g_multi && nrot[b] == 1;        // partner with a single state
-            const unsigned long long m = __ballot(fold);
-            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (fold && pos < R.adj_cap) adj[pos] = sl;
-            count += __popcll(m);
-            count_bp += __popcll(__ballot(sl >= 0 && g_multi && nrot[b] > 1));
+        __syncthreads();
+        // ---- per node: partners above it in its own class / in a higher class, 1-state partners, BP partners
+        const int a = tid;
+        const int na = a < NN ? nrot[a] : 0;
+        const int cend = na == 1 ? e1 : (na == 3 ? e3 : NN);  // end of a's own class
+        int c_lo = 0, c_hi = 0, d1 = 0, dbp = 0;
+        if (a < NN) {
+            for (int c = 0; c < W; ++c) {
+                const unsigned long long w = bits[a * W + c];
+                const unsigned long long up = w & ~below(a + 1, c);
+                c_lo += __popcll(up & below(cend, c));
+                c_hi += __popcll(up & ~below(cend, c));
+                d1 += __popcll(w & below(e1, c));
+                dbp += __popcll(w & ~below(e1, c));
+            }
+            if (na == 1) dbp = 0;
+            deg1[a] = d1;
         }
-        if (lane == 0) {
-            R.adj_cnt[(size_t)s * NN + g] = count < R.adj_cap ? count : R.adj_cap;
-            if (count > R.adj_cap) *G.error_flag = 3;
-            deg_bp[g] = count_bp;
+        int tot_lo, tot_hi, tot_bp;
+        const int x_lo = block_excl_scan(c_lo, scratch, &tot_lo);
+        const int x_hi = block_excl_scan(c_hi, scratch, &tot_hi);
+        const int x_bp = block_excl_scan(dbp, scratch, &tot_bp);
+        if (a < NN) { row_lo[a] = x_lo; row_hi[a] = x_hi; bp_s[a] = x_bp; }
+        if (tid == 0) bp_s[NN] = tot_bp;
+        __syncthreads();
+        // class sizes from the scans: class (1,1) = lo counts of the 1-state rows, (1,x) = their hi counts, ...
+        if (tid == 0) {
+            auto at = [&](const int* x, int i, int tot) { return i < NN ? x[i] : tot; };
+            int cnt[N_CLASS];
+            cnt[CL11] = at(row_lo, e1, tot_lo);
+            cnt[CL1X] = at(row_hi, e1, tot_hi);
+            cnt[CL33] = at(row_lo, e3, tot_lo) - at(row_lo, e1, tot_lo);
+            cnt[CL36] = at(row_hi, e3, tot_hi) - at(row_hi, e1, tot_hi);
+            cnt[CL66] = tot_lo - at(row_lo, e3, tot_lo);
+            int acc = 0;
+            for (int c = 0; c < N_CLASS; ++c) { cls_lds[c] = acc; acc += cnt[c]; }
+            cls_lds[N_CLASS] = acc;
+            int* cs = R.class_start + (size_t)s * (N_CLASS + 1);
+            for (int c = 0; c <= N_CLASS; ++c) cs[c] = cls_lds[c] < R.slot_cap ? cls_lds[c] : R.slot_cap;
+            R.n_slot[s] = acc < R.slot_cap ? acc : R.slot_cap;
+            if (acc > R.slot_cap) *G.error_flag = 2;
         }
-    }
-    __syncthreads();
-    int* bp_start = R.bp_start + (size_t)s * (NN + 1);
-    if (tid == 0) {
-        int acc = 0;
-        for (int g = 0; g < NN; ++g) { bp_start[g] = acc; row_pos[0][g] = acc; acc += deg_bp[g]; }
-        bp_start[NN] = acc;
-    }
-    __syncthreads();
-    // messages TO node g are stored contiguously at inbox[(bp_start[g]+k)*8 ...] (8-float rows, 6 used)
-    int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
-    for (int g = wave; g < NN; g += n_wave) {
-        if (nrot[g] == 1) continue;
-        int base = row_pos[0][g];
-        for (int b0 = 0; b0 < NN; b0 += 64) {
-            const int b = b0 + lane;
-            const int sl = b < NN ? slot_of[g * NN + b] : -1;
-            const bool hit = sl >= 0 && nrot[b] > 1;
-            const unsigned long long m = __ballot(hit);
-            if (hit) slot_off[sl * 2 + (g < b ? 0 : 1)] = (base + __popcll(m & ((1ull << lane) - 1ull))) * 8;
-            base += __popcll(m);
+        __syncthreads();
+        int* bp_start = R.bp_start + (size_t)s * (NN + 1);
+        for (int g = tid; g <= NN; g += blockDim.x) bp_start[g] = bp_s[g];
+        if (a < NN) {
+            const int d = na > 1 ? deg1[a] : 0;
+            R.adj_cnt[(size_t)s * NN + a] = d < R.adj_cap ? d : R.adj_cap;
+            if (d > R.adj_cap) *G.error_flag = 3;
         }
-    }
+        // ---- assign: node a numbers its pairs (a, b > a) in ascending b; everything a pair needs follows from
+        // popcounts of the two rows (messages TO node g sit at inbox rows bp_start[g] + rank among g's multi-state
+        // partners, 8 floats each; folded 1-state partners of g are listed in ascending id)
+        if (a < NN) {
+            int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
+            int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
+            int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
+            const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
+            const int first = na == 1 ? 0 : (na == 3 ? e1 : e3);          // first row of a's class
+            const int base_lo = first < NN ? row_lo[first] : 0, base_hi = first < NN ? row_hi[first] : 0;
+            int p_lo = cls_lds[cl_lo] + row_lo[a] - base_lo, p_hi = cls_lds[cl_hi] + row_hi[a] - base_hi;
+            int k_multi = na > 1 ? rank_below(a, a) - deg1[a] : 0;        // multi-state partners of a below b so far
+            for (int c = a / 64; c < W; ++c) {
+                unsigned long long w = bits[a * W + c] & ~below(a + 1, c);
+                while (w) {
+                    const int b = c * 64 + __builtin_ctzll(w);
+                    w &= w - 1;
+                    const bool lo = b < cend;
+                    const int sl = lo ? p_lo++ : p_hi++;
+                    const int nb = nrot[b];
+                    if (sl < R.slot_cap) {
+                        slot_a[sl] = a; slot_b[sl] = b; slot_of[(size_t)a * NN + b] = sl; slot_of[(size_t)b * NN + a] = sl;
+                        if (na == 1 && nb > 1) {
+                            const int pos = rank_below(b, a);              // 1-state partners of b below a
+                            if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
+                        } else if (na > 1) {
+                            slot_off[sl * 2] = (bp_s[a] + k_multi) * 8;
+                            slot_off[sl * 2 + 1] = (bp_s[b] + rank_below(b, a) - deg1[b]) * 8;
+                        }
+                    } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
+                    if (na > 1) ++k_multi;
+                }
+            }
+        }
     }
 }
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     if (R->n_node > 1024) return 9003;
-    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 64 ? L->n_system : 64), dim3(BP_BLOCK), 0, ST(L), *R);
+    const size_t lds = (size_t)R->n_node * ((R->n_node + 63) / 64) * 8;
+    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 64 ? L->n_system : 64), dim3(BP_BLOCK), lds, ST(L), *R);
     return launch_status();
 }
 

@@ -631,6 +631,7 @@ struct RotamerSidechain : public PotentialNode {
     int n_node, n1, n3, n6;
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
+    DevBuf<unsigned char> mark;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
     DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
@@ -687,7 +688,9 @@ struct RotamerSidechain : public PotentialNode {
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
         iters.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); nbr_slot.alloc((size_t)S * ig.G.n1 * ig.G.cap1); slot_active_last.alloc((size_t)S * R.slot_cap);
-        ig.G.mark_table = slot_of.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
+        ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
+        mark.alloc((size_t)S * ig.G.mark_stride);
+        ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
         node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6); nb_old.alloc((size_t)S * n_node * 6);
         P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
         msg_cur.alloc((size_t)S * R.slot_cap * 16);
@@ -707,7 +710,7 @@ struct RotamerSidechain : public PotentialNode {
         R.n_prob = (int)prob_nodes.size(); R.prob_out = d_prob_out.p; R.prob_sens = d_prob_sens.p; R.prob_stride = d_prob_stride.p;
         R.prob_sys_stride = d_prob_sys_stride.p;
         R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p; R.nb_old = nb_old.p;
-        R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p;
+        R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p; R.mark = mark.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
@@ -798,6 +801,18 @@ int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pai
     if (!ig) return -1;
     out = ig->pairlist(sys);
     return (int)out.size();
+}
+int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags) {
+    auto* c = e.get(node_name).computation.get();
+    IGraphHost* ig = nullptr;
+    if (auto* r = dynamic_cast<RotamerSidechain*>(c)) ig = &r->ig;
+    else if (auto* h = dynamic_cast<HBondCoverage*>(c)) ig = &h->ig;
+    else if (auto* en = dynamic_cast<EnvironmentCoverage*>(c)) ig = &en->ig;
+    else if (auto* p = dynamic_cast<ProteinHBond*>(c)) ig = &p->ig;
+    if (!ig) return -1;
+    e.sync();
+    flags = ig->rebuild_flag.download();
+    return 0;
 }
 int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters) {
     for (auto& n : e.nodes)
