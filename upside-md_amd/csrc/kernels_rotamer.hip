@@ -232,6 +232,7 @@ __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
     const int* __restrict__ nb_start = R.node_bead_start; const int* __restrict__ nb_list = R.node_bead_list;
     const int s = blockIdx.y;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && R.bp_bar) R.bp_bar[s] = 0;             // cluster barrier counter of the solve that follows
     if (g >= R.n_node) return;
     const int n_rot = R.node_nrot[g];
     float e[6];
@@ -496,9 +497,10 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
 
-__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy) {
+__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
     const int NN = R.n_node;
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
     float* nb0 = lds + NN * 6;         // [NN][6]
@@ -676,9 +678,416 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Belief propagation with the pair matrices ON CHIP: a cluster of C workgroups serves one system.  Workgroup c
+// owns a contiguous share of every multi-state slot class (its exp(-E) matrices live in LDS for the whole
+// solve, its two messages per slot in registers) and a contiguous share of the multi-state nodes.  Per sweep the
+// cluster exchanges only the messages (slot owner -> node owner) and the node beliefs (node owner -> everyone)
+// through device-scope loads/stores, separated by two counter barriers.  HBM/L2 traffic per sweep drops from
+// P + 3 x messages to 2 x messages, and a system gets C x 1024 lanes.
+//
+// Cross-workgroup protocol (placement independent, cdna_hip_programming.md guideline 16): payload is written with
+// 16-byte write-through (sc1) buffer stores, every storing wave drains them, __syncthreads, ONE lane bumps an
+// agent-scope counter and polls it relaxed, ONE agent-scope acquire drops the CU's stale L1 lines, __syncthreads,
+// then plain loads.  All C workgroups of a cluster must be resident at once: the launcher sends at most
+// (CUs / C) systems per launch, one workgroup per CU, and every spin is bounded.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const uintptr_t p = (uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void st_wt16(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b, float c, float d) {   // 16-byte sc1 store
+    u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, 16);
+}
+
+struct BpcShared {            // cluster-visible state of one system
+    const float* inbox;       // message rows [rows][8] (plain loads after an acquire)
+    __amdgpu_buffer_rsrc_t inbox_w, nbx_w;   // write-through views of the inbox and of nbx
+    const float* nbx;         // [2][NN][8] node beliefs, double buffered by sweep
+    float* dev;               // [2][16] per-workgroup max deviation, double buffered
+    float* en_part;           // [16] energy partial sums
+    int* bar;                 // barrier counter (zeroed by upk_rotamer_node_prob)
+};
+__device__ __forceinline__ void cluster_barrier(int* bar, int& phase, int C, int* error_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores have landed
+    __syncthreads();
+    ++phase;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = phase * C;
+        int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { *error_flag = 7; break; }   // a partner never arrived: report instead of hanging the device
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // one buffer_inv for the whole CU
+    }
+    __syncthreads();
+}
+
+template <int NA, int NB> struct BpcSlot { int a, b, offa, offb, sl; bool live; float ma[NA], mb[NB]; };
+
+template <int NA, int NB>
+__device__ __forceinline__ void bpc_init(BpcSlot<NA, NB>& st, const upk_rotamer_t& R, int s, int lo, int n_own, __amdgpu_buffer_rsrc_t inbox) {
+    const int i = threadIdx.x;
+    st.sl = i < n_own ? lo + i : -1; st.live = false; st.a = st.b = 0; st.offa = st.offb = 0;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) st.ma[k] = 1.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) st.mb[k] = 1.f;
+    if (st.sl < 0) return;
+    const size_t so = (size_t)s * R.slot_cap + st.sl;
+    st.live = R.slot_active[so] != 0;
+    st.a = R.slot_a[so]; st.b = R.slot_b[so];
+    st.offa = R.slot_off[so * 2]; st.offb = R.slot_off[so * 2 + 1];
+    // old edge beliefs = 1 (rotamer.cpp:1015-1032), also for slots without an in-range bead pair this step
+    st_wt16(inbox, st.offa, 1.f, 1.f, 1.f, 1.f);
+    if (NA == 6) st_wt16(inbox, st.offa + 4, 1.f, 1.f, 1.f, 1.f);
+    st_wt16(inbox, st.offb, 1.f, 1.f, 1.f, 1.f);
+    if (NB == 6) st_wt16(inbox, st.offb + 4, 1.f, 1.f, 1.f, 1.f);
+}
+// stage exp(-E) of the own slots of one class: Pl[(i*NB+j)*n_own + local]
+template <int NA, int NB>
+__device__ __forceinline__ void bpc_stage(float* Pl, const upk_rotamer_t& R, int s, int lo, int n_own) {
+    const float* P = R.P + (size_t)s * R.slot_cap * 36;
+    for (int t = threadIdx.x; t < n_own * NA * NB; t += blockDim.x) {
+        const int e = t / n_own, l = t - e * n_own, i = e / NB, j = e - i * NB;
+        Pl[t] = expf(-P[(size_t)(i * 6 + j) * R.slot_cap + lo + l]);
+    }
+}
+// update_beliefs for one slot (rotamer.cpp:468-499, 506-521); messages stay in registers, copies go to the inbox
+template <int NA, int NB>
+__device__ __forceinline__ void bpc_edge(BpcSlot<NA, NB>& st, const float* Pl, int n_own, const float* nb_old, __amdgpu_buffer_rsrc_t inbox) {
+    if (!st.live) return;
+    const int l = threadIdx.x;
+    float P[NA][NB], va[NA], vb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) P[i][j] = Pl[(i * NB + j) * n_own + l];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) va[i] = nb_old[st.a * 6 + i] * fast_rcp(1e-10f + st.ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) vb[j] = nb_old[st.b * 6 + j] * fast_rcp(1e-10f + st.mb[j]);
+    float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) t += P[i][j] * vb[j];
+        ta[i] = t; sa += t; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
+        tb[j] = t; sb += t; }
+    const float ra = fast_rcp(sa), rb = fast_rcp(sb);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) st.ma[i] = ta[i] * ra;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) st.mb[j] = tb[j] * rb;
+    st_wt16(inbox, st.offa, st.ma[0], st.ma[1], st.ma[2], NA == 6 ? st.ma[NA - 3] : 1.f);
+    if (NA == 6) st_wt16(inbox, st.offa + 4, st.ma[NA - 2], st.ma[NA - 1], 1.f, 1.f);
+    st_wt16(inbox, st.offb, st.mb[0], st.mb[1], st.mb[2], NB == 6 ? st.mb[NB - 3] : 1.f);
+    if (NB == 6) st_wt16(inbox, st.offb + 4, st.mb[NB - 2], st.mb[NB - 1], 1.f, 1.f);
+}
+// pair marginal of one slot and its Bethe term (rotamer.cpp:405-451)
+template <int NA, int NB>
+__device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const float* Pl, int n_own, const float* nbm, float* marg, int cap,
+                                              bool want_energy) {
+    if (!st.live) return 0.f;
+    const int l = threadIdx.x;
+    float en = 0.f, P[NA][NB], bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) P[i][j] = Pl[(i * NB + j) * n_own + l];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bc1[i] = nbm[st.a * 6 + i] * rcp(1e-10f + st.ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bc2[j] = nbm[st.b * 6 + j] * rcp(1e-10f + st.mb[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { mg[i][j] = P[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
+    const float rs = rcp(sum);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float pm = mg[i][j] * rs;
+            marg[(size_t)(i * 6 + j) * cap + st.sl] = pm;
+            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i][j] * nbm[st.a * 6 + i] * nbm[st.b * 6 + j]));
+        }
+    return en;
+}
+
+#define BPC_GROUP 16  // lanes cooperating on one node
+
+__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= n_sys) return;
+    const int s = sys0 + blockIdx.x, c = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int NN = R.n_node, e1 = R.n_node1;
+    // ---- ownership
+    const int* cls = R.class_start + (size_t)s * (N_CLASS + 1);
+    int lo[3], n_own[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int b = cls[k], n = cls[k + 1] - b;
+        lo[k] = b + (int)((long)n * c / C); n_own[k] = b + (int)((long)n * (c + 1) / C) - lo[k];
+    }
+    const int n_multi = NN - e1;
+    const int g_lo = e1 + (int)((long)n_multi * c / C), g_hi = e1 + (int)((long)n_multi * (c + 1) / C);
+    const int need = n_own[0] * 9 + n_own[1] * 18 + n_own[2] * 36;
+    // every workgroup of the cluster must reach the same verdict: test all shares, not only the own one
+    bool fits = true;
+    for (int cc = 0; cc < C; ++cc) {
+        int nd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int b = cls[k], n = cls[k + 1] - b;
+            const int m = (int)((long)n * (cc + 1) / C) - (int)((long)n * cc / C);
+            if (m > BP_BLOCK) fits = false;
+            nd += m * (k == 0 ? 9 : (k == 1 ? 18 : 36));
+        }
+        if (nd > p_cap) fits = false;
+    }
+    if (!fits) { if (c == 0 && tid == 0) R.bp_fallback[s] = 1; return; }   // the single-workgroup kernel takes this system
+    if (c == 0 && tid == 0) R.bp_fallback[s] = 0;
+
+    float* nb = lds;                          // [NN][6] latest node beliefs (all nodes)
+    float* prob = lds + NN * 6;               // [NN][6] own nodes only are valid: probabilities with 1-state partners folded
+    float* scratch = lds + NN * 12;           // [32]
+    int* nrot = (int*)(lds + NN * 12 + 32);   // [NN]
+    int* bp_start = nrot + NN;                // [NN+1]
+    float* Pl0 = (float*)(bp_start + NN + 1 + 3);
+    Pl0 = (float*)(((size_t)Pl0 + 15) & ~(size_t)15);
+    float* Pl1 = Pl0 + n_own[0] * 9;
+    float* Pl2 = Pl1 + n_own[1] * 18;
+    (void)need;
+    BpcShared X;
+    X.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
+    X.inbox_w = make_rsrc(X.inbox, (unsigned)R.slot_cap * 64u);
+    X.nbx = R.bp_nbx + (size_t)s * NN * 16;
+    X.nbx_w = make_rsrc(X.nbx, (unsigned)NN * 64u);   // 2 halves x NN rows x 32 bytes
+    X.dev = R.bp_dev + (size_t)s * 2 * 16;
+    X.en_part = R.bp_en_part + (size_t)s * 16;
+    X.bar = R.bp_bar + s;
+    int phase = 0;
+
+    for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
+    for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
+    bpc_stage<3, 3>(Pl0, R, s, lo[0], n_own[0]);
+    bpc_stage<3, 6>(Pl1, R, s, lo[1], n_own[1]);
+    bpc_stage<6, 6>(Pl2, R, s, lo[2], n_own[2]);
+    BpcSlot<3, 3> s33; BpcSlot<3, 6> s36; BpcSlot<6, 6> s66;
+    bpc_init(s33, R, s, lo[0], n_own[0], X.inbox_w);
+    bpc_init(s36, R, s, lo[1], n_own[1], X.inbox_w);
+    bpc_init(s66, R, s, lo[2], n_own[2], X.inbox_w);
+    // fold the edges to 1-state partners into the probabilities of the own nodes (rotamer.cpp:378-385)
+    {
+        const float* P = R.P + (size_t)s * R.slot_cap * 36;
+        const int* active = R.slot_active + (size_t)s * R.slot_cap;
+        const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
+        const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
+        for (int g = g_lo + tid; g < g_hi; g += nt) {
+            const int n = R.node_nrot[g], na = adj_cnt[g];
+            float p[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) p[r] = R.node_prob[((size_t)s * NN + g) * 6 + r];
+            for (int k = 0; k < na; ++k) {
+                const int sl = adj_slot[g * R.adj_cap + k];
+                if (!active[sl]) continue;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) if (r < n) p[r] *= expf(-P[(size_t)r * R.slot_cap + sl]);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) prob[g * 6 + r] = p[r];
+            st_wt16(X.nbx_w, g * 8, p[0], p[1], p[2], p[3]);          // old node belief = prob (rotamer.cpp:1009-1013)
+            st_wt16(X.nbx_w, g * 8 + 4, p[4], p[5], 0.f, 0.f);
+        }
+    }
+    cluster_barrier(X.bar, phase, C, R.G.error_flag);
+    auto reload = [&](int half) {   // beliefs of every multi-state node from the exchange buffer into LDS
+        for (int g = tid; g < NN; g += nt) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float2 b = make_float2(0.f, 0.f);
+            if (g >= e1) { const float* src = X.nbx + ((size_t)half * NN + g) * 8; a = *(const float4*)src; b = *(const float2*)(src + 4); }
+            nb[g * 6] = a.x; nb[g * 6 + 1] = a.y; nb[g * 6 + 2] = a.z; nb[g * 6 + 3] = a.w; nb[g * 6 + 4] = b.x; nb[g * 6 + 5] = b.y;
+        }
+        __syncthreads();
+    };
+    reload(0);
+
+    int iter = 0, cur = 0;                    // nbx half holding the beliefs in `nb`
+    const int gl = tid % BPC_GROUP, n_grp = nt / BPC_GROUP;
+    for (int sweep = -1;; ++sweep) {
+        // ---- edge phase
+        bpc_edge(s33, Pl0, n_own[0], nb, X.inbox_w);
+        bpc_edge(s36, Pl1, n_own[1], nb, X.inbox_w);
+        bpc_edge(s66, Pl2, n_own[2], nb, X.inbox_w);
+        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        // ---- node phase over the own nodes
+        float dev = 0.f;
+        const int new_row0 = (cur ^ 1) * NN;
+        for (int g0 = g_lo; g0 < g_hi; g0 += n_grp) {
+            const int g = g0 + tid / BPC_GROUP;
+            const bool live = g < g_hi;
+            const int n = live ? nrot[g] : 0;
+            float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+            if (live && sweep >= 0) {
+                const int k1 = bp_start[g + 1];
+                for (int kb = bp_start[g] + gl; kb < k1; kb += BPC_GROUP * 4) {   // 4 independent row loads in flight
+                    float4 lo4[4]; float2 hi2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kb + u * BPC_GROUP;
+                        lo4[u] = make_float4(1.f, 1.f, 1.f, 1.f); hi2[u] = make_float2(1.f, 1.f);
+                        if (k < k1) {
+                            lo4[u] = *(const float4*)(X.inbox + (size_t)k * 8);
+                            if (n == 6) hi2[u] = *(const float2*)(X.inbox + (size_t)k * 8 + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        bb[0] *= lo4[u].x; bb[1] *= lo4[u].y; bb[2] *= lo4[u].z;
+                        if (n == 6) { bb[3] *= lo4[u].w; bb[4] *= hi2[u].x; bb[5] *= hi2[u].y; }
+                    }
+                    // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
+                    float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
+                    if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
+                    const float rm = fast_rcp(mx);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                }
+            }
+#pragma unroll
+            for (int off = BPC_GROUP / 2; off > 0; off >>= 1) {
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { bb[r] *= __shfl_xor(bb[r], off, UP_WAVE); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+            }
+            if (live && gl == 0) {
+                // b = prob * product, then standardize (rotamer.cpp:258-273) and damp
+                float v[6], nv[6], mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { v[r] = r < n ? prob[g * 6 + r] * bb[r] : 0.f; mx = fmaxf(mx, v[r]); }
+                const float rm = rcp(mx);
+                const float damp = sweep < 0 ? 0.f : R.damping;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    nv[r] = 0.f;
+                    if (r < n) {
+                        const float o = nb[g * 6 + r];
+                        nv[r] = damp != 0.f ? (1.f - damp) * rm * v[r] + damp * o : rm * v[r];
+                        dev = fmaxf(nv[r] - o, dev);                  // signed, rotamer.cpp:275-281
+                    }
+                }
+                st_wt16(X.nbx_w, (new_row0 + g) * 8, nv[0], nv[1], nv[2], nv[3]);
+                st_wt16(X.nbx_w, (new_row0 + g) * 8 + 4, nv[4], nv[5], 0.f, 0.f);
+            }
+        }
+        const bool check = sweep >= 0 && ((iter + 1) % R.chunk == 0);
+        if (check) {
+            const float wg_dev = block_max(dev, scratch);
+            if (tid == 0) st_agent(X.dev + (cur ^ 1) * 16 + c, wg_dev);
+        }
+        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        cur ^= 1;
+        reload(cur);
+        if (sweep >= 0) {
+            ++iter;
+            if (check) {
+                float maxdev = 0.f;
+                for (int cc = 0; cc < C; ++cc) maxdev = fmaxf(maxdev, ld_agent(X.dev + cur * 16 + cc));
+                if (!(maxdev > R.tol && iter < R.max_iter)) break;     // rotamer.cpp:1038
+            }
+        }
+    }
+    if (c == 0 && tid == 0) R.iters[s] = iter;
+
+    // ---- marginals (rotamer.cpp:1053-1059): own nodes normalise, everyone reloads
+    float* out_nb = R.nb_cur + (size_t)s * NN * 6;
+    for (int g = g_lo + tid; g < g_hi; g += nt) {
+        const int n = nrot[g];
+        float sum = 0.f;
+        for (int r = 0; r < n; ++r) sum += nb[g * 6 + r];
+        const float rs = rcp(sum);
+        for (int r = 0; r < 6; ++r) st_agent(out_nb + g * 6 + r, r < n ? nb[g * 6 + r] * rs : 0.f);
+    }
+    if (c == 0) for (int g = tid; g < e1; g += nt) { st_agent(out_nb + g * 6, 1.f); for (int r = 1; r < 6; ++r) st_agent(out_nb + g * 6 + r, 0.f); }
+    cluster_barrier(X.bar, phase, C, R.G.error_flag);
+    for (int i = tid; i < NN * 6; i += nt) nb[i] = ld_agent(out_nb + i);
+    __syncthreads();
+    float* marg = R.marg + (size_t)s * R.slot_cap * 36;
+    float en = 0.f;
+    en += bpc_marginal(s33, Pl0, n_own[0], nb, marg, R.slot_cap, want_energy);
+    en += bpc_marginal(s36, Pl1, n_own[1], nb, marg, R.slot_cap, want_energy);
+    en += bpc_marginal(s66, Pl2, n_own[2], nb, marg, R.slot_cap, want_energy);
+    // ---- leave the accumulators clean for the next force evaluation (every class, split over the cluster)
+    const int n_slot = R.n_slot[s];
+    float* P = R.P + (size_t)s * R.slot_cap * 36;
+    int* active_w = R.slot_active + (size_t)s * R.slot_cap;
+    int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
+    const int z_lo = (int)((long)n_slot * c / C), z_hi = (int)((long)n_slot * (c + 1) / C), z_n = z_hi - z_lo;
+    if (want_energy) {
+        for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)       // 1-1 edges (rotamer.cpp:861): -log(exp(-E))
+            if (sl >= z_lo && sl < z_hi && active_w[sl]) en += P[sl];
+        for (int g = g_lo + tid; g < g_hi; g += nt) {                      // node_free_energy, rotamer.cpp:292-302
+            const int n = nrot[g];
+            float e = R.node_off[(size_t)s * NN + g];
+            for (int r = 0; r < n; ++r) { const float b = nb[g * 6 + r]; e += b * logf((1e-10f + b) * rcp(1e-10f + prob[g * 6 + r])); }
+            en += e;
+        }
+        if (c == 0) for (int g = tid; g < e1; g += nt) {                   // 1-state nodes: b = prob = 1
+            en += R.node_off[(size_t)s * NN + g] + 1.f * logf((1e-10f + 1.f) * rcp(1e-10f + R.node_prob[((size_t)s * NN + g) * 6]));
+        }
+        const float tot = block_sum(en, scratch);
+        if (tid == 0) st_agent(X.en_part + c, tot);
+    }
+    __syncthreads();   // all reads of P / active by this workgroup are done
+    for (int i = tid; i < z_n * 36; i += nt) P[(size_t)(i / z_n) * R.slot_cap + z_lo + (i % z_n)] = 0.f;
+    for (int i = z_lo + tid; i < z_hi; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
+    if (want_energy) {
+        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        if (c == 0 && tid == 0) { float t = 0.f; for (int cc = 0; cc < C; ++cc) t += ld_agent(X.en_part + cc); R.energy[s] = t; }
+    }
+}
+
+static int device_cu_count() {
+    static int n = 0;
+    if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64; }
+    return n;
+}
+extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // floats of pair matrices one workgroup can hold
+    const int fixed = R->n_node * 14 + 48;
+    return (int)(156 * 1024 / sizeof(float)) - fixed;
+}
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
     const size_t lds = ((size_t)R->n_node * 20 + 64) * sizeof(float);
     if (lds > 155 * 1024) return 9004;
-    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy);
+    const int C = R->bp_C;
+    if (C > 1) {
+        // clusters of C co-resident workgroups, one per CU: at most CUs / C systems per launch (multiples of 8 keep a
+        // cluster on one XCD under round-robin workgroup dispatch, so its exchange stays in that XCD's L2)
+        int chunk = device_cu_count() / C;
+        if (chunk >= 8) chunk &= ~7;
+        if (chunk >= 1) {
+            const int p_cap = upk_rotamer_bp_cluster_capacity(R);
+            for (int s0 = 0; s0 < L->n_system; s0 += chunk) {
+                const int n = L->n_system - s0 < chunk ? L->n_system - s0 : chunk;
+                hipLaunchKernelGGL(k_rotamer_bp_cluster, dim3(n, C), dim3(BP_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
+            }
+            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1);
+            return launch_status();
+        }
+    }
+    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 0);
     return launch_status();
 }

@@ -632,6 +632,8 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part;
+    bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
     DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
@@ -715,6 +717,9 @@ struct RotamerSidechain : public PotentialNode {
         R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
         R.iters = iters.p; R.energy = energy.p;
+        { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
+        R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
+        R.bp_C = 1;
         R.bp_trace = nullptr;
         prepare_deps.push_back(ig.node1);   // the list upkeep reads the bead positions only, not the 1-body energies
         if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
@@ -729,7 +734,32 @@ struct RotamerSidechain : public PotentialNode {
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
         upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
     }
+    // workgroups per system of the belief-propagation solve: enough that the exp(-E) matrices of the multi-state
+    // residue pairs fit their LDS (15% slack for the fluctuation of the pair count; systems that outgrow it fall
+    // back to the one-workgroup kernel on the device).  Decided once, from the first pair list.
+    void choose_bp_cluster() {
+        bp_C_chosen = true;
+        const int want = env_int("UPSIDE_HIP_BP_CLUSTER", -1);   // 1 disables, >1 forces
+        if (want == 1) { R.bp_C = 1; return; }
+        hip_check(hipStreamSynchronize(ctx->stream), "sync");
+        auto cs = class_start.download();
+        long need = 0;
+        for (int s = 0; s < ctx->n_system; ++s) {
+            const int* c = &cs[(size_t)s * 6];
+            need = max(need, 9L * (c[1] - c[0]) + 18L * (c[2] - c[1]) + 36L * (c[3] - c[2]));
+        }
+        const int cap = upk_rotamer_bp_cluster_capacity(&R);
+        int C = cap > 0 ? (int)((need * 115 / 100 + cap - 1) / cap) : 1;
+        if (want > 1) C = want;
+        if (C > 8 || n_node - R.n_node1 < C) C = 1;              // too large for a co-resident cluster: one-workgroup solve
+        // The cluster solve trades HBM traffic for two device-scope barriers per sweep (~18 us per sweep alone, measured):
+        // it wins while the batch is small enough that one-workgroup solves would leave most CUs idle, and loses
+        // once every CU has its own system to solve.
+        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 16)) C = 1;
+        R.bp_C = C < 1 ? 1 : C;
+    }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
+        if (!bp_C_chosen) choose_bp_cluster();
         upk_check(upk_rotamer_node_prob(&ctx->L, &R), "rotamer_node_prob");
         { IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
           upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy"); }
