@@ -736,14 +736,20 @@ __device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, flo
     float cs, dcs; compact_sigmoid(cs, dcs, r_mag2 - wall * wall, sharpness);
     v = 4.f * cs; dv_over_r = 2.f * (4.f * dcs);
 }
-__global__ void k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residue, const int* __restrict__ id,
+#define BBP_ROWS 64       // residues per workgroup (16 waves x 4)
+#define BBP_QUEUE 72      // per-wave queue of close residues (64 new + < 4 left over)
+__global__ void __launch_bounds__(1024) k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residue, const int* __restrict__ id,
                                  const int* __restrict__ n_atom, const float* __restrict__ ref_pos, int n_res, float dist_cutoff,
                                  float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ pot_terms) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // per residue: 4 atoms x 3 + centre 3 + (n_atom,id) as float bits
+    // One wavefront per residue: 64 lanes test 64 partner residues at a time (centre distance, sequence separation),
+    // close partners are compacted into a small LDS queue and evaluated four at a time, one lane per atom pair
+    // (4 partners x 4 x 4 atoms), so the steric kernel runs with dense lanes; wave reduction, no scatter.
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // per residue: 4 atoms x 3 + centre 3 + (n_atom,id) as int bits
     const int s = blockIdx.y;
     float* atoms = lds;                       // [n_res][12]
     float* ctr = lds + (size_t)n_res * 12;    // [n_res][3]
     int* meta = (int*)(ctr + (size_t)n_res * 3);   // [n_res][2]
+    int* queues = meta + (size_t)n_res * 2;   // [n_wave][BBP_QUEUE]
     for (int nr = threadIdx.x; nr < n_res; nr += blockDim.x) {
         const float* a = C_OUT(aff, s) + (size_t)residue[nr] * aff.stride;
         float U[9]; quat_to_rot(U, a[3], a[4], a[5], a[6]);
@@ -758,42 +764,74 @@ __global__ void k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residu
     __syncthreads();
     const float cutoff2_atom = 3.f * 3.f + 0.1f * 3.f;
     const float cut2 = dist_cutoff * dist_cutoff;
-    for (int nr1 = blockIdx.x * blockDim.x + threadIdx.x; nr1 < n_res; nr1 += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    int* q = queues + wave * BBP_QUEUE;
+    const int qi = lane >> 4, i1 = (lane >> 2) & 3, i2 = lane & 3;
+    for (int r = wave; r < BBP_ROWS; r += n_wave) {
+        const int nr1 = blockIdx.x * BBP_ROWS + r;
+        if (nr1 >= n_res) break;
         const f3 t1 = ld3(ctr + nr1 * 3);
         const int na1 = meta[nr1 * 2], id1 = meta[nr1 * 2 + 1];
-        f3 d1 = mk3(0.f, 0.f, 0.f), tq1 = mk3(0.f, 0.f, 0.f);
-        float pot = 0.f;
-        for (int nr2 = 0; nr2 < n_res; ++nr2) {
-            const int id2 = meta[nr2 * 2 + 1];
-            if (!((1 < id1 - id2) || (1 < id2 - id1))) continue;                 // backbone_steric.cpp:32-35
-            const f3 t2 = ld3(ctr + nr2 * 3);
-            if (!(dist2_exact(t1.x, t1.y, t1.z, t2.x, t2.y, t2.z) < cut2)) continue;
-            const int na2 = meta[nr2 * 2];
-            for (int i1 = 0; i1 < na1; ++i1) {
-                const f3 x1 = ld3(atoms + nr1 * 12 + i1 * 3);
-                for (int i2 = 0; i2 < na2; ++i2) {
-                    const f3 r = x1 - ld3(atoms + nr2 * 12 + i2 * 3);
-                    const float r2 = mag2(r);
-                    if (r2 > cutoff2_atom) continue;
-                    float v, dor; nonbonded_kernel(v, dor, r2);
-                    const f3 g = dor * r;
-                    d1 = d1 + g; tq1 = tq1 + cross(x1 - t1, g);
-                    if (nr1 < nr2) pot += v;                                     // each pair's energy once
+        const f3 x1 = ld3(atoms + nr1 * 12 + i1 * 3);
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        int nq = 0;
+        auto eval4 = [&](int base, int n_valid) {   // partners q[base .. base+3], the first n_valid of them real
+            if (qi < n_valid) {
+                const int nr2 = q[base + qi];
+                if (i1 < na1 && i2 < meta[nr2 * 2]) {
+                    const f3 rr = x1 - ld3(atoms + nr2 * 12 + i2 * 3);
+                    const float r2 = mag2(rr);
+                    if (!(r2 > cutoff2_atom)) {
+                        float v, dor; nonbonded_kernel(v, dor, r2);
+                        const f3 g = dor * rr;
+                        const f3 tq = cross(x1 - t1, g);
+                        acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += tq.x; acc[4] += tq.y; acc[5] += tq.z;
+                        if (nr1 < nr2) acc[6] += v;                                  // each pair's energy once
+                    }
                 }
             }
+        };
+        for (int c0 = 0; c0 < n_res; c0 += 64) {
+            const int nr2 = c0 + lane;
+            bool hit = false;
+            if (nr2 < n_res) {
+                const int id2 = meta[nr2 * 2 + 1];
+                const f3 t2 = ld3(ctr + nr2 * 3);
+                hit = ((1 < id1 - id2) || (1 < id2 - id1)) &&                        // backbone_steric.cpp:32-35
+                      (dist2_exact(t1.x, t1.y, t1.z, t2.x, t2.y, t2.z) < cut2);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = nr2;
+            nq += __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int done = 0;
+            for (; done + 4 <= nq; done += 4) eval4(done, 4);
+            const int left = nq - done;
+            int keep = 0;
+            if (lane < left) keep = q[done + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < left) q[lane] = keep;
+            nq = left;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        float* o = aff_contrib + (size_t)s * aff_stride + (size_t)nr1 * 6;
-        o[0] = d1.x; o[1] = d1.y; o[2] = d1.z; o[3] = tq1.x; o[4] = tq1.y; o[5] = tq1.z;
-        if (pot_terms) pot_terms[(size_t)s * n_res + nr1] = pot;
+        if (nq > 0) eval4(0, nq);
+        const float t = wave_sum8(acc, lane);       // lane 8*c holds component c
+        const int c = lane >> 3;
+        if ((lane & 7) == 0) {
+            if (c < 6) aff_contrib[(size_t)s * aff_stride + (size_t)nr1 * 6 + c] = t;
+            else if (c == 6 && pot_terms) pot_terms[(size_t)s * n_res + nr1] = t;
+        }
     }
 }
 extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
                                   const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
                                   float* pot_terms) {
-    const size_t lds = (size_t)n_res * (12 + 3 + 2) * sizeof(float);
+    const size_t lds = ((size_t)n_res * (12 + 3 + 2) + 16 * BBP_QUEUE) * sizeof(float);
     if (lds > 150 * 1024) return 9001;   // > ~2200 residues: needs the tiled variant
-    const int blocks = (n_res + UPK_BLOCK - 1) / UPK_BLOCK;
-    hipLaunchKernelGGL(k_backbone_pairs, dim3(blocks, L->n_system), dim3(UPK_BLOCK), lds, ST(L), aff, residue, id, n_atom, ref_pos, n_res,
+    const int blocks = (n_res + BBP_ROWS - 1) / BBP_ROWS;
+    hipLaunchKernelGGL(k_backbone_pairs, dim3(blocks, L->n_system), dim3(1024), lds, ST(L), aff, residue, id, n_atom, ref_pos, n_res,
                        dist_cutoff, aff_contrib, aff_stride, pot_terms);
     return launch_status();
 }
