@@ -90,6 +90,19 @@ int upside_hip_recenter(DerivEngine* engine);
 int upside_hip_replica_swap(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
                             uint64_t round, int* accepted);
 
+/* Replica exchange ACROSS engines / GPUs.  Each rank all-gathers one energy per system
+ * (upside_hip_compute), every rank then calls upside_replica_decide on the identical global arrays: host arithmetic
+ * only (no device needed), the same Metropolis test and random stream as main.cpp:251-273 with
+ * lboltz_diff = (beta1-beta2)(E1-E2); pairs (n_pair,2) index the GLOBAL system list; accepted has n_pair+1 entries,
+ * the last one is the generator position to pass as draw0 for the next swap set of the same round.
+ * Accepted pairs exchange coordinates (momenta stay with the temperature slot, main.cpp:244-247): two systems of one
+ * engine with upside_hip_swap_systems, otherwise get/set_system_pos around a point-to-point transfer. */
+int upside_replica_decide(int n_pair, const int* pairs, const float* beta, const float* energy, uint32_t base_seed,
+                          uint64_t round, int draw0, int* accepted);
+int upside_hip_get_system_pos(DerivEngine* engine, int system, float* pos);        /* host (n_atom,3) */
+int upside_hip_set_system_pos(DerivEngine* engine, int system, const float* pos);
+int upside_hip_swap_systems(DerivEngine* engine, int system1, int system2);
+
 /* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */
 int upside_hip_rebuild_flags(DerivEngine* engine, const char* node_name, int* flags);
 /* Parity/diagnostic access: the in-range pair list of an interaction-graph node of system `sys` after the

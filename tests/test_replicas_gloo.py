@@ -80,3 +80,109 @@ def test_single_process_degenerates():
     assert value == 150.0 and worst == 2.0
     with pytest.raises(ValueError):
         rep.shard(10, 2, 2)
+
+
+# ---- replica exchange (main.cpp:227-275) -------------------------------------------------------------------
+import ctypes as ct  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def _expected_decisions(pairs, beta, energy, seed, round_num, draw0=0):
+    """restatement of main.cpp:251-273 for temperature exchange with the oracle's RandomGenerator
+    (oracle_random_uniform4 is pinned to the Random123 known answers in test_oracle_pinning.py)"""
+    import parity_util as P
+    orc = P.oracle_library().calc
+    orc.oracle_random_uniform4.restype = None
+    orc.oracle_random_uniform4.argtypes = [ct.c_void_p, ct.c_uint32, ct.c_uint32, ct.c_uint32, ct.c_uint64, ct.c_uint32]
+    beta = np.asarray(beta, 'f4'); energy = np.asarray(energy, 'f4')
+    acc, draw = [], draw0
+    for s1, s2 in pairs:
+        new = np.float32(-beta[s1] * energy[s2]) + np.float32(-beta[s2] * energy[s1])
+        old = np.float32(-beta[s1] * energy[s1]) + np.float32(-beta[s2] * energy[s2])
+        lb = np.float32(new - old)
+        ok = True
+        if lb < 0:
+            u = np.zeros(4, 'f4')
+            orc.oracle_random_uniform4(u.ctypes.data, seed, 1, 0, round_num, draw)   # stream 1 = REPLICA_EXCHANGE
+            draw += 1
+            if np.float32(np.exp(lb, dtype='f4')) < u[0]:
+                ok = False
+        acc.append(ok)
+    return np.array(acc), draw
+
+
+def test_replica_decide_matches_reference_rule():
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    rs = np.random.RandomState(3)
+    n = 16
+    temps = pkg.replicas.geometric_ladder(0.7, 1.1, n)
+    beta = (1.0 / temps).astype('f4')
+    n_reject = 0
+    for round_num in range(40):
+        energy = (-300 + 4.0 * rs.randn(n)).astype('f4')
+        draw = 0
+        for pairs in pkg.replicas.neighbour_swap_sets(n):
+            got, draw_got = pkg.engine.replica_decide(pairs, beta, energy, 77, round_num, draw)
+            want, draw_want = _expected_decisions(pairs, beta, energy, 77, round_num, draw)
+            assert np.array_equal(got, want) and draw_got == draw_want
+            n_reject += int((~got).sum())
+            draw = draw_got
+    assert n_reject > 20          # the random branch was exercised
+    assert pkg.replicas.neighbour_swap_sets(5) == [[(0, 1), (2, 3)], [(1, 2), (3, 4)]]
+
+
+class _FakeEnsemble(object):
+    """numpy stand-in with the interface exchange_swap_set needs; energy = sum of the coordinates"""
+
+    def __init__(self, pos):
+        self.pos = pos.copy(); self.n_system = pos.shape[0]
+
+    def energies(self):
+        return self.pos.sum(axis=(1, 2)).astype('f4')
+
+    def get_system_pos(self, i):
+        return self.pos[i].copy()
+
+    def set_system_pos(self, i, x):
+        self.pos[i] = x
+
+    def swap_systems(self, i, j):
+        self.pos[[i, j]] = self.pos[[j, i]]
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    rep = pkg.replicas
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        per_rank, n_atom = 4, 6
+        n = per_rank * world
+        rs = np.random.RandomState(11)
+        all_pos = rs.randn(n, n_atom, 3).astype('f4')
+        beta = (1.0 / rep.geometric_ladder(0.5, 2.0, n)).astype('f4')
+        lo, hi = rep.weak_shard(per_rank, world, rank)
+        ens = _FakeEnsemble(all_pos[lo:hi])
+        ref = _FakeEnsemble(all_pos)                         # the same run in one process
+        for round_num in range(6):
+            draw = draw_ref = 0
+            for pairs in rep.neighbour_swap_sets(n):         # set 1 has the cross-rank pair (3,4)
+                acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, 5, round_num, draw)
+                acc_ref, draw_ref = rep.exchange_swap_set(None, ref, pairs, beta, 5, round_num, draw_ref)
+                assert np.array_equal(acc, acc_ref) and draw == draw_ref
+            assert np.array_equal(ens.pos, ref.pos[lo:hi]), 'sharded exchange must equal the single-process one'
+        moved = not np.array_equal(ref.pos, all_pos)
+        with open(os.path.join(out_dir, 'x%d' % rank), 'w') as f:
+            f.write('%d' % moved)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replica_exchange(tmp_path):
+    world = 2
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert [open(os.path.join(str(tmp_path), 'x%d' % r)).read() for r in range(world)] == ['1', '1']

@@ -288,6 +288,89 @@ extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pa
     API_CATCH(1)
 }
 
+// ---- replica exchange across engines / GPUs (main.cpp:227-275) --------------------------------
+// Host arithmetic only: every rank holds the same all-gathered energies and reaches the same verdicts.
+namespace {
+inline uint32_t h_rotl32(uint32_t x, unsigned n) { return (x << (n & 31)) | (x >> ((32 - n) & 31)); }
+void h_threefry4x32_20(uint32_t X[4], const uint32_t key[4]) {   // Random123/threefry.h:110-117,172,296-430
+    static const unsigned R[8][2] = {{10, 26}, {11, 21}, {13, 27}, {23, 5}, {6, 20}, {17, 11}, {25, 10}, {18, 20}};
+    uint32_t ks[5]; ks[4] = 0x1BD11BDAu;
+    for (int i = 0; i < 4; ++i) { ks[i] = key[i]; ks[4] ^= key[i]; }
+    for (int i = 0; i < 4; ++i) X[i] += ks[i];
+    for (int r = 0; r < 20; ++r) {
+        if (r % 2 == 0) { X[0] += X[1]; X[1] = h_rotl32(X[1], R[r % 8][0]); X[1] ^= X[0]; X[2] += X[3]; X[3] = h_rotl32(X[3], R[r % 8][1]); X[3] ^= X[2]; }
+        else            { X[0] += X[3]; X[3] = h_rotl32(X[3], R[r % 8][0]); X[3] ^= X[0]; X[2] += X[1]; X[1] = h_rotl32(X[1], R[r % 8][1]); X[1] ^= X[2]; }
+        if (r % 4 == 3) { const int k = r / 4 + 1; for (int i = 0; i < 4; ++i) X[i] += ks[(k + i) % 5]; X[3] += k; }
+    }
+}
+float h_u01(uint32_t in) {   // uniform.hpp:145-179, the product and the sum rounded separately
+#pragma clang fp contract(off)
+    const float factor = 1.f / 4294967296.f;
+    volatile float t = (float)in * factor;
+    return t + 0.5f * factor;
+}
+}  // namespace
+extern "C" int upside_replica_decide(int n_pair, const int* pairs, const float* beta, const float* energy, uint32_t base_seed,
+                                     uint64_t round, int draw0, int* accepted) {
+    API_TRY
+    int draw = draw0;
+    for (int p = 0; p < n_pair; ++p) {
+        const int s1 = pairs[p * 2], s2 = pairs[p * 2 + 1];
+        if (s1 < 0 || s2 < 0) throw string("invalid system");
+        // temperature exchange of one Hamiltonian: (new_lboltz[s1]+new_lboltz[s2]) - (old_lboltz[s1]+old_lboltz[s2])
+        const float lb = (-beta[s1] * energy[s2] + -beta[s2] * energy[s1]) - (-beta[s1] * energy[s1] + -beta[s2] * energy[s2]);
+        int ok = 1;
+        if (lb < 0.f) {   // a uniform is drawn only for a rejectable pair (main.cpp:268)
+            const uint32_t key[4] = {base_seed, 1u /* REPLICA_EXCHANGE_RANDOM_STREAM */, 0u, 0u};
+            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, (uint32_t)draw};
+            h_threefry4x32_20(X, key);
+            ++draw;
+            if (expf(lb) < h_u01(X[0])) ok = 0;
+        }
+        accepted[p] = ok;
+    }
+    accepted[n_pair] = draw;   // generator position for the next swap set of this round
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_get_system_pos(DerivEngine* e, int sys, float* pos) {
+    API_TRY
+    if (sys < 0 || sys >= e->ctx.n_system) throw string("invalid system");
+    const int na = e->pos->n_atom, st = e->pos->stride;
+    vector<float> buf((size_t)na * st);
+    e->sync();
+    hip_check(hipMemcpy(buf.data(), e->pos->output.p + (size_t)sys * na * st, buf.size() * sizeof(float), hipMemcpyDeviceToHost), "D2H");
+    for (int a = 0; a < na; ++a) for (int d = 0; d < 3; ++d) pos[a * 3 + d] = buf[(size_t)a * st + d];
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_set_system_pos(DerivEngine* e, int sys, const float* pos) {
+    API_TRY
+    if (sys < 0 || sys >= e->ctx.n_system) throw string("invalid system");
+    const int na = e->pos->n_atom, st = e->pos->stride;
+    vector<float> buf((size_t)na * st, 0.f);
+    for (int a = 0; a < na; ++a) for (int d = 0; d < 3; ++d) buf[(size_t)a * st + d] = pos[a * 3 + d];
+    e->sync();
+    hip_check(hipMemcpy(e->pos->output.p + (size_t)sys * na * st, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_swap_systems(DerivEngine* e, int s1, int s2) {
+    API_TRY
+    const int S = e->ctx.n_system;
+    if (s1 < 0 || s1 >= S || s2 < 0 || s2 >= S) throw string("invalid system");
+    if (s1 == s2) return 0;
+    const size_t n = (size_t)e->pos->n_atom * e->pos->stride;
+    DevBuf<float> tmp; tmp.alloc(n);
+    float* a = e->pos->output.p + (size_t)s1 * n; float* b = e->pos->output.p + (size_t)s2 * n;
+    e->sync();
+    hip_check(hipMemcpy(tmp.p, a, n * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hip_check(hipMemcpy(a, b, n * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hip_check(hipMemcpy(b, tmp.p, n * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hip_check(hipDeviceSynchronize(), "sync");
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_rebuild_flags(DerivEngine* e, const char* node_name, int* flags) {
     API_TRY
     vector<int> f;

@@ -201,3 +201,128 @@ class Upside(object):
             self.close()
         except Exception:
             pass
+
+
+class Ensemble(object):
+    """S systems of one topology resident on one GPU, driven through the `upside_hip_*` extension of the C-ABI
+    (include/upside_engine_c.h): what `upside_main` does for its `systems` vector (main.cpp:441-700), with the
+    state kept on the device between calls."""
+
+    def __init__(self, config_file_path, n_system, device=None, quiet=True, library=None):
+        self.lib = library if library is not None else default_library()
+        c = self.calc = self.lib.calc
+        self._bind(c)
+        self.config_file_path = str(config_file_path)
+        self.n_system = int(n_system)
+        with h5lite.open_file(self.config_file_path) as t:
+            self.initial_pos = t.read('input/pos', 'f4')[:, :, 0]
+        self.n_atom = self.initial_pos.shape[0]
+        if device is not None:
+            self._check(c.upside_hip_set_device(int(device)), 'set_device')
+        self.engine = c.upside_hip_construct(self.n_atom, _b(self.config_file_path), self.n_system, bool(quiet))
+        if not self.engine:
+            raise RuntimeError('Unable to initialize upside engine: %s' % c.upside_hip_last_error().decode())
+
+    @staticmethod
+    def _bind(c):
+        if getattr(c, '_ensemble_bound', False):
+            return
+        vp, i32, u32, u64, f32 = ct.c_void_p, ct.c_int, ct.c_uint32, ct.c_uint64, ct.c_float
+        c.upside_hip_set_device.argtypes = [i32]
+        c.upside_hip_construct.restype = vp
+        c.upside_hip_construct.argtypes = [i32, ct.c_char_p, i32, ct.c_bool]
+        for nm in ('set_pos', 'get_pos', 'set_mom', 'get_mom'):
+            getattr(c, 'upside_hip_' + nm).argtypes = [vp, vp]
+        c.upside_hip_compute.argtypes = [vp, vp, vp]
+        c.upside_hip_init_md.argtypes = [vp, vp, u32, f32, f32, i32]
+        c.upside_hip_run_md.argtypes = [vp, i32]
+        c.upside_hip_run_steps.argtypes = [vp, i32]
+        c.upside_hip_recenter.argtypes = [vp]
+        c.upside_hip_replica_swap.argtypes = [vp, i32, vp, u32, u64, vp]
+        c.upside_replica_decide.argtypes = [i32, vp, vp, vp, u32, u64, i32, vp]
+        c.upside_hip_get_system_pos.argtypes = [vp, i32, vp]
+        c.upside_hip_set_system_pos.argtypes = [vp, i32, vp]
+        c.upside_hip_swap_systems.argtypes = [vp, i32, i32]
+        c.upside_hip_last_error.restype = ct.c_char_p
+        c._ensemble_bound = True
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError('%s failed: %s' % (what, self.calc.upside_hip_last_error().decode()))
+
+    # -- state ----------------------------------------------------------------------------------
+    def set_pos(self, pos):
+        pos = np.require(pos, dtype='f4', requirements='C')
+        if pos.shape == (self.n_atom, 3):
+            pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_system, self.n_atom, 3)))
+        assert pos.shape == (self.n_system, self.n_atom, 3)
+        self._check(self.calc.upside_hip_set_pos(self.engine, pos.ctypes.data), 'set_pos')
+
+    def get_pos(self):
+        out = np.zeros((self.n_system, self.n_atom, 3), 'f4')
+        self._check(self.calc.upside_hip_get_pos(self.engine, out.ctypes.data), 'get_pos')
+        return out
+
+    def get_system_pos(self, system):
+        out = np.zeros((self.n_atom, 3), 'f4')
+        self._check(self.calc.upside_hip_get_system_pos(self.engine, int(system), out.ctypes.data), 'get_system_pos')
+        return out
+
+    def set_system_pos(self, system, pos):
+        pos = np.require(pos, dtype='f4', requirements='C')
+        assert pos.shape == (self.n_atom, 3)
+        self._check(self.calc.upside_hip_set_system_pos(self.engine, int(system), pos.ctypes.data), 'set_system_pos')
+
+    def swap_systems(self, s1, s2):
+        self._check(self.calc.upside_hip_swap_systems(self.engine, int(s1), int(s2)), 'swap_systems')
+
+    # -- force pass / MD ------------------------------------------------------------------------
+    def energies(self):
+        e = np.zeros(self.n_system, 'f4')
+        self._check(self.calc.upside_hip_compute(self.engine, e.ctypes.data, None), 'compute')
+        return e
+
+    def energies_and_derivs(self):
+        e = np.zeros(self.n_system, 'f4'); d = np.zeros((self.n_system, self.n_atom, 3), 'f4')
+        self._check(self.calc.upside_hip_compute(self.engine, e.ctypes.data, d.ctypes.data), 'compute')
+        return e, d
+
+    def init_md(self, temperature, base_seed, thermostat_timescale=5.0, dt=0.009, thermostat_interval=1):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(temperature, 'f4'), (self.n_system,)))
+        self.temperature = t.copy()
+        self._check(self.calc.upside_hip_init_md(self.engine, t.ctypes.data, int(base_seed) & 0xFFFFFFFF,
+                                                 float(thermostat_timescale), float(dt), int(thermostat_interval)), 'init_md')
+
+    def run_steps(self, n_step):
+        self._check(self.calc.upside_hip_run_steps(self.engine, int(n_step)), 'run_steps')
+
+    def run_rounds(self, n_round):
+        self._check(self.calc.upside_hip_run_md(self.engine, int(n_round)), 'run_md')
+
+    def close(self):
+        if getattr(self, 'engine', None):
+            self.calc.free_deriv_engine(ct.c_void_p(self.engine))
+            self.engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def replica_decide(pairs, beta, energy, base_seed, round_num, draw0=0, library=None):
+    """Metropolis verdicts of one swap set from known energies (host arithmetic of main.cpp:251-273; needs no GPU).
+    Returns (accepted[n_pair] as bool array, next draw index)."""
+    lib = library if library is not None else default_library()
+    Ensemble._bind(lib.calc)
+    pairs = np.require(pairs, dtype='i4', requirements='C').reshape(-1, 2)
+    beta = np.require(beta, dtype='f4', requirements='C')
+    energy = np.require(energy, dtype='f4', requirements='C')
+    if pairs.size and (pairs.min() < 0 or pairs.max() >= len(energy) or len(beta) != len(energy)):
+        raise ValueError('swap pairs outside the system list')
+    acc = np.zeros(len(pairs) + 1, 'i4')
+    if lib.calc.upside_replica_decide(len(pairs), pairs.ctypes.data, beta.ctypes.data, energy.ctypes.data,
+                                      int(base_seed) & 0xFFFFFFFF, int(round_num), int(draw0), acc.ctypes.data):
+        raise RuntimeError('replica_decide failed')
+    return acc[:-1].astype(bool), int(acc[-1])

@@ -71,3 +71,72 @@ def job_throughput(dist, units_this_rank, seconds_this_rank, device='cpu'):
     total = sum_over_ranks(dist, units_this_rank, device)
     worst = max_over_ranks(dist, seconds_this_rank, device)
     return total / worst, worst
+
+
+# ---- replica exchange across ranks (main.cpp:227-275) -------------------------------------------
+def all_gather_f32(dist, local, device='cpu'):
+    """concatenate one float32 vector per rank in rank order (the ncclAllGather of one energy per replica)"""
+    import numpy as np
+    import torch
+    local = np.ascontiguousarray(local, dtype='f4')
+    if dist is None or not dist.is_initialized():
+        return local.copy()
+    t = torch.from_numpy(local).to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.cat(out).cpu().numpy()
+
+
+def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, draw0=0, device='cpu', decide=None):
+    """One swap set of a replica-exchange attempt over systems spread across ranks (weak shard: rank r owns the
+    global systems [r*n, (r+1)*n), n = ensemble.n_system).
+
+    1. every rank evaluates the energies of its systems and all-gathers them (one float per replica);
+    2. every rank runs the identical Metropolis test on the identical arrays (`upside_replica_decide`: shared
+       counter RNG, a uniform drawn only for a rejectable pair) -- no verdict is communicated;
+    3. accepted pairs exchange coordinates: on-rank pairs on the device, cross-rank pairs by one grouped
+       send/recv of 3*n_atom floats per pair.  Momenta and temperatures stay where they are (main.cpp:244-247).
+
+    `ensemble` needs n_system, energies(), get_system_pos(i), set_system_pos(i, x), swap_systems(i, j).
+    Returns (accepted bool array over `pairs`, next draw index)."""
+    import numpy as np
+    import torch
+    if decide is None:
+        from .engine import replica_decide as decide
+    rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+    n = ensemble.n_system
+    lo = rank * n
+    pairs = np.asarray(pairs, dtype='i4').reshape(-1, 2)
+    energy = all_gather_f32(dist, ensemble.energies(), device)
+    accepted, draw = decide(pairs, beta_global, energy, base_seed, round_num, draw0)
+    ops, incoming = [], []
+    for (s1, s2), ok in zip(pairs.tolist(), accepted.tolist()):
+        if not ok:
+            continue
+        r1, r2 = s1 // n, s2 // n
+        if r1 == rank and r2 == rank:
+            ensemble.swap_systems(s1 - lo, s2 - lo)
+        elif rank in (r1, r2):
+            mine, peer = (s1, r2) if r1 == rank else (s2, r1)
+            out = torch.from_numpy(np.ascontiguousarray(ensemble.get_system_pos(mine - lo))).to(device)
+            inc = torch.empty_like(out)
+            ops.append(dist.P2POp(dist.isend, out, peer))
+            ops.append(dist.P2POp(dist.irecv, inc, peer))
+            incoming.append((mine - lo, inc))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for sys_local, inc in incoming:
+            ensemble.set_system_pos(sys_local, inc.cpu().numpy())
+    return accepted, draw
+
+
+def geometric_ladder(t_low, t_high, n):
+    """temperature ladder of a replica-exchange run (README.md:189-193 pattern)"""
+    import numpy as np
+    return (t_low * (t_high / t_low) ** (np.arange(n) / max(n - 1, 1))).astype('f4')
+
+
+def neighbour_swap_sets(n):
+    """the two alternating swap sets of nearest temperature neighbours: (0,1),(2,3),... and (1,2),(3,4),..."""
+    return [[(i, i + 1) for i in range(0, n - 1, 2)], [(i, i + 1) for i in range(1, n - 1, 2)]]
