@@ -107,12 +107,25 @@ def cpu_baseline(fixture, variant, budget_s=15.0):
                 sample='%d steps of the C restatement (oracle/upside_oracle.c), 1 core' % (3 * n_round))
 
 
+def measured_traffic(kernel_label, workload, replicas):
+    """HBM bytes per launch of `kernel_label` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this very command; tools/hbm_traffic.py applies the guide's gfx950
+    corrections).  None when no profile exists for this workload / replica count."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        return tab['%s/R%d' % (workload, replicas)][kernel_label]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--replicas', type=int, default=int(os.environ.get('UPSIDE_BENCH_REPLICAS', '64')),
+    ap.add_argument('--replicas', type=int, default=int(os.environ.get('UPSIDE_BENCH_REPLICAS', '1024')),
                     help='independent replicas resident per GPU')
     ap.add_argument('--workload', default='syn300_10A')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -184,7 +197,7 @@ def main():
         bytes_per_launch = dom[3] / dom[2]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound='hbm', kernel=dom[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms,
+                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom[0], args.workload, R), avg_launch_ms=avg_ms,
                         algorithmic_bytes_per_launch=bytes_per_launch,
                         kernels={r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
                                             GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows})

@@ -151,7 +151,9 @@ int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int 
 int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags);
 
 /* ---- rotamer (src/rotamer.cpp) ------------------------------------------------------------------- */
-#define UPK_FLAG_GRID 16   /* grid.y of the rebuild kernels */
+/* grid.y of the rebuild kernels: enough slices that the systems flagged in one step (about one in ten) are
+ * rebuilt side by side, few enough that a quiet step retires almost no idle workgroups */
+#define UPK_FLAG_GRID(S) ((S) < 16 ? (S) : ((S) / 8 > 16 ? (S) / 8 : 16))
 #define UPK_FLAG_LIST(G) ((G).flagged + (size_t)(G).parity * (G).flag_stride)
 
 typedef struct {

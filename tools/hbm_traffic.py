@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE in one run, WRITE_SIZE in another -- they do not fit one pass on
+gfx950) into HBM bytes per launch and merge them into profiles/hbm_traffic.json, the table bench.py reads.
+
+Corrections (MI355X_MICROARCH.md, section HBM): the counters are in KiB-sized units (bytes = value * 1024) and on
+gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so a wide coalesced read is under-counted by 2x; the
+pair kernels here gather 16- and 32-byte rows, for which the factor is uncalibrated, so both the raw figure and
+the doubled upper bound are recorded and `bytes_per_launch` uses the raw read + write (a LOWER bound on traffic).
+
+usage: hbm_traffic.py fetch.db write.db workload replicas [out.json]"""
+import collections, json, os, sqlite3, sys
+
+LABEL = {  # rocprof kernel name prefix -> (bench.py profile label, index of the launch of that kernel within one force pass)
+    'k_rotamer_grad': 'igraph_bwd:rotamer',
+    'k_rotamer_pair_energy': 'igraph_fwd:rotamer',
+    'k_rotamer_bp': 'bp:rotamer',
+}
+
+
+def per_kernel(dbfile, counter):
+    db = sqlite3.connect(dbfile)
+    rows = db.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    acc = collections.defaultdict(list)
+    for k, c, v in rows:
+        if c == counter:
+            acc[k.split('(')[0]].append(v)
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch_db, write_db, workload, replicas = sys.argv[1:5]
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'hbm_traffic.json')
+    f = per_kernel(fetch_db, 'FETCH_SIZE'); w = per_kernel(write_db, 'WRITE_SIZE')
+    try:
+        tab = json.load(open(out))
+    except (OSError, ValueError):
+        tab = {}
+    entry = {}
+    for k in sorted(set(f) | set(w)):
+        fb = f.get(k, (0, 0))[0] * 1024.0; wb = w.get(k, (0, 0))[0] * 1024.0
+        label = LABEL.get(k, k)
+        entry[label] = dict(rocprof_kernel=k, launches_sampled=f.get(k, (0, 0))[1], fetch_bytes=fb, fetch_bytes_if_wide=2 * fb,
+                            write_bytes=wb, bytes_per_launch=fb + wb)
+    tab['%s/R%s' % (workload, replicas)] = entry
+    json.dump(tab, open(out, 'w'), indent=1, sort_keys=True)
+    for k, v in sorted(entry.items(), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:
+        print('%-40s read %8.1f MB  write %8.1f MB' % (k, v['fetch_bytes'] / 1e6, v['write_bytes'] / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -258,7 +258,7 @@ extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) 
     const int blocks2 = G->symmetric ? 0 : (G->n2 + PLB_ROWS - 1) / PLB_ROWS;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     const size_t lds = (size_t)n_max * 16;
-    const dim3 grid(blocks1 + blocks2, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID);
+    const dim3 grid(blocks1 + blocks2, UPK_FLAG_GRID(L->n_system));
     if (lds <= 150 * 1024) hipLaunchKernelGGL((k_pairlist_build<true>), grid, dim3(1024), lds, ST(L), *G, blocks1);
     else hipLaunchKernelGGL((k_pairlist_build<false>), grid, dim3(1024), 0, ST(L), *G, blocks1);
     return launch_status();

@@ -48,7 +48,7 @@ __global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     const int n16 = (R->n_node * R->n_node + 15) / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(1024), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(1024), 0, ST(L), *R);
     return launch_status();
 }
 
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     if (R->n_node > 1024) return 9003;
     const size_t lds = (size_t)R->n_node * ((R->n_node + 63) / 64) * 8;
-    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 64 ? L->n_system : 64), dim3(BP_BLOCK), lds, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 256 ? L->n_system : 256), dim3(BP_BLOCK), lds, ST(L), *R);
     return launch_status();
 }
 
@@ -222,7 +222,7 @@ __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
 }
 extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     int blocks = (R->G.n1 + 3) / 4;
-    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, L->n_system < UPK_FLAG_GRID ? L->n_system : UPK_FLAG_GRID), dim3(256), 0, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(256), 0, ST(L), *R);
     return launch_status();
 }
 
