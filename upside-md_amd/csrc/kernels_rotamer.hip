@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                 d1 += __popcll(w & below(e1, c));
                 dbp += __popcll(w & ~below(e1, c));
             }
-            if (na == 1) dbp = 0;
+            dbp = na == 1 ? 0 : dbp * (na == 6 ? 2 : 1);     // inbox size in 16-byte quads: 1 per message to a 3-state node, 2 to a 6-state node
             deg1[a] = d1;
         }
         int tot_lo, tot_hi, tot_bp;
@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
             if (d > R.adj_cap) *G.error_flag = 3;
         }
         // ---- assign: node a numbers its pairs (a, b > a) in ascending b; everything a pair needs follows from
-        // popcounts of the two rows (messages TO node g sit at inbox rows bp_start[g] + rank among g's multi-state
-        // partners, 8 floats each; folded 1-state partners of g are listed in ascending id)
+        // popcounts of the two rows (messages TO node g sit at inbox quad bp_start[g] + rank among g's multi-state
+        // partners x (1 quad = 4 floats for a 3-state g, 2 for a 6-state g); folded 1-state partners of g are listed
+        // in ascending id)
         if (a < NN) {
             int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
             int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
@@ -185,8 +186,8 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                             const int pos = rank_below(b, a);              // 1-state partners of b below a
                             if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
                         } else if (na > 1) {
-                            slot_off[sl * 2] = (bp_s[a] + k_multi) * 8;
-                            slot_off[sl * 2 + 1] = (bp_s[b] + rank_below(b, a) - deg1[b]) * 8;
+                            slot_off[sl * 2] = (bp_s[a] + k_multi * (na == 6 ? 2 : 1)) * 4;
+                            slot_off[sl * 2 + 1] = (bp_s[b] + (rank_below(b, a) - deg1[b]) * (nb == 6 ? 2 : 1)) * 4;
                         }
                     } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
                     if (na > 1) ++k_multi;
@@ -415,6 +416,25 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
+// zero the accumulator entries a slot class uses, for slots [lo, hi)
+template <int NA, int NB>
+__device__ __forceinline__ void clear_class(float* P, int cap, int lo, int hi, int tid, int nt) {
+    const int n = hi - lo;
+    for (int i = tid; i < n * NA * NB; i += nt) {
+        const int e = i / n, l = i - e * n;
+        P[(size_t)((e / NB) * 6 + e % NB) * cap + lo + l] = 0.f;
+    }
+}
+__device__ __forceinline__ void clear_all_classes(float* P, int cap, const int* cls, int part, int n_part, int tid, int nt) {
+    auto sub = [&](int c, int& lo, int& hi) { const int b = cls[c], n = cls[c + 1] - b; lo = b + (int)((long)n * part / n_part); hi = b + (int)((long)n * (part + 1) / n_part); };
+    int lo, hi;
+    sub(CL33, lo, hi); clear_class<3, 3>(P, cap, lo, hi, tid, nt);
+    sub(CL36, lo, hi); clear_class<3, 6>(P, cap, lo, hi, tid, nt);
+    sub(CL66, lo, hi); clear_class<6, 6>(P, cap, lo, hi, tid, nt);
+    sub(CL11, lo, hi); clear_class<1, 1>(P, cap, lo, hi, tid, nt);
+    sub(CL1X, lo, hi); clear_class<1, 6>(P, cap, lo, hi, tid, nt);
+}
+
 struct BpCtx {
     const int *slot_a, *slot_b, *active, *slot_off;
     float *P, *inbox, *marg;
@@ -540,7 +560,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     }
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
-    for (int i = tid; i < bp_start[NN] * 8; i += nt) C.inbox[i] = 1.f;
+    for (int i = tid; i < bp_start[NN] * 4; i += nt) C.inbox[i] = 1.f;
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     for (int g = tid; g < NN; g += nt) {
@@ -580,13 +600,13 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int k1 = bp_start[g + 1];
+                const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 int parity = 0;
-                for (int k = bp_start[g] + gl; k < k1; k += BP_GROUP) {
-                    const float4 m0 = *(const float4*)(C.inbox + (size_t)k * 8);
-                    const float2 m1 = *(const float2*)(C.inbox + (size_t)k * 8 + 4);
+                for (int k = gl; k < deg; k += BP_GROUP) {
+                    const float* m = C.inbox + (size_t)(base + k * q) * 4;
+                    const float4 m0 = *(const float4*)m;
                     bb[0] *= m0.x; bb[1] *= m0.y; bb[2] *= m0.z;
-                    if (n == 6) { bb[3] *= m0.w; bb[4] *= m1.x; bb[5] *= m1.y; }
+                    if (n == 6) { const float2 m1 = *(const float2*)(m + 4); bb[3] *= m0.w; bb[4] *= m1.x; bb[5] *= m1.y; }
                     if ((++parity & 1) == 0) {          // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
                         float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
                         if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
@@ -666,7 +686,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[i];
     __syncthreads();
     // leave the accumulators clean for the next force evaluation
-    for (int i = tid; i < n_slot * 36; i += nt) C.P[(size_t)(i / n_slot) * C.cap + (i % n_slot)] = 0.f;
+    clear_all_classes(C.P, C.cap, cls, 0, 1, tid, nt);
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
     for (int i = tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
@@ -939,16 +959,17 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int k1 = bp_start[g + 1];
-                for (int kb = bp_start[g] + gl; kb < k1; kb += BPC_GROUP * 4) {   // 4 independent row loads in flight
+                const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
+                for (int kb = gl; kb < deg; kb += BPC_GROUP * 4) {   // 4 independent row loads in flight
                     float4 lo4[4]; float2 hi2[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int k = kb + u * BPC_GROUP;
                         lo4[u] = make_float4(1.f, 1.f, 1.f, 1.f); hi2[u] = make_float2(1.f, 1.f);
-                        if (k < k1) {
-                            lo4[u] = *(const float4*)(X.inbox + (size_t)k * 8);
-                            if (n == 6) hi2[u] = *(const float2*)(X.inbox + (size_t)k * 8 + 4);
+                        if (k < deg) {
+                            const float* m = X.inbox + (size_t)(base + k * q) * 4;
+                            lo4[u] = *(const float4*)m;
+                            if (n == 6) hi2[u] = *(const float2*)(m + 4);
                         }
                     }
 #pragma unroll
@@ -1035,10 +1056,11 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
-    const int z_lo = (int)((long)n_slot * c / C), z_hi = (int)((long)n_slot * (c + 1) / C), z_n = z_hi - z_lo;
+    const int z_lo = (int)((long)n_slot * c / C), z_hi = (int)((long)n_slot * (c + 1) / C);
+    const int n11 = cls[CL11 + 1] - cls[CL11], lo11 = cls[CL11] + (int)((long)n11 * c / C), hi11 = cls[CL11] + (int)((long)n11 * (c + 1) / C);   // as clear_all_classes splits it
     if (want_energy) {
-        for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)       // 1-1 edges (rotamer.cpp:861): -log(exp(-E))
-            if (sl >= z_lo && sl < z_hi && active_w[sl]) en += P[sl];
+        for (int sl = lo11 + tid; sl < hi11; sl += nt)                     // 1-1 edges (rotamer.cpp:861): -log(exp(-E))
+            if (active_w[sl]) en += P[sl];
         for (int g = g_lo + tid; g < g_hi; g += nt) {                      // node_free_energy, rotamer.cpp:292-302
             const int n = nrot[g];
             float e = R.node_off[(size_t)s * NN + g];
@@ -1052,7 +1074,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R
         if (tid == 0) st_agent(X.en_part + c, tot);
     }
     __syncthreads();   // all reads of P / active by this workgroup are done
-    for (int i = tid; i < z_n * 36; i += nt) P[(size_t)(i / z_n) * R.slot_cap + z_lo + (i % z_n)] = 0.f;
+    clear_all_classes(P, R.slot_cap, cls, c, C, tid, nt);
     for (int i = z_lo + tid; i < z_hi; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
     if (want_energy) {
         cluster_barrier(X.bar, phase, C, R.G.error_flag);
