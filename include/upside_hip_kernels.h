@@ -200,6 +200,7 @@ int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R);
 int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy);
 /* floats of exp(-E) pair matrices one workgroup of the cluster solve can keep in LDS (to choose bp_C) */
 int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R);
+int upk_rotamer_bp_cluster_threads(void);   /* and the number of slots of one class it can own (one per lane) */
 /* derivative push: pair marginal x pair gradient gathered per bead, node marginals to the 1-body parents
  * (rotamer.cpp:956-985, interaction_graph.h:525-555) */
 int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R);

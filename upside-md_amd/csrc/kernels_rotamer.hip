@@ -820,7 +820,7 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
                                               bool want_energy) {
     if (!st.live) return 0.f;
     const int l = threadIdx.x;
-    float en = 0.f, P[NA][NB], bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
+    float en = 0.f, P[NA][NB], bc1[NA], bc2[NB], sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -832,13 +832,13 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { mg[i][j] = P[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
+        for (int j = 0; j < NB; ++j) sum += P[i][j] * bc1[i] * bc2[j];
     const float rs = rcp(sum);
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const float pm = mg[i][j] * rs;
+            const float pm = (P[i][j] * bc1[i] * bc2[j]) * rs;      // recomputed: no second 36-register matrix
             marg[(size_t)(i * 6 + j) * cap + st.sl] = pm;
             if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i][j] * nbm[st.a * 6 + i] * nbm[st.b * 6 + j]));
         }
@@ -847,7 +847,8 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
 
 #define BPC_GROUP 16  // lanes cooperating on one node
 
-__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
+#define BPC_BLOCK 512   // 8 waves: 256 VGPRs per lane keep the three slot states + a 6x6 matrix out of scratch
+__global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x >= n_sys) return;
     const int s = sys0 + blockIdx.x, c = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -871,7 +872,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R
         for (int k = 0; k < 3; ++k) {
             const int b = cls[k], n = cls[k + 1] - b;
             const int m = (int)((long)n * (cc + 1) / C) - (int)((long)n * cc / C);
-            if (m > BP_BLOCK) fits = false;
+            if (m > BPC_BLOCK) fits = false;
             nd += m * (k == 0 ? 9 : (k == 1 ? 18 : 36));
         }
         if (nd > p_cap) fits = false;
@@ -1087,6 +1088,7 @@ static int device_cu_count() {
     if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64; }
     return n;
 }
+extern "C" int upk_rotamer_bp_cluster_threads() { return BPC_BLOCK; }   // slots of one class a workgroup can own
 extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // floats of pair matrices one workgroup can hold
     const int fixed = R->n_node * 14 + 48;
     return (int)(156 * 1024 / sizeof(float)) - fixed;
@@ -1104,7 +1106,7 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
             const int p_cap = upk_rotamer_bp_cluster_capacity(R);
             for (int s0 = 0; s0 < L->n_system; s0 += chunk) {
                 const int n = L->n_system - s0 < chunk ? L->n_system - s0 : chunk;
-                hipLaunchKernelGGL(k_rotamer_bp_cluster, dim3(n, C), dim3(BP_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
+                hipLaunchKernelGGL(k_rotamer_bp_cluster, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
             hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1);
             return launch_status();

@@ -743,15 +743,17 @@ struct RotamerSidechain : public PotentialNode {
         if (want == 1) { R.bp_C = 1; return; }
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
         auto cs = class_start.download();
-        long need = 0;
+        long need = 0, widest = 0;
         for (int s = 0; s < ctx->n_system; ++s) {
             const int* c = &cs[(size_t)s * 6];
             need = max(need, 9L * (c[1] - c[0]) + 18L * (c[2] - c[1]) + 36L * (c[3] - c[2]));
+            widest = max(widest, (long)max(c[1] - c[0], max(c[2] - c[1], c[3] - c[2])));
         }
-        const int cap = upk_rotamer_bp_cluster_capacity(&R);
+        const int cap = upk_rotamer_bp_cluster_capacity(&R), lanes = upk_rotamer_bp_cluster_threads();
         int C = cap > 0 ? (int)((need * 115 / 100 + cap - 1) / cap) : 1;
+        C = max(C, (int)((widest * 115 / 100 + lanes - 1) / lanes));   // one slot per class per lane
         if (want > 1) C = want;
-        if (C > 8 || n_node - R.n_node1 < C) C = 1;              // too large for a co-resident cluster: one-workgroup solve
+        if (C > 16 || n_node - R.n_node1 < C) C = 1;             // too large for a co-resident cluster: one-workgroup solve
         // The cluster solve trades HBM traffic for two device-scope barriers per sweep (~18 us per sweep alone, measured):
         // it wins while the batch is small enough that one-workgroup solves would leave most CUs idle, and loses
         // once every CU has its own system to solve.
