@@ -754,10 +754,10 @@ struct RotamerSidechain : public PotentialNode {
         C = max(C, (int)((widest * 115 / 100 + lanes - 1) / lanes));   // one slot per class per lane
         if (want > 1) C = want;
         if (C > 16 || n_node - R.n_node1 < C) C = 1;             // too large for a co-resident cluster: one-workgroup solve
-        // The cluster solve trades HBM traffic for two device-scope barriers per sweep (~18 us per sweep alone, measured):
-        // it wins while the batch is small enough that one-workgroup solves would leave most CUs idle, and loses
-        // once every CU has its own system to solve.
-        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 16)) C = 1;
+        // The cluster solve trades HBM traffic for two device-scope barriers per sweep: it wins while the whole batch
+        // fits ONE cluster launch (CUs / C systems; measured 0.20 vs 0.53 ms at 1 system, 0.46 vs 0.75 ms at 32) and
+        // loses once every CU has its own system to solve (0.97 vs 0.93 ms at 64, 3.9 vs 1.6 ms at 256).
+        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 32)) C = 1;
         R.bp_C = C < 1 ? 1 : C;
     }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
