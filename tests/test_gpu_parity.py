@@ -7,6 +7,7 @@ relative fp32, where "relative" for an array is the reference's own relative RMS
 the per-node potentials (the total is a difference of large terms)."""
 import ctypes as ct
 import os
+import sys
 import numpy as np
 import pytest
 import parity_util as P
@@ -288,3 +289,39 @@ def test_ensemble_exchange_matches_device_swap(hip):
     assert np.array_equal(a.get_system_pos(3), x)
     a.set_system_pos(0, x); assert np.array_equal(a.get_pos()[0], x)
     a.close(); b.close()
+
+
+ALT_PATHS = [
+    {'UPSIDE_HIP_BP_CLUSTER': '1'},          # one-workgroup belief propagation instead of the cluster solve
+    {'UPSIDE_HIP_BP_CLUSTER': '3'},          # cluster too small for the pair matrices: on-device fallback flag
+    {'UPSIDE_HIP_ASYNC_PREPARE': '0'},       # list upkeep inline on the main stream
+    {'UPSIDE_HIP_IG_UNSTAGED': '1'},         # coverage graphs through the kernels for systems too large for LDS
+    {'UPSIDE_HIP_IG_WGS': '4096'},           # many thin workgroups per pair kernel
+]
+
+
+def test_alternate_code_paths_agree(tmp_path):
+    """every selectable code path gives the golden forces and the same short MD trajectory as the default path"""
+    import subprocess
+    name = 'syn150_10A'
+    g = P.golden(name)
+
+    def run(env_extra, tag):
+        out = str(tmp_path / (tag + '.npz'))
+        env = dict(os.environ); env.update(env_extra)
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'alt_path_worker.py')
+        subprocess.run([sys.executable, worker, name, out], check=True, env=env, timeout=600,
+                       cwd=os.path.dirname(os.path.abspath(__file__)))
+        return np.load(out)
+
+    base = run({}, 'default')
+    for tag in ('pos', 'pos2'):
+        assert P.rel_rms(g['deriv' if tag == 'pos' else 'deriv2'], base['force_' + tag]) < 3e-4
+    assert P.rel_rms(base['force_pos'], base['ens_force'][0]) < 1e-6
+    for i, env_extra in enumerate(ALT_PATHS):
+        alt = run(env_extra, 'alt%d' % i)
+        for k in ('force_pos', 'force_pos2', 'ens_force'):
+            assert P.rel_rms(base[k], alt[k]) < 2e-6, (env_extra, k)
+        for k in ('energy_pos', 'energy_pos2', 'ens_energy'):
+            assert np.allclose(base[k], alt[k], rtol=2e-6, atol=1e-3), (env_extra, k)
+        assert P.rel_rms(base['md_pos'], alt['md_pos']) < 1e-5, env_extra

@@ -510,7 +510,9 @@ static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_row
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
     const int waves = 16;
     lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
-    if (lds_bytes > 158 * 1024) return false;
+    static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
+    if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
+    if (lds_bytes > 158 * 1024 || force_unstaged) return false;
     int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;   // workgroups in flight across systems
     const int max_bps = (n_rows + waves - 1) / waves;
     if (bps > max_bps) bps = max_bps;
