@@ -297,6 +297,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_ASYNC_PREPARE': '0'},       # list upkeep inline on the main stream
     {'UPSIDE_HIP_IG_UNSTAGED': '1'},         # coverage graphs through the kernels for systems too large for LDS
     {'UPSIDE_HIP_IG_WGS': '4096'},           # many thin workgroups per pair kernel
+    {'UPSIDE_HIP_ROT_UNSTAGED': '1'},        # rotamer pair kernels with bead rows in global memory (large systems)
 ]
 
 

@@ -261,24 +261,45 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // ------------------------------------------------------------------------------------------------
 // bead-pair kernels: table + all beads of the system in LDS.  Bead row: [0,6) pos+dir, [6] type | rot<<8 |
 // nrot<<12, [7] node id (raw int bits).
-struct RotLds { float* tab; float* rows; int* q; };
+// STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
+// written by k_rotamer_pack_beads; the table and the queues stay in LDS.
+struct RotLds { float* tab; const float* rows; int* q; };
+template <bool STAGED>
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
     RotLds r;
-    r.tab = lds; r.rows = lds + ((tab_floats + 3) & ~3);
-    r.q = (int*)(r.rows + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
+    r.tab = lds;
+    float* lds_rows = lds + ((tab_floats + 3) & ~3);
     stage_table(r.tab, R.G.param, tab_floats);
-    stage_rows(r.rows, R.G.node1, s, R.G.loc1, R.G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
+    if (STAGED) {
+        r.rows = lds_rows;
+        r.q = (int*)(lds_rows + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
+        stage_rows(lds_rows, R.G.node1, s, R.G.loc1, R.G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
+    } else {
+        r.rows = R.bead_pack + (size_t)s * R.G.n1 * 8;
+        r.q = (int*)lds_rows + (threadIdx.x >> 6) * IG_QUEUE;
+    }
     __syncthreads();
     return r;
 }
+__global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
+    const int s = blockIdx.y, n = R.G.n1;
+    const float* base = R.G.node1.out + (size_t)s * R.G.node1.n_elem * R.G.node1.stride;
+    float* out = R.bead_pack + (size_t)s * n * 8;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += gridDim.x * blockDim.x) {
+        const int i = t >> 3, c = t & 7;
+        out[t] = c < 6 ? base[(size_t)R.G.loc1[i] * R.G.node1.stride + c]
+                       : __int_as_float(c == 6 ? R.bead_meta[i] : R.bead_node[i]);
+    }
+}
 
 // bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
+template <bool STAGED>
 __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    const RotLds L = rot_stage(R, lds, s, tab_floats);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
     const float cut2 = G.cutoff * G.cutoff;
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active = R.slot_active + (size_t)s * R.slot_cap;
@@ -312,32 +333,44 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
     }
 }
 
-static bool rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+// 1 = table + beads staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
+static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
     const int waves = 16;
-    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)R->G.n1 * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
-    if (lds_bytes > 158 * 1024) return false;
+    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + (size_t)waves * IG_QUEUE) * sizeof(float);
+    static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
+    if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
+    int staged = 1;
+    lds_bytes = fixed + (size_t)R->G.n1 * 8 * sizeof(float);
+    if (lds_bytes > 158 * 1024 || force_unstaged) { staged = 0; lds_bytes = fixed; }
+    if (lds_bytes > 158 * 1024 || (!staged && !R->bead_pack)) return -1;
     int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;
     const int max_bps = (R->G.n1 + waves - 1) / waves;
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
     grid = dim3(bps, L->n_system); block = dim3(waves * 64);
-    return true;
+    return staged;
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
-    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;   // more beads than LDS can stage
-    hipLaunchKernelGGL(k_rotamer_pair_energy, grid, block, lds, ST(L), *R, tab_floats);
+    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    if (staged < 0) return 9005;   // interaction table larger than LDS
+    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats);
+    else {
+        hipLaunchKernelGGL(k_rotamer_pack_beads, dim3((R->G.n1 * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);   // also serves upk_rotamer_grad
+        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats);
+    }
     return launch_status();
 }
 
 // derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
+template <bool STAGED>
 __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    const RotLds L = rot_stage(R, lds, s, tab_floats);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
     const int NN = R.n_node;
     const float cut2 = G.cutoff * G.cutoff;
     const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
@@ -390,8 +423,10 @@ __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
-    if (!rot_geometry(L, R, tab_floats, lds, grid, block)) return 9005;
-    hipLaunchKernelGGL(k_rotamer_grad, grid, block, lds, ST(L), *R, tab_floats);
+    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    if (staged < 0) return 9005;
+    if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
+    else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step
     return launch_status();
 }
 

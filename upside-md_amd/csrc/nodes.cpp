@@ -632,7 +632,7 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
-    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
     DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
@@ -720,6 +720,11 @@ struct RotamerSidechain : public PotentialNode {
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
         R.bp_C = 1;
+        R.bead_pack = nullptr;   // packed global bead rows: only when table + beads exceed the LDS budget of the pair kernels
+        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 8 + 16 * 128) * sizeof(float) > 158 * 1024 ||
+            env_int("UPSIDE_HIP_ROT_UNSTAGED", 0)) {
+            bead_pack.alloc((size_t)ctx->n_system * ig.G.n1 * 8); R.bead_pack = bead_pack.p;
+        }
         R.bp_trace = nullptr;
         prepare_deps.push_back(ig.node1);   // the list upkeep reads the bead positions only, not the 1-body energies
         if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
