@@ -34,8 +34,10 @@ int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_str
 /* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
 int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
                           float max_force);
-/* n_invocations is common to all systems (they are thermalised at the same rounds); mom is [S][n_atom][4] */
-int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, uint64_t n_invocations,
+/* n_invocations is common to all systems (they are thermalised at the same rounds) and lives on the device: the
+ * launcher reads it and then increments it in stream order, so a captured MD graph replays correctly;
+ * mom is [S][n_atom][4] */
+int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,
                    const float* mom_scale, const float* noise_scale);
 int upk_recenter(const upk_launch_t* L, upk_coord_t pos, int xy_only);
 int upk_kinetic(const upk_launch_t* L, const float* mom, int n_atom, float* kin);

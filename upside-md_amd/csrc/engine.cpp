@@ -130,6 +130,7 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
 }
 DerivEngine::~DerivEngine() {
     if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); }
+    invalidate_graph();
     for (auto& kv : side) {
         (void)hipStreamSynchronize(kv.second.stream);
         (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); (void)hipStreamDestroy(kv.second.stream);
@@ -232,6 +233,7 @@ void DerivEngine::finalize() {
 }
 
 void DerivEngine::compute(ComputeMode mode) {
+    ++n_compute;
     // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
     // node's sens before that node's own forward step
     upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
@@ -285,6 +287,63 @@ void DerivEngine::integration_cycle(float dt_, float max_force) {
     for (int stage = 0; stage < 3; ++stage) integration_stage(stage, dt_, max_force);
 }
 
+void DerivEngine::set_invocations(uint64_t n) {
+    n_invocations = n;
+    if (!n_invocations_dev.n) n_invocations_dev.alloc(1);
+    unsigned long long v = n;
+    sync();
+    hip_check(hipMemcpy(n_invocations_dev.p, &v, sizeof(v), hipMemcpyHostToDevice), "H2D");
+}
+void DerivEngine::md_step() {
+    if (stage_num == 0 && !(round_num % thermostat_interval)) {   // main.cpp:657-662
+        upk_check(upk_thermostat(&ctx.L, mom.p, pos->n_atom, seed.p, n_invocations_dev.p, mom_scale.p, noise_scale.p), "thermostat");
+        n_invocations++;
+    }
+    integration_stage(stage_num, dt, 0.f);                        // main.cpp:663
+    if (++stage_num == 3) { stage_num = 0; ++round_num; }
+    ++steps_done;
+}
+void DerivEngine::invalidate_graph() {
+    md_graph_ready = false;
+    if (md_graph_exec) { (void)hipGraphExecDestroy(md_graph_exec); md_graph_exec = nullptr; }
+    if (md_graph) { (void)hipGraphDestroy(md_graph); md_graph = nullptr; }
+}
+bool DerivEngine::capture_md_graph() {
+    invalidate_graph();
+    const int sn = stage_num; const uint64_t rn = round_num, ni = n_invocations, sd = steps_done, nc = n_compute;
+    static const bool debug = getenv("UPSIDE_HIP_GRAPH_DEBUG") != nullptr;
+    hipError_t err = hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeGlobal);
+    if (err != hipSuccess) { if (debug) fprintf(stderr, "graph: begin capture failed: %s\n", hipGetErrorString(err)); (void)hipGetLastError(); return false; }
+    bool ok = true;
+    try { for (int i = 0; i < 6; ++i) md_step(); }
+    catch (const string& e) { ok = false; if (debug) fprintf(stderr, "graph: capture threw: %s\n", e.c_str()); }
+    catch (...) { ok = false; }
+    hipGraph_t g = nullptr;
+    err = hipStreamEndCapture(ctx.stream, &g);
+    if (err != hipSuccess || !g) { if (debug) fprintf(stderr, "graph: end capture failed: %s\n", hipGetErrorString(err)); (void)hipGetLastError(); ok = false; }
+    if (debug && ok) { size_t nn = 0; (void)hipGraphGetNodes(g, nullptr, &nn); fprintf(stderr, "graph: captured 6 MD steps, %zu nodes\n", nn); }
+    stage_num = sn; round_num = rn; n_invocations = ni; steps_done = sd; n_compute = nc;   // nothing ran: capture only records
+    if (!ok) { if (g) (void)hipGraphDestroy(g); return false; }
+    md_graph = g;
+    if (hipGraphInstantiate(&md_graph_exec, md_graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); invalidate_graph(); return false; }
+    md_graph_parity = (int)(n_compute & 1);   // the pair-list double buffers alternate with every force pass
+    md_graph_ready = true;
+    return true;
+}
+void DerivEngine::run_steps(int n_step) {
+    static const int use_graph = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : 1; }();
+    int left = n_step;
+    while (left > 0) {
+        const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;
+        if (use_graph && !graph_failed && aligned && left >= 6 && (!md_graph_ready || md_graph_parity == (int)(n_compute & 1))) {
+            if (!md_graph_ready && !capture_md_graph()) { graph_failed = true; md_step(); --left; continue; }
+            hip_check(hipGraphLaunch(md_graph_exec, ctx.stream), "hipGraphLaunch");
+            round_num += 2; n_invocations += 2; steps_done += 6; n_compute += 6; left -= 6;
+            continue;
+        }
+        md_step(); --left;
+    }
+}
 void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
 
 void DerivEngine::check_device_errors() {

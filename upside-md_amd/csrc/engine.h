@@ -154,7 +154,9 @@ struct DerivEngine {   // deriv_engine.h:145-237
     DevBuf<uint32_t> seed; DevBuf<float> mom_scale, noise_scale;
     std::vector<float> temperature; std::vector<uint32_t> seeds;
     float thermostat_timescale = 5.f, dt = 0.009f; int thermostat_interval = 1;
-    uint64_t n_invocations = 0, round_num = 0;
+    uint64_t n_invocations = 0, round_num = 0;      // host mirrors; the thermostat reads the device copy below
+    DevBuf<unsigned long long> n_invocations_dev;   // [1]
+    void set_invocations(uint64_t n);
 
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
     struct Step { int node; bool backward; bool prepare = false; };
@@ -179,6 +181,17 @@ struct DerivEngine {   // deriv_engine.h:145-237
     void integration_cycle(float dt, float max_force = 0.f);   // deriv_engine.cpp:172-192 (Verlet weights)
     void integration_stage(int stage, float dt, float max_force);   // one force evaluation + leapfrog sub-step (deriv_engine.cpp:172-192)
     int stage_num = 0;                                              // sub-step the next upside_hip_run_steps call starts with
+    void md_step();                                                 // thermostat (at round starts) + one integration stage, enqueued
+    void run_steps(int n_step);                                     // n_step MD steps; replays a captured hipGraph where it can
+
+    // A launch-bound batch (few systems) spends more time between kernels than in them: 6 MD steps (two rounds: the
+    // period of the leapfrog stage AND of the list-parity pattern) are captured once into a hipGraph, side streams
+    // included, and replayed.  Invalidated by anything that changes a kernel argument.
+    hipGraph_t md_graph = nullptr; hipGraphExec_t md_graph_exec = nullptr;
+    bool md_graph_ready = false; int md_graph_parity = 0; uint64_t steps_done = 0, n_compute = 0;
+    bool graph_failed = false;   // capture was refused once: stay on plain launches
+    void invalidate_graph();
+    bool capture_md_graph();
     void check_device_errors();                // throws if a capacity overflow was flagged
     void sync();
 };

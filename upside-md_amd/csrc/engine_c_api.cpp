@@ -117,7 +117,9 @@ extern "C" int evaluate_deriv(float* deriv, DerivEngine* e, const float* pos) {
 
 // ---- parameters and node inspection (engine_c_library.cpp:67-193) ---------------------------------------
 extern "C" int set_param(int n_param, const float* param, DerivEngine* e, const char* node_name) {
-    API_TRY e->get(string(node_name)).computation->set_param(vector<float>(param, param + n_param)); return 0; API_CATCH(1) }
+    API_TRY
+    e->invalidate_graph();   // cut-offs travel as kernel arguments
+    e->get(string(node_name)).computation->set_param(vector<float>(param, param + n_param)); return 0; API_CATCH(1) }
 extern "C" int get_param(int n_param, float* param, DerivEngine* e, const char* node_name) {
     API_TRY
     auto v = e->get(string(node_name)).computation->get_param();
@@ -231,9 +233,10 @@ extern "C" int upside_hip_init_md(DerivEngine* e, const float* temperature, uint
     for (int s = 0; s < S; ++s) { e->temperature[s] = temperature[s]; e->seeds[s] = base_seed + (uint32_t)s; }   // main.cpp:459
     e->seed.upload(e->seeds);
     e->mom.fill_bytes(0);
-    e->n_invocations = 0; e->round_num = 0;
+    e->invalidate_graph();
+    e->set_invocations(0); e->round_num = 0; e->stage_num = 0;
     thermostat_params(e, 1e8f);                     // mom_scale = 0: momenta fully resampled (main.cpp:515-522)
-    upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
+    upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations_dev.p, e->mom_scale.p, e->noise_scale.p), "thermostat");
     e->n_invocations++;
     e->sync();
     thermostat_params(e, thermostat_interval_rounds * 3 * dt);   // main.cpp:523
@@ -242,27 +245,15 @@ extern "C" int upside_hip_init_md(DerivEngine* e, const float* temperature, uint
 }
 extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
     API_TRY
-    for (int r = 0; r < n_round; ++r, ++e->round_num) {
-        if (!(e->round_num % e->thermostat_interval)) {   // main.cpp:657-662
-            upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
-            e->n_invocations++;
-        }
-        e->integration_cycle(e->dt, 0.f);                  // main.cpp:663
-    }
+    if (e->stage_num != 0) throw string("an integration cycle is in progress (upside_hip_run_steps left it unfinished)");
+    e->run_steps(3 * n_round);                             // main.cpp:657-663
     e->check_device_errors();
     return 0;
     API_CATCH(1)
 }
 extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
     API_TRY
-    for (int i = 0; i < n_step; ++i) {
-        if (e->stage_num == 0 && !(e->round_num % e->thermostat_interval)) {
-            upk_check(upk_thermostat(&e->ctx.L, e->mom.p, e->pos->n_atom, e->seed.p, e->n_invocations, e->mom_scale.p, e->noise_scale.p), "thermostat");
-            e->n_invocations++;
-        }
-        e->integration_stage(e->stage_num, e->dt, 0.f);
-        if (++e->stage_num == 3) { e->stage_num = 0; ++e->round_num; }
-    }
+    e->run_steps(n_step);
     e->check_device_errors();
     return 0;
     API_CATCH(1)

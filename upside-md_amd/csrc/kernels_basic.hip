@@ -103,12 +103,12 @@ extern "C" int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coor
 }
 
 __global__ void k_thermostat(float* __restrict__ mom, int n_atom, const uint32_t* __restrict__ seed,
-                             uint64_t n_inv, const float* __restrict__ mom_scale,
+                             const unsigned long long* __restrict__ n_inv, const float* __restrict__ mom_scale,
                              const float* __restrict__ noise_scale) {
     const int na = blockIdx.x * blockDim.x + threadIdx.x;
     if (na >= n_atom) return;
     const int s = blockIdx.y;
-    const uint64_t t = n_inv;
+    const uint64_t t = *n_inv;   // invocation counter lives on the device so that a captured graph can be replayed
     const uint32_t key[4] = {seed[s], 0u /* THERMOSTAT_RANDOM_STREAM, random.h:25 */, 0u, 0u};
     uint32_t X[4] = {(uint32_t)(t & 0xffffffffu), (uint32_t)(t >> 32), (uint32_t)na, 0u};
     threefry4x32_20(X, key);
@@ -119,10 +119,12 @@ __global__ void k_thermostat(float* __restrict__ mom, int n_atom, const uint32_t
     const float ms = mom_scale[s], ns = noise_scale[s];
     m[0] = ms * m[0] + ns * n0; m[1] = ms * m[1] + ns * n1; m[2] = ms * m[2] + ns * n2;
 }
-extern "C" int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, uint64_t n_invocations,
+__global__ void k_counter_add(unsigned long long* ctr, unsigned long long inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += inc; }
+extern "C" int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,
                               const float* mom_scale, const float* noise_scale) {
     hipLaunchKernelGGL(k_thermostat, grid1(n_atom, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, n_atom, seed, n_invocations,
                        mom_scale, noise_scale);
+    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(64), 0, ST(L), n_invocations, 1ull);   // after every lane has read it (stream order)
     return launch_status();
 }
 
