@@ -89,6 +89,10 @@ int upside_hip_recenter(DerivEngine* engine);
  * (random.h:26, keyed by round) and accepted pairs exchange coordinates.  accepted (n_pair) out. */
 int upside_hip_replica_swap(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
                             uint64_t round, int* accepted);
+/* the same for the second and later swap sets of one attempt (main.cpp:249: ONE generator per attempt_swaps call):
+ * draw0 = accepted[n_pair] returned for the previous set; accepted has n_pair+1 entries here. */
+int upside_hip_replica_swap_from(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
+                                 uint64_t round, int draw0, int* accepted);
 
 /* Replica exchange ACROSS engines / GPUs.  Each rank all-gathers one energy per system
  * (upside_hip_compute), every rank then calls upside_replica_decide on the identical global arrays: host arithmetic

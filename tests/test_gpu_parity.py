@@ -326,3 +326,65 @@ def test_alternate_code_paths_agree(tmp_path):
         for k in ('energy_pos', 'energy_pos2', 'ens_energy'):
             assert np.allclose(base[k], alt[k], rtol=2e-6, atol=1e-3), (env_extra, k)
         assert P.rel_rms(base['md_pos'], alt['md_pos']) < 1e-5, env_extra
+
+
+def _read_output(path):
+    from upside_md_amd import h5lite
+    with h5lite.open_file(path) as f:
+        out = f.group('output')
+        return {k: out.read(k) for k in out.keys()}, out.get_attr('invocation') if out.has_attr('invocation') else None
+
+
+def test_upside_main_output_matches_reference(hip, tmp_path):
+    """`upside_main` (the CLI entry of the C-ABI) against the unmodified reference executable on the same
+    configuration: same /output datasets, shapes and types; identical frame 0 and time axis; kinetic energy of the
+    first frames from the same thermostat stream; trajectories agree over the first rounds (fp32 MD diverges after
+    that).  Also a two-system replica-exchange run: replica_index and temperature datasets."""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'proteinG56_7A'
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up')
+    shutil.copyfile(P.fixture(name), a); shutil.copyfile(P.fixture(name), b)
+    args = ['--duration', '1.08', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '7']   # 40 rounds, frame every 10
+    subprocess.run([ref_exe] + args + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                   env=dict(os.environ, OMP_NUM_THREADS='1'))
+    hip.in_process_upside(args + [b], verbose=False)
+    ref, inv_ref = _read_output(a)
+    got, inv = _read_output(b)
+    assert inv is not None and '--duration' in (inv.decode() if isinstance(inv, bytes) else str(inv))
+    for k in ('pos', 'kinetic', 'potential', 'time', 'temperature'):
+        assert k in got, k
+        assert got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype, (k, got[k].shape, ref[k].shape, got[k].dtype, ref[k].dtype)
+    n_atom = P.golden(name)['pos'].shape[0]
+    assert got['pos'].shape == (4, 1, n_atom, 3) and got['time'].shape == (4,)
+    assert np.array_equal(got['time'], ref['time'])
+    assert np.allclose(got['temperature'], 0.8)
+    assert np.abs(got['pos'][0] - ref['pos'][0]).max() < 2e-5                 # recentred initial structure
+    assert abs(got['potential'][0, 0] - ref['potential'][0, 0]) < 1e-4 * max(1., abs(ref['potential'][0, 0]))
+    assert abs(got['kinetic'][0, 0] - ref['kinetic'][0, 0]) < 1e-5 * ref['kinetic'][0, 0]   # same Threefry/Box-Muller draws
+    # 30 and 60 MD steps later: the two fp32 trajectories are still the same trajectory
+    assert P.rel_rms(ref['pos'][1], got['pos'][1]) < 1e-4
+    assert P.rel_rms(ref['pos'][2], got['pos'][2]) < 1e-3
+    assert abs(got['kinetic'][1, 0] - ref['kinetic'][1, 0]) < 2e-3 * ref['kinetic'][1, 0]
+
+    # replica exchange between two temperatures (README.md:189-193 pattern): per-system files, replica_index logged
+    files = []
+    for tag in ('ref', 'hip'):
+        fs = [str(tmp_path / ('%s_%d.up' % (tag, i))) for i in range(2)]
+        for f in fs:
+            shutil.copyfile(P.fixture(name), f)
+        files.append(fs)
+    rargs = ['--duration', '0.54', '--frame-interval', '0.135', '--temperature', '0.8,0.85', '--seed', '3',
+             '--replica-interval', '0.135', '--swap-set', '0-1']
+    subprocess.run([ref_exe] + rargs + files[0], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                   env=dict(os.environ, OMP_NUM_THREADS='2'))
+    hip.in_process_upside(rargs + files[1], verbose=False)
+    for i in range(2):
+        r, _ = _read_output(files[0][i]); g_, _ = _read_output(files[1][i])
+        assert g_['replica_index'].shape == r['replica_index'].shape and g_['replica_index'].dtype == r['replica_index'].dtype
+        assert np.array_equal(g_['replica_index'], r['replica_index']), (g_['replica_index'].ravel(), r['replica_index'].ravel())
+        assert np.allclose(g_['temperature'], r['temperature'])
+        assert P.rel_rms(r['pos'][1], g_['pos'][1]) < 1e-3

@@ -261,7 +261,7 @@ extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
 extern "C" int upside_hip_recenter(DerivEngine* e) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 
-extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int* accepted) {
+extern "C" int upside_hip_replica_swap_from(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
     API_TRY
     const int S = e->ctx.n_system;
     for (int i = 0; i < 2 * n_pair; ++i) if (pairs[i] < 0 || pairs[i] >= S) throw string("invalid system");
@@ -271,12 +271,18 @@ extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pa
     for (int s = 0; s < S; ++s) beta[s] = 1.f / e->temperature[s];
     DevBuf<float> d_en, d_beta; d_en.upload(e->potential); d_beta.upload(beta);
     DevBuf<int> d_pairs, d_acc; d_pairs.upload(vector<int>(pairs, pairs + 2 * n_pair)); d_acc.alloc(n_pair + 1);
-    upk_check(upk_replica_swap(&e->ctx.L, e->pos->coord(), d_en.p, d_beta.p, n_pair, d_pairs.p, base_seed, round, 0, d_acc.p), "replica_swap");
+    upk_check(upk_replica_swap(&e->ctx.L, e->pos->coord(), d_en.p, d_beta.p, n_pair, d_pairs.p, base_seed, round, draw0, d_acc.p), "replica_swap");
     e->sync();
     auto acc = d_acc.download();
-    for (int i = 0; i < n_pair; ++i) accepted[i] = acc[i];
+    for (int i = 0; i <= n_pair; ++i) accepted[i] = acc[i];   // accepted[n_pair] = generator position for the next set
     return 0;
     API_CATCH(1)
+}
+extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int* accepted) {
+    std::vector<int> acc((size_t)n_pair + 1);
+    const int rc = upside_hip_replica_swap_from(e, n_pair, pairs, base_seed, round, 0, acc.data());
+    if (!rc) for (int i = 0; i < n_pair; ++i) accepted[i] = acc[i];
+    return rc;
 }
 
 // ---- replica exchange across engines / GPUs (main.cpp:227-275) --------------------------------

@@ -2,8 +2,12 @@
 // one topology (replicas / ensemble members).  Supported flags are the ones that drive the hot path:
 //   --duration --time-step --frame-interval --temperature a,b,c --seed --thermostat-timescale
 //   --thermostat-interval --replica-interval --swap-set i-j,k-l (repeatable) --disable-recentering
-// Trajectory output to /output (H5Logger, state_logger.h) is not written by this build;
-// the per-frame stdout line and the final "us/systems/step" line follow main.cpp:648-654,677-682.
+// Trajectory output follows the reference's /output layout (state_logger.h:17-141, h5_support.cpp:181-274,
+// main.cpp:473-541,594-596): extensible chunked datasets pos (frame,1,n_atom,3) f32, kinetic/potential/temperature
+// (frame,1) f64, time (frame) f64, replica_index (frame,1) i32 under replica exchange, attribute `invocation`;
+// a frame is taken at the START of every frame_interval-th round (frame 0 = the initial structure), after
+// recentering, exactly as main.cpp:633-636.  The per-frame stdout line and the final "us/systems/step" line follow
+// main.cpp:648-654,677-682.
 #include "../../include/upside_engine_c.h"
 #include "engine.h"
 #include "h5util.h"
@@ -17,6 +21,86 @@
 #include <vector>
 
 using namespace std;
+
+// ---- /output logger ------------------------------------------------------------------------------------------
+namespace {
+struct EArray {   // h5_support.cpp:199-274: extensible along dimension 0, chunked (100 frames), shuffle + fletcher32 (+ deflate 1)
+    hid_t dset = -1; hid_t type = -1; vector<hsize_t> row; size_t row_size = 1; vector<char> buffer; size_t elem = 4;
+    void create(hid_t group, const char* name, hid_t type_, size_t elem_, vector<hsize_t> row_dims) {
+        type = type_; elem = elem_; row = row_dims;
+        vector<hsize_t> dims{0}, maxd{H5S_UNLIMITED}, chunk{100};
+        for (auto d : row) { dims.push_back(d); maxd.push_back(d); chunk.push_back(d ? d : 1); row_size *= d; }
+        hid_t space = H5Screate_simple((int)dims.size(), dims.data(), maxd.data());
+        hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
+        H5Pset_chunk(dcpl, (int)chunk.size(), chunk.data());
+        H5Pset_shuffle(dcpl);
+        H5Pset_fletcher32(dcpl);
+        if (H5Zfilter_avail(H5Z_FILTER_DEFLATE) > 0) H5Pset_deflate(dcpl, 1);
+        dset = H5Dcreate2(group, name, type, space, H5P_DEFAULT, dcpl, H5P_DEFAULT);
+        H5Pclose(dcpl); H5Sclose(space);
+        if (dset < 0) throw string("unable to create /output/") + name;
+    }
+    void push(const void* data) { const char* c = (const char*)data; buffer.insert(buffer.end(), c, c + row_size * elem); }
+    void flush() {
+        const size_t n_rec = buffer.size() / (row_size * elem);
+        if (!n_rec) return;
+        hid_t space = H5Dget_space(dset);
+        vector<hsize_t> dims(1 + row.size());
+        H5Sget_simple_extent_dims(space, dims.data(), nullptr); H5Sclose(space);
+        vector<hsize_t> start(dims.size(), 0), count = dims;
+        start[0] = dims[0]; count[0] = n_rec; dims[0] += n_rec;
+        if (H5Dset_extent(dset, dims.data()) < 0) throw string("H5Dset_extent failed");
+        hid_t fspace = H5Dget_space(dset);
+        hid_t mspace = H5Screate_simple((int)count.size(), count.data(), nullptr);
+        H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start.data(), nullptr, count.data(), nullptr);
+        const herr_t rc = H5Dwrite(dset, type, mspace, fspace, H5P_DEFAULT, buffer.data());
+        H5Sclose(mspace); H5Sclose(fspace);
+        if (rc < 0) throw string("H5Dwrite failed");
+        buffer.clear();
+    }
+    void close() { if (dset >= 0) { flush(); H5Dclose(dset); dset = -1; } }
+};
+struct OutputLogger {   // one per system / configuration file (H5Logger, state_logger.h:70-141)
+    hid_t file = -1, group = -1; int n_buffered = 0;
+    EArray pos, kinetic, potential, time, temperature, replica_index; bool log_replica = false;
+    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index) {
+        file = H5Fopen(path.c_str(), H5F_ACC_RDWR, H5P_DEFAULT);
+        if (file < 0) throw string("Unable to open configuration file at ") + path;
+        if (H5Lexists(file, "output", H5P_DEFAULT) > 0) H5Ldelete(file, "/output", H5P_DEFAULT);   // main.cpp:473-477
+        group = H5Gcreate2(file, "output", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+        if (group < 0) throw string("unable to create /output in ") + path;
+        {   // write_string_attribute(config, "output", "invocation", ...), main.cpp:490
+            hid_t st = H5Tcopy(H5T_C_S1); H5Tset_size(st, invocation.size() + 1);
+            hid_t sp = H5Screate(H5S_SCALAR);
+            hid_t at = H5Acreate2(group, "invocation", st, sp, H5P_DEFAULT, H5P_DEFAULT);
+            if (at >= 0) { H5Awrite(at, st, invocation.c_str()); H5Aclose(at); }
+            H5Sclose(sp); H5Tclose(st);
+        }
+        pos.create(group, "pos", H5T_NATIVE_FLOAT, 4, {1, (hsize_t)n_atom, 3});
+        kinetic.create(group, "kinetic", H5T_NATIVE_DOUBLE, 8, {1});
+        potential.create(group, "potential", H5T_NATIVE_DOUBLE, 8, {1});
+        time.create(group, "time", H5T_NATIVE_DOUBLE, 8, {});
+        temperature.create(group, "temperature", H5T_NATIVE_DOUBLE, 8, {1});
+        log_replica = with_replica_index;
+        if (log_replica) replica_index.create(group, "replica_index", H5T_NATIVE_INT, 4, {1});
+    }
+    void sample(const float* x, double kin, double pot, double t, double temp, int rep) {
+        pos.push(x); kinetic.push(&kin); potential.push(&pot); time.push(&t); temperature.push(&temp);
+        if (log_replica) replica_index.push(&rep);
+        if (!(++n_buffered % 100)) flush();                       // state_logger.h:91-92
+    }
+    void flush() {
+        pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) replica_index.flush();
+        if (file >= 0) H5Fflush(file, H5F_SCOPE_LOCAL);
+    }
+    void close() {
+        if (file < 0) return;
+        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close();
+        H5Gclose(group); H5Fclose(file); file = group = -1;
+    }
+    ~OutputLogger() { try { close(); } catch (...) {} }
+};
+}  // namespace
 
 static vector<string> split_string(const string& src, const string& sep) {
     vector<string> ret;
@@ -35,7 +119,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     double duration = -1., frame_interval = -1., time_step = 0.009, thermostat_timescale = 5., thermostat_interval = -1., replica_interval = 0.;
     string temperature_str = "1.0";
     unsigned long seed = 42;
-    bool recenter = true;
+    bool recenter = true, write_output = true;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -50,6 +134,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--replica-interval") replica_interval = stod(need("--replica-interval"));
         else if (a == "--swap-set") swap_sets.push_back(need("--swap-set"));
         else if (a == "--disable-recentering") recenter = false;
+        else if (a == "--no-output") write_output = false;       // extension: leave the configuration files untouched
         else if (a == "--re-raise-signal" || a == "--disable-z-recentering") {}
         else if (a == "--log-level" || a == "--monte-carlo-interval" || a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
@@ -110,30 +195,57 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
 
     vector<float> energy(n_system);
     if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
-    if (verbose) for (int ns = 0; ns < n_system; ++ns) printf("%i: Initial potential energy: %.2f\n", ns, energy[ns]);
+    if (verbose) { printf("Initial potential energy:"); for (int ns = 0; ns < n_system; ++ns) printf(" %.2f", energy[ns]); printf("\n"); }
+
+    // one logger per configuration file (the engine has closed its read-only handles by now)
+    string invocation;
+    for (int i = 0; i < argc; ++i) { if (i) invocation += " "; invocation += argv[i]; }
+    vector<OutputLogger> loggers(n_system);
+    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty());
+    vector<int> replica_index(n_system);
+    for (int ns = 0; ns < n_system; ++ns) replica_index[ns] = ns;
+    vector<float> frame_pos((size_t)n_system * n_atom * 3), frame_mom((size_t)n_system * n_atom * 3);
 
     auto tstart = chrono::high_resolution_clock::now();
     vector<long> n_attempt(sets.size(), 0), n_success(sets.size(), 0);
     for (uint64_t rnd = 0; rnd < n_round;) {
+        if (!(rnd % frame_rounds)) {   // main.cpp:633-654: recenter, energy, log, print -- before the round is integrated
+            if (recenter) upside_hip_recenter(e);
+            if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
+            if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
+            for (int ns = 0; ns < n_system; ++ns) {
+                const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
+                double sum_kin = 0.;
+                for (int i = 0; i < n_atom * 3; ++i) sum_kin += (double)(m[i] * m[i]);
+                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns]);
+                double com[3] = {0, 0, 0}, rg = 0.;
+                for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
+                for (int d = 0; d < 3; ++d) com[d] /= n_atom;
+                for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) rg += (x[i * 3 + d] - com[d]) * (x[i * 3 + d] - com[d]);
+                if (verbose) printf("%*.0f / %*.0f elapsed %2i system %.2f temp, Rg %5.1f A, potential % 8.2f\n", 8, rnd * 3 * double(dt), 8,
+                                    duration, ns, temps[ns], sqrt(rg / n_atom), energy[ns]);
+            }
+            fflush(stdout);
+        }
         uint64_t next = min<uint64_t>(n_round, (rnd / frame_rounds + 1) * (uint64_t)frame_rounds);
         if (replica_rounds) next = min<uint64_t>(next, (rnd / replica_rounds + 1) * (uint64_t)replica_rounds);
         if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error());
         rnd = next;
-        if (replica_rounds && !(rnd % replica_rounds))
+        if (replica_rounds && !(rnd % replica_rounds)) {   // main.cpp:667-668; one generator per attempt (main.cpp:249)
+            int draw = 0;
             for (size_t k = 0; k < sets.size(); ++k) {
                 vector<int> acc(sets[k].size() / 2 + 1);
-                if (upside_hip_replica_swap(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, acc.data())) throw string(upside_hip_last_error());
-                for (size_t i = 0; i < sets[k].size() / 2; ++i) { n_attempt[k]++; n_success[k] += acc[i]; }
+                if (upside_hip_replica_swap_from(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, draw, acc.data())) throw string(upside_hip_last_error());
+                draw = acc.back();
+                for (size_t i = 0; i < sets[k].size() / 2; ++i) {
+                    n_attempt[k]++; n_success[k] += acc[i];
+                    if (acc[i]) swap(replica_index[sets[k][2 * i]], replica_index[sets[k][2 * i + 1]]);
+                }
             }
-        if (!(rnd % frame_rounds)) {
-            if (recenter) upside_hip_recenter(e);
-            if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
-            if (verbose) for (int ns = 0; ns < n_system; ++ns)
-                printf("%*.0f / %*.0f | %5.1f%% | potential % 8.2f\n", 8, rnd * 3 * double(dt), 8, n_round * 3 * double(dt),
-                       100. * rnd / double(n_round), energy[ns]);
         }
     }
     e->sync();
+    for (auto& lg : loggers) lg.close();
     double elapsed = chrono::duration<double>(chrono::high_resolution_clock::now() - tstart).count();
     printf("\n\nfinished in %.1f seconds (%.2f us/systems/step, %.1e simulation_time_unit/hour)\n", elapsed,
            elapsed * 1e6 / n_system / max<uint64_t>(n_round, 1) / 3, n_round * 3 * time_step / elapsed * 3600.);
