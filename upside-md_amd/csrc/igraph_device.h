@@ -180,6 +180,83 @@ __device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, in
     }
 }
 
+// ---- dense-lane pair loop over a contiguous CHUNK of rows owned by one wavefront -----------------------------
+// A row has 10-90 in-range neighbours, so running the pair functor row by row leaves about half of the 64 lanes
+// idle (a 66-hit row costs two functor passes).  Here the hits of consecutive rows share one queue: the functor
+// always runs on 64 queued (row, neighbour) entries, whatever rows they belong to, and the per-row sums are
+// recovered by a segmented wave reduction into a small per-wave LDS accumulator (rows are contiguous in the queue,
+// a batch spans ~1-6 of them).  Per wave: DR_QUEUE ints of row ids, DR_QUEUE ints of payload, DR_CHUNK x 8 floats.
+#define DR_CHUNK 32             // rows accumulated in LDS before they are flushed
+#define DR_QUEUE 128
+#define DR_WAVE_LDS (2 * DR_QUEUE + DR_CHUNK * 8)   // 32-bit words per wave
+
+//   test(row, k, j, payload&) -> is cached neighbour k (= element j) of `row` in range?  (sets the payload word)
+//   batch(row_local, payload, valid): called with ALL lanes converged on 64 (or, at the end of the chunk, fewer) entries
+template <typename TestFn, typename BatchFn>
+__device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __restrict__ cnt_arr, const int* __restrict__ nbr_base, int cap,
+                                               int lane, int* qrow, int* qpay, TestFn test, BatchFn batch) {
+    int nq = 0;
+    for (int row = cb; row < ce; ++row) {
+        const int cnt = cnt_arr[row];
+        const int* __restrict__ nbr = nbr_base + (size_t)row * cap;
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int k = k0 + lane;
+            int pay = 0; bool hit = false;
+            if (k < cnt) hit = test(row, k, nbr[k], pay);
+            const unsigned long long m = __ballot(hit);
+            if (hit) { const int p = nq + __popcll(m & ((1ull << lane) - 1ull)); qrow[p] = row - cb; qpay[p] = pay; }
+            nq += __popcll(m);
+            wave_lds_fence();
+            if (nq >= 64) {
+                const int rl = qrow[lane], pw = qpay[lane];
+                const bool more = lane + 64 < nq;
+                const int krow = more ? qrow[lane + 64] : 0, kpay = more ? qpay[lane + 64] : 0;
+                wave_lds_fence();
+                batch(rl, pw, true);
+                if (more) { qrow[lane] = krow; qpay[lane] = kpay; }
+                nq -= 64;
+                wave_lds_fence();
+            }
+        }
+    }
+    if (nq > 0) {
+        const bool valid = lane < nq;
+        const int rl = valid ? qrow[lane] : 0, pw = valid ? qpay[lane] : 0;
+        wave_lds_fence();
+        batch(rl, pw, valid);
+    }
+}
+// acc[rl*8 + c] += sum over the lanes of row rl of v[c]; lanes of one row are adjacent, invalid lanes carry nothing
+template <int N>
+__device__ __forceinline__ void seg_accumulate(float* acc, int rl, bool valid, const float v[8], int lane) {
+    unsigned long long pending = __ballot(valid);
+    while (pending) {
+        const int r0 = __shfl(rl, __builtin_ctzll(pending), UP_WAVE);
+        const bool mine = valid && rl == r0;
+        if (N == 1) {
+            const float t = wave_sum(mine ? v[0] : 0.f);
+            if (lane == 0) acc[r0 * 8] += t;
+        } else {
+            float w[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) w[c] = mine ? v[c] : 0.f;
+            const float t = wave_sum8(w, lane);           // lane 8*c holds component c
+            if ((lane & 7) == 0) acc[r0 * 8 + (lane >> 3)] += t;
+        }
+        pending &= ~__ballot(mine);
+    }
+    wave_lds_fence();
+}
+// rows [first, first + n) of a wave: contiguous split of [0, n_rows) over the workgroups of a system and their waves
+__device__ __forceinline__ void wave_row_range(int n_rows, int& w0, int& w1) {
+    const int wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const int per_wg = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int g0 = blockIdx.x * per_wg, g1 = g0 + per_wg < n_rows ? g0 + per_wg : n_rows;
+    const int per_wave = g1 > g0 ? (g1 - g0 + n_wave - 1) / n_wave : 0;
+    w0 = g0 + wave * per_wave; w1 = w0 + per_wave < g1 ? w0 + per_wave : g1;
+    if (w0 > w1) w0 = w1;
+}
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 
 }  // namespace up

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     float* tab = lds;
     float* c1 = lds + ((A.tab_floats + 3) & ~3);
     float* c2 = c1 + G.n1 * 8;
-    int* q = (int*)(c2 + G.n2 * 8) + wave * IG_QUEUE;
+    int* qrow = (int*)(c2 + G.n2 * 8) + wave * DR_WAVE_LDS; int* qpay = qrow + DR_QUEUE; float* acc = (float*)(qrow + 2 * DR_QUEUE);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(tab, G.param, A.tab_floats);
@@ -450,66 +450,75 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     const float cut2 = G.cutoff * G.cutoff;
     const float* crow = ROW_SIDE == 1 ? c1 : c2;
     const float* coth = ROW_SIDE == 1 ? c2 : c1;
-    for (int row = blockIdx.x * n_wave + wave; row < n_rows; row += gridDim.x * n_wave) {
-        const int cap = ROW_SIDE == 1 ? G.cap1 : G.cap2;
-        const int* nbr = (ROW_SIDE == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)row * cap;
-        const int cnt = (ROW_SIDE == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[row];
-        float xr[8];
+    const int cap = ROW_SIDE == 1 ? G.cap1 : G.cap2;
+    const int* nbr_base = ROW_SIDE == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2;
+    const int* cnt_arr = ROW_SIDE == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2;
+    // pair sensitivity = (row part) + (other part); a part is 0 when that side does not contribute
+    const bool row_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == ROW_SIDE));
+    const bool oth_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == 3 - ROW_SIDE));
+    const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
+    const upk_coord_t& row_node = ROW_SIDE == 1 ? G.node1 : G.node2;
+    const int* row_loc = ROW_SIDE == 1 ? G.loc1 : G.loc2;
+    int w0, w1;
+    wave_row_range(n_rows, w0, w1);
+    (void)n_wave;
+    for (int cb = w0; cb < w1; cb += DR_CHUNK) {
+        const int ce = cb + DR_CHUNK < w1 ? cb + DR_CHUNK : w1;
+        for (int t = lane; t < DR_CHUNK * 8; t += 64) acc[t] = 0.f;
+        wave_lds_fence();
+        dense_row_loop(cb, ce, cnt_arr, nbr_base, cap, lane, qrow, qpay,
+            [&](int row, int, int j, int& pay) {
+                const float* x = crow + row * 8; const float* y = coth + j * 8;
+                pay = j;
+                return dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
+            },
+            [&](int rl, int j, bool valid) {
+                float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xr[c] = crow[row * 8 + c];
-        const int tr = __float_as_int(xr[7]);
-        // pair sensitivity = (row part) + (other part); a part is 0 when that side does not contribute
-        const bool row_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == ROW_SIDE));
-        const bool oth_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == 3 - ROW_SIDE));
-        const float srow = row_has ? xr[6] : 0.f;
-        float acc[8], vacc = 0.f;
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+                if (valid) {
+                    float xr[8], xo[8], d[8];
+                    const float* pr = crow + (cb + rl) * 8; const float* po = coth + j * 8;
+                    const float4 rlo = *(const float4*)pr, rhi = *(const float4*)(pr + 4), lo = *(const float4*)po, hi = *(const float4*)(po + 4);
+                    xr[0] = rlo.x; xr[1] = rlo.y; xr[2] = rlo.z; xr[3] = rlo.w; xr[4] = rhi.x; xr[5] = rhi.y; xr[6] = rhi.z; xr[7] = rhi.w;
+                    xo[0] = lo.x; xo[1] = lo.y; xo[2] = lo.z; xo[3] = lo.w; xo[4] = hi.x; xo[5] = hi.y; xo[6] = hi.z; xo[7] = hi.w;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-        for_each_inrange(nbr, cnt, xr, coth, cut2, q, lane, -1, [&](int j, int, bool valid) {
-            if (!valid) return;
-            float xo[8], d[8];
-            const float4 lo = *(const float4*)(coth + j * 8), hi = *(const float4*)(coth + j * 8 + 4);
-            xo[0] = lo.x; xo[1] = lo.y; xo[2] = lo.z; xo[3] = lo.w; xo[4] = hi.x; xo[5] = hi.y; xo[6] = hi.z; xo[7] = hi.w;
+                    for (int c = 0; c < 8; ++c) d[c] = 0.f;
+                    const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
+                    const float val = ROW_SIDE == 1 ? pair_eval2<IT, 1, WANT_D>(G, Q, tab, tr, to, xr, xo, d)
+                                                    : pair_eval2<IT, 2, WANT_D>(G, Q, tab, to, tr, xo, xr, d);
+                    if (MODE == 0) v[0] = val;
+                    if (MODE == 1) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) d[c] = 0.f;
-            const int to = __float_as_int(xo[7]);
-            const float v = ROW_SIDE == 1 ? pair_eval2<IT, 1, WANT_D>(G, Q, tab, tr, to, xr, xo, d)
-                                          : pair_eval2<IT, 2, WANT_D>(G, Q, tab, to, tr, xo, xr, d);
-            if (MODE != 2) vacc += v;
-            if (MODE == 1) {
+                        for (int c = 0; c < 7; ++c) v[c] = d[c];
+                        v[7] = val;
+                    }
+                    if (MODE == 2) {
+                        const float ps = (row_has ? xr[6] : 0.f) + (oth_has ? xo[6] : 0.f);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += d[c];
-            }
-            if (MODE == 2) {
-                const float ps = srow + (oth_has ? xo[6] : 0.f);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] += ps * d[c];
-            }
-        });
-        if (MODE != 2) {
-            const float t = wave_sum(vacc);
-            if (lane == 0) A.out[(size_t)s * A.out_sys_stride + (size_t)(A.out_row0 + row) * A.out_stride + A.out_comp] = t;
-        }
-        if (MODE != 0) {
-            const float t = wave_sum8(acc, lane);          // lane 8*c holds component c
-            const int c = lane >> 3;
-            if ((lane & 7) == 0) {
-                if (MODE == 1) A.own_grad[((size_t)s * n_rows + row) * 8 + c] = t;
-                else {
-                    const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
-                    const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
-                    float* o = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1[row] : G.loc2[row]) * node.stride;
-                    if (c < dim_row) o[c] += t;
+                        for (int c = 0; c < 8; ++c) v[c] = ps * d[c];
+                    }
                 }
-            }
+                seg_accumulate<MODE == 0 ? 1 : 8>(acc, rl, valid, v, lane);
+            });
+        wave_lds_fence();
+        // flush the chunk: lane = (row, component)
+        for (int t = lane; t < (ce - cb) * 8; t += 64) {
+            const int row = cb + (t >> 3), c = t & 7;
+            const float val = acc[t];
+            float* out_p = A.out + (size_t)s * A.out_sys_stride + (size_t)(A.out_row0 + row) * A.out_stride + A.out_comp;
+            if (MODE == 0) { if (c == 0) *out_p = val; }
+            else if (MODE == 1) { if (c == 7) *out_p = val; else A.own_grad[((size_t)s * n_rows + row) * 8 + c] = val; }
+            else if (c < dim_row) C_SENS(row_node, s)[(size_t)row_loc[row] * row_node.stride + c] += val;
         }
+        wave_lds_fence();
     }
 }
 
 static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
     const int waves = 16;
-    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * IG_QUEUE) * sizeof(float);
+    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * DR_WAVE_LDS) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     if (lds_bytes > 158 * 1024 || force_unstaged) return false;
