@@ -17,6 +17,19 @@
 #include <cstdlib>
 // total workgroups an LDS-staged pair kernel aims at (each re-stages its system, so fewer + fatter is cheaper;
 // 2 x 16-wave workgroups fill a CU)
+#define DR_CHUNK 8              // most rows per work item (accumulated in LDS, then flushed)
+#define DR_QUEUE 128
+#define DR_WAVE_LDS (DR_QUEUE + DR_CHUNK * 8)   // 32-bit words per wave
+// rows per work item: 1 for a single system (latency), a quarter of a wave's share as the chip fills up (~4096 waves
+// in flight) so that the LDS counter can still balance the waves, 6 at most: measured on the 300-residue benchmark,
+// system-steps/s at 1024 systems by rows per item: 1: 61.2 k, 2: 63.2 k, 4: 64.2 k, 6: 64.7 k, 8: 64.4 k, 16: 63.4 k
+static inline int dr_chunk_rows(int n_system, int n_rows) {
+    static int forced = -1;   // UPSIDE_HIP_DR_CHUNK=n pins it (experiments)
+    if (forced < 0) { const char* e = getenv("UPSIDE_HIP_DR_CHUNK"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return forced > DR_CHUNK ? DR_CHUNK : forced;
+    long c = ((long)n_system * n_rows) / (4096 * 4);
+    return c < 1 ? 1 : (c > 6 ? 6 : (int)c);
+}
 static inline int ig_target_wgs() {
     static int v = 0;
     if (!v) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); v = e ? atoi(e) : 256; if (v < 1) v = 256; }
@@ -185,35 +198,36 @@ __device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, in
 // idle (a 66-hit row costs two functor passes).  Here the hits of consecutive rows share one queue: the functor
 // always runs on 64 queued (row, neighbour) entries, whatever rows they belong to, and the per-row sums are
 // recovered by a segmented wave reduction into a small per-wave LDS accumulator (rows are contiguous in the queue,
-// a batch spans ~1-6 of them).  Per wave: DR_QUEUE ints of row ids, DR_QUEUE ints of payload, DR_CHUNK x 8 floats.
-#define DR_CHUNK 32             // rows accumulated in LDS before they are flushed
-#define DR_QUEUE 128
-#define DR_WAVE_LDS (2 * DR_QUEUE + DR_CHUNK * 8)   // 32-bit words per wave
+// a batch spans ~1-6 of them).  Per wave: DR_QUEUE queue words, DR_CHUNK x 8 floats.
 
-//   test(row, k, j, payload&) -> is cached neighbour k (= element j) of `row` in range?  (sets the payload word)
+//   row_xyz(row, x[3]): position of the row element (wave-uniform; kept in registers while its list is scanned)
+//   test(x, row, k, j, payload&) -> is cached neighbour k (= element j) of `row` in range?  payload < 2^28
 //   batch(row_local, payload, valid): called with ALL lanes converged on 64 (or, at the end of the chunk, fewer) entries
-template <typename TestFn, typename BatchFn>
+// One queue word per hit: row_local << 28 | payload (DR_CHUNK <= 16).
+template <typename RowFn, typename TestFn, typename BatchFn>
 __device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __restrict__ cnt_arr, const int* __restrict__ nbr_base, int cap,
-                                               int lane, int* qrow, int* qpay, TestFn test, BatchFn batch) {
+                                               int lane, int* q, RowFn row_xyz, TestFn test, BatchFn batch) {
     int nq = 0;
     for (int row = cb; row < ce; ++row) {
         const int cnt = cnt_arr[row];
         const int* __restrict__ nbr = nbr_base + (size_t)row * cap;
+        float x[3];
+        row_xyz(row, x);
         for (int k0 = 0; k0 < cnt; k0 += 64) {
             const int k = k0 + lane;
             int pay = 0; bool hit = false;
-            if (k < cnt) hit = test(row, k, nbr[k], pay);
+            if (k < cnt) hit = test(x, row, k, nbr[k], pay);
             const unsigned long long m = __ballot(hit);
-            if (hit) { const int p = nq + __popcll(m & ((1ull << lane) - 1ull)); qrow[p] = row - cb; qpay[p] = pay; }
+            if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = ((row - cb) << 28) | pay;
             nq += __popcll(m);
             wave_lds_fence();
             if (nq >= 64) {
-                const int rl = qrow[lane], pw = qpay[lane];
+                const int w = q[lane];
                 const bool more = lane + 64 < nq;
-                const int krow = more ? qrow[lane + 64] : 0, kpay = more ? qpay[lane + 64] : 0;
+                const int keep = more ? q[lane + 64] : 0;
                 wave_lds_fence();
-                batch(rl, pw, true);
-                if (more) { qrow[lane] = krow; qpay[lane] = kpay; }
+                batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, true);
+                if (more) q[lane] = keep;
                 nq -= 64;
                 wave_lds_fence();
             }
@@ -221,9 +235,9 @@ __device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __rest
     }
     if (nq > 0) {
         const bool valid = lane < nq;
-        const int rl = valid ? qrow[lane] : 0, pw = valid ? qpay[lane] : 0;
+        const int w = valid ? q[lane] : 0;
         wave_lds_fence();
-        batch(rl, pw, valid);
+        batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, valid);
     }
 }
 // acc[rl*8 + c] += sum over the lanes of row rl of v[c]; lanes of one row are adjacent, invalid lanes carry nothing
@@ -247,14 +261,21 @@ __device__ __forceinline__ void seg_accumulate(float* acc, int rl, bool valid, c
     }
     wave_lds_fence();
 }
-// rows [first, first + n) of a wave: contiguous split of [0, n_rows) over the workgroups of a system and their waves
-__device__ __forceinline__ void wave_row_range(int n_rows, int& w0, int& w1) {
-    const int wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    const int per_wg = (n_rows + gridDim.x - 1) / gridDim.x;
-    const int g0 = blockIdx.x * per_wg, g1 = g0 + per_wg < n_rows ? g0 + per_wg : n_rows;
-    const int per_wave = g1 > g0 ? (g1 - g0 + n_wave - 1) / n_wave : 0;
-    w0 = g0 + wave * per_wave; w1 = w0 + per_wave < g1 ? w0 + per_wave : g1;
-    if (w0 > w1) w0 = w1;
+// Work distribution: the rows of a system are cut into chunks of DR_CHUNK; the workgroups of the system take
+// contiguous shares and, inside a workgroup, the waves pull chunks from an LDS counter (rows differ a lot in cost --
+// in the symmetric "partner index above the row" pass the first rows have all the work -- so a static split leaves
+// waves idle).  The result does not depend on which wave runs a chunk.
+__device__ __forceinline__ void workgroup_row_range(int n_rows, int chunk, int& g0, int& g1) {
+    const int n_chunk = (n_rows + chunk - 1) / chunk;
+    const int per_wg = (n_chunk + gridDim.x - 1) / gridDim.x;
+    g0 = blockIdx.x * per_wg * chunk; g1 = g0 + per_wg * chunk;
+    if (g1 > n_rows) g1 = n_rows;
+    if (g0 > g1) g0 = g1;
+}
+__device__ __forceinline__ int next_chunk(int* counter, int lane) {
+    int c = 0;
+    if (lane == 0) c = atomicAdd(counter, 1);
+    return __shfl(c, 0, UP_WAVE);
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp

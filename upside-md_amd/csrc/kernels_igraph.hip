@@ -421,7 +421,7 @@ struct Ig2Args {
     float* out; long out_sys_stride; int out_stride, out_comp, out_row0;      // rowsum
     float* own_grad;                                                          // rowsum: [S][n_rows][8] sum of d(value)/d(row element)
     int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // grad
-    int tab_floats;
+    int tab_floats, chunk_rows;
 };
 
 // MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element) (so that a backward
@@ -437,7 +437,9 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     float* tab = lds;
     float* c1 = lds + ((A.tab_floats + 3) & ~3);
     float* c2 = c1 + G.n1 * 8;
-    int* qrow = (int*)(c2 + G.n2 * 8) + wave * DR_WAVE_LDS; int* qpay = qrow + DR_QUEUE; float* acc = (float*)(qrow + 2 * DR_QUEUE);
+    int* q = (int*)(c2 + G.n2 * 8) + wave * DR_WAVE_LDS; float* acc = (float*)(q + DR_QUEUE);
+    int* chunk_counter = (int*)(c2 + G.n2 * 8) + n_wave * DR_WAVE_LDS;
+    if (threadIdx.x == 0) *chunk_counter = 0;
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(tab, G.param, A.tab_floats);
@@ -459,16 +461,19 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
     const upk_coord_t& row_node = ROW_SIDE == 1 ? G.node1 : G.node2;
     const int* row_loc = ROW_SIDE == 1 ? G.loc1 : G.loc2;
-    int w0, w1;
-    wave_row_range(n_rows, w0, w1);
-    (void)n_wave;
-    for (int cb = w0; cb < w1; cb += DR_CHUNK) {
-        const int ce = cb + DR_CHUNK < w1 ? cb + DR_CHUNK : w1;
+    int g0, g1;
+    const int chunk = A.chunk_rows;
+    workgroup_row_range(n_rows, chunk, g0, g1);
+    for (;;) {
+        const int cb = g0 + next_chunk(chunk_counter, lane) * chunk;
+        if (cb >= g1) break;
+        const int ce = cb + chunk < g1 ? cb + chunk : g1;
         for (int t = lane; t < DR_CHUNK * 8; t += 64) acc[t] = 0.f;
         wave_lds_fence();
-        dense_row_loop(cb, ce, cnt_arr, nbr_base, cap, lane, qrow, qpay,
-            [&](int row, int, int j, int& pay) {
-                const float* x = crow + row * 8; const float* y = coth + j * 8;
+        dense_row_loop(cb, ce, cnt_arr, nbr_base, cap, lane, q,
+            [&](int row, float* x) { const float* p = crow + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
+            [&](const float* x, int, int, int j, int& pay) {
+                const float* y = coth + j * 8;
                 pay = j;
                 return dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
             },
@@ -515,15 +520,16 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
     }
 }
 
-static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, int& chunk_rows, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
     const int waves = 16;
-    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * DR_WAVE_LDS) * sizeof(float);
+    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * DR_WAVE_LDS + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     if (lds_bytes > 158 * 1024 || force_unstaged) return false;
     int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;   // workgroups in flight across systems
-    const int max_bps = (n_rows + waves - 1) / waves;
+    chunk_rows = dr_chunk_rows(L->n_system, n_rows);
+    const int max_bps = (n_rows + waves * chunk_rows - 1) / (waves * chunk_rows);   // at least one chunk per wave
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
     grid = dim3(bps, L->n_system); block = dim3(waves * 64);
@@ -533,7 +539,7 @@ static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_row
 template <int IT, int SIDE>
 static int ig2_launch(const upk_launch_t* L, const upk_igraph_t* G, int mode, const Ig2Args& A0) {
     Ig2Args A = A0; size_t lds; dim3 grid, block;
-    if (!ig2_geometry(L, G, SIDE == 1 ? G->n1 : G->n2, A.tab_floats, lds, grid, block)) return -1;
+    if (!ig2_geometry(L, G, SIDE == 1 ? G->n1 : G->n2, A.tab_floats, A.chunk_rows, lds, grid, block)) return -1;
     if (mode == 0) hipLaunchKernelGGL((k_ig2<IT, SIDE, 0>), grid, block, lds, ST(L), *G, A);
     else if (mode == 1) hipLaunchKernelGGL((k_ig2<IT, SIDE, 1>), grid, block, lds, ST(L), *G, A);
     else hipLaunchKernelGGL((k_ig2<IT, SIDE, 2>), grid, block, lds, ST(L), *G, A);

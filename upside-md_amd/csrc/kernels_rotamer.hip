@@ -263,7 +263,7 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // nrot<<12, [7] node id (raw int bits).
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
 // written by k_rotamer_pack_beads; the table and the queues stay in LDS.
-struct RotLds { float* tab; const float* rows; int* q; };
+struct RotLds { float* tab; const float* rows; int* q; int* chunk_counter; };
 template <bool STAGED>
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
     RotLds r;
@@ -272,12 +272,15 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
     stage_table(r.tab, R.G.param, tab_floats);
     if (STAGED) {
         r.rows = lds_rows;
-        r.q = (int*)(lds_rows + R.G.n1 * 8) + (threadIdx.x >> 6) * IG_QUEUE;
+        r.q = (int*)(lds_rows + R.G.n1 * 8) + (threadIdx.x >> 6) * DR_WAVE_LDS;
+        r.chunk_counter = (int*)(lds_rows + R.G.n1 * 8) + (blockDim.x >> 6) * DR_WAVE_LDS;
         stage_rows(lds_rows, R.G.node1, s, R.G.loc1, R.G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
     } else {
         r.rows = R.bead_pack + (size_t)s * R.G.n1 * 8;
-        r.q = (int*)lds_rows + (threadIdx.x >> 6) * IG_QUEUE;
+        r.q = (int*)lds_rows + (threadIdx.x >> 6) * DR_WAVE_LDS;
+        r.chunk_counter = (int*)lds_rows + (blockDim.x >> 6) * DR_WAVE_LDS;
     }
+    if (threadIdx.x == 0) *r.chunk_counter = 0;
     __syncthreads();
     return r;
 }
@@ -294,7 +297,7 @@ __global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
 
 // bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
 template <bool STAGED>
-__global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
+__global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
@@ -304,40 +307,50 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active = R.slot_active + (size_t)s * R.slot_cap;
     QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
-    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
-        const int* nbr = G.nbr1 + base;
-        const int* nsl = R.nbr_slot + base;
-        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[8];
+    // hits of consecutive beads share the queue (igraph_device.h: dense_row_loop); payload = partner | list position << 16
+    const int* nbr_base = G.nbr1 + (size_t)s * G.n1 * G.cap1;
+    const int* nsl_base = R.nbr_slot + (size_t)s * G.n1 * G.cap1;
+    const int* cnt_arr = G.cnt1 + (size_t)s * G.n1;
+    int g0, g1;
+    workgroup_row_range(G.n1, chunk, g0, g1);
+    (void)wave; (void)n_wave;
+    for (;;) {
+        const int cb = g0 + next_chunk(L.chunk_counter, lane) * chunk;
+        if (cb >= g1) break;
+        const int ce = cb + chunk < g1 ? cb + chunk : g1;
+        dense_row_loop(cb, ce, cnt_arr, nbr_base, G.cap1, lane, L.q,
+            [&](int row, float* x) { const float* p = L.rows + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
+            [&](const float* x, int row, int k, int j, int& pay) {
+                // each pair once: only partners with a larger bead index (i1 < i2 as in the reference)
+                const float* y = L.rows + j * 8;
+                pay = j | (k << 16);
+                return j > row && dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
+            },
+            [&](int rl, int pay, bool valid) {
+                if (!valid) return;
+                const int row = cb + rl, j = pay & 0xFFFF, k = (int)((unsigned)pay >> 16);
+                float xr[8], xo[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xr[c] = L.rows[row * 8 + c];
-        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
-        const int tr = mr & 0xFF, ra = (mr >> 8) & 0xF;
-        // each pair once: only partners with a larger bead index (i1 < i2 as in the reference)
-        for_each_inrange(nbr, cnt, xr, L.rows, cut2, L.q, lane, row, [&](int j, int k, bool valid) {
-            if (!valid) return;
-            float xo[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) xo[c] = L.rows[j * 8 + c];
-            const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-            const float* p = L.tab + (tr * G.n_type2 + (mo & 0xFF)) * G.n_param;
-            const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
-            const int sl = nsl[k];
-            if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
-            const int rb = (mo >> 8) & 0xF;
-            const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
-            atomicAdd(&P[PIDX(R, sl, idx)], E);           // one bead per rotamer state => a single contributor
-            active[sl] = 1;
-        });
+                for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
+                const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+                const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+                const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
+                const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
+                const int sl = nsl_base[(size_t)row * G.cap1 + k];
+                if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
+                const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
+                const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
+                atomicAdd(&P[PIDX(R, sl, idx)], E);           // one bead per rotamer state => a single contributor
+                active[sl] = 1;
+            });
     }
 }
 
 // 1 = table + beads staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
-static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, int& chunk, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
     const int waves = 16;
-    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + (size_t)waves * IG_QUEUE) * sizeof(float);
+    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + (size_t)waves * DR_WAVE_LDS + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     int staged = 1;
@@ -345,20 +358,21 @@ static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_
     if (lds_bytes > 158 * 1024 || force_unstaged) { staged = 0; lds_bytes = fixed; }
     if (lds_bytes > 158 * 1024 || (!staged && !R->bead_pack)) return -1;
     int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;
-    const int max_bps = (R->G.n1 + waves - 1) / waves;
+    chunk = dr_chunk_rows(L->n_system, R->G.n1);
+    const int max_bps = (R->G.n1 + waves * chunk - 1) / (waves * chunk);
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
     grid = dim3(bps, L->n_system); block = dim3(waves * 64);
     return staged;
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int tab_floats; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    int tab_floats, chunk; size_t lds; dim3 grid, block;
+    const int staged = rot_geometry(L, R, tab_floats, chunk, lds, grid, block);
     if (staged < 0) return 9005;   // interaction table larger than LDS
-    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats);
+    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats, chunk);
     else {
         hipLaunchKernelGGL(k_rotamer_pack_beads, dim3((R->G.n1 * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);   // also serves upk_rotamer_grad
-        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats);
+        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats, chunk);
     }
     return launch_status();
 }
@@ -422,8 +436,8 @@ __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_
     }
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int tab_floats; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    int tab_floats, chunk; size_t lds; dim3 grid, block;
+    const int staged = rot_geometry(L, R, tab_floats, chunk, lds, grid, block);
     if (staged < 0) return 9005;
     if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
     else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step

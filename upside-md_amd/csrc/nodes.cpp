@@ -719,9 +719,10 @@ struct RotamerSidechain : public PotentialNode {
         R.iters = iters.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
+        if (ig.G.n1 >= 65536 || ig.G.cap1 > 4096) throw string("rotamer pair kernels pack (bead, list position) into 16 + 12 bits: UPSIDE_HIP_NBR_CAP <= 4096");
         R.bp_C = 1;
         R.bead_pack = nullptr;   // packed global bead rows: only when table + beads exceed the LDS budget of the pair kernels
-        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 8 + 16 * 128) * sizeof(float) > 158 * 1024 ||
+        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 8 + 16 * 256 + 4) * sizeof(float) > 158 * 1024 ||
             env_int("UPSIDE_HIP_ROT_UNSTAGED", 0)) {
             bead_pack.alloc((size_t)ctx->n_system * ig.G.n1 * 8); R.bead_pack = bead_pack.p;
         }
