@@ -6,10 +6,10 @@
 //       - the packed coordinates of every element of both sides (8 floats per element, <= ~60 KB),
 //     so the per-pair gathers (4 coefficient windows + neighbour coordinates) hit LDS instead of issuing
 //     64-line scattered global loads per wave instruction;
-//   * one wavefront owns one row of the cached Verlet list; candidates are distance-tested 64 at a time and the
-//     survivors are compacted (ballot + popcount) into a small per-wave LDS queue so that the expensive pair
-//     functor always runs with (nearly) all 64 lanes busy;
-//   * row results are reduced with wavefront shuffles; nothing is scattered.
+//   * one wavefront owns a few consecutive rows of the cached Verlet list at a time; candidates are distance-tested
+//     64 at a time and the survivors of ALL its rows are compacted (ballot + popcount) into one small per-wave LDS
+//     queue, so that the expensive pair functor always runs with 64 busy lanes;
+//   * row results are recovered by a segmented wavefront reduction into LDS accumulators; nothing is scattered.
 #pragma once
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
@@ -38,8 +38,6 @@ static inline int ig_target_wgs() {
 
 namespace up {
 
-#define IG_MAX_WAVES 16
-#define IG_QUEUE 128            // per-wave compaction queue (ints)
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wavefront execute in order; this only stops the compiler from reordering them and
@@ -154,43 +152,6 @@ __device__ __forceinline__ void stage_coords(float* lds, const upk_coord_t& node
 }
 __device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
-}
-
-// Iterate over the in-range neighbours of one row with dense lanes.
-//   nbr/cnt: the row's cached list; xr: row coordinates; other: LDS rows [n][8] of the other side
-//   q: this wave's LDS queue (IG_QUEUE ints).  f(j, k, valid) is called with ALL lanes converged; k is the position
-//   of neighbour j in the row's cached list (j < 2^20, k < 2^12 are packed into one queue word).
-template <typename F>
-__device__ __forceinline__ void for_each_inrange(const int* __restrict__ nbr, int cnt, const float* xr, const float* other, float cut2,
-                                                 int* q, int lane, int skip_le /* symmetric energy pass: ignore j <= skip_le */, F f) {
-    int nq = 0;
-    for (int k0 = 0; k0 < cnt; k0 += 64) {
-        const int k = k0 + lane;
-        int j = -1; bool hit = false;
-        if (k < cnt) {
-            j = nbr[k];
-            const float* y = other + j * 8;
-            hit = (j > skip_le) && (dist2_exact(xr[0], xr[1], xr[2], y[0], y[1], y[2]) < cut2);
-        }
-        const unsigned long long m = __ballot(hit);
-        if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = j | (k << 20);
-        nq += __popcll(m);
-        wave_lds_fence();
-        if (nq >= 64) {
-            const int w = q[lane];
-            const int keep = lane + 64 < nq ? q[lane + 64] : 0;
-            wave_lds_fence();
-            f(w & 0xFFFFF, (int)((unsigned)w >> 20), true);
-            if (lane + 64 < nq) q[lane] = keep;
-            nq -= 64;
-            wave_lds_fence();
-        }
-    }
-    if (nq > 0) {
-        const int w = lane < nq ? q[lane] : 0;
-        wave_lds_fence();
-        f(w & 0xFFFFF, (int)((unsigned)w >> 20), lane < nq);
-    }
 }
 
 // ---- dense-lane pair loop over a contiguous CHUNK of rows owned by one wavefront -----------------------------

@@ -379,7 +379,7 @@ extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_
 
 // derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
 template <bool STAGED>
-__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
+__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
@@ -390,57 +390,74 @@ __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_
     const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
     const float* nbm = R.nb_cur + (size_t)s * NN * 6;
     QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
-    for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-        const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
-        const int* nbr = G.nbr1 + base;
-        const int* nsl = R.nbr_slot + base;
-        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-        float xr[8];
+    float* acc = (float*)(L.q + DR_QUEUE);
+    const int* nbr_base = G.nbr1 + (size_t)s * G.n1 * G.cap1;
+    const int* nsl_base = R.nbr_slot + (size_t)s * G.n1 * G.cap1;
+    const int* cnt_arr = G.cnt1 + (size_t)s * G.n1;
+    int g0, g1;
+    workgroup_row_range(G.n1, chunk, g0, g1);
+    (void)wave; (void)n_wave;
+    for (;;) {
+        const int cb = g0 + next_chunk(L.chunk_counter, lane) * chunk;
+        if (cb >= g1) break;
+        const int ce = cb + chunk < g1 ? cb + chunk : g1;
+        for (int t = lane; t < DR_CHUNK * 8; t += 64) acc[t] = 0.f;
+        wave_lds_fence();
+        dense_row_loop(cb, ce, cnt_arr, nbr_base, G.cap1, lane, L.q,
+            [&](int row, float* x) { const float* p = L.rows + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
+            [&](const float* x, int, int k, int j, int& pay) {
+                const float* y = L.rows + j * 8;
+                pay = j | (k << 16);
+                return dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
+            },
+            [&](int rl, int pay, bool valid) {
+                float v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xr[c] = L.rows[row * 8 + c];
-        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
-        const int tr = mr & 0xFF, ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF;
-        float acc[6];
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+                if (valid) {
+                    const int row = cb + rl, j = pay & 0xFFFF, k = (int)((unsigned)pay >> 16);
+                    float xr[8], xo[8], d1[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] = 0.f;
-        for_each_inrange(nbr, cnt, xr, L.rows, cut2, L.q, lane, -1, [&](int j, int k, bool valid) {
-            if (!valid) return;
-            float xo[8], d1[6];
+                    for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
+                    const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+                    const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+                    const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
+                    quadspline2<1>(Q, p, xr, xo, d1);
+                    const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
+                    float ps;
+                    if (na == 1 && nb == 1) ps = 1.f;
+                    else if (na == 1) ps = nbm[b * 6 + rb];
+                    else if (nb == 1) ps = nbm[a * 6 + ra];
+                    else {
+                        const int sl = nsl_base[(size_t)row * G.cap1 + k];
+                        ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
+                    }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xo[c] = L.rows[j * 8 + c];
-            const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-            const float* p = L.tab + (tr * G.n_type2 + (mo & 0xFF)) * G.n_param;
-            quadspline2<1>(Q, p, xr, xo, d1);
-            const int rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
-            float ps;
-            if (na == 1 && nb == 1) ps = 1.f;
-            else if (na == 1) ps = nbm[b * 6 + rb];
-            else if (nb == 1) ps = nbm[a * 6 + ra];
-            else {
-                const int sl = nsl[k];
-                ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[c] += ps * d1[c];
-        });
-#pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
-        if (lane == 0) {
+                    for (int c = 0; c < 6; ++c) v[c] = ps * d1[c];
+                }
+                seg_accumulate<8>(acc, rl, valid, v, lane);
+            });
+        wave_lds_fence();
+        // flush: lane = (bead, component); component 6 pushes the node marginal to the 1-body parents
+        for (int t = lane; t < (ce - cb) * 8; t += 64) {
+            const int row = cb + (t >> 3), c = t & 7;
             const int loc = G.loc1[row];
-            float* t = C_SENS(G.node1, s) + (size_t)loc * G.node1.stride;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) t[c] += acc[c];
-            const float mg = nbm[a * 6 + ra];
-            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+            if (c < 6) C_SENS(G.node1, s)[(size_t)loc * G.node1.stride + c] += acc[t];
+            else if (c == 6) {
+                const int mr = __float_as_int(L.rows[row * 8 + 6]), a = __float_as_int(L.rows[row * 8 + 7]);
+                const float mg = nbm[a * 6 + ((mr >> 8) & 0xF)];
+                for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+            }
         }
+        wave_lds_fence();
     }
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats, chunk; size_t lds; dim3 grid, block;
     const int staged = rot_geometry(L, R, tab_floats, chunk, lds, grid, block);
     if (staged < 0) return 9005;
-    if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
-    else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step
+    if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats, chunk);
+    else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats, chunk);   // beads packed by upk_rotamer_pair_energy this step
     return launch_status();
 }
 
