@@ -1178,6 +1178,8 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
             return launch_status();
         }
     }
-    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 0);
+    static int bp_threads = 0;   // UPSIDE_HIP_BP_THREADS (experiments): lanes per one-workgroup solve
+    if (!bp_threads) { const char* e = getenv("UPSIDE_HIP_BP_THREADS"); bp_threads = e ? atoi(e) : BP_BLOCK; if (bp_threads < 64 || bp_threads > BP_BLOCK) bp_threads = BP_BLOCK; }
+    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(bp_threads), lds, ST(L), *R, want_energy, 0);
     return launch_status();
 }
