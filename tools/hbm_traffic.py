@@ -38,7 +38,7 @@ def main():
     entry = {}
     for k in sorted(set(f) | set(w)):
         fb = f.get(k, (0, 0))[0] * 1024.0; wb = w.get(k, (0, 0))[0] * 1024.0
-        label = LABEL.get(k, k)
+        label = next((v for key, v in LABEL.items() if key in k), k)   # template instances carry a 'void ...<true>' decoration
         entry[label] = dict(rocprof_kernel=k, launches_sampled=f.get(k, (0, 0))[1], fetch_bytes=fb, fetch_bytes_if_wide=2 * fb,
                             write_bytes=wb, bytes_per_launch=fb + wb)
     tab['%s/R%s' % (workload, replicas)] = entry
