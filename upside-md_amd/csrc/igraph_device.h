@@ -169,28 +169,37 @@ template <typename RowFn, typename TestFn, typename BatchFn>
 __device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __restrict__ cnt_arr, const int* __restrict__ nbr_base, int cap,
                                                int lane, int* q, RowFn row_xyz, TestFn test, BatchFn batch) {
     int nq = 0;
+    const int my_cnt = lane < ce - cb ? cnt_arr[cb + lane] : 0;       // the chunk's list lengths in one load
     for (int row = cb; row < ce; ++row) {
-        const int cnt = cnt_arr[row];
+        const int cnt = __shfl(my_cnt, row - cb, UP_WAVE);
         const int* __restrict__ nbr = nbr_base + (size_t)row * cap;
         float x[3];
         row_xyz(row, x);
-        for (int k0 = 0; k0 < cnt; k0 += 64) {
-            const int k = k0 + lane;
-            int pay = 0; bool hit = false;
-            if (k < cnt) hit = test(x, row, k, nbr[k], pay);
-            const unsigned long long m = __ballot(hit);
-            if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = ((row - cb) << 28) | pay;
-            nq += __popcll(m);
-            wave_lds_fence();
-            if (nq >= 64) {
-                const int w = q[lane];
-                const bool more = lane + 64 < nq;
-                const int keep = more ? q[lane + 64] : 0;
+        for (int k0 = 0; k0 < cnt; k0 += 256) {
+            // the list scan is a chain of dependent global loads per wave: keep four of them in flight
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = k0 + u * 64 + lane; jj[u] = k < cnt ? nbr[k] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u * 64 >= cnt) break;
+                const int k = k0 + u * 64 + lane;
+                int pay = 0; bool hit = false;
+                if (jj[u] >= 0) hit = test(x, row, k, jj[u], pay);
+                const unsigned long long m = __ballot(hit);
+                if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = ((row - cb) << 28) | pay;
+                nq += __popcll(m);
                 wave_lds_fence();
-                batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, true);
-                if (more) q[lane] = keep;
-                nq -= 64;
-                wave_lds_fence();
+                if (nq >= 64) {
+                    const int w = q[lane];
+                    const bool more = lane + 64 < nq;
+                    const int keep = more ? q[lane + 64] : 0;
+                    wave_lds_fence();
+                    batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, true);
+                    if (more) q[lane] = keep;
+                    nq -= 64;
+                    wave_lds_fence();
+                }
             }
         }
     }
