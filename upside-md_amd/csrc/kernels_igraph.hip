@@ -522,13 +522,17 @@ __global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
 
 static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, int& chunk_rows, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
-    const int waves = 16;
+    chunk_rows = dr_chunk_rows(L->n_system, n_rows);
+    // a small graph (a few hundred rows) cannot feed 16 waves with several chunks each: smaller workgroups, more of
+    // them per CU (they overlap each other's staging and list latency)
+    const int n_chunk = (n_rows + chunk_rows - 1) / chunk_rows;
+    int waves = n_chunk / 4;
+    waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
     lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * DR_WAVE_LDS + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     if (lds_bytes > 158 * 1024 || force_unstaged) return false;
     int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;   // workgroups in flight across systems
-    chunk_rows = dr_chunk_rows(L->n_system, n_rows);
     const int max_bps = (n_rows + waves * chunk_rows - 1) / (waves * chunk_rows);   // at least one chunk per wave
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
