@@ -191,16 +191,21 @@ def main():
         for ln in buf.value.decode().strip().split('\n'):
             nm, ms, n, by = ln.split()
             rows.append((nm, float(ms), int(n), float(by)))
-        ig = [r for r in rows if r[0].startswith('igraph')]
-        dom = max(ig, key=lambda r: r[1])
-        avg_ms = dom[1] / dom[2]
-        bytes_per_launch = dom[3] / dom[2]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = dict(bound='hbm', kernel=dom[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom[0], args.workload, R), avg_launch_ms=avg_ms,
-                        algorithmic_bytes_per_launch=bytes_per_launch,
-                        kernels={r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
-                                            GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows})
+        def entry(r):
+            avg_ms = r[1] / r[2]
+            bytes_per_launch = r[3] / r[2]
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            return dict(bound='hbm', kernel=r[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(r[0], args.workload, R), avg_launch_ms=avg_ms,
+                        algorithmic_bytes_per_launch=bytes_per_launch)
+        # the dominant kernel of the step (most time): belief propagation, which streams the pair matrices and messages
+        # every sweep and IS bandwidth bound; the dominant interaction-graph pair kernel (VALU bound) is
+        # reported beside it because north_star's target names it
+        dom = max(rows, key=lambda r: r[1])
+        roofline = entry(dom)
+        roofline['igraph'] = entry(max([r for r in rows if r[0].startswith('igraph')], key=lambda r: r[1]))
+        roofline['kernels'] = {r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
+                                          GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows}
 
     if rank == 0:
         res = dict(metric='MD steps/sec (force evals/sec) per 300-res protein', value=value, unit='system-steps/s',

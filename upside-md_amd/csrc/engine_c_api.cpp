@@ -18,6 +18,7 @@ using namespace std;
 int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pair<int, int>>& out);
 int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters);
 int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags);
+double engine_bp_bytes(DerivEngine& e);
 double engine_igraph_bytes(DerivEngine& e);
 int upside_main_impl(int argc, const char* const* argv, int verbose);
 
@@ -401,7 +402,9 @@ extern "C" int upside_hip_profile_dump(DerivEngine* e, char* buf, int buflen) {
     e->sync(); e->ctx.flush_profile();
     string out;
     char line[512];
+    const double bp_bytes = engine_bp_bytes(*e);   // of the last solve; the step-to-step variation is a few per cent
     for (auto& kv : e->ctx.families) {
+        if (kv.first.compare(0, 3, "bp:") == 0 && kv.second.bytes == 0.) kv.second.bytes = bp_bytes * kv.second.launches;
         snprintf(line, sizeof(line), "%s %.6f %ld %.1f\n", kv.first.c_str(), kv.second.ms, kv.second.launches, kv.second.bytes);
         out += line;
     }

@@ -840,6 +840,32 @@ int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pai
     out = ig->pairlist(sys);
     return (int)out.size();
 }
+// Algorithmic bytes of the LAST belief-propagation launch, all systems:
+//   per sweep  4 * sum_t e_t * (P_t + 2 b_t) + 8 * sum_nodes w   with (P,b) = (12,8), (24,12), (48,16) floats for the
+//   3x3 / 3x6 / 6x6 residue pairs that are active this step (the reference's padded rows, rotamer.cpp:331-334) and
+//   w = 4 / 8 floats of belief per 3- / 6-state node; times the sweeps the solve took (+1 initial pass).
+double engine_bp_bytes(DerivEngine& e) {
+    for (auto& n : e.nodes)
+        if (auto* r = dynamic_cast<RotamerSidechain*>(n.computation.get())) {
+            e.sync();
+            auto cs = r->class_start.download(); auto act = r->slot_active_last.download(); auto it = r->iters.download();
+            const int S = e.ctx.n_system, cap = r->R.slot_cap;
+            const double Pt[3] = {12, 24, 48}, bt[3] = {8, 12, 16};
+            const int n3 = r->R.n_node3, n6 = r->R.n_node - r->R.n_node1 - r->R.n_node3;
+            double total = 0.;
+            for (int s = 0; s < S; ++s) {
+                double per_sweep = 8. * (4. * n3 + 8. * n6);
+                for (int c = 0; c < 3; ++c) {
+                    long e_t = 0;
+                    for (int sl = cs[(size_t)s * 6 + c]; sl < cs[(size_t)s * 6 + c + 1]; ++sl) e_t += act[(size_t)s * cap + sl] != 0;
+                    per_sweep += 4. * e_t * (Pt[c] + 2. * bt[c]);
+                }
+                total += per_sweep * (it[s] + 1);
+            }
+            return total;
+        }
+    return 0.;
+}
 int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags) {
     auto* c = e.get(node_name).computation.get();
     IGraphHost* ig = nullptr;
