@@ -216,7 +216,7 @@ def main():
                                         'Langevin thermostat every round' % (args.workload, R, TEMPERATURE, DT),
                                replicas_per_gpu=R, n_atom=int(n_atom), per_system_steps_per_s=steps_done / elapsed),
                    roofline=roofline)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (rank 0 has the host to itself)
             res['cpu_baseline'] = cpu_baseline(fixture, variant)
         print(json.dumps(res))
     lib.calc.free_deriv_engine(ct.c_void_p(eng))
