@@ -81,6 +81,14 @@ int upside_hip_run_md(DerivEngine* engine, int n_round);
  * "steps/s", main.cpp:677-682); a cycle left unfinished is resumed by the next call. */
 int upside_hip_run_steps(DerivEngine* engine, int n_step);
 
+/* Monte-Carlo pivot moves (monte_carlo_sampler.cpp:3-155,255-284): load /input/pivot_moves of a configuration
+ * (returns the number of samplers found, 0 if the group is absent, -1 on error); one MC step of EVERY system at
+ * `round` = the round number of main.cpp:628-630 (two energy evaluations, proposal from the Ramachandran proposal
+ * map with random stream 2, Metropolis at the system's temperature); stats (n_system,2) = {n_success, n_attempt}. */
+int upside_hip_load_mc(DerivEngine* engine, const char* config_file);
+int upside_hip_mc_step(DerivEngine* engine, uint64_t round);
+int upside_hip_mc_stats(DerivEngine* engine, int* stats, int reset);
+
 /* recenter (deriv_engine.cpp:37-48) all systems */
 int upside_hip_recenter(DerivEngine* engine);
 

@@ -31,6 +31,24 @@ int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, 
 int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_stride, const int* csr_start,
                        const int* csr_entry, upk_coord_t target, int width, int comp_offset);
 
+/* ---- Monte-Carlo pivot moves (src/monte_carlo_sampler.cpp:3-155, 255-284) -------------------------------- */
+typedef struct {
+    int n_loc, n_bin, n_layer;
+    const int* atoms;          /* [n_loc][5] prevC, N, CA, C, nextN */
+    const int* range;          /* [n_loc][2] rigid tail [first, end) rotated with the pivot */
+    const int* restype;        /* [n_loc] layer of the proposal map */
+    const float* pot;          /* [n_layer][n_bin*n_bin] -log proposal probability, normalised */
+    const float* cdf;          /* [n_layer][n_bin*n_bin] cumulative proposal probability */
+} upk_pivot_t;
+/* every system: save the positions, draw a pivot (stream 2 keyed by `round`), rotate the tail; delta_lprob[s] out */
+int upk_pivot_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_pivot_t* P, const uint32_t* seed,
+                      uint64_t round, float* delta_lprob);
+/* Metropolis test of monte_carlo_step (second draw of the same generator); rejected systems get pos_copy back;
+ * stats[s] = {n_success, n_attempt} accumulate */
+int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy, const float* e_old, const float* e_new,
+                  const float* delta_lprob, const float* temperature, const uint32_t* seed, uint64_t round, int stream,
+                  int* stats);
+
 /* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
 int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
                           float max_force);

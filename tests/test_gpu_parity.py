@@ -388,3 +388,32 @@ def test_upside_main_output_matches_reference(hip, tmp_path):
         assert np.array_equal(g_['replica_index'], r['replica_index']), (g_['replica_index'].ravel(), r['replica_index'].ravel())
         assert np.allclose(g_['temperature'], r['temperature'])
         assert P.rel_rms(r['pos'][1], g_['pos'][1]) < 1e-3
+
+
+def test_upside_main_pivot_moves_match_reference(hip, tmp_path):
+    """Monte-Carlo pivot moves (monte_carlo_sampler.cpp) through `upside_main --monte-carlo-interval`: the same
+    proposals (random stream 2), the same Metropolis verdicts and therefore the same `pivot_stats` and the same
+    trajectory as the unmodified reference executable on a configuration with /input/pivot_moves."""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'trpcage20_7A'                      # small and hot enough that a good fraction of the pivots is accepted
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up')
+    shutil.copyfile(P.fixture(name), a)
+    P.pkg.config.add_pivot_moves(a)
+    shutil.copyfile(a, b)
+    args = ['--duration', '0.54', '--frame-interval', '0.135', '--temperature', '2.5', '--seed', '11',
+            '--monte-carlo-interval', '0.027']         # 20 rounds, a pivot attempt every round, a frame every 5
+    subprocess.run([ref_exe] + args + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                   env=dict(os.environ, OMP_NUM_THREADS='1'))
+    hip.in_process_upside(args + [b], verbose=False)
+    ref, _ = _read_output(a)
+    got, _ = _read_output(b)
+    assert got['pivot_stats'].shape == ref['pivot_stats'].shape and got['pivot_stats'].dtype == ref['pivot_stats'].dtype
+    assert np.array_equal(got['pivot_stats'], ref['pivot_stats']), (got['pivot_stats'], ref['pivot_stats'])
+    n_try, n_ok = int(ref['pivot_stats'][:, 1].sum()), int(ref['pivot_stats'][:, 0].sum())
+    assert n_try == 15 and 0 < n_ok < n_try, ref['pivot_stats']          # both verdicts occurred
+    for f in range(1, 4):
+        assert P.rel_rms(ref['pos'][f], got['pos'][f]) < 2e-3, f

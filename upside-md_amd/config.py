@@ -382,3 +382,24 @@ def read_last_frame(path):
     with h5lite.open_file(path) as f:
         p = f.read('output/pos', 'f4')
     return p[-1, 0]
+
+
+def add_pivot_moves(path):
+    """write /input/pivot_moves into an existing configuration, exactly as py/upside_config.py:1660-1669 does from the
+    rama_coord and rama_map_pot nodes: one pivot location per non-terminal residue (the 5 Ramachandran atoms), the
+    rigid tail [nextN+1, n_atom) that a pivot rotates, and the residue's Ramachandran map as proposal potential."""
+    with h5lite.open_file(path, 'r+') as f:
+        inp = f.group('input')
+        pot = inp.group('potential')
+        pivot_atom = pot.group('rama_coord').read('id', 'i4')
+        rama_pot = pot.group('rama_map_pot').read('rama_pot', 'f4')
+        map_id = pot.group('rama_map_pot').read('rama_map_id', 'i4')
+        n_atom = inp.shape('pos')[0]
+        keep = ~(pivot_atom == -1).any(axis=1)
+        if 'pivot_moves' in inp:
+            inp.delete('pivot_moves')
+        g = inp.create_group('pivot_moves')
+        g.write('proposal_pot', rama_pot)
+        g.write('pivot_atom', pivot_atom[keep])
+        g.write('pivot_restype', map_id[keep])
+        g.write('pivot_range', np.column_stack((pivot_atom[keep][:, 4] + 1, np.full(int(keep.sum()), n_atom, 'i4'))).astype('i4'))

@@ -344,6 +344,57 @@ void DerivEngine::run_steps(int n_step) {
         md_step(); --left;
     }
 }
+void DerivEngine::load_pivot_moves(hid_t_compat input_group_) {
+    const hid_t input = (hid_t)input_group_;
+    auto grp = h5u::open_group(input, "pivot_moves");
+    vector<hsize_t> d;
+    auto pot = h5u::read<float>(grp, "proposal_pot", 3, &d);
+    const int n_layer = (int)d[0], n_bin = (int)d[1];
+    if (d[2] != d[1]) throw string("proposal_pot must be (n_layer, n_bin, n_bin)");
+    auto atoms = h5u::read<int>(grp, "pivot_atom", 2, &d);
+    const int n_loc = (int)d[0];
+    if (d[1] != 5) throw string("pivot_atom must be (n_pivot_loc, 5)");
+    h5u::check_size(grp, "pivot_range", {(size_t)n_loc, 2}); h5u::check_size(grp, "pivot_restype", {(size_t)n_loc});
+    auto range = h5u::read<int>(grp, "pivot_range", 2); auto restype = h5u::read<int>(grp, "pivot_restype", 1);
+    for (int l = 0; l < n_loc; ++l) {   // monte_carlo_sampler.cpp:49-58
+        if (restype[l] < 0 || restype[l] >= n_layer) throw string("invalid pivot restype");
+        for (int a = 0; a < 5; ++a) {
+            const int at = atoms[l * 5 + a];
+            if (at < 0 || at >= pos->n_atom) throw string("pivot_atom out of range");
+            if (range[l * 2] <= at && at < range[l * 2 + 1]) throw string("pivot_range cannot contain any atoms in pivot_atom");
+        }
+        if (range[l * 2] < 0 || range[l * 2 + 1] > pos->n_atom || range[l * 2] > range[l * 2 + 1]) throw string("invalid pivot_range");
+    }
+    // normalise -log p and build the cdf in double (monte_carlo_sampler.cpp:62-78)
+    vector<float> cdf(pot.size());
+    const size_t nb2 = (size_t)n_bin * n_bin;
+    for (int nl = 0; nl < n_layer; ++nl) {
+        double sum_prob = 0.;
+        for (size_t i = 0; i < nb2; ++i) { sum_prob += exp(-pot[nl * nb2 + i]); cdf[nl * nb2 + i] = (float)sum_prob; }
+        const double inv = 1. / sum_prob, ls = log(sum_prob);
+        for (size_t i = 0; i < nb2; ++i) { cdf[nl * nb2 + i] = (float)(cdf[nl * nb2 + i] * inv); pot[nl * nb2 + i] = (float)(pot[nl * nb2 + i] + ls); }
+        cdf[(nl + 1) * nb2 - 1] = 1.f;
+    }
+    const int S = ctx.n_system;
+    pivot.atoms.upload(atoms); pivot.range.upload(range); pivot.restype.upload(restype); pivot.pot.upload(pot); pivot.cdf.upload(cdf);
+    pivot.stats.alloc((size_t)S * 2); pivot.pos_copy.alloc((size_t)S * pos->n_atom * pos->stride);
+    pivot.delta_lprob.alloc(S); pivot.e_old.alloc(S); pivot.e_new.alloc(S);
+    pivot.P.n_loc = n_loc; pivot.P.n_bin = n_bin; pivot.P.n_layer = n_layer;
+    pivot.P.atoms = pivot.atoms.p; pivot.P.range = pivot.range.p; pivot.P.restype = pivot.restype.p; pivot.P.pot = pivot.pot.p; pivot.P.cdf = pivot.cdf.p;
+    pivot.loaded = n_loc > 0;
+}
+void DerivEngine::mc_pivot_step(uint64_t round) {   // MonteCarloSampler::monte_carlo_step, monte_carlo_sampler.cpp:255-284
+    if (!pivot.loaded) throw string("no pivot moves loaded");
+    compute(PotentialAndDerivMode); fetch_potentials();
+    pivot.e_old.upload(potential);
+    pivot.temperature.upload(temperature);
+    upk_check(upk_pivot_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &pivot.P, seed.p, round, pivot.delta_lprob.p), "pivot_propose");
+    compute(PotentialAndDerivMode); fetch_potentials();
+    pivot.e_new.upload(potential);
+    upk_check(upk_mc_accept(&ctx.L, pos->coord(), pivot.pos_copy.p, pivot.e_old.p, pivot.e_new.p, pivot.delta_lprob.p, pivot.temperature.p,
+                            seed.p, round, 2, pivot.stats.p), "mc_accept");
+    sync();
+}
 void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
 
 void DerivEngine::check_device_errors() {

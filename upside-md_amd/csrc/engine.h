@@ -192,6 +192,13 @@ struct DerivEngine {   // deriv_engine.h:145-237
     bool graph_failed = false;   // capture was refused once: stay on plain launches
     void invalidate_graph();
     bool capture_md_graph();
+    // Monte-Carlo pivot sampler (monte_carlo_sampler.cpp): loaded from /input/pivot_moves, all systems step together
+    struct Pivot {
+        bool loaded = false; upk_pivot_t P{};
+        DevBuf<int> atoms, range, restype, stats; DevBuf<float> pot, cdf, pos_copy, delta_lprob, e_old, e_new, temperature;
+    } pivot;
+    void load_pivot_moves(hid_t_compat input_group);   // throws if the group is malformed
+    void mc_pivot_step(uint64_t round);                // two energy evaluations + proposal + Metropolis, every system
     void check_device_errors();                // throws if a capacity overflow was flagged
     void sync();
 };

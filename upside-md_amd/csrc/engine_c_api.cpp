@@ -259,6 +259,34 @@ extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
     return 0;
     API_CATCH(1)
 }
+// ---- Monte-Carlo pivot moves (monte_carlo_sampler.cpp; main.cpp:628-630) ---------------------------------
+extern "C" int upside_hip_load_mc(DerivEngine* e, const char* config_file) {
+    API_TRY
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t f = H5Fopen(config_file, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f < 0) throw string("unable to open ") + config_file;
+    h5u::Handle config(f, H5Fclose);
+    auto input = h5u::open_group(config, "/input");
+    if (h5u::exists(input, "jump_moves")) throw string("jump moves (multi-chain rigid-body Monte Carlo) are not implemented");
+    if (!h5u::exists(input, "pivot_moves")) return 0;
+    e->invalidate_graph();
+    e->load_pivot_moves((hid_t_compat)(hid_t)input);
+    return 1;                                   // number of samplers loaded
+    API_CATCH(-1)
+}
+extern "C" int upside_hip_mc_step(DerivEngine* e, uint64_t round) {
+    API_TRY e->mc_pivot_step(round); e->check_device_errors(); return 0; API_CATCH(1)
+}
+extern "C" int upside_hip_mc_stats(DerivEngine* e, int* stats, int reset) {
+    API_TRY
+    if (!e->pivot.loaded) throw string("no pivot moves loaded");
+    e->sync();
+    auto st = e->pivot.stats.download();
+    for (size_t i = 0; i < st.size(); ++i) stats[i] = st[i];
+    if (reset) e->pivot.stats.fill_bytes(0);
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_recenter(DerivEngine* e) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 

@@ -839,6 +839,105 @@ extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Monte-Carlo pivot move (monte_carlo_sampler.cpp:80-155): one workgroup per system
+__device__ __forceinline__ void axis_angle_to_rot(float* U, float angle, f3 axis) {   // affine.h:49-64
+    const float x = axis.x, y = axis.y, z = axis.z;
+    const float c = cosf(angle), sn = sinf(angle), C = 1.f - c;
+    U[0] = x * x * C + c;      U[1] = x * y * C - z * sn; U[2] = x * z * C + y * sn;
+    U[3] = y * x * C + z * sn; U[4] = y * y * C + c;      U[5] = y * z * C - x * sn;
+    U[6] = z * x * C - y * sn; U[7] = z * y * C + x * sn; U[8] = z * z * C + c;
+}
+__device__ __forceinline__ f3 rot_apply(const float* U, f3 r) {
+    return mk3(U[0] * r.x + U[1] * r.y + U[2] * r.z, U[3] * r.x + U[4] * r.y + U[5] * r.z, U[6] * r.x + U[7] * r.y + U[8] * r.z);
+}
+__global__ void k_pivot_propose(upk_coord_t pos, float* __restrict__ pos_copy, upk_pivot_t Pv, const uint32_t* __restrict__ seed,
+                                uint64_t round, float* __restrict__ delta_lprob) {
+    __shared__ float sh_U[18], sh_o[6];
+    __shared__ int sh_i[4];
+    const int s = blockIdx.y;
+    float* x = C_OUT(pos, s);
+    float* cp = pos_copy + (size_t)s * pos.n_elem * pos.stride;
+    for (int i = threadIdx.x; i < pos.n_elem * pos.stride; i += blockDim.x) cp[i] = x[i];
+    if (threadIdx.x == 0) {
+        const float PI = 3.14159265358979323846f;
+        const uint32_t key[4] = {seed[s], 2u /* PIVOT_MOVE_RANDOM_STREAM, random.h:15 */, 0u, 0u};
+        uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, 0u};
+        threefry4x32_20(X, key);
+        const float u0 = u01f(X[0]), u1 = u01f(X[1]), u2 = u01f(X[2]), u3 = u01f(X[3]);
+        int loc = (int)(Pv.n_loc * u2);
+        if (loc == Pv.n_loc) loc--;
+        const int* at = Pv.atoms + loc * 5;
+        const int rt = Pv.restype[loc], nb2 = Pv.n_bin * Pv.n_bin;
+        const float* cdf = Pv.cdf + (size_t)rt * nb2;
+        int lo = 0, hi = nb2;                     // std::lower_bound: first entry with cdf >= value
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] < u3) lo = mid + 1; else hi = mid; }
+        const int bin = lo < nb2 ? lo : nb2 - 1;
+        const float new_lprob = Pv.pot[(size_t)rt * nb2 + bin];
+        const int phi_bin = bin / Pv.n_bin, psi_bin = bin % Pv.n_bin;
+        const float w = 2.f * PI / Pv.n_bin;
+        const float new_phi = w * (phi_bin + u0 - 0.5f) - PI, new_psi = w * (psi_bin + u1 - 0.5f) - PI;
+        const f3 prevC = ld3(x + (size_t)at[0] * pos.stride), N = ld3(x + (size_t)at[1] * pos.stride), CA = ld3(x + (size_t)at[2] * pos.stride),
+                 Cc = ld3(x + (size_t)at[3] * pos.stride), nextN = ld3(x + (size_t)at[4] * pos.stride);
+        f3 d1, d2, d3, d4;
+        const float old_phi = dihedral_germ(prevC, N, CA, Cc, d1, d2, d3, d4), old_psi = dihedral_germ(N, CA, Cc, nextN, d1, d2, d3, d4);
+        int ob1 = (int)((old_phi + PI) * (0.5f / PI) * Pv.n_bin + 0.5f), ob2 = (int)((old_psi + PI) * (0.5f / PI) * Pv.n_bin + 0.5f);
+        ob1 = ob1 >= Pv.n_bin ? 0 : ob1; ob2 = ob2 >= Pv.n_bin ? 0 : ob2;
+        const float old_lprob = Pv.pot[((size_t)rt * Pv.n_bin + ob1) * Pv.n_bin + ob2];
+        const f3 a1 = CA - N, a2 = Cc - CA;
+        axis_angle_to_rot(sh_U, new_phi - old_phi, (1.f / sqrtf(mag2(a1))) * a1);
+        axis_angle_to_rot(sh_U + 9, new_psi - old_psi, (1.f / sqrtf(mag2(a2))) * a2);
+        sh_o[0] = CA.x; sh_o[1] = CA.y; sh_o[2] = CA.z; sh_o[3] = Cc.x; sh_o[4] = Cc.y; sh_o[5] = Cc.z;
+        sh_i[0] = at[3]; sh_i[1] = at[4]; sh_i[2] = Pv.range[loc * 2]; sh_i[3] = Pv.range[loc * 2 + 1];
+        delta_lprob[s] = new_lprob - old_lprob;
+    }
+    __syncthreads();
+    const f3 phi_o = mk3(sh_o[0], sh_o[1], sh_o[2]), psi_o = mk3(sh_o[3], sh_o[4], sh_o[5]);
+    const int n_tail = sh_i[3] - sh_i[2];
+    for (int t = threadIdx.x; t < n_tail + 2; t += blockDim.x) {
+        const int na = t < 2 ? sh_i[t] : sh_i[2] + (t - 2);
+        float* y = x + (size_t)na * pos.stride;
+        const f3 after_psi = psi_o + rot_apply(sh_U + 9, ld3(y) - psi_o);
+        const f3 after_phi = phi_o + rot_apply(sh_U, after_psi - phi_o);
+        y[0] = after_phi.x; y[1] = after_phi.y; y[2] = after_phi.z;
+    }
+}
+extern "C" int upk_pivot_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_pivot_t* P, const uint32_t* seed,
+                                 uint64_t round, float* delta_lprob) {
+    hipLaunchKernelGGL(k_pivot_propose, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, *P, seed, round, delta_lprob);
+    return launch_status();
+}
+__global__ void k_mc_accept(upk_coord_t pos, const float* __restrict__ pos_copy, const float* __restrict__ e_old, const float* __restrict__ e_new,
+                            const float* __restrict__ delta_lprob, const float* __restrict__ temperature, const uint32_t* __restrict__ seed,
+                            uint64_t round, int stream, int* __restrict__ stats) {
+    __shared__ int accept;
+    const int s = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const float lb = delta_lprob[s] - (1.f / temperature[s]) * (e_new[s] - e_old[s]);   // monte_carlo_sampler.cpp:272
+        int ok = 1;
+        if (!(lb >= 0.f)) {
+            const uint32_t key[4] = {seed[s], (uint32_t)stream, 0u, 0u};
+            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, 1u};   // second draw of the generator
+            threefry4x32_20(X, key);
+            ok = expf(lb) >= u01f(X[0]);
+        }
+        accept = ok;
+        stats[s * 2] += ok; stats[s * 2 + 1] += 1;
+    }
+    __syncthreads();
+    if (accept) return;
+    float* x = C_OUT(pos, s);
+    const float* cp = pos_copy + (size_t)s * pos.n_elem * pos.stride;
+    for (int i = threadIdx.x; i < pos.n_elem * pos.stride; i += blockDim.x) x[i] = cp[i];
+}
+extern "C" int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy, const float* e_old, const float* e_new,
+                             const float* delta_lprob, const float* temperature, const uint32_t* seed, uint64_t round, int stream,
+                             int* stats) {
+    hipLaunchKernelGGL(k_mc_accept, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, e_old, e_new, delta_lprob, temperature,
+                       seed, round, stream, stats);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // replica exchange Metropolis on the device (main.cpp:251-273); one lane per swap pair, pairs are disjoint.
 __global__ void k_replica_swap(upk_coord_t pos, const float* __restrict__ energy, const float* __restrict__ beta, int n_pair,
                                const int* __restrict__ pairs, uint32_t seed, uint64_t round, int draw0, int* __restrict__ accepted) {

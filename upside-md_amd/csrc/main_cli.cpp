@@ -62,8 +62,8 @@ struct EArray {   // h5_support.cpp:199-274: extensible along dimension 0, chunk
 };
 struct OutputLogger {   // one per system / configuration file (H5Logger, state_logger.h:70-141)
     hid_t file = -1, group = -1; int n_buffered = 0;
-    EArray pos, kinetic, potential, time, temperature, replica_index; bool log_replica = false;
-    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index) {
+    EArray pos, kinetic, potential, time, temperature, replica_index, pivot_stats; bool log_replica = false, log_pivot = false;
+    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index, bool with_pivot) {
         file = H5Fopen(path.c_str(), H5F_ACC_RDWR, H5P_DEFAULT);
         if (file < 0) throw string("Unable to open configuration file at ") + path;
         if (H5Lexists(file, "output", H5P_DEFAULT) > 0) H5Ldelete(file, "/output", H5P_DEFAULT);   // main.cpp:473-477
@@ -83,19 +83,23 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
         temperature.create(group, "temperature", H5T_NATIVE_DOUBLE, 8, {1});
         log_replica = with_replica_index;
         if (log_replica) replica_index.create(group, "replica_index", H5T_NATIVE_INT, 4, {1});
+        log_pivot = with_pivot;
+        if (log_pivot) pivot_stats.create(group, "pivot_stats", H5T_NATIVE_INT, 4, {2});   // monte_carlo_sampler.h:33-37
     }
-    void sample(const float* x, double kin, double pot, double t, double temp, int rep) {
+    void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc) {
         pos.push(x); kinetic.push(&kin); potential.push(&pot); time.push(&t); temperature.push(&temp);
         if (log_replica) replica_index.push(&rep);
+        if (log_pivot) pivot_stats.push(mc);
         if (!(++n_buffered % 100)) flush();                       // state_logger.h:91-92
     }
     void flush() {
         pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) replica_index.flush();
+        if (log_pivot) pivot_stats.flush();
         if (file >= 0) H5Fflush(file, H5F_SCOPE_LOCAL);
     }
     void close() {
         if (file < 0) return;
-        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close();
+        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); pivot_stats.close();
         H5Gclose(group); H5Fclose(file); file = group = -1;
     }
     ~OutputLogger() { try { close(); } catch (...) {} }
@@ -116,7 +120,7 @@ static vector<string> split_string(const string& src, const string& sep) {
 }
 
 int upside_main_impl(int argc, const char* const* argv, int verbose) {
-    double duration = -1., frame_interval = -1., time_step = 0.009, thermostat_timescale = 5., thermostat_interval = -1., replica_interval = 0.;
+    double duration = -1., frame_interval = -1., time_step = 0.009, thermostat_timescale = 5., thermostat_interval = -1., replica_interval = 0., mc_interval = 0.;
     string temperature_str = "1.0";
     unsigned long seed = 42;
     bool recenter = true, write_output = true;
@@ -136,7 +140,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--disable-recentering") recenter = false;
         else if (a == "--no-output") write_output = false;       // extension: leave the configuration files untouched
         else if (a == "--re-raise-signal" || a == "--disable-z-recentering") {}
-        else if (a == "--log-level" || a == "--monte-carlo-interval" || a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
+        else if (a == "--monte-carlo-interval") mc_interval = stod(need("--monte-carlo-interval"));
+        else if (a == "--log-level" || a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
         else files.push_back(a);
     }
@@ -147,9 +152,10 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     const float dt = (float)time_step;
     // intervals in rounds of 3 steps (main.cpp:399-411,445-447)
     const uint64_t n_round = (uint64_t)round(duration / (3 * dt));
-    const int frame_rounds = max(1, (int)(frame_interval / (3 * dt)));
-    const int thermo_rounds = thermostat_interval <= 0. ? 1 : max(1, (int)(thermostat_interval / (3 * dt)));
+    const int frame_rounds = (int)max(1., round(frame_interval / (3 * dt)));                                   // main.cpp:400
+    const int thermo_rounds = thermostat_interval <= 0. ? 1 : (int)max(1., round(thermostat_interval / (3 * dt)));   // main.cpp:399
     const int replica_rounds = replica_interval > 0. ? max(1, (int)(replica_interval / (3 * dt))) : 0;
+    const int mc_rounds = mc_interval > 0. ? max(1, (int)(mc_interval / (3 * dt))) : 0;   // main.cpp:411
     const uint32_t base_seed = (uint32_t)(seed % 4294967291ul);   // main.cpp:403-404
 
     vector<float> temps;
@@ -201,7 +207,14 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     string invocation;
     for (int i = 0; i < argc; ++i) { if (i) invocation += " "; invocation += argv[i]; }
     vector<OutputLogger> loggers(n_system);
-    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty());
+    bool have_mc = false;
+    if (mc_rounds) {
+        const int n_sampler = upside_hip_load_mc(e, files[0].c_str());
+        if (n_sampler < 0) throw string(upside_hip_last_error());
+        have_mc = n_sampler > 0;
+    }
+    vector<int> mc_stats((size_t)n_system * 2, 0);
+    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_mc);
     vector<int> replica_index(n_system);
     for (int ns = 0; ns < n_system; ++ns) replica_index[ns] = ns;
     vector<float> frame_pos((size_t)n_system * n_atom * 3), frame_mom((size_t)n_system * n_atom * 3);
@@ -209,15 +222,18 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     auto tstart = chrono::high_resolution_clock::now();
     vector<long> n_attempt(sets.size(), 0), n_success(sets.size(), 0);
     for (uint64_t rnd = 0; rnd < n_round;) {
+        // pivots before the frame of the same round, never at t = 0 (main.cpp:626-630)
+        if (have_mc && rnd && !(rnd % mc_rounds)) if (upside_hip_mc_step(e, rnd)) throw string(upside_hip_last_error());
         if (!(rnd % frame_rounds)) {   // main.cpp:633-654: recenter, energy, log, print -- before the round is integrated
             if (recenter) upside_hip_recenter(e);
             if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
             if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
+            if (have_mc && upside_hip_mc_stats(e, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame
             for (int ns = 0; ns < n_system; ++ns) {
                 const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
                 double sum_kin = 0.;
                 for (int i = 0; i < n_atom * 3; ++i) sum_kin += (double)(m[i] * m[i]);
-                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns]);
+                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns], &mc_stats[(size_t)ns * 2]);
                 double com[3] = {0, 0, 0}, rg = 0.;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
                 for (int d = 0; d < 3; ++d) com[d] /= n_atom;
@@ -229,6 +245,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
         uint64_t next = min<uint64_t>(n_round, (rnd / frame_rounds + 1) * (uint64_t)frame_rounds);
         if (replica_rounds) next = min<uint64_t>(next, (rnd / replica_rounds + 1) * (uint64_t)replica_rounds);
+        if (have_mc) next = min<uint64_t>(next, (rnd / mc_rounds + 1) * (uint64_t)mc_rounds);
         if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error());
         rnd = next;
         if (replica_rounds && !(rnd % replica_rounds)) {   // main.cpp:667-668; one generator per attempt (main.cpp:249)
