@@ -187,7 +187,7 @@ typedef struct {
     int n_prob; const float* const* prob_out; float* const* prob_sens; const int* prob_stride;   /* 1-body parents (device arrays of device ptrs) */
     const long* prob_sys_stride;
     /* per system state */
-    float *node_prob, *node_off, *nb_cur, *nb_old;      /* [S][n_node][6], off [S][n_node] */
+    float *node_prob, *node_off, *nb_cur;               /* [S][n_node][6], off [S][n_node] */
     int slot_cap, adj_cap;
     int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
     unsigned char* mark;                 /* [S][n_node^2] residue pairs owning a cached bead pair (= G.mark_table) */
@@ -196,7 +196,8 @@ typedef struct {
     int *class_start;                    /* [S][6] slot ranges by class: 3x3, 3x6, 6x6, 1x1, 1xN */
     int *nbr_slot;                       /* [S][n_bead][cap1] slot of every cached bead pair */
     int *slot_active_last;               /* [S][cap] activity flags of the last solve (diagnostics) */
-    float *P, *msg_cur, *msg_old, *marg; /* P, marg: SoA [S][36][cap]; msg_cur: inbox [S][cap][16] (8-float message rows grouped by receiving node); msg_old unused */
+    float *P, *msg_cur, *marg;           /* P, marg: SoA [S][36][cap]; msg_cur: inbox [S][cap][16] floats at most: message rows grouped by
+                                          * receiving node, 4 floats per message to a 3-state node, 8 to a 6-state node */
     float damping, tol; int max_iter, chunk;
     int* iters;                          /* [S] sweeps of the last solve */
     long long* bp_trace;                 /* [S][16] 100 MHz phase clocks of the last solve, or NULL (diagnostics) */

@@ -635,7 +635,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
-    DevBuf<float> node_prob, node_off, nb_cur, nb_old, P, msg_cur, msg_old, marg, energy;
+    DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     long n_bad_solve = 0;
 
@@ -693,7 +693,7 @@ struct RotamerSidechain : public PotentialNode {
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
         mark.alloc((size_t)S * ig.G.mark_stride);
         ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
-        node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6); nb_old.alloc((size_t)S * n_node * 6);
+        node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6);
         P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
         msg_cur.alloc((size_t)S * R.slot_cap * 16);
     }
@@ -711,11 +711,11 @@ struct RotamerSidechain : public PotentialNode {
         R.node_bead_start = d_nb_start.p; R.node_bead_list = d_nb_list.p;
         R.n_prob = (int)prob_nodes.size(); R.prob_out = d_prob_out.p; R.prob_sens = d_prob_sens.p; R.prob_stride = d_prob_stride.p;
         R.prob_sys_stride = d_prob_sys_stride.p;
-        R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p; R.nb_old = nb_old.p;
+        R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p;
         R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p; R.mark = mark.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
-        R.P = P.p; R.msg_cur = msg_cur.p; R.msg_old = msg_old.p; R.marg = marg.p;
+        R.P = P.p; R.msg_cur = msg_cur.p; R.marg = marg.p;
         R.iters = iters.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
