@@ -60,7 +60,7 @@ def check(c, rc, what):
         raise RuntimeError('%s failed: %s' % (what, c.upside_hip_last_error().decode()))
 
 
-def cpu_baseline(fixture, variant, budget_s=15.0):
+def cpu_baseline(fixture, variant, budget_s=float(os.environ.get('UPSIDE_BENCH_CPU_BUDGET_S', '15'))):
     """the unmodified reference (oracle/_ref, kind "reference") timed on this host's cores over a bounded
     sample; falls back to the C restatement (kind "port", 1 core) when the reference binary is absent."""
     exe = os.path.join(ROOT, 'oracle', '_ref', 'upside_' + variant)

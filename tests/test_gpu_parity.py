@@ -417,3 +417,32 @@ def test_upside_main_pivot_moves_match_reference(hip, tmp_path):
     assert n_try == 15 and 0 < n_ok < n_try, ref['pivot_stats']          # both verdicts occurred
     for f in range(1, 4):
         assert P.rel_rms(ref['pos'][f], got['pos'][f]) < 2e-3, f
+
+
+def test_bench_contract(tmp_path):
+    """bench.py prints ONE JSON line with the fields the driver reads (metric, value, steps exactly as asked,
+    roofline of the dominant kernel with live HIP-event timing, cpu_baseline object at N=1)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(P.ROOT, 'bench.py'), '--gpus', '1', '--steps', '7', '--warmup', '4',
+                          '--replicas', '3', '--workload', 'syn150_10A'], check=True, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=900, env=dict(os.environ, UPSIDE_BENCH_CPU_BUDGET_S='1')).stdout.decode()
+    lines = [ln for ln in out.strip().split('\n') if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['steps'] == 7 and d['warmup'] == 4 and d['n_gpus'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 3 * 7 / (d['ms_per_step'] * 7e-3)) < 1e-6 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert r['achieved'] > 0 and 'igraph' in r and r['igraph']['achieved'] > 0
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['value'] > 0
