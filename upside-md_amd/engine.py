@@ -263,6 +263,11 @@ class Ensemble(object):
         self._check(self.calc.upside_hip_get_pos(self.engine, out.ctypes.data), 'get_pos')
         return out
 
+    def get_mom(self):
+        out = np.zeros((self.n_system, self.n_atom, 3), 'f4')
+        self._check(self.calc.upside_hip_get_mom(self.engine, out.ctypes.data), 'get_mom')
+        return out
+
     def get_system_pos(self, system):
         out = np.zeros((self.n_atom, 3), 'f4')
         self._check(self.calc.upside_hip_get_system_pos(self.engine, int(system), out.ctypes.data), 'get_system_pos')
