@@ -203,7 +203,7 @@ typedef struct {
     long long* bp_trace;                 /* [S][16] 100 MHz phase clocks of the last solve, or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */
-    int bp_C;
+    int bp_C, bp_resident;               /* workgroups per system; 1 = matrices resident in LDS (512 lanes), 0 = split solve over global memory */
     int *bp_bar, *bp_fallback;           /* [S] barrier counter; [S] 1 = system did not fit, solved by the one-workgroup kernel */
     float *bp_nbx, *bp_dev, *bp_en_part; /* [S][2][n_node][8] exchanged node beliefs, [S][2][16] deviations, [S][16] energy partial sums */
 } upk_rotamer_t;
@@ -222,7 +222,8 @@ int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R);
 int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy);
 /* floats of exp(-E) pair matrices one workgroup of the cluster solve can keep in LDS (to choose bp_C) */
 int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R);
-int upk_rotamer_bp_cluster_threads(void);   /* and the number of slots of one class it can own (one per lane) */
+int upk_rotamer_bp_cluster_threads(void);
+int upk_device_cu_count(void);   /* and the number of slots of one class it can own (one per lane) */
 /* derivative push: pair marginal x pair gradient gathered per bead, node marginals to the 1-body parents
  * (rotamer.cpp:956-985, interaction_graph.h:525-555) */
 int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R);

@@ -294,6 +294,7 @@ def test_ensemble_exchange_matches_device_swap(hip):
 ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1'},          # one-workgroup belief propagation instead of the cluster solve
     {'UPSIDE_HIP_BP_CLUSTER': '3'},          # cluster too small for the pair matrices: on-device fallback flag
+    {'UPSIDE_HIP_BP_SPLIT': '3'},            # split cluster solve: 3 workgroups per system over global-memory matrices
     {'UPSIDE_HIP_ASYNC_PREPARE': '0'},       # list upkeep inline on the main stream
     {'UPSIDE_HIP_IG_UNSTAGED': '1'},         # coverage graphs through the kernels for systems too large for LDS
     {'UPSIDE_HIP_IG_WGS': '4096'},           # many thin workgroups per pair kernel

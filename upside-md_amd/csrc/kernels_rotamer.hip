@@ -482,6 +482,20 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
     return r;
 }
 
+// write-through / agent-scope helpers of the cluster solve (protocol: see k_rotamer_bp_cluster)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const uintptr_t p = (uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void st_wt16(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b, float c, float d) {   // 16-byte sc1 store
+    u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, 16);
+}
+
 // zero the accumulator entries a slot class uses, for slots [lo, hi)
 template <int NA, int NB>
 __device__ __forceinline__ void clear_class(float* P, int cap, int lo, int hi, int tid, int nt) {
@@ -510,8 +524,9 @@ struct BpCtx {
 // edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
 // L1 normalisation of 506-521), rewritten in place.  1-ulp hardware reciprocals: the reference itself uses the
 // 12-bit rcpps here (Float4.h:199-212).
-template <int NA, int NB>
-__device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
+template <int NA, int NB, bool WT>   // WT: messages leave through 16-byte write-through stores (cluster solve)
+__device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
+                                                   __amdgpu_buffer_rsrc_t inbox_w) {
     for (int sl = lo + tid; sl < hi; sl += nt) {
         if (!C.active[sl]) continue;
         const int a = C.slot_a[sl], b = C.slot_b[sl];
@@ -538,10 +553,36 @@ __device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, co
             for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
             tb[j] = t; sb += t; }
         const float ra = fast_rcp(sa), rb = fast_rcp(sb);
+        if (WT) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+            for (int i = 0; i < NA; ++i) ta[i] *= ra;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+            for (int j = 0; j < NB; ++j) tb[j] *= rb;
+            const int oa = C.slot_off[sl * 2], ob = C.slot_off[sl * 2 + 1];
+            st_wt16(inbox_w, oa, ta[0], ta[1], ta[2], NA == 6 ? ta[NA - 3] : 1.f);
+            if (NA == 6) st_wt16(inbox_w, oa + 4, ta[NA - 2], ta[NA - 1], 1.f, 1.f);
+            st_wt16(inbox_w, ob, tb[0], tb[1], tb[2], NB == 6 ? tb[NB - 3] : 1.f);
+            if (NB == 6) st_wt16(inbox_w, ob + 4, tb[NB - 2], tb[NB - 1], 1.f, 1.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+        }
+    }
+}
+template <int NA, int NB>
+__device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
+    bp_edge_range_impl<NA, NB, false>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
+}
+// energies -> probabilities, in place, for slots [lo, hi) of one class (rotamer.cpp:835)
+template <int NA, int NB>
+__device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int tid, int nt) {
+    const int n = hi - lo;
+    for (int i = tid; i < n * NA * NB; i += nt) {
+        const int e = i / n, l = i - e * n;
+        float* p = P + (size_t)((e / NB) * 6 + e % NB) * cap + lo + l;
+        *p = expf(-*p);
     }
 }
 
@@ -777,19 +818,6 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
 // agent-scope counter and polls it relaxed, ONE agent-scope acquire drops the CU's stale L1 lines, __syncthreads,
 // then plain loads.  All C workgroups of a cluster must be resident at once: the launcher sends at most
 // (CUs / C) systems per launch, one workgroup per CU, and every spin is bounded.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-    const uintptr_t p = (uintptr_t)base;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-__device__ __forceinline__ void st_wt16(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b, float c, float d) {   // 16-byte sc1 store
-    u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, 16);
-}
-
 struct BpcShared {            // cluster-visible state of one system
     const float* inbox;       // message rows [rows][8] (plain loads after an acquire)
     __amdgpu_buffer_rsrc_t inbox_w, nbx_w;   // write-through views of the inbox and of nbx
@@ -914,7 +942,12 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
 #define BPC_GROUP 16  // lanes cooperating on one node
 
 #define BPC_BLOCK 512   // 8 waves: 256 VGPRs per lane keep the three slot states + a 6x6 matrix out of scratch
-__global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
+// RESIDENT = true: the form described above (512 lanes, needs C large enough for the matrices to fit LDS).
+// RESIDENT = false ("split" solve, 1024 lanes): the same exchange protocol, but the matrices stay in global memory and
+// a lane loops over its share of the slots like the one-workgroup kernel does -- any C works; used for mid-size
+// batches that leave CUs idle under the one-workgroup solve.
+template <bool RESIDENT>
+__global__ void __launch_bounds__(RESIDENT ? BPC_BLOCK : BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x >= n_sys) return;
     const int s = sys0 + blockIdx.x, c = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -932,7 +965,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     const int need = n_own[0] * 9 + n_own[1] * 18 + n_own[2] * 36;
     // every workgroup of the cluster must reach the same verdict: test all shares, not only the own one
     bool fits = true;
-    for (int cc = 0; cc < C; ++cc) {
+    for (int cc = 0; RESIDENT && cc < C; ++cc) {
         int nd = 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -968,13 +1001,34 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
 
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
     for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
-    bpc_stage<3, 3>(Pl0, R, s, lo[0], n_own[0]);
-    bpc_stage<3, 6>(Pl1, R, s, lo[1], n_own[1]);
-    bpc_stage<6, 6>(Pl2, R, s, lo[2], n_own[2]);
     BpcSlot<3, 3> s33; BpcSlot<3, 6> s36; BpcSlot<6, 6> s66;
-    bpc_init(s33, R, s, lo[0], n_own[0], X.inbox_w);
-    bpc_init(s36, R, s, lo[1], n_own[1], X.inbox_w);
-    bpc_init(s66, R, s, lo[2], n_own[2], X.inbox_w);
+    BpCtx Cx;                                  // split solve: slot data in global memory
+    Cx.cap = R.slot_cap;
+    Cx.slot_a = R.slot_a + (size_t)s * R.slot_cap; Cx.slot_b = R.slot_b + (size_t)s * R.slot_cap;
+    Cx.active = R.slot_active + (size_t)s * R.slot_cap; Cx.slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
+    Cx.P = R.P + (size_t)s * R.slot_cap * 36; Cx.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
+    Cx.marg = R.marg + (size_t)s * R.slot_cap * 36;
+    if (RESIDENT) {
+        bpc_stage<3, 3>(Pl0, R, s, lo[0], n_own[0]);
+        bpc_stage<3, 6>(Pl1, R, s, lo[1], n_own[1]);
+        bpc_stage<6, 6>(Pl2, R, s, lo[2], n_own[2]);
+        bpc_init(s33, R, s, lo[0], n_own[0], X.inbox_w);
+        bpc_init(s36, R, s, lo[1], n_own[1], X.inbox_w);
+        bpc_init(s66, R, s, lo[2], n_own[2], X.inbox_w);
+    } else {
+        // exp(-E) in place for the own multi-state slots only: nobody else reads them (the 1-state classes stay
+        // energies: the fold below and the 1-1 energy term take exp / the energy themselves)
+        exp_class<3, 3>(Cx.P, Cx.cap, lo[0], lo[0] + n_own[0], tid, nt);
+        exp_class<3, 6>(Cx.P, Cx.cap, lo[1], lo[1] + n_own[1], tid, nt);
+        exp_class<6, 6>(Cx.P, Cx.cap, lo[2], lo[2] + n_own[2], tid, nt);
+        for (int k = 0; k < 3; ++k)            // old edge beliefs = 1 (rotamer.cpp:1015-1032), both rows of every own slot
+            for (int sl = lo[k] + tid; sl < lo[k] + n_own[k]; sl += nt) {
+                const int oa = Cx.slot_off[sl * 2], ob = Cx.slot_off[sl * 2 + 1];
+                st_wt16(X.inbox_w, oa, 1.f, 1.f, 1.f, 1.f); st_wt16(X.inbox_w, ob, 1.f, 1.f, 1.f, 1.f);
+                if (k == 2) st_wt16(X.inbox_w, oa + 4, 1.f, 1.f, 1.f, 1.f);
+                if (k >= 1) st_wt16(X.inbox_w, ob + 4, 1.f, 1.f, 1.f, 1.f);
+            }
+    }
     // fold the edges to 1-state partners into the probabilities of the own nodes (rotamer.cpp:378-385)
     {
         const float* P = R.P + (size_t)s * R.slot_cap * 36;
@@ -1013,9 +1067,15 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     const int gl = tid % BPC_GROUP, n_grp = nt / BPC_GROUP;
     for (int sweep = -1;; ++sweep) {
         // ---- edge phase
-        bpc_edge(s33, Pl0, n_own[0], nb, X.inbox_w);
-        bpc_edge(s36, Pl1, n_own[1], nb, X.inbox_w);
-        bpc_edge(s66, Pl2, n_own[2], nb, X.inbox_w);
+        if (RESIDENT) {
+            bpc_edge(s33, Pl0, n_own[0], nb, X.inbox_w);
+            bpc_edge(s36, Pl1, n_own[1], nb, X.inbox_w);
+            bpc_edge(s66, Pl2, n_own[2], nb, X.inbox_w);
+        } else {
+            bp_edge_range_impl<3, 3, true>(Cx, lo[0], lo[0] + n_own[0], nb, tid, nt, X.inbox_w);
+            bp_edge_range_impl<3, 6, true>(Cx, lo[1], lo[1] + n_own[1], nb, tid, nt, X.inbox_w);
+            bp_edge_range_impl<6, 6, true>(Cx, lo[2], lo[2] + n_own[2], nb, tid, nt, X.inbox_w);
+        }
         cluster_barrier(X.bar, phase, C, R.G.error_flag);
         // ---- node phase over the own nodes
         float dev = 0.f;
@@ -1115,15 +1175,19 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     __syncthreads();
     float* marg = R.marg + (size_t)s * R.slot_cap * 36;
     float en = 0.f;
-    en += bpc_marginal(s33, Pl0, n_own[0], nb, marg, R.slot_cap, want_energy);
-    en += bpc_marginal(s36, Pl1, n_own[1], nb, marg, R.slot_cap, want_energy);
-    en += bpc_marginal(s66, Pl2, n_own[2], nb, marg, R.slot_cap, want_energy);
+    if (RESIDENT) {
+        en += bpc_marginal(s33, Pl0, n_own[0], nb, marg, R.slot_cap, want_energy);
+        en += bpc_marginal(s36, Pl1, n_own[1], nb, marg, R.slot_cap, want_energy);
+        en += bpc_marginal(s66, Pl2, n_own[2], nb, marg, R.slot_cap, want_energy);
+    } else {
+        en += bp_marginal_range<3, 3>(Cx, lo[0], lo[0] + n_own[0], nb, tid, nt, want_energy);
+        en += bp_marginal_range<3, 6>(Cx, lo[1], lo[1] + n_own[1], nb, tid, nt, want_energy);
+        en += bp_marginal_range<6, 6>(Cx, lo[2], lo[2] + n_own[2], nb, tid, nt, want_energy);
+    }
     // ---- leave the accumulators clean for the next force evaluation (every class, split over the cluster)
-    const int n_slot = R.n_slot[s];
     float* P = R.P + (size_t)s * R.slot_cap * 36;
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
-    const int z_lo = (int)((long)n_slot * c / C), z_hi = (int)((long)n_slot * (c + 1) / C);
     const int n11 = cls[CL11 + 1] - cls[CL11], lo11 = cls[CL11] + (int)((long)n11 * c / C), hi11 = cls[CL11] + (int)((long)n11 * (c + 1) / C);   // as clear_all_classes splits it
     if (want_energy) {
         for (int sl = lo11 + tid; sl < hi11; sl += nt)                     // 1-1 edges (rotamer.cpp:861): -log(exp(-E))
@@ -1142,7 +1206,11 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     }
     __syncthreads();   // all reads of P / active by this workgroup are done
     clear_all_classes(P, R.slot_cap, cls, c, C, tid, nt);
-    for (int i = z_lo + tid; i < z_hi; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
+    for (int k = 0; k < N_CLASS; ++k) {   // retire the activity flags over the SAME per-class shares this workgroup read them on
+        const int b = cls[k], n = cls[k + 1] - b;
+        const int lo_k = b + (int)((long)n * c / C), hi_k = b + (int)((long)n * (c + 1) / C);
+        for (int i = lo_k + tid; i < hi_k; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
+    }
     if (want_energy) {
         cluster_barrier(X.bar, phase, C, R.G.error_flag);
         if (c == 0 && tid == 0) { float t = 0.f; for (int cc = 0; cc < C; ++cc) t += ld_agent(X.en_part + cc); R.energy[s] = t; }
@@ -1154,6 +1222,7 @@ static int device_cu_count() {
     if (!n) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64; }
     return n;
 }
+extern "C" int upk_device_cu_count() { return device_cu_count(); }
 extern "C" int upk_rotamer_bp_cluster_threads() { return BPC_BLOCK; }   // slots of one class a workgroup can own
 extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // floats of pair matrices one workgroup can hold
     const int fixed = R->n_node * 14 + 48;
@@ -1170,9 +1239,11 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
         if (chunk >= 8) chunk &= ~7;
         if (chunk >= 1) {
             const int p_cap = upk_rotamer_bp_cluster_capacity(R);
+            const size_t split_lds = ((size_t)R->n_node * 14 + 64) * sizeof(float);
             for (int s0 = 0; s0 < L->n_system; s0 += chunk) {
                 const int n = L->n_system - s0 < chunk ? L->n_system - s0 : chunk;
-                hipLaunchKernelGGL(k_rotamer_bp_cluster, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
+                if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
+                else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BP_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
             hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1);
             return launch_status();

@@ -746,6 +746,7 @@ struct RotamerSidechain : public PotentialNode {
     void choose_bp_cluster() {
         bp_C_chosen = true;
         const int want = env_int("UPSIDE_HIP_BP_CLUSTER", -1);   // 1 disables, >1 forces
+        R.bp_resident = 1;
         if (want == 1) { R.bp_C = 1; return; }
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
         auto cs = class_start.download();
@@ -760,10 +761,20 @@ struct RotamerSidechain : public PotentialNode {
         C = max(C, (int)((widest * 115 / 100 + lanes - 1) / lanes));   // one slot per class per lane
         if (want > 1) C = want;
         if (C > 16 || n_node - R.n_node1 < C) C = 1;             // too large for a co-resident cluster: one-workgroup solve
-        // The cluster solve trades HBM traffic for two device-scope barriers per sweep: it wins while the whole batch
-        // fits ONE cluster launch (CUs / C systems; measured 0.20 vs 0.53 ms at 1 system, 0.46 vs 0.75 ms at 32) and
-        // loses once every CU has its own system to solve (0.97 vs 0.93 ms at 64, 3.9 vs 1.6 ms at 256).
-        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 32)) C = 1;
+        R.bp_resident = 1;
+        // The cluster solves trade HBM traffic for two device-scope barriers per sweep.  Resident form: wins while the
+        // whole batch fits ONE cluster launch (CUs / C systems; measured 0.20 vs 0.53 ms at 1 system, 0.46 vs 0.75 ms
+        // at 32).  Beyond that, while at least four CUs per system are free, the split form spreads each system over
+        // the CUs the one-workgroup solve would leave idle (measured 0.68 vs 0.83 ms at 48 systems, 0.88 vs 0.92 at 64;
+        // with two workgroups per system it loses: 1.16 vs 0.98 ms at 96); once every CU has its own system the
+        // one-workgroup solve is best (3.9 vs 1.6 ms at 256).
+        const int n_cu = upk_device_cu_count();
+        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 32)) {
+            C = 1;
+            const int split_max = env_int("UPSIDE_HIP_BP_SPLIT_MAX_SYSTEMS", n_cu / 4);
+            if (ctx->n_system <= split_max) { C = min(8, n_cu / ctx->n_system); R.bp_resident = 0; if (C < 2 || n_node - R.n_node1 < C) C = 1; }
+        }
+        if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
     }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
