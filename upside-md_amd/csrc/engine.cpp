@@ -118,7 +118,7 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev < 1) throw string("no HIP device available (this library has no CPU fallback)");
     ctx.n_system = n_system;
-    hip_check(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking), "hipStreamCreate");   // (stream priorities were tried: a low-priority upkeep stream delays the joins, -10 to -27 %)
     ctx.L.n_system = n_system; ctx.L.stream = (void*)ctx.stream;
     ctx.error_flag.alloc(1);
     potential.assign(n_system, 0.f);
@@ -230,6 +230,14 @@ void DerivEngine::finalize() {
         }
     }
     schedule.swap(hoisted);
+    if (getenv("UPSIDE_HIP_PRINT_SCHEDULE"))
+        for (auto& st : schedule) {
+            auto& n = nodes[st.node];
+            fprintf(stderr, "%-8s L%-2d %-44s parents:", st.prepare ? "prepare" : (st.backward ? "backward" : "forward"),
+                    st.backward ? n.deriv_exec_level : n.germ_exec_level, n.name.c_str());
+            for (size_t ip : n.parents) fprintf(stderr, " %s", nodes[ip].name.c_str());
+            fprintf(stderr, "\n");
+        }
 }
 
 void DerivEngine::compute(ComputeMode mode) {
