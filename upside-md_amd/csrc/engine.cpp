@@ -4,6 +4,7 @@
 #include "engine.h"
 #include "h5util.h"
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -198,34 +199,46 @@ void DerivEngine::finalize() {
     // side stream
     const char* env = getenv("UPSIDE_HIP_ASYNC_PREPARE");
     if (env && atoi(env) == 0) return;
-    std::vector<Step> hoisted;
-    std::vector<int> n_parent_left(nodes.size(), 0);
-    auto is_dep = [&](size_t child, size_t parent) {
-        auto& deps = nodes[child].computation->prepare_deps;
-        return deps.empty() || std::find(begin(deps), end(deps), nodes[parent].computation.get()) != end(deps);
-    };
+    // nodes a prepare() reads: the ones it names (any node of the graph, e.g. a grandparent whose output a parent copies
+    // through), else all its parents
+    std::vector<std::vector<size_t>> deps_of(nodes.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
-        n_parent_left[i] = -1;
         if (!nodes[i].computation->has_prepare()) continue;
-        n_parent_left[i] = 0;
-        for (size_t ip : nodes[i].parents) if (is_dep(i, ip)) ++n_parent_left[i];
+        auto& named = nodes[i].computation->prepare_deps;
+        if (named.empty()) deps_of[i] = nodes[i].parents;
+        else for (size_t j = 0; j < nodes.size(); ++j)
+            if (std::find(begin(named), end(named), nodes[j].computation.get()) != end(named)) deps_of[i].push_back(j);
+        std::sort(begin(deps_of[i]), end(deps_of[i]));
+        deps_of[i].erase(std::unique(begin(deps_of[i]), end(deps_of[i])), end(deps_of[i]));
     }
+    {   // Run the forward steps that the upkeep waits for (and their ancestors) FIRST, everything else after them in
+        // the original order: the list rebuilds then start as early as the graph allows and overlap with the
+        // forward steps nobody is waiting for (springs, Ramachandran maps, backbone sterics).  The moved set is closed
+        // under "parent of", so every step still follows the steps it depends on.
+        std::vector<char> unlock(nodes.size(), 0);
+        std::function<void(size_t)> mark = [&](size_t i) { if (unlock[i]) return; unlock[i] = 1; for (size_t ip : nodes[i].parents) mark(ip); };
+        for (size_t i = 0; i < nodes.size(); ++i) for (size_t d : deps_of[i]) mark(d);
+        std::vector<Step> first, rest;
+        for (auto& st : schedule) ((!st.backward && unlock[st.node]) ? first : rest).push_back(st);
+        first.insert(first.end(), rest.begin(), rest.end());
+        schedule.swap(first);
+    }
+    std::vector<Step> hoisted;
+    std::vector<int> n_dep_left(nodes.size(), -1);
+    for (size_t i = 0; i < nodes.size(); ++i) if (nodes[i].computation->has_prepare()) n_dep_left[i] = (int)deps_of[i].size();
     for (auto& st : schedule) {
         hoisted.push_back(st);
         if (st.backward) continue;
-        for (size_t c : nodes[st.node].children) {
-            if (n_parent_left[c] <= 0 || !is_dep(c, (size_t)st.node)) continue;
-            // a parent may be listed twice (same node as two arguments)
-            const int mult = (int)std::count(begin(nodes[c].parents), end(nodes[c].parents), (size_t)st.node);
-            n_parent_left[c] -= mult;
-            if (n_parent_left[c] == 0) {
+        for (size_t c = 0; c < nodes.size(); ++c) {
+            if (n_dep_left[c] <= 0 || !std::binary_search(begin(deps_of[c]), end(deps_of[c]), (size_t)st.node)) continue;
+            if (--n_dep_left[c] == 0) {
                 Step ps{(int)c, false}; ps.prepare = true; hoisted.push_back(ps);
                 Side sd;
                 hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
                 hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
                 hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
                 side[(int)c] = sd;
-                n_parent_left[c] = -1;
+                n_dep_left[c] = -1;
             }
         }
     }

@@ -512,9 +512,26 @@ struct HBondCoverage : public CoordNode {
     HBondCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& infer_, CoordNode& sidechains_)
         : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {
         own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
+        // protein_hbond copies the inferred H/O sites through unchanged (hbond.cpp:320-335) and only adds the bond
+        // probability: the list upkeep needs positions only, so it can read them from infer_H_O and start before
+        // protein_hbond's own pair kernels have run
+        if (auto* ph = dynamic_cast<ProteinHBond*>(&infer_)) {
+            if (ph->infer.n_elem == infer_.n_elem && ph->infer.stride == infer_.stride) {
+                site_positions = &ph->infer;
+                prepare_deps.push_back(site_positions); prepare_deps.push_back(&sidechains_);
+            }
+        }
     }
+    const CoordNode* site_positions = nullptr;
     bool has_prepare() const override { return true; }
-    void prepare() override { ig.update_lists(); }
+    void prepare() override {
+        if (!site_positions) { ig.update_lists(); return; }
+        ig.begin_step();
+        upk_igraph_t Gp = ig.G;
+        Gp.node1 = site_positions->coord();
+        upk_check(upk_pairlist_check(&ctx->L, &Gp), "pairlist_check");
+        upk_check(upk_pairlist_build(&ctx->L, &Gp), "pairlist_build");
+    }
     void compute_value(ComputeMode) override {
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
         upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0, own_grad.p), "hbond_coverage rowsum");
