@@ -81,13 +81,16 @@ int upside_hip_run_md(DerivEngine* engine, int n_round);
  * "steps/s", main.cpp:677-682); a cycle left unfinished is resumed by the next call. */
 int upside_hip_run_steps(DerivEngine* engine, int n_step);
 
-/* Monte-Carlo pivot moves (monte_carlo_sampler.cpp:3-155,255-284): load /input/pivot_moves of a configuration
- * (returns the number of samplers found, 0 if the group is absent, -1 on error); one MC step of EVERY system at
- * `round` = the round number of main.cpp:628-630 (two energy evaluations, proposal from the Ramachandran proposal
- * map with random stream 2, Metropolis at the system's temperature); stats (n_system,2) = {n_success, n_attempt}. */
+/* Monte-Carlo moves (monte_carlo_sampler.cpp): load /input/pivot_moves and /input/jump_moves of a configuration
+ * (returns the number of samplers found, 0 if neither group is present, -1 on error); one MC step of EVERY system at
+ * `round` = the round number of main.cpp:628-630: each loaded sampler in the reference's order (pivot: proposal
+ * from the Ramachandran proposal map, random stream 2; jump: rigid-body move of a chain segment, stream 3) spends two
+ * energy evaluations and a Metropolis test at the system's temperature.  stats (n_system,2) = {n_success,
+ * n_attempt} of sampler 0 (pivot) or 1 (jump). */
 int upside_hip_load_mc(DerivEngine* engine, const char* config_file);
 int upside_hip_mc_step(DerivEngine* engine, uint64_t round);
-int upside_hip_mc_stats(DerivEngine* engine, int* stats, int reset);
+int upside_hip_mc_stats(DerivEngine* engine, int sampler, int* stats, int reset);
+int upside_hip_mc_loaded(DerivEngine* engine, int sampler);
 
 /* recenter (deriv_engine.cpp:37-48) all systems */
 int upside_hip_recenter(DerivEngine* engine);

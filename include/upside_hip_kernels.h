@@ -43,11 +43,16 @@ typedef struct {
 /* every system: save the positions, draw a pivot (stream 2 keyed by `round`), rotate the tail; delta_lprob[s] out */
 int upk_pivot_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_pivot_t* P, const uint32_t* seed,
                       uint64_t round, float* delta_lprob);
+/* rigid-body jump of one chain segment (monte_carlo_sampler.cpp:157-251): translation by sigma_trans/sqrt(3) * N(0,1)^3
+ * or rotation about the centre of mass by sigma_rot * N(0,1) around a random axis; random stream 3; delta_lprob = 0 */
+typedef struct { int n_chain; const int* atom_range; /* [n_chain][2] */ const float* sigma_trans; const float* sigma_rot; } upk_jump_t;
+int upk_jump_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_jump_t* J, const uint32_t* seed,
+                     uint64_t round, float* delta_lprob);
 /* Metropolis test of monte_carlo_step (second draw of the same generator); rejected systems get pos_copy back;
  * stats[s] = {n_success, n_attempt} accumulate */
 int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy, const float* e_old, const float* e_new,
                   const float* delta_lprob, const float* temperature, const uint32_t* seed, uint64_t round, int stream,
-                  int* stats);
+                  int accept_draw, int* stats);   /* accept_draw: index of the generator's draw used for the test */
 
 /* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
 int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,

@@ -478,3 +478,38 @@ def test_long_md_is_thermalised_and_stable(hip):
     assert len({round(float(x), 3) for x in e1}) == 8          # independent thermostat streams -> distinct trajectories
     e0b, e1b, ratios_b, pos_b = run()
     assert np.array_equal(pos, pos_b) and np.array_equal(e1, e1b)   # bit-reproducible run to run
+
+
+def test_upside_main_jump_moves_match_reference(hip, tmp_path):
+    """rigid-body jump moves (monte_carlo_sampler.cpp:157-251), alone and together with pivots: `jump_stats` /
+    `pivot_stats` and the trajectory equal the reference executable's.  The "chains" are two tail segments of the
+    single-chain fixture moved by a small fraction of an Angstrom, so that some moves are accepted."""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'trpcage20_7A'
+    n_atom = P.golden(name)['pos'].shape[0]
+    for with_pivot in (False, True):
+        a = str(tmp_path / ('ref%d.up' % with_pivot)); b = str(tmp_path / ('hip%d.up' % with_pivot))
+        shutil.copyfile(P.fixture(name), a)
+        P.pkg.config.add_jump_moves(a, [[0, 9], [n_atom - 12, n_atom]], [0.15, 0.1], [0.05, 0.08])
+        if with_pivot:
+            P.pkg.config.add_pivot_moves(a)
+        shutil.copyfile(a, b)
+        args = ['--duration', '0.54', '--frame-interval', '0.135', '--temperature', '2.5', '--seed', '5',
+                '--monte-carlo-interval', '0.027']
+        subprocess.run([ref_exe] + args + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS='1'))
+        hip.in_process_upside(args + [b], verbose=False)
+        ref, _ = _read_output(a)
+        got, _ = _read_output(b)
+        keys = ['jump_stats'] + (['pivot_stats'] if with_pivot else [])
+        for k in keys:
+            assert got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype, k
+            assert np.array_equal(got[k], ref[k]), (k, got[k], ref[k])
+        n_try, n_ok = int(ref['jump_stats'][:, 1].sum()), int(ref['jump_stats'][:, 0].sum())
+        assert n_try == 15 and 0 < n_ok < n_try, ref['jump_stats']
+        for f in range(1, 4):
+            assert P.rel_rms(ref['pos'][f], got['pos'][f]) < 2e-3, (with_pivot, f)

@@ -403,3 +403,16 @@ def add_pivot_moves(path):
         g.write('pivot_atom', pivot_atom[keep])
         g.write('pivot_restype', map_id[keep])
         g.write('pivot_range', np.column_stack((pivot_atom[keep][:, 4] + 1, np.full(int(keep.sum()), n_atom, 'i4'))).astype('i4'))
+
+
+def add_jump_moves(path, atom_ranges, sigma_trans, sigma_rot):
+    """write /input/jump_moves (monte_carlo_sampler.cpp:173-201): rigid-body Monte-Carlo moves of the atom ranges
+    [first, end) -- the chains of a multi-chain system -- with the given translation / rotation scales."""
+    with h5lite.open_file(path, 'r+') as f:
+        inp = f.group('input')
+        if 'jump_moves' in inp:
+            inp.delete('jump_moves')
+        g = inp.create_group('jump_moves')
+        g.write('atom_range', np.asarray(atom_ranges, 'i4').reshape(-1, 2))
+        g.write('sigma_trans', np.asarray(sigma_trans, 'f4').reshape(-1))
+        g.write('sigma_rot', np.asarray(sigma_rot, 'f4').reshape(-1))

@@ -404,17 +404,40 @@ void DerivEngine::load_pivot_moves(hid_t_compat input_group_) {
     pivot.P.atoms = pivot.atoms.p; pivot.P.range = pivot.range.p; pivot.P.restype = pivot.restype.p; pivot.P.pot = pivot.pot.p; pivot.P.cdf = pivot.cdf.p;
     pivot.loaded = n_loc > 0;
 }
-void DerivEngine::mc_pivot_step(uint64_t round) {   // MonteCarloSampler::monte_carlo_step, monte_carlo_sampler.cpp:255-284
-    if (!pivot.loaded) throw string("no pivot moves loaded");
-    compute(PotentialAndDerivMode); fetch_potentials();
-    pivot.e_old.upload(potential);
+void DerivEngine::load_jump_moves(hid_t_compat input_group_) {
+    const hid_t input = (hid_t)input_group_;
+    auto grp = h5u::open_group(input, "jump_moves");
+    vector<hsize_t> d;
+    auto range = h5u::read<int>(grp, "atom_range", 2, &d);
+    const int n_chain = (int)d[0];
+    if (d[1] != 2) throw string("atom_range must be (n_chain, 2)");
+    h5u::check_size(grp, "sigma_trans", {(size_t)n_chain}); h5u::check_size(grp, "sigma_rot", {(size_t)n_chain});
+    auto st = h5u::read<float>(grp, "sigma_trans", 1); auto sr = h5u::read<float>(grp, "sigma_rot", 1);
+    for (int i = 0; i < n_chain; ++i)
+        if (range[i * 2] < 0 || range[i * 2 + 1] > pos->n_atom || range[i * 2] >= range[i * 2 + 1]) throw string("invalid jump atom_range");
+    const int S = ctx.n_system;
+    jump.range.upload(range); jump.sigma_trans.upload(st); jump.sigma_rot.upload(sr);
+    jump.stats.alloc((size_t)S * 2);
+    if (!pivot.pos_copy.n) { pivot.pos_copy.alloc((size_t)S * pos->n_atom * pos->stride); pivot.delta_lprob.alloc(S); pivot.e_old.alloc(S); pivot.e_new.alloc(S); }
+    jump.J.n_chain = n_chain; jump.J.atom_range = jump.range.p; jump.J.sigma_trans = jump.sigma_trans.p; jump.J.sigma_rot = jump.sigma_rot.p;
+    jump.loaded = n_chain > 0;
+}
+void DerivEngine::mc_step(uint64_t round) {   // MultipleMonteCarloSampler::execute, monte_carlo_sampler.cpp:255-288
+    if (!pivot.loaded && !jump.loaded) throw string("no Monte-Carlo moves loaded");
     pivot.temperature.upload(temperature);
-    upk_check(upk_pivot_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &pivot.P, seed.p, round, pivot.delta_lprob.p), "pivot_propose");
-    compute(PotentialAndDerivMode); fetch_potentials();
-    pivot.e_new.upload(potential);
-    upk_check(upk_mc_accept(&ctx.L, pos->coord(), pivot.pos_copy.p, pivot.e_old.p, pivot.e_new.p, pivot.delta_lprob.p, pivot.temperature.p,
-                            seed.p, round, 2, pivot.stats.p), "mc_accept");
-    sync();
+    for (int sampler = 0; sampler < 2; ++sampler) {
+        if (sampler == 0 ? !pivot.loaded : !jump.loaded) continue;
+        compute(PotentialAndDerivMode); fetch_potentials();
+        pivot.e_old.upload(potential);
+        if (sampler == 0) upk_check(upk_pivot_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &pivot.P, seed.p, round, pivot.delta_lprob.p), "pivot_propose");
+        else upk_check(upk_jump_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &jump.J, seed.p, round, pivot.delta_lprob.p), "jump_propose");
+        compute(PotentialAndDerivMode); fetch_potentials();
+        pivot.e_new.upload(potential);
+        // the acceptance uniform is the generator's next draw: the pivot proposal used one, the jump proposal two
+        upk_check(upk_mc_accept(&ctx.L, pos->coord(), pivot.pos_copy.p, pivot.e_old.p, pivot.e_new.p, pivot.delta_lprob.p, pivot.temperature.p,
+                                seed.p, round, sampler == 0 ? 2 : 3, sampler == 0 ? 1 : 2, (sampler == 0 ? pivot.stats : jump.stats).p), "mc_accept");
+        sync();
+    }
 }
 void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
 

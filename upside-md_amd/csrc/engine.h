@@ -197,8 +197,14 @@ struct DerivEngine {   // deriv_engine.h:145-237
         bool loaded = false; upk_pivot_t P{};
         DevBuf<int> atoms, range, restype, stats; DevBuf<float> pot, cdf, pos_copy, delta_lprob, e_old, e_new, temperature;
     } pivot;
+    struct Jump {   // rigid-body moves of chain segments (monte_carlo_sampler.cpp:157-251)
+        bool loaded = false; upk_jump_t J{};
+        DevBuf<int> range, stats; DevBuf<float> sigma_trans, sigma_rot;
+    } jump;
     void load_pivot_moves(hid_t_compat input_group);   // throws if the group is malformed
-    void mc_pivot_step(uint64_t round);                // two energy evaluations + proposal + Metropolis, every system
+    void load_jump_moves(hid_t_compat input_group);
+    void mc_step(uint64_t round);                      // every loaded sampler in the reference's order (pivot, jump): two
+                                                       // energy evaluations + proposal + Metropolis each, every system
     void check_device_errors();                // throws if a capacity overflow was flagged
     void sync();
 };

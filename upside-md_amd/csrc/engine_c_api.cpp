@@ -267,26 +267,29 @@ extern "C" int upside_hip_load_mc(DerivEngine* e, const char* config_file) {
     if (f < 0) throw string("unable to open ") + config_file;
     h5u::Handle config(f, H5Fclose);
     auto input = h5u::open_group(config, "/input");
-    if (h5u::exists(input, "jump_moves")) throw string("jump moves (multi-chain rigid-body Monte Carlo) are not implemented");
-    if (!h5u::exists(input, "pivot_moves")) return 0;
+    int n = 0;
     e->invalidate_graph();
-    e->load_pivot_moves((hid_t_compat)(hid_t)input);
-    return 1;                                   // number of samplers loaded
+    if (h5u::exists(input, "pivot_moves")) { e->load_pivot_moves((hid_t_compat)(hid_t)input); n += e->pivot.loaded; }
+    if (h5u::exists(input, "jump_moves")) { e->load_jump_moves((hid_t_compat)(hid_t)input); n += e->jump.loaded; }
+    return n;                                   // number of samplers loaded
     API_CATCH(-1)
 }
 extern "C" int upside_hip_mc_step(DerivEngine* e, uint64_t round) {
-    API_TRY e->mc_pivot_step(round); e->check_device_errors(); return 0; API_CATCH(1)
+    API_TRY e->mc_step(round); e->check_device_errors(); return 0; API_CATCH(1)
 }
-extern "C" int upside_hip_mc_stats(DerivEngine* e, int* stats, int reset) {
+extern "C" int upside_hip_mc_stats(DerivEngine* e, int sampler, int* stats, int reset) {
     API_TRY
-    if (!e->pivot.loaded) throw string("no pivot moves loaded");
+    if (sampler != 0 && sampler != 1) throw string("sampler must be 0 (pivot) or 1 (jump)");
+    if (sampler == 0 ? !e->pivot.loaded : !e->jump.loaded) throw string("sampler not loaded");
+    auto& buf = sampler == 0 ? e->pivot.stats : e->jump.stats;
     e->sync();
-    auto st = e->pivot.stats.download();
+    auto st = buf.download();
     for (size_t i = 0; i < st.size(); ++i) stats[i] = st[i];
-    if (reset) e->pivot.stats.fill_bytes(0);
+    if (reset) buf.fill_bytes(0);
     return 0;
     API_CATCH(1)
 }
+extern "C" int upside_hip_mc_loaded(DerivEngine* e, int sampler) { return e ? (sampler == 0 ? e->pivot.loaded : (sampler == 1 ? e->jump.loaded : 0)) : 0; }
 extern "C" int upside_hip_recenter(DerivEngine* e) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 

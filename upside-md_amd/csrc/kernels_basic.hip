@@ -906,9 +906,70 @@ extern "C" int upk_pivot_propose(const upk_launch_t* L, upk_coord_t pos, float* 
     hipLaunchKernelGGL(k_pivot_propose, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, *P, seed, round, delta_lprob);
     return launch_status();
 }
+__global__ void k_jump_propose(upk_coord_t pos, float* __restrict__ pos_copy, upk_jump_t J, const uint32_t* __restrict__ seed, uint64_t round,
+                               float* __restrict__ delta_lprob) {
+    __shared__ float sh_U[9], sh_v[3], sh_com[3], part[3][UPK_BLOCK / UP_WAVE];
+    __shared__ int sh_i[3];
+    const int s = blockIdx.y;
+    float* x = C_OUT(pos, s);
+    float* cp = pos_copy + (size_t)s * pos.n_elem * pos.stride;
+    for (int i = threadIdx.x; i < pos.n_elem * pos.stride; i += blockDim.x) cp[i] = x[i];
+    if (threadIdx.x == 0) {
+        const uint32_t key[4] = {seed[s], 3u /* JUMP_MOVE_RANDOM_STREAM, random.h:16 */, 0u, 0u};
+        uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, 0u};
+        threefry4x32_20(X, key);
+        const int type = (int)(2 * u01f(X[0]));
+        int chain = (int)(J.n_chain * u01f(X[3]));
+        if (chain == J.n_chain) chain--;
+        uint32_t Y[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, 1u};   // second draw: the normals
+        threefry4x32_20(Y, key);
+        float n0, n1, n2, n3;
+        boxmuller(n0, n1, Y[0], Y[1]); boxmuller(n2, n3, Y[2], Y[3]);
+        sh_i[0] = type; sh_i[1] = J.atom_range[chain * 2]; sh_i[2] = J.atom_range[chain * 2 + 1];
+        if (type == 0) {
+            const float f = J.sigma_trans[chain] / sqrtf(3.f);
+            sh_v[0] = f * n0; sh_v[1] = f * n1; sh_v[2] = f * n2;
+        } else {
+            f3 axis = mk3(n1, n2, n3);
+            const float inv = 1.f / (sqrtf(mag2(axis)) + 1e-16f);
+            axis_angle_to_rot(sh_U, J.sigma_rot[chain] * n0, inv * axis);
+        }
+        delta_lprob[s] = 0.f;
+    }
+    __syncthreads();
+    const int first = sh_i[1], next = sh_i[2];
+    if (sh_i[0] == 0) {
+        for (int na = first + threadIdx.x; na < next; na += blockDim.x) {
+            float* y = x + (size_t)na * pos.stride;
+            y[0] = sh_v[0] + y[0]; y[1] = sh_v[1] + y[1]; y[2] = sh_v[2] + y[2];
+        }
+        return;
+    }
+    float a[3] = {0.f, 0.f, 0.f};   // centre of mass of the segment
+    for (int na = first + threadIdx.x; na < next; na += blockDim.x) for (int c = 0; c < 3; ++c) a[c] += x[(size_t)na * pos.stride + c];
+    for (int c = 0; c < 3; ++c) { a[c] = wave_sum(a[c]); if ((threadIdx.x & 63) == 0) part[c][threadIdx.x >> 6] = a[c]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[threadIdx.x][w];
+        sh_com[threadIdx.x] = t * (1.f / (next - first));
+    }
+    __syncthreads();
+    const f3 com = mk3(sh_com[0], sh_com[1], sh_com[2]);
+    for (int na = first + threadIdx.x; na < next; na += blockDim.x) {
+        float* y = x + (size_t)na * pos.stride;
+        const f3 r = com + rot_apply(sh_U, ld3(y) - com);
+        y[0] = r.x; y[1] = r.y; y[2] = r.z;
+    }
+}
+extern "C" int upk_jump_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_jump_t* J, const uint32_t* seed,
+                                uint64_t round, float* delta_lprob) {
+    hipLaunchKernelGGL(k_jump_propose, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, *J, seed, round, delta_lprob);
+    return launch_status();
+}
 __global__ void k_mc_accept(upk_coord_t pos, const float* __restrict__ pos_copy, const float* __restrict__ e_old, const float* __restrict__ e_new,
                             const float* __restrict__ delta_lprob, const float* __restrict__ temperature, const uint32_t* __restrict__ seed,
-                            uint64_t round, int stream, int* __restrict__ stats) {
+                            uint64_t round, int stream, int accept_draw, int* __restrict__ stats) {
     __shared__ int accept;
     const int s = blockIdx.y;
     if (threadIdx.x == 0) {
@@ -916,7 +977,7 @@ __global__ void k_mc_accept(upk_coord_t pos, const float* __restrict__ pos_copy,
         int ok = 1;
         if (!(lb >= 0.f)) {
             const uint32_t key[4] = {seed[s], (uint32_t)stream, 0u, 0u};
-            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, 1u};   // second draw of the generator
+            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, (uint32_t)accept_draw};   // next draw of the move's generator
             threefry4x32_20(X, key);
             ok = expf(lb) >= u01f(X[0]);
         }
@@ -931,9 +992,9 @@ __global__ void k_mc_accept(upk_coord_t pos, const float* __restrict__ pos_copy,
 }
 extern "C" int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy, const float* e_old, const float* e_new,
                              const float* delta_lprob, const float* temperature, const uint32_t* seed, uint64_t round, int stream,
-                             int* stats) {
+                             int accept_draw, int* stats) {
     hipLaunchKernelGGL(k_mc_accept, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, e_old, e_new, delta_lprob, temperature,
-                       seed, round, stream, stats);
+                       seed, round, stream, accept_draw, stats);
     return launch_status();
 }
 

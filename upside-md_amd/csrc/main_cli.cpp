@@ -62,8 +62,8 @@ struct EArray {   // h5_support.cpp:199-274: extensible along dimension 0, chunk
 };
 struct OutputLogger {   // one per system / configuration file (H5Logger, state_logger.h:70-141)
     hid_t file = -1, group = -1; int n_buffered = 0;
-    EArray pos, kinetic, potential, time, temperature, replica_index, pivot_stats; bool log_replica = false, log_pivot = false;
-    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index, bool with_pivot) {
+    EArray pos, kinetic, potential, time, temperature, replica_index, pivot_stats, jump_stats; bool log_replica = false, log_pivot = false, log_jump = false;
+    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index, bool with_pivot, bool with_jump) {
         file = H5Fopen(path.c_str(), H5F_ACC_RDWR, H5P_DEFAULT);
         if (file < 0) throw string("Unable to open configuration file at ") + path;
         if (H5Lexists(file, "output", H5P_DEFAULT) > 0) H5Ldelete(file, "/output", H5P_DEFAULT);   // main.cpp:473-477
@@ -85,21 +85,25 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
         if (log_replica) replica_index.create(group, "replica_index", H5T_NATIVE_INT, 4, {1});
         log_pivot = with_pivot;
         if (log_pivot) pivot_stats.create(group, "pivot_stats", H5T_NATIVE_INT, 4, {2});   // monte_carlo_sampler.h:33-37
+        log_jump = with_jump;
+        if (log_jump) jump_stats.create(group, "jump_stats", H5T_NATIVE_INT, 4, {2});
     }
-    void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc) {
+    void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc, const int* mcj) {
         pos.push(x); kinetic.push(&kin); potential.push(&pot); time.push(&t); temperature.push(&temp);
         if (log_replica) replica_index.push(&rep);
         if (log_pivot) pivot_stats.push(mc);
+        if (log_jump) jump_stats.push(mcj);
         if (!(++n_buffered % 100)) flush();                       // state_logger.h:91-92
     }
     void flush() {
         pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) replica_index.flush();
         if (log_pivot) pivot_stats.flush();
+        if (log_jump) jump_stats.flush();
         if (file >= 0) H5Fflush(file, H5F_SCOPE_LOCAL);
     }
     void close() {
         if (file < 0) return;
-        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); pivot_stats.close();
+        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); pivot_stats.close(); jump_stats.close();
         H5Gclose(group); H5Fclose(file); file = group = -1;
     }
     ~OutputLogger() { try { close(); } catch (...) {} }
@@ -213,8 +217,9 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         if (n_sampler < 0) throw string(upside_hip_last_error());
         have_mc = n_sampler > 0;
     }
-    vector<int> mc_stats((size_t)n_system * 2, 0);
-    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_mc);
+    const bool have_pivot = have_mc && upside_hip_mc_loaded(e, 0), have_jump = have_mc && upside_hip_mc_loaded(e, 1);
+    vector<int> mc_stats((size_t)n_system * 2, 0), mcj_stats((size_t)n_system * 2, 0);
+    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_pivot, have_jump);
     vector<int> replica_index(n_system);
     for (int ns = 0; ns < n_system; ++ns) replica_index[ns] = ns;
     vector<float> frame_pos((size_t)n_system * n_atom * 3), frame_mom((size_t)n_system * n_atom * 3);
@@ -228,12 +233,13 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             if (recenter) upside_hip_recenter(e);
             if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
             if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
-            if (have_mc && upside_hip_mc_stats(e, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame
+            if (have_pivot && upside_hip_mc_stats(e, 0, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame
+            if (have_jump && upside_hip_mc_stats(e, 1, mcj_stats.data(), 1)) throw string(upside_hip_last_error());
             for (int ns = 0; ns < n_system; ++ns) {
                 const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
                 double sum_kin = 0.;
                 for (int i = 0; i < n_atom * 3; ++i) sum_kin += (double)(m[i] * m[i]);
-                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns], &mc_stats[(size_t)ns * 2]);
+                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns], &mc_stats[(size_t)ns * 2], &mcj_stats[(size_t)ns * 2]);
                 double com[3] = {0, 0, 0}, rg = 0.;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
                 for (int d = 0; d < 3; ++d) com[d] /= n_atom;
