@@ -519,6 +519,10 @@ struct BpCtx {
     const int *slot_a, *slot_b, *active, *slot_off;
     float *P, *inbox, *marg;
     int cap;
+    // the first lds_floats floats of the inbox (messages to the 3-state nodes come first) may live in LDS instead of
+    // global memory: the one-workgroup solve re-reads and rewrites them every sweep
+    float* inbox_lds = nullptr; int lds_floats = 0;
+    __device__ __forceinline__ float* msg(int off) const { return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
 
 // edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
@@ -530,8 +534,8 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
     for (int sl = lo + tid; sl < hi; sl += nt) {
         if (!C.active[sl]) continue;
         const int a = C.slot_a[sl], b = C.slot_b[sl];
-        float* ma = C.inbox + C.slot_off[sl * 2];
-        float* mb = C.inbox + C.slot_off[sl * 2 + 1];
+        float* ma = C.msg(C.slot_off[sl * 2]);
+        float* mb = C.msg(C.slot_off[sl * 2 + 1]);
         float P[NA][NB], va[NA], vb[NB];
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -594,8 +598,8 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
     for (int sl = lo + tid; sl < hi; sl += nt) {
         if (!C.active[sl]) continue;
         const int a = C.slot_a[sl], b = C.slot_b[sl];
-        const float* ma = C.inbox + C.slot_off[sl * 2];
-        const float* mb = C.inbox + C.slot_off[sl * 2 + 1];
+        const float* ma = C.msg(C.slot_off[sl * 2]);
+        const float* mb = C.msg(C.slot_off[sl * 2 + 1]);
         float P[NA][NB], bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -624,7 +628,7 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
 
-__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback) {
+__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
@@ -649,6 +653,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     C.P = R.P + (size_t)s * R.slot_cap * 36;
     C.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
     C.marg = R.marg + (size_t)s * R.slot_cap * 36;
+    C.inbox_lds = (float*)(((size_t)(cls + N_CLASS + 2) + 15) & ~(size_t)15);   // [lds_msg_floats], 16-byte aligned
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
@@ -667,7 +672,15 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     }
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
-    for (int i = tid; i < bp_start[NN] * 4; i += nt) C.inbox[i] = 1.f;
+    // the head of the inbox stays in LDS as far as it reaches: the 4-float rows to the 3-state nodes come first, then
+    // the 8-float rows to the 6-state nodes (the boundary never cuts a row)
+    {
+        const int q3 = bp_start[R.n_node1 + R.n_node3] * 4, q_all = bp_start[NN] * 4;
+        int n = lds_msg_floats < q_all ? lds_msg_floats : q_all;
+        if (n > q3) n = q3 + ((n - q3) / 8) * 8;
+        C.lds_floats = n;
+    }
+    for (int i = tid; i < bp_start[NN] * 4; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     for (int g = tid; g < NN; g += nt) {
@@ -710,7 +723,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
                 const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 int parity = 0;
                 for (int k = gl; k < deg; k += BP_GROUP) {
-                    const float* m = C.inbox + (size_t)(base + k * q) * 4;
+                    const float* m = C.msg((base + k * q) * 4);
                     const float4 m0 = *(const float4*)m;
                     bb[0] *= m0.x; bb[1] *= m0.y; bb[2] *= m0.z;
                     if (n == 6) { const float2 m1 = *(const float2*)(m + 4); bb[3] *= m0.w; bb[4] *= m1.x; bb[5] *= m1.y; }
@@ -1229,8 +1242,17 @@ extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // fl
     return (int)(156 * 1024 / sizeof(float)) - fixed;
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
-    const size_t lds = ((size_t)R->n_node * 20 + 64) * sizeof(float);
-    if (lds > 155 * 1024) return 9004;
+    const size_t lds_base = ((size_t)R->n_node * 20 + 64 + 8) * sizeof(float);
+    if (lds_base > 155 * 1024) return 9004;
+    // LDS left over holds the messages to the 3-state nodes (at most all of the inbox: 16 floats per slot)
+    static int lds_msg_kb = -1;   // UPSIDE_HIP_BP_LDS_MSG_KB (experiments): 0 keeps every message in global memory
+    if (lds_msg_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_MSG_KB"); lds_msg_kb = e ? atoi(e) : 150; }
+    size_t msg_bytes = (size_t)lds_msg_kb * 1024;
+    if (lds_base + msg_bytes > 150 * 1024) msg_bytes = 150 * 1024 - lds_base;
+    if (msg_bytes > (size_t)R->slot_cap * 64) msg_bytes = (size_t)R->slot_cap * 64;
+    msg_bytes &= ~(size_t)15;
+    const int lds_msg_floats = (int)(msg_bytes / sizeof(float));
+    const size_t lds = lds_base + msg_bytes;
     const int C = R->bp_C;
     if (C > 1) {
         // clusters of C co-resident workgroups, one per CU: at most CUs / C systems per launch (multiples of 8 keep a
@@ -1245,12 +1267,12 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
                 if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
                 else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BP_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
-            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1);
+            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1, lds_msg_floats);
             return launch_status();
         }
     }
     static int bp_threads = 0;   // UPSIDE_HIP_BP_THREADS (experiments): lanes per one-workgroup solve
     if (!bp_threads) { const char* e = getenv("UPSIDE_HIP_BP_THREADS"); bp_threads = e ? atoi(e) : BP_BLOCK; if (bp_threads < 64 || bp_threads > BP_BLOCK) bp_threads = BP_BLOCK; }
-    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(bp_threads), lds, ST(L), *R, want_energy, 0);
+    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(bp_threads), lds, ST(L), *R, want_energy, 0, lds_msg_floats);
     return launch_status();
 }
