@@ -352,7 +352,7 @@ bool DerivEngine::capture_md_graph() {
     return true;
 }
 void DerivEngine::run_steps(int n_step) {
-    static const int use_graph = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : 1; }();
+    static const int use_graph = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : 0; }();   // opt-in: see DESIGN.md
     int left = n_step;
     while (left > 0) {
         const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;

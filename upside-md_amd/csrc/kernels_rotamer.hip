@@ -1267,7 +1267,7 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
                 if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
                 else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BP_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
-            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds, ST(L), *R, want_energy, 1, lds_msg_floats);
+            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds_base, ST(L), *R, want_energy, 1, 0);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
             return launch_status();
         }
     }
