@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
             [&](int rl, int pay, bool valid) {
                 if (!valid) return;
                 const int row = cb + rl, j = pay & 0xFFFF, k = (int)((unsigned)pay >> 16);
+                const int sl = nsl_base[(size_t)row * G.cap1 + k];       // issued first: its latency hides behind the functor
                 float xr[8], xo[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
@@ -336,7 +337,6 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
                 const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
                 const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
                 const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
-                const int sl = nsl_base[(size_t)row * G.cap1 + k];
                 if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
                 const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
                 const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
@@ -421,9 +421,8 @@ __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_
                     for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
                     const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
                     const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-                    const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
-                    quadspline2<1>(Q, p, xr, xo, d1);
                     const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
+                    // the pair sensitivity is two dependent gathers (slot, then marginal): issue them before the functor
                     float ps;
                     if (na == 1 && nb == 1) ps = 1.f;
                     else if (na == 1) ps = nbm[b * 6 + rb];
@@ -432,6 +431,8 @@ __global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_
                         const int sl = nsl_base[(size_t)row * G.cap1 + k];
                         ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
                     }
+                    const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
+                    quadspline2<1>(Q, p, xr, xo, d1);
 #pragma unroll
                     for (int c = 0; c < 6; ++c) v[c] = ps * d1[c];
                 }
