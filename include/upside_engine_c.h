@@ -6,7 +6,9 @@
  *   - construct_deriv_engine opens `potential_file` read-only and builds the DerivComputation graph from
  *     group /input/potential (engine_c_library.cpp:9-20); returns NULL on failure, never throws.
  *   - all other calls return 0 on success, 1 on failure after printing "ERROR: ..." to stderr
- *     (engine_c_library.cpp:37-45); get_param_deriv returns -1 (built without PARAM_DERIV, :101-102).
+ *     (engine_c_library.cpp:37-45); get_param_deriv behaves like a -DPARAM_DERIV build of the reference (:93-100):
+ *     the derivative of the potential w.r.t. get_param() of the named node, from the state the last evaluate_deriv
+ *     left behind; a node without parameter derivatives has an empty vector (n_param must then be 0).
  *   - pos / deriv are dense row-major (n_atom,3) fp32 HOST buffers owned by the caller (:30-33,57-60);
  *     node outputs are dense (n_elem, elem_width) (:146-149); potential nodes report (1,1).
  *   - evaluate_* always run PotentialAndDerivMode and leave node output/sens inspectable (:34,55).
@@ -128,6 +130,8 @@ int upside_hip_get_pairlist(DerivEngine* engine, const char* node_name, int sys,
 int upside_hip_rotamer_iterations(DerivEngine* engine, int* iters);
 
 /* last error text of this thread ("" if none) */
+/* get_param_deriv (engine_c_library.h:20) for any system of the batch */
+int upside_hip_get_param_deriv(DerivEngine* engine, const char* node_name, int system, int n_param, float* deriv);
 const char* upside_hip_last_error(void);
 
 /* Per-kernel timing hooks used by bench.py.  With profiling enabled every interaction-graph / BP kernel

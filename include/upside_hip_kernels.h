@@ -233,6 +233,23 @@ int upk_device_cu_count(void);   /* and the number of slots of one class it can 
  * (rotamer.cpp:956-985, interaction_graph.h:525-555) */
 int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R);
 
+/* ---- parameter derivatives (the reference's get_param_deriv under -DPARAM_DERIV, deriv_engine.h:71-74) ------------
+ * Each call handles ONE system of the batch and ADDS into `table`, which the caller has zeroed; layout = the node's
+ * get_param().  They read the outputs, sensitivities and cached lists of the last evaluate_deriv.  Off the MD path. */
+/* interaction_graph.h:404-416: hbond_coverage (quadspline coefficients), environment_coverage (zeros,
+ * environment.cpp:62-65); sens_mode as in upk_igraph_grad */
+int upk_igraph_param_deriv(const upk_launch_t* L, const upk_igraph_t* G, int system, int sens_mode, const float* sens1,
+                           const float* sens2, long sens_sys_stride, int sens_stride, float* table);
+/* rotamer.cpp:1064-1066: bead pairs weighted by the beliefs / pair marginals of the last solve */
+int upk_rotamer_param_deriv(const upk_launch_t* L, const upk_rotamer_t* R, int system, float* table);
+/* placement.cpp:144-160 (fixed placements: [n_layer][n_pos_dim]) */
+int upk_placement_param_deriv(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out, int system, float* table);
+/* environment.cpp:375-389 ([n_restype][n_coeff]) */
+int upk_nonlinear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t input, const int* types, int n_coeff, float offset,
+                                       float inv_dx, int system, float* table);
+/* sum over the elements of output component `comp` (hbond.cpp:436-448: n_hbond) */
+int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, int system, float* out);
+
 /* protein_hbond finish (src/hbond.cpp:320-335): copy the 6 infer components, out[6] = 1 - exp(-sum) */
 int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out);
 /* protein_hbond backward prologue/epilogue (src/hbond.cpp:343-365): sens_scaled and pass-through */

@@ -969,6 +969,55 @@ static void igraph_propagate(IGraph* g, Node* n1, Node* n2) {
     if (!g->symmetric) for (int i = 0; i < g->n_elem2; ++i) for (int c = 0; c < g->n_dim2; ++c) VA(n2->sens, c, g->loc2[i]) += g->pos2_deriv[i * 8 + c];
 }
 
+/* bead_interaction.h:86-130: derivative of the quadspline value w.r.t. the n_param spline coefficients */
+static void quadspline_param_deriv(const IGraph* g, float* d_param, const float* p, const float* x1, const float* x2) {
+    int ka = g->n_knot_angular, k = g->n_knot; float inv_dx = g->inv_dx, inv_dtheta = g->inv_dtheta;
+    for (int i = 0; i < g->n_param; ++i) d_param[i] = 0.f;
+    f3 displace = f3_make(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
+    f3 rvec1 = f3_make(x1[3], x1[4], x1[5]), rvec2 = f3_make(x2[3], x2[4], x2[5]);
+    float dist2 = f3_mag2(displace), inv_dist = rsqrtf_(dist2);
+    float dist_coord = dist2 * (inv_dist * inv_dx);
+    f3 u = f3_scale(inv_dist, displace);
+    float cos1 = f3_dot(rvec1, u), cos2 = f3_dot(rvec2, f3_scale(-1.f, u));
+    float a1[2], a2[2], narrow[2], result[4]; int sb;
+    deBoor_vd(a1, p, (cos1 + 1.f) * inv_dtheta + 1.f);
+    deBoor_vd(a2, p + ka, (cos2 + 1.f) * inv_dtheta + 1.f);
+    clamped_deBoor_coeff_deriv(&sb, result, dist_coord, k);
+    for (int i = 0; i < 4; ++i) d_param[2 * ka + sb + i] = result[i];                           /* wide_cover */
+    for (int i = 0; i < 4; ++i) d_param[2 * ka + k + sb + i] = a1[0] * a2[0] * result[i];       /* narrow_cover */
+    clamped_deBoor_vd_scalar(narrow, p + 2 * ka + k, dist_coord, k);
+    deBoor_coeff_deriv(&sb, result, (cos1 + 1.f) * inv_dtheta + 1.f);
+    for (int i = 0; i < 4; ++i) d_param[sb + i] = a2[0] * narrow[0] * result[i];
+    deBoor_coeff_deriv(&sb, result, (cos2 + 1.f) * inv_dtheta + 1.f);
+    for (int i = 0; i < 4; ++i) d_param[ka + sb + i] = a1[0] * narrow[0] * result[i];
+}
+
+/* interaction_graph.h:404-416 get_param_deriv: the edges and edge sensitivities of the last evaluation
+ * (compute_edges<true> re-derives the same edges from the same positions), :497-503 and :537-543 */
+static void igraph_param_deriv(IGraph* g, float* out) {
+    int n = g->n_type1 * g->n_type2 * g->n_param;
+    for (int i = 0; i < n; ++i) out[i] = 0.f;
+    float* dp = (float*)xcalloc((size_t)g->n_param, sizeof(float));
+    for (int e = 0; e < g->n_edge; ++e) {
+        int i1 = g->edge_i1[e], i2 = g->edge_i2[e];
+        int t = g->types1[i1] * g->n_type2 + g->types2[i2];
+        const float* p = g->param + t * g->n_param;
+        const float* x1 = g->pos1 + i1 * 8; const float* x2 = g->pos2 + i2 * 8;
+        switch (g->itype) {
+            case IT_ROTAMER: quadspline_param_deriv(g, dp, p, x1, x2); break;                    /* bead_interaction.h:204-207 */
+            case IT_HBOND_COVERAGE: {                                                             /* hbond.cpp:278-283 */
+                quadspline_param_deriv(g, dp, p, x1, x2);
+                float prefactor = sqr(1.f - x1[6]);
+                for (int d = 0; d < g->n_param; ++d) dp[d] *= prefactor;
+            } break;
+            case IT_ENVIRONMENT: for (int d = 0; d < g->n_param; ++d) dp[d] = 0.f; break;        /* environment.cpp:62-65 */
+            default: for (int d = 0; d < g->n_param; ++d) dp[d] = -1.f; break;                   /* hbond.cpp:232-235 */
+        }
+        for (int d = 0; d < g->n_param; ++d) out[t * g->n_param + d] += g->edge_sens[e] * dp[d];
+    }
+    free(dp);
+}
+
 static void igraph_count_edges_by_type(IGraph* g, float* out) {   /* interaction_graph.h:427-441 */
     for (int i = 0; i < g->n_type1 * g->n_type2; ++i) out[i] = 0.f;
     for (int e = 0; e < g->n_edge; ++e) out[g->types1[g->edge_i1[e]] * g->n_type2 + g->types2[g->edge_i2[e]]] += 1.f;
@@ -1097,12 +1146,14 @@ typedef struct {
     int* affine_residue; int* layer; int* rama_residue;
     int is_rama; int n_layer; float* fixed_data;       /* (n_layer, n_pos_dim) */
     PeriodicSpline2D s; float* rama_deriv;             /* (n_elem, 2*n_pos_dim) */
+    float* param_deriv;                                /* (n_layer, n_pos_dim), fixed placements (placement.cpp:113-148) */
 } PlacementData;
 
 static void placement_value(Engine* e, Node* n, int mode) {   /* placement.cpp:264-281, 60-78, 139-141, 183-201 */
     (void)mode;
     PlacementData* d = (PlacementData*)n->data; Node* aff = parent(e, n, 0);
     Node* rama = d->is_rama ? parent(e, n, 1) : NULL;
+    if (d->param_deriv) memset(d->param_deriv, 0, sizeof(float) * (size_t)d->n_layer * d->n_pos_dim);   /* placement.cpp:133-137 reset() */
     for (int ne = 0; ne < d->n_elem; ++ne) {
         int ar = d->affine_residue[ne];
         f3 t = f3_load(aff->output, ar);
@@ -1149,6 +1200,7 @@ static void placement_deriv(Engine* e, Node* n) {   /* placement.cpp:283-307, 80
                 off += 3;
             }
         }
+        if (d->param_deriv) for (int c = 0; c < d->n_pos_dim; ++c) d->param_deriv[d->layer[ne] * d->n_pos_dim + c] += ref_sens[c];   /* placement.cpp:143-148 */
         if (d->is_rama) {
             const float scale_x = d->s.nx * (0.5f / M_PI_F - 1e-7f), scale_y = d->s.ny * (0.5f / M_PI_F - 1e-7f);
             const float* rd = d->rama_deriv + ne * 2 * d->n_pos_dim;
@@ -1704,6 +1756,7 @@ static int build_node(Engine* e, Node* n, hid_t grp, const char* name) {
         } else {
             d->fixed_data = h5_read_f(grp, "placement_data", 2, dims); if (!d->fixed_data || (int)dims[1] != d->n_pos_dim) return -1;
             d->n_layer = (int)dims[0];
+            d->param_deriv = (float*)xcalloc((size_t)d->n_layer * d->n_pos_dim, sizeof(float));
         }
         coord_node(n, d->n_elem, d->n_pos_dim); n->data = d; n->compute_value = placement_value; n->propagate_deriv = placement_deriv; return 0;
     }
@@ -1886,7 +1939,33 @@ int get_param(int n_param, float* param, DerivEngine* e, const char* node_name) 
     memcpy(param, g->param, sizeof(float) * n_param);
     return 0;
 }
-int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_name) { (void)n_param; (void)deriv; (void)e; (void)node_name; return -1; }
+/* engine_c_library.cpp:93-100 as compiled with -DPARAM_DERIV; nodes without an override have an empty vector
+ * (deriv_engine.h:71-74) */
+int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_name) {
+    int i = find_node(e, node_name); if (i < 0) { fprintf(stderr, "ERROR: name not found\n"); return 1; }
+    Node* n = &e->nodes[i];
+    int expected = 0;
+    IGraph* g = NULL;
+    if (is_prefix("rotamer", n->name)) g = &((RotamerData*)n->data)->g;                                  /* rotamer.cpp:1064-1066 */
+    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name)) g = (IGraph*)n->data;   /* hbond.cpp:401-402, environment.cpp:104-105 */
+    if (g) expected = g->n_type1 * g->n_type2 * g->n_param;
+    else if (is_prefix("hbond_energy", n->name)) expected = 1;
+    else if (is_prefix("nonlinear_coupling", n->name)) { NonlinearData* d = (NonlinearData*)n->data; expected = d->n_restype * d->n_coeff; }
+    else if (is_prefix("placement_fixed", n->name)) { PlacementData* d = (PlacementData*)n->data; expected = d->n_layer * d->n_pos_dim; }
+    if (n_param != expected) { fprintf(stderr, "ERROR: Wrong number of parameters, expected %i but got %i\n", expected, n_param); return 1; }
+    if (g) igraph_param_deriv(g, deriv);
+    else if (is_prefix("hbond_energy", n->name)) deriv[0] = ((HBondEnergyData*)n->data)->n_hbond;       /* hbond.cpp:447-448 */
+    else if (is_prefix("nonlinear_coupling", n->name)) {                                                 /* environment.cpp:375-389 */
+        NonlinearData* d = (NonlinearData*)n->data; Node* in = &e->nodes[n->parents[0]];
+        for (int k = 0; k < expected; ++k) deriv[k] = 0.f;
+        for (int ne = 0; ne < in->n_elem; ++ne) {
+            int sb; float result[4];
+            clamped_deBoor_coeff_deriv(&sb, result, (VA(in->output, 0, ne) - d->offset) * d->inv_dx, d->n_coeff);
+            for (int k = 0; k < 4; ++k) deriv[d->types[ne] * d->n_coeff + sb + k] += result[k];
+        }
+    } else if (is_prefix("placement_fixed", n->name)) memcpy(deriv, ((PlacementData*)n->data)->param_deriv, sizeof(float) * (size_t)expected);   /* placement.cpp:156-160 */
+    return 0;
+}
 
 int get_output_dims(int* n_elem, int* elem_width, DerivEngine* e, const char* node_name) {
     int i = find_node(e, node_name); if (i < 0) { fprintf(stderr, "ERROR: name not found\n"); return 1; }

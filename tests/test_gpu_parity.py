@@ -99,6 +99,56 @@ def test_forces_match_reference_golden(hip, name):
     up.close()
 
 
+@pytest.mark.parametrize('name', FIXTURES)
+def test_param_derivs_match_reference_golden(hip, name):
+    """get_param_deriv (engine_c_library.h:20) against the reference compiled with -DPARAM_DERIV (golden vectors from
+    tools/make_fixtures.py).  Tolerance: 1e-5 relative RMS of the table (measured 2e-7 .. 7e-6) except the fixed
+    placements, whose derivative is a sum of the sensitivities that flow back through the belief-propagation solve:
+    5e-5 there (measured up to 2.1e-5; the reference's own converged marginals spread more than that between
+    builds, profiles/r01_reference_noise_floor.txt)."""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    up.deriv(g['pos'])
+    keys = sorted(k for k in g if k.startswith('param_deriv/'))
+    assert len(keys) >= 9
+    for k in keys:
+        node = k.split('/', 1)[1]
+        act = up.get_param_deriv(g[k].shape, node)
+        if not np.any(g[k]):
+            assert not np.any(act), k                    # environment_coverage: zeros (environment.cpp:62-65)
+            continue
+        tol = 5e-5 if node.startswith('placement') else 1e-5
+        assert P.rel_rms(g[k], act) < tol, (k, P.rel_rms(g[k], act))
+        assert np.array_equal(g[k] == 0, act == 0) or node.startswith('placement'), k   # same support in the tables
+    up.close()
+
+
+def test_param_deriv_of_every_system(hip):
+    """the batched extension returns each system's own derivative"""
+    name = 'proteinG56_7A'
+    g = P.golden(name)
+    c = hip.calc
+    c.upside_hip_get_param_deriv.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int, ct.c_void_p]
+    e = c.upside_hip_construct(g['pos'].shape[0], P.fixture(name).encode(), 3, True)
+    x = np.stack([g['pos'], g['pos2'], g['pos']]).astype('f4')
+    assert c.upside_hip_set_pos(e, x.ctypes.data) == 0
+    en = np.zeros(3, 'f4')
+    assert c.upside_hip_compute(e, en.ctypes.data, None) == 0
+    shp = g['param_deriv/rotamer'].shape
+    out = np.zeros((3,) + shp, 'f4')
+    for s in range(3):
+        assert c.upside_hip_get_param_deriv(e, b'rotamer', s, int(np.prod(shp)), out[s].ctypes.data) == 0
+    assert c.upside_hip_get_param_deriv(e, b'rotamer', 3, int(np.prod(shp)), out[0].ctypes.data) == 1   # no such system
+    assert P.rel_rms(g['param_deriv/rotamer'], out[0]) < 1e-5
+    assert P.rel_rms(out[0], out[2]) < 1e-6
+    assert P.rel_rms(out[0], out[1]) > 1e-3          # a different structure
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())    # ... whose derivative the oracle confirms
+    orc.deriv(g['pos2'])
+    assert P.rel_rms(orc.get_param_deriv(shp, 'rotamer'), out[1]) < RTOL
+    orc.close()
+    c.free_deriv_engine(ct.c_void_p(e))
+
+
 def test_empty_and_degenerate_requests(hip):
     """error behaviour of the C-ABI mirrors engine_c_library.cpp: wrong sizes and unknown names return 1"""
     up = P.pkg.Upside(P.fixture('trpcage20_7A'))
@@ -106,7 +156,8 @@ def test_empty_and_degenerate_requests(hip):
     buf = np.zeros(5, 'f4')
     assert up.calc.get_output(5, buf.ctypes.data, up.engine, b'rama_coord') == 1        # wrong size
     assert up.calc.get_output(1, buf.ctypes.data, up.engine, b'no_such_node') == 1
-    assert up.calc.get_param_deriv(1, buf.ctypes.data, up.engine, b'rotamer') == -1     # built without PARAM_DERIV
+    assert up.calc.get_param_deriv(1, buf.ctypes.data, up.engine, b'rotamer') == 1      # wrong size (engine_c_library.cpp:96-98)
+    assert up.calc.get_param_deriv(0, buf.ctypes.data, up.engine, b'protein_hbond') == 0   # no derivative: empty vector
     assert up.calc.get_output(1, buf.ctypes.data, up.engine, b'rotamer') == 0           # potential node -> (1,1)
     with pytest.raises((RuntimeError, OSError)):
         P.pkg.Upside('/nonexistent/file.up')

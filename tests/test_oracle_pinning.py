@@ -47,6 +47,28 @@ def test_oracle_matches_reference_golden(oracle, name):
 
 
 @pytest.mark.parametrize('name', FIXTURES)
+def test_oracle_param_derivs_match_reference_golden(oracle, name):
+    """get_param_deriv of the restatement against the reference built with -DPARAM_DERIV (golden param_deriv/*):
+    spline-coefficient tables within TOL_OUT, the fixed placements (sums of sensitivities) within TOL_SENS"""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name), library=oracle)
+    up.deriv(g['pos'])
+    keys = sorted(k for k in g if k.startswith('param_deriv/'))
+    assert len(keys) >= 9
+    for k in keys:
+        node = k.split('/', 1)[1]
+        act = up.get_param_deriv(g[k].shape, node)
+        if not np.any(g[k]):
+            assert not np.any(act), k
+            continue
+        assert P.rel_rms(g[k], act) < (TOL_SENS if node.startswith('placement') else TOL_OUT), (k, P.rel_rms(g[k], act))
+    buf = np.zeros(1, 'f4')
+    assert up.calc.get_param_deriv(0, buf.ctypes.data, up.engine, b'protein_hbond') == 0    # no override in the reference
+    assert up.calc.get_param_deriv(1, buf.ctypes.data, up.engine, b'rotamer') == 1          # wrong size
+    up.close()
+
+
+@pytest.mark.parametrize('name', FIXTURES)
 def test_oracle_pairlist_bit_exact(oracle, name):
     """pair-list indices in the reference's canonical order, exact (integer work)."""
     g = P.golden(name)

@@ -8,6 +8,7 @@ C-ABI: total energy, (n_atom,3) derivative, every node's output/sens, the rotame
 and the canonical pair list.  Nothing here is needed at test time; tests read only tests/golden/.
 
 usage: python tools/make_fixtures.py [name ...]
+       python tools/make_fixtures.py --add-param-derivs [name ...]   (adds param_deriv/<node> to existing golden files)
 """
 import os
 import subprocess
@@ -44,6 +45,41 @@ POTENTIALS = ['rama_map_pot', 'rama_map_pot_ref', 'angle_spring', 'backbone_pair
 
 def rg(pos):
     return float(np.sqrt(((pos - pos.mean(axis=0)) ** 2).sum(axis=1).mean()))
+
+
+def param_shapes(config):
+    """get_param() shapes of the nodes that have parameter derivatives, read from the configuration"""
+    shapes = {}
+    with pkg.h5lite.open_file(config) as t:
+        pot = t.group('input/potential')
+        for nm in pot.keys():
+            g = pot.group(nm)
+            if nm == 'rotamer': shapes[nm] = g.group('pair_interaction').shape('interaction_param')
+            elif 'interaction_param' in g.keys() and nm != 'protein_hbond': shapes[nm] = g.shape('interaction_param')
+            elif nm.startswith('placement_fixed'): shapes[nm] = g.shape('placement_data')
+            elif nm.startswith('nonlinear_coupling'): shapes[nm] = g.shape('coeff')
+            elif nm == 'hbond_energy': shapes[nm] = (1,)
+    return shapes
+
+
+def param_derivs(up, config):
+    """get_param_deriv of every parametrised node after one evaluate_deriv at the initial structure (the reference
+    is compiled with -DPARAM_DERIV, oracle/Makefile)"""
+    up.deriv(up.initial_pos.copy())
+    return dict(('param_deriv/' + nm, up.get_param_deriv(tuple(shp), nm)) for nm, shp in sorted(param_shapes(config).items()))
+
+
+def add_param_derivs(name):
+    """extend an existing golden file in place (the other vectors stay byte-identical)"""
+    variant = FIXTURES[name][1]
+    out = os.path.join(GOLD, name + '.up')
+    g = dict(np.load(os.path.join(GOLD, name + '.golden.npz')))
+    lib = pkg.UpsideLibrary(os.path.join(REF, 'libupside_%s.so' % variant))
+    up = pkg.Upside(out, library=lib)
+    g.update(param_derivs(up, out))
+    up.close()
+    np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
+    print(name, dict((k, (v.shape, float(np.abs(v).max()))) for k, v in g.items() if k.startswith('param_deriv/')))
 
 
 def make(name):
@@ -96,6 +132,7 @@ def make(name):
     if n_res <= 60:
         em = up.get_value_by_name((n_node, n_node, 6, 6), 'rotamer', 'edge_marginal_in_graph_order')
         g['rotamer/node_marginal'] = np.stack([em[i, i].diagonal() for i in range(n_node)])
+    g.update(param_derivs(up, out))
     # a second, perturbed evaluation through the cached pair list (no rebuild)
     rs = np.random.RandomState(seed + 100)
     x2 = (x + 0.05 * rs.normal(size=x.shape)).astype('f4')
@@ -122,6 +159,10 @@ def make(name):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--add-param-derivs']:      # extend the committed golden files without regenerating them
+        for nm in sys.argv[2:] or list(FIXTURES):
+            add_param_derivs(nm)
+        sys.exit(0)
     names = sys.argv[1:] or list(FIXTURES)
     for nm in names:
         make(nm)

@@ -94,6 +94,9 @@ struct DerivComputation {   // deriv_engine.h:48-80
     virtual void propagate_deriv() = 0;
     virtual std::vector<float> get_param() const { return std::vector<float>(); }
     virtual void set_param(const std::vector<float>&) {}
+    // derivative of the total potential w.r.t. get_param(), for system `system` of the batch, from the state the last
+    // evaluate_deriv left on the device (deriv_engine.h:71-74; always compiled here)
+    virtual std::vector<float> get_param_deriv(int system) { (void)system; return std::vector<float>(); }
     virtual std::vector<float> get_value_by_name(const char*) { throw std::string("No values implemented"); }
     virtual void finalize() {}   // called once after the whole graph exists (scatter plans, device pointer tables)
     // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).

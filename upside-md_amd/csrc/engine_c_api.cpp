@@ -129,7 +129,20 @@ extern "C" int get_param(int n_param, float* param, DerivEngine* e, const char* 
     return 0;
     API_CATCH(1)
 }
-extern "C" int get_param_deriv(int, float*, DerivEngine*, const char*) { return -1; }   // built without PARAM_DERIV (:101-102)
+// engine_c_library.cpp:93-109 as built with -DPARAM_DERIV: system 0 of the batch
+static int param_deriv_of(int n_param, float* deriv, DerivEngine* e, const char* node_name, int system) {
+    if (system < 0 || system >= e->ctx.n_system) throw string("system index out of range");
+    auto v = e->get(string(node_name)).computation->get_param_deriv(system);
+    if (v.size() != size_t(n_param)) throw string("Wrong number of parameters, expected ") + to_string(v.size()) + " but got " + to_string(n_param);
+    copy(begin(v), end(v), deriv);
+    return 0;
+}
+extern "C" int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_name) {
+    API_TRY
+    return param_deriv_of(n_param, deriv, e, node_name, 0); API_CATCH(1) }
+extern "C" int upside_hip_get_param_deriv(DerivEngine* e, const char* node_name, int system, int n_param, float* deriv) {
+    API_TRY
+    return param_deriv_of(n_param, deriv, e, node_name, system); API_CATCH(1) }
 
 extern "C" int get_output_dims(int* n_elem, int* elem_width, DerivEngine* e, const char* node_name) {
     API_TRY

@@ -127,6 +127,41 @@ __device__ __forceinline__ float quadspline2(const QuadShape& Q, P p, const floa
     return wide + angular_weight * narrow;
 }
 
+// Parameter derivative of one quadspline pair (bead_interaction.h:86-130): the value is linear in the spline
+// coefficients, so d(value)/d(coefficient) is the basis weight of that coefficient (spline.h:318-336, 375-392) times
+// the other factors of  wide + a1*a2*narrow.  `scale` (pair sensitivity) * those weights is added to the parameter
+// row `out` of the pair's type combination.  Not on the MD path: plain global atomics.
+template <typename P>
+__device__ __forceinline__ void quadspline_param_accum(const QuadShape& Q, P p, const float* x1, const float* x2, float scale, float* out) {
+    const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
+    const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
+    const float dist2 = mag2(displace), inv_dist = rsqrtf(dist2);
+    const float dist_coord = dist2 * (inv_dist * Q.inv_dx);
+    const f3 u = inv_dist * displace;
+    const float cos1 = dot(rvec1, u), cos2 = -dot(rvec2, u);
+    float b1[4], b2[4], br[4], db[4];
+    const float xa1 = (cos1 + 1.f) * Q.inv_dtheta + 1.f, xa2 = (cos2 + 1.f) * Q.inv_dtheta + 1.f;
+    const int bin1 = (int)xa1, bin2 = (int)xa2;
+    float a1, a2, narrow, unused;
+    bspline_basis(xa1 - (float)bin1, b1, db); bspline_vd(a1, unused, p, bin1, b1, db);
+    bspline_basis(xa2 - (float)bin2, b2, db); bspline_vd(a2, unused, p + Q.ka, bin2, b2, db);
+    int rbin;   // first coefficient of the radial window
+    if (dist_coord <= 1.f) { rbin = 0; br[0] = 1.f / 6.f; br[1] = 2.f / 3.f; br[2] = 1.f / 6.f; br[3] = 0.f; }
+    else if (dist_coord >= (float)(Q.k - 2)) { rbin = Q.k - 4; br[0] = 0.f; br[1] = 1.f / 6.f; br[2] = 2.f / 3.f; br[3] = 1.f / 6.f; }
+    else { const int bin = (int)dist_coord; rbin = bin - 1; bspline_basis(dist_coord - (float)bin, br, db); }
+    {
+        P pn = p + 2 * Q.ka + Q.k;
+        narrow = pn[rbin] * br[0] + pn[rbin + 1] * br[1] + pn[rbin + 2] * br[2] + pn[rbin + 3] * br[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        atomicAdd(out + 2 * Q.ka + rbin + i, scale * br[i]);
+        atomicAdd(out + 2 * Q.ka + Q.k + rbin + i, scale * (a1 * a2 * br[i]));
+        atomicAdd(out + bin1 - 1 + i, scale * (a2 * narrow * b1[i]));
+        atomicAdd(out + Q.ka + bin2 - 1 + i, scale * (a1 * narrow * b2[i]));
+    }
+}
+
 // cooperative staging of one system's packed elements: element i of `node` (gathered through `loc`) becomes the
 // 8-float LDS row  [0,dim) coordinates | [6] aux0 | [7] aux1  where the aux words carry per-element metadata so
 // that the pair loop never touches global memory for them:

@@ -1038,3 +1038,73 @@ extern "C" int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const fl
     hipLaunchKernelGGL(k_replica_swap, dim3(1), dim3(UPK_BLOCK), 0, ST(L), pos, energy, beta, n_pair, pairs, seed, round, draw0, accepted);
     return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Parameter derivatives of the per-element nodes, for ONE system, into a zeroed table (the reference's
+// get_param_deriv under PARAM_DERIV).  Off the MD path: global atomics.
+
+// placement_fixed_*: sum over the elements of a layer of the sensitivity rotated into the reference frame
+// (placement.cpp:144-148 called from :296, read back by :156-160)
+__global__ void k_placement_param_deriv(upk_placement_t P, upk_coord_t aff, upk_coord_t out, int s, float* __restrict__ table) {
+    const int ne = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ne >= P.n_elem) return;
+    const float* a = C_OUT(aff, s) + (size_t)P.affine_residue[ne] * aff.stride;
+    float U[9]; quat_to_rot(U, a[3], a[4], a[5], a[6]);
+    const float* sn = C_SENS(out, s) + (size_t)ne * out.stride;
+    float* t = table + (size_t)P.layer[ne] * P.n_pos_dim;
+    int off = 0;
+    for (int k = 0; k < P.n_sig; ++k) {
+        if (P.sig[k] == 0) { atomicAdd(t + off, sn[off]); off += 1; }
+        else {
+            const f3 rs = apply_inverse_rotation(U, ld3(sn + off));
+            atomicAdd(t + off, rs.x); atomicAdd(t + off + 1, rs.y); atomicAdd(t + off + 2, rs.z);
+            off += 3;
+        }
+    }
+}
+extern "C" int upk_placement_param_deriv(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out, int system,
+                                         float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_placement_param_deriv, grid1(P->n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), *P, aff, out, system, table);
+    return launch_status();
+}
+
+// nonlinear_coupling: basis weights of the 4 coefficients under each element's coordinate (environment.cpp:375-389)
+__global__ void k_nonlinear_coupling_param_deriv(upk_coord_t input, const int* __restrict__ types, int n_coeff, float offset, float inv_dx,
+                                                 int s, float* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= input.n_elem) return;
+    const float x = (C_OUT(input, s)[(size_t)i * input.stride] - offset) * inv_dx;
+    int bin; float w[4];
+    if (x <= 1.f) { bin = 0; w[0] = 1.f / 6.f; w[1] = 2.f / 3.f; w[2] = 1.f / 6.f; w[3] = 0.f; }                       // spline.h:375-392
+    else if (x >= (float)(n_coeff - 2)) { bin = n_coeff - 4; w[0] = 0.f; w[1] = 1.f / 6.f; w[2] = 2.f / 3.f; w[3] = 1.f / 6.f; }
+    else {                                                                                                              // spline.h:318-336
+        const int x_bin = (int)x; bin = x_bin - 1;
+        const float excess = x - (float)x_bin;
+        float der;
+        uniform_deBoor(w[0], der, 1.f, 0.f, 0.f, 0.f, excess);
+        uniform_deBoor(w[1], der, 0.f, 1.f, 0.f, 0.f, excess);
+        uniform_deBoor(w[2], der, 0.f, 0.f, 1.f, 0.f, excess);
+        uniform_deBoor(w[3], der, 0.f, 0.f, 0.f, 1.f, excess);
+    }
+    for (int k = 0; k < 4; ++k) atomicAdd(table + (size_t)types[i] * n_coeff + bin + k, w[k]);
+}
+extern "C" int upk_nonlinear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t input, const int* types, int n_coeff, float offset,
+                                                  float inv_dx, int system, float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_nonlinear_coupling_param_deriv, grid1(input.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), input, types, n_coeff, offset,
+                       inv_dx, system, table);
+    return launch_status();
+}
+
+// hbond_energy: d(potential)/d(E_protein) = the number of protein hydrogen bonds (hbond.cpp:436-448)
+__global__ void k_column_sum(upk_coord_t c, int comp, int s, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_elem) return;
+    atomicAdd(out, C_OUT(c, s)[(size_t)i * c.stride + comp]);
+}
+extern "C" int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, int system, float* out) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_column_sum, grid1(c.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), c, comp, system, out);
+    return launch_status();
+}

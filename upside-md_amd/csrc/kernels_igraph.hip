@@ -618,3 +618,46 @@ extern "C" int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, 
     hipLaunchKernelGGL(k_igraph_inrange, dim3((G->n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, flags);
     return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Parameter derivative of one system's pair potential (interaction_graph.h:404-416, 497-503, 537-543): every
+// in-range pair adds  pair_sensitivity * d(pair value)/d(interaction_param[type1][type2][:])  to `table`
+// ([n_type1][n_type2][n_param], zeroed by the caller).  sens_mode as in k_igraph_grad.  Off the MD path.
+__global__ void k_igraph_param_deriv(upk_igraph_t G, int s, int sens_mode, const float* __restrict__ sens1, const float* __restrict__ sens2,
+                                     long sens_sys_stride, int sens_stride, float* __restrict__ table) {
+    const int lane = threadIdx.x & 63;
+    const float cut2 = G.cutoff * G.cutoff;
+    const float* S1 = sens1 ? sens1 + (size_t)s * sens_sys_stride : nullptr;
+    const float* S2 = sens2 ? sens2 + (size_t)s * sens_sys_stride : nullptr;
+    const QuadShape Q = quad_shape(G);
+    for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * ROWS_PER_BLOCK) {
+        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
+        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+        float xr[8];
+        load_elem(xr, G.node1, s, G.loc1[row], G.dim1);
+        const int t1 = G.type1[row];
+        for (int k = lane; k < cnt; k += 64) {
+            const int j = nbr[k];
+            float xo[8];
+            load_elem(xo, G.node2, s, G.loc2[j], G.dim2);
+            if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
+            float ps = 0.f;
+            if (sens_mode == 1 || sens_mode == 3) ps += S1[(size_t)row * sens_stride];
+            if (sens_mode == 2 || sens_mode == 3) ps += S2[(size_t)j * sens_stride];
+            const size_t prow = (size_t)(t1 * G.n_type2 + G.type2[j]) * G.n_param;
+            float* out = table + prow;
+            if (G.itype == UPK_IT_HBOND_COVERAGE) {                      // hbond.cpp:278-283
+                const float one_m = 1.f - xr[6];
+                quadspline_param_accum(Q, G.param + prow, xr, xo, ps * (one_m * one_m), out);
+            }   // environment.cpp:62-65: "not implemented" = zeros; protein_hbond has no get_param_deriv in the reference
+        }
+    }
+}
+extern "C" int upk_igraph_param_deriv(const upk_launch_t* L, const upk_igraph_t* G, int system, int sens_mode, const float* sens1,
+                                      const float* sens2, long sens_sys_stride, int sens_stride, float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    if (G->itype == UPK_IT_ROTAMER) return 9102;   // upk_rotamer_param_deriv owns the pair sensitivities of that graph
+    hipLaunchKernelGGL(k_igraph_param_deriv, dim3((G->n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(IG_BLOCK), 0, ST(L), *G, system,
+                       sens_mode, sens1, sens2, sens_sys_stride, sens_stride, table);
+    return launch_status();
+}

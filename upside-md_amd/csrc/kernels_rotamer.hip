@@ -462,6 +462,51 @@ extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     return launch_status();
 }
 
+// parameter derivative of one system (rotamer.cpp:1064-1066 -> interaction_graph.h:404-416): every in-range bead pair
+// (i1 < i2, types [type(i1)][type(i2)]) weighted by the pair sensitivity of rotamer.cpp:956-966 -- the same weight
+// k_rotamer_grad uses.  Reads the beads, the converged beliefs and pair marginals of the last solve.
+__global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict__ table) {
+    const upk_igraph_t& G = R.G;
+    const int lane = threadIdx.x & 63;
+    const float cut2 = G.cutoff * G.cutoff;
+    const float* base = G.node1.out + (size_t)s * G.node1.n_elem * G.node1.stride;
+    const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
+    const float* nbm = R.nb_cur + (size_t)s * R.n_node * 6;
+    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
+    for (int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * (blockDim.x >> 6)) {
+        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
+        const int* nsl = R.nbr_slot + ((size_t)s * G.n1 + row) * G.cap1;
+        const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+        float xr[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xr[c] = base[(size_t)G.loc1[row] * G.node1.stride + c];
+        const int mr = R.bead_meta[row], a = R.bead_node[row];
+        const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF;
+        for (int k = lane; k < cnt; k += 64) {
+            const int j = nbr[k];
+            if (j <= row) continue;
+            float xo[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) xo[c] = base[(size_t)G.loc1[j] * G.node1.stride + c];
+            if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
+            const int mo = R.bead_meta[j], b = R.bead_node[j];
+            const int rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
+            float ps;
+            if (na == 1 && nb == 1) ps = 1.f;
+            else if (na == 1) ps = nbm[b * 6 + rb];
+            else if (nb == 1) ps = nbm[a * 6 + ra];
+            else { const int sl = nsl[k]; ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)]; }
+            const size_t prow = (size_t)((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
+            quadspline_param_accum(Q, G.param + prow, xr, xo, ps, table + prow);
+        }
+    }
+}
+extern "C" int upk_rotamer_param_deriv(const upk_launch_t* L, const upk_rotamer_t* R, int system, float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_rotamer_param_deriv, dim3((R->G.n1 + 3) / 4), dim3(256), 0, ST(L), *R, system, table);
+    return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // belief propagation: one persistent workgroup per system (rotamer.cpp:1005-1061)
 __device__ __forceinline__ float block_max(float v, float* scratch) {

@@ -155,6 +155,15 @@ struct Infer_H_O : public CoordNode {
 };
 RegisterNodeType<Infer_H_O, 1> infer_node("infer_H_O");
 
+// get_param_deriv plumbing: a zeroed device table of the get_param() layout, filled by `launch` on the engine stream
+template <typename F>
+static vector<float> param_deriv_table(DeviceCtx* ctx, size_t n, F launch) {
+    DevBuf<float> table(n);
+    launch(table.p);
+    hip_check(hipStreamSynchronize(ctx->stream), "sync");
+    return table.download();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // placement: placement.cpp:233-325.  signature: 0 scalar, 1 vector, 2 point
 struct PlacementNode : public CoordNode {
@@ -224,6 +233,11 @@ struct PlacementNode : public CoordNode {
     }
     DevBuf<float> scalar_sink;
     vector<float> get_param() const override { return host_fixed; }
+    vector<float> get_param_deriv(int system) override {   // placement.cpp:95-96 (rama placements: none), :156-160
+        if (rama) return vector<float>();
+        return param_deriv_table(ctx, host_fixed.size(), [&](float* t) {
+            upk_check(upk_placement_param_deriv(&ctx->L, &P, alignment.coord(), coord(), system, t), "placement_param_deriv"); });
+    }
     void set_param(const vector<float>& p) override {
         if (rama) return;
         if (p.size() != host_fixed.size()) throw string("wrong param size");
@@ -502,6 +516,7 @@ struct ProteinHBond : public CoordNode {
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
+    // no get_param_deriv: the reference's ProteinHBond does not override it either (hbond.cpp:290-368) -> empty
 };
 RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
 
@@ -543,6 +558,10 @@ struct HBondCoverage : public CoordNode {
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
+    vector<float> get_param_deriv(int system) override {   // hbond.cpp:401-402 (this class); pair sensitivity of :395-397
+        return param_deriv_table(ctx, ig.param.size(), [&](float* t) {
+            upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 2, nullptr, sens.p, sys_stride(), stride, t), "hbond_coverage param_deriv"); });
+    }
     vector<float> get_value_by_name(const char* log_name) override {
         if (!strcmp(log_name, "count_edges_by_type")) return ig.count_edges_by_type(0);
         throw string("Value ") + log_name + string(" not implemented");
@@ -571,6 +590,10 @@ struct EnvironmentCoverage : public CoordNode {
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
+    vector<float> get_param_deriv(int system) override {   // environment.cpp:104-105; the functor's derivative is all zeros (:62-65)
+        return param_deriv_table(ctx, ig.param.size(), [&](float* t) {
+            upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 1, sens.p, nullptr, sys_stride(), stride, t), "environment_coverage param_deriv"); });
+    }
 };
 RegisterNodeType<EnvironmentCoverage, 2> environment_coverage_node("environment_coverage");
 
@@ -586,6 +609,9 @@ struct HBondEnergy : public HBondCounter {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
     vector<float> get_param() const override { return vector<float>(1, E_protein); }
+    vector<float> get_param_deriv(int system) override {   // hbond.cpp:447-448: n_hbond of the last evaluation
+        return param_deriv_table(ctx, 1, [&](float* t) { upk_check(upk_column_sum(&ctx->L, protein_hbond.coord(), 6, system, t), "hbond_energy param_deriv"); });
+    }
     void set_param(const vector<float>& p) override {
         if (p.size() != 1u) throw string("expected 1 param to hbond_energy but got " + to_string(p.size()));
         E_protein = p[0];
@@ -632,6 +658,10 @@ struct NonlinearCoupling : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
     vector<float> get_param() const override { return coeff; }
+    vector<float> get_param_deriv(int system) override {   // environment.cpp:375-389
+        return param_deriv_table(ctx, coeff.size(), [&](float* t) {
+            upk_check(upk_nonlinear_coupling_param_deriv(&ctx->L, input.coord(), types.p, n_coeff, spline_offset, spline_inv_dx, system, t), "nonlinear_coupling param_deriv"); });
+    }
     void set_param(const vector<float>& p) override {
         if (p.size() != coeff.size()) throw string("attempting to change size of coeff vector on set_param");
         coeff = p; hip_check(hipMemcpy(d_coeff.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
@@ -809,6 +839,9 @@ struct RotamerSidechain : public PotentialNode {
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); R.G = ig.G; }
+    vector<float> get_param_deriv(int system) override {   // rotamer.cpp:1064-1066
+        return param_deriv_table(ctx, ig.param.size(), [&](float* t) { upk_check(upk_rotamer_param_deriv(&ctx->L, &R, system, t), "rotamer param_deriv"); });
+    }
 
     vector<float> get_value_by_name(const char* log_name) override {   // rotamer.cpp:675-773 (system 0)
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
