@@ -577,11 +577,15 @@ struct BpCtx {
 template <int NA, int NB, bool WT>   // WT: messages leave through 16-byte write-through stores (cluster solve)
 __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
                                                    __amdgpu_buffer_rsrc_t inbox_w) {
+    // (measured and rejected: fetching the next slot's flag and message offsets one trip ahead.  In the 6x6 instance it
+    // spills 58 VGPRs (sweep 34.5 -> 47.7 us at 1024 systems); in the 3x3 / 3x6 instances alone it costs 1 % of the
+    // benchmark -- under load the sweep is limited by memory throughput, not by the two-trip chain)
     for (int sl = lo + tid; sl < hi; sl += nt) {
-        if (!C.active[sl]) continue;
+        const int act = C.active[sl], oa = C.slot_off[sl * 2], ob = C.slot_off[sl * 2 + 1];
+        if (!act) continue;
         const int a = C.slot_a[sl], b = C.slot_b[sl];
-        float* ma = C.msg(C.slot_off[sl * 2]);
-        float* mb = C.msg(C.slot_off[sl * 2 + 1]);
+        float* ma = C.msg(oa);
+        float* mb = C.msg(ob);
         float P[NA][NB], va[NA], vb[NB];
 #pragma unroll
         for (int i = 0; i < NA; ++i)
@@ -608,7 +612,6 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
             for (int i = 0; i < NA; ++i) ta[i] *= ra;
 #pragma unroll
             for (int j = 0; j < NB; ++j) tb[j] *= rb;
-            const int oa = C.slot_off[sl * 2], ob = C.slot_off[sl * 2 + 1];
             st_wt16(inbox_w, oa, ta[0], ta[1], ta[2], NA == 6 ? ta[NA - 3] : 1.f);
             if (NA == 6) st_wt16(inbox_w, oa + 4, ta[NA - 2], ta[NA - 1], 1.f, 1.f);
             st_wt16(inbox_w, ob, tb[0], tb[1], tb[2], NB == 6 ? tb[NB - 3] : 1.f);
@@ -626,13 +629,16 @@ __device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, co
     bp_edge_range_impl<NA, NB, false>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
 }
 // energies -> probabilities, in place, for slots [lo, hi) of one class (rotamer.cpp:835)
+// One slot per lane and trip: all NA*NB loads of the slot are issued before the first store, so a trip costs one
+// memory round trip instead of NA*NB dependent ones (the in-place update otherwise serialises load -> store -> load).
 template <int NA, int NB>
 __device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int tid, int nt) {
-    const int n = hi - lo;
-    for (int i = tid; i < n * NA * NB; i += nt) {
-        const int e = i / n, l = i - e * n;
-        float* p = P + (size_t)((e / NB) * 6 + e % NB) * cap + lo + l;
-        *p = expf(-*p);
+    for (int sl = lo + tid; sl < hi; sl += nt) {
+        float v[NA * NB];
+#pragma unroll
+        for (int e = 0; e < NA * NB; ++e) v[e] = P[(size_t)((e / NB) * 6 + e % NB) * cap + sl];
+#pragma unroll
+        for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = expf(-v[e]);
     }
 }
 
@@ -708,14 +714,13 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
 
-    // energies -> probabilities for the entries each class uses (rotamer.cpp:835)
-    for (int i = tid; i < n_slot * 36; i += nt) {
-        const int e = i / n_slot, sl = i % n_slot, ra = e / 6, rb = e % 6;
-        const int c = sl < cls[1] ? CL33 : (sl < cls[2] ? CL36 : (sl < cls[3] ? CL66 : (sl < cls[4] ? CL11 : CL1X)));
-        const int na = c == CL66 ? 6 : (c == CL33 || c == CL36 ? 3 : 1);
-        const int nb = c == CL33 ? 3 : (c == CL11 ? 1 : 6);       // 1xN: up to 6 columns (unused ones stay exp(0) = 1, never read)
-        if (ra < na && rb < nb) { const size_t pi = (size_t)e * C.cap + sl; C.P[pi] = expf(-C.P[pi]); }
-    }
+    // energies -> probabilities for the entries each class uses (rotamer.cpp:835); 1xN rows carry up to 6 columns
+    // (unused ones stay exp(0) = 1, never read)
+    exp_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], tid, nt);
+    exp_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], tid, nt);
+    exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt);
+    exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt);
+    exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt);
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
     // the head of the inbox stays in LDS as far as it reaches: the 4-float rows to the 3-state nodes come first, then
@@ -729,14 +734,32 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     for (int i = tid; i < bp_start[NN] * 4; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
+    // (four partners per trip: slot ids, then flags, then the rows, each as one batch of loads; same product order)
     for (int g = tid; g < NN; g += nt) {
         const int n = nrot[g];
         if (n == 1) continue;
-        for (int k = 0; k < adj_cnt[g]; ++k) {
-            const int sl = adj_slot[g * R.adj_cap + k];
-            if (!C.active[sl]) continue;
-            for (int r = 0; r < n; ++r) prob[g * 6 + r] *= C.P[(size_t)r * C.cap + sl];
+        const int cnt = adj_cnt[g];
+        float pr[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) pr[r] = prob[g * 6 + r];
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            int sl[4], act[4]; float row[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = adj_slot[g * R.adj_cap + (k0 + u < cnt ? k0 + u : k0)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) act[u] = k0 + u < cnt ? C.active[sl[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) row[u][r] = (r < 3 || n == 6) ? C.P[(size_t)r * C.cap + sl[u]] : 1.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (act[u])
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) if (r < n) pr[r] *= row[u][r];
         }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) if (r < n) prob[g * 6 + r] = pr[r];
     }
     __syncthreads();
     for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }   // old node belief = prob (rotamer.cpp:1009-1013)
@@ -767,18 +790,31 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
                 const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
-                int parity = 0;
-                for (int k = gl; k < deg; k += BP_GROUP) {
-                    const float* m = C.msg((base + k * q) * 4);
-                    const float4 m0 = *(const float4*)m;
-                    bb[0] *= m0.x; bb[1] *= m0.y; bb[2] *= m0.z;
-                    if (n == 6) { const float2 m1 = *(const float2*)(m + 4); bb[3] *= m0.w; bb[4] *= m1.x; bb[5] *= m1.y; }
-                    if ((++parity & 1) == 0) {          // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
-                        float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
-                        if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
-                        const float rm = fast_rcp(mx);
+                // four rows per trip are fetched before the first multiply (same operation order as one at a time)
+                for (int k0 = gl; k0 < deg; k0 += 4 * BP_GROUP) {
+                    float4 m0[4]; float2 m1[4];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + u * BP_GROUP;
+                        m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
+                        if (k < deg) {
+                            const float* m = C.msg((base + k * q) * 4);
+                            m0[u] = *(const float4*)m;
+                            if (n == 6) m1[u] = *(const float2*)(m + 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (k0 + u * BP_GROUP >= deg) break;
+                        bb[0] *= m0[u].x; bb[1] *= m0[u].y; bb[2] *= m0[u].z;
+                        if (n == 6) { bb[3] *= m0[u].w; bb[4] *= m1[u].x; bb[5] *= m1[u].y; }
+                        if (u & 1) {                    // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
+                            float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
+                            if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
+                            const float rm = fast_rcp(mx);
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                        }
                     }
                 }
             }
