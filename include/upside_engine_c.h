@@ -96,6 +96,8 @@ int upside_hip_mc_loaded(DerivEngine* engine, int sampler);
 
 /* recenter (deriv_engine.cpp:37-48) all systems */
 int upside_hip_recenter(DerivEngine* engine);
+/* the same with the z component left alone when xy_only != 0 (--disable-z-recentering, main.cpp:358-360,416) */
+int upside_hip_recenter_axes(DerivEngine* engine, int xy_only);
 
 /* Replica-exchange swap attempt among the systems of THIS engine (main.cpp:227-275): pairs (n_pair,2) are
  * one swap set; energies are evaluated, Metropolis tested with the REPLICA_EXCHANGE random stream

@@ -250,6 +250,44 @@ int upk_nonlinear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t input,
 /* sum over the elements of output component `comp` (hbond.cpp:436-448: n_hbond) */
 int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, int system, float* out);
 
+/* ---- optional restraint / external-field nodes (not emitted by the README configuration) ------------------------- */
+/* single-atom potentials on pos; par is [n][8]:
+ *   kind 0 atom_pos_spring (bonds.cpp:9-50)    x0[3], k
+ *   kind 1 tension         (bonds.cpp:53-90)   tension_coeff[3]
+ *   kind 2 AFM             (bonds.cpp:93-168)  k, starting_tip_pos[3], pulling_vel[3]; `time` = time_estimate
+ *   kind 3 z_flat_bottom   (bonds.cpp:377-427) z0, radius, k
+ * contrib: (n,3) contribution rows of pos' scatter plan */
+int upk_point_potential(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* par, int n, float time,
+                        float* contrib, long contrib_stride, float* pot_terms);
+/* contact (sidechain_radial.cpp:139-205): id (n,2); par [n][4] = energy, dist, 1/width, cutoff; contrib (n,2,3) */
+int upk_contact(const upk_launch_t* L, upk_coord_t bead, const int* id, const float* par, int n, float* contrib, long contrib_stride,
+                float* pot_terms);
+/* constant (bonds.cpp:550-587), slice (bonds.cpp:589-621) */
+int upk_broadcast_rows(const upk_launch_t* L, const float* value, upk_coord_t out);
+int upk_slice_fwd(const upk_launch_t* L, upk_coord_t in, const int* id, upk_coord_t out);
+int upk_slice_bwd(const upk_launch_t* L, upk_coord_t self, float* contrib, long contrib_stride);
+/* uniform_transform (environment.cpp:158-235); jac [S][n_elem] */
+int upk_uniform_transform_fwd(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset, float inv_dx,
+                              upk_coord_t out, float* jac);
+int upk_uniform_transform_bwd(const upk_launch_t* L, upk_coord_t in, upk_coord_t self, const float* jac);
+int upk_uniform_transform_param_deriv(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset, float inv_dx,
+                                      int system, float* table);
+/* linear_coupling_uniform / linear_coupling_with_inactivation (environment.cpp:237-321) */
+int upk_linear_coupling(const upk_launch_t* L, upk_coord_t in, const int* types, const float* couplings, upk_coord_t inact, int has_inact,
+                        int inact_dim, float* pot_terms);
+int upk_linear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t in, const int* types, upk_coord_t inact, int has_inact, int inact_dim,
+                                    int system, float* table);
+/* membrane_potential (membrane_potential.cpp:13-155) */
+typedef struct {
+    int n_res, n_donor;
+    const int *cb_index, *env_index, *restype;         /* [n_res] */
+    const float *cov_midpoint, *cov_sharpness;          /* [n_restype] */
+    const float *cb_coeff, *cb_table; int cb_nx;        /* monomial pieces [n_restype][cb_nx-1][4], raw table [n_restype][cb_nx] */
+    const float *uhb_coeff, *uhb_table; int uhb_nx;     /* 2 layers: unpaired donor, unpaired acceptor */
+    float cb_z_shift, cb_z_scale, uhb_z_shift, uhb_z_scale;
+} upk_membrane_t;
+int upk_membrane(const upk_launch_t* L, const upk_membrane_t* M, upk_coord_t cb, upk_coord_t env, upk_coord_t hb, float* pot_terms);
+
 /* protein_hbond finish (src/hbond.cpp:320-335): copy the 6 infer components, out[6] = 1 - exp(-sum) */
 int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out);
 /* protein_hbond backward prologue/epilogue (src/hbond.cpp:343-365): sens_scaled and pass-through */

@@ -1213,6 +1213,173 @@ static void placement_deriv(Engine* e, Node* n) {   /* placement.cpp:283-307, 80
     }
 }
 
+/* ---- optional restraint / external-field nodes (bonds.cpp, environment.cpp, sidechain_radial.cpp, membrane_potential.cpp) ---- */
+typedef struct { int kind, n; int* id; float* x0; float* k; float* v3; float* a; float* b; float time_initial, time_step; int round_num; } PointData;
+static void point_potential_value(Engine* e, Node* n, int mode) {
+    PointData* d = (PointData*)n->data; Node* pos = parent(e, n, 0);
+    float pot = 0.f;
+    if (d->kind == 2 && mode == DerivMode) d->round_num += 1;                     /* bonds.cpp:150 */
+    float time_estimate = d->time_initial + d->time_step * d->round_num;          /* bonds.cpp:151 */
+    for (int nt = 0; nt < d->n; ++nt) {
+        f3 x = f3_load(pos->output, d->id[nt]);
+        if (d->kind == 0) {                                                        /* atom_pos_spring, bonds.cpp:36-48 */
+            f3 disp = f3_sub(x, f3_make(d->x0[nt * 3], d->x0[nt * 3 + 1], d->x0[nt * 3 + 2]));
+            pot += 0.5f * d->k[nt] * f3_mag2(disp);
+            f3_update(pos->sens, d->id[nt], f3_scale(d->k[nt], disp));
+        } else if (d->kind == 1) {                                                 /* tension, bonds.cpp:73-88 */
+            f3 c = f3_make(d->v3[nt * 3], d->v3[nt * 3 + 1], d->v3[nt * 3 + 2]);
+            pot -= f3_dot(x, c);
+            f3_update(pos->sens, d->id[nt], f3_scale(-1.f, c));
+        } else if (d->kind == 2) {                                                 /* AFM, bonds.cpp:147-166 */
+            f3 tip = f3_add(f3_make(d->x0[nt * 3], d->x0[nt * 3 + 1], d->x0[nt * 3 + 2]),
+                            f3_scale(time_estimate, f3_make(d->v3[nt * 3], d->v3[nt * 3 + 1], d->v3[nt * 3 + 2])));
+            f3 diff = f3_sub(x, tip);
+            pot += 0.5 * d->k[nt] * f3_mag2(diff);
+            f3_update(pos->sens, d->id[nt], f3_scale(d->k[nt], diff));
+        } else {                                                                   /* z_flat_bottom, bonds.cpp:406-425 */
+            float z = x.v[2], z0 = d->a[nt], radius = d->b[nt];
+            float excess = z - z0 > radius ? z - z0 - radius : (z - z0 < -radius ? z - z0 + radius : 0.f);
+            VA(pos->sens, 2, d->id[nt]) += d->k[nt] * excess;
+            pot += 0.5f * d->k[nt] * sqr(excess);
+        }
+    }
+    if (mode == PotentialAndDerivMode || d->kind == 1 || d->kind == 2) n->potential = pot;
+}
+
+typedef struct { int n; int* id; float* energy; float* dist; float* scale; float* cutoff; } ContactData;
+static void contact_value(Engine* e, Node* n, int mode) {   /* sidechain_radial.cpp:187-204 */
+    (void)mode;
+    ContactData* d = (ContactData*)n->data; Node* bead = parent(e, n, 0);
+    float pot = 0.f;
+    for (int nc = 0; nc < d->n; ++nc) {
+        f3 disp = f3_sub(f3_load(bead->output, d->id[nc * 2]), f3_load(bead->output, d->id[nc * 2 + 1]));
+        float dist = sqrtf(f3_mag2(disp));
+        if (dist >= d->cutoff[nc]) continue;
+        float c[2]; compact_sigmoid(c, dist - d->dist[nc], d->scale[nc]);
+        pot += d->energy[nc] * c[0];
+        f3 deriv = f3_scale(d->energy[nc] * c[1] * rcpf(dist), disp);
+        f3_update(bead->sens, d->id[nc * 2], deriv);
+        f3_update(bead->sens, d->id[nc * 2 + 1], f3_scale(-1.f, deriv));
+    }
+    n->potential = pot;
+}
+
+typedef struct { float* value; } ConstantData;
+static void constant_value(Engine* e, Node* n, int mode) {   /* bonds.cpp:562-564 */
+    (void)e; (void)mode;
+    ConstantData* d = (ConstantData*)n->data;
+    for (int ne = 0; ne < n->n_elem; ++ne) for (int c = 0; c < n->elem_width; ++c) VA(n->output, c, ne) = d->value[ne * n->elem_width + c];
+}
+static void no_deriv(Engine* e, Node* n) { (void)e; (void)n; }
+
+typedef struct { int* id; } SliceData;
+static void slice_value(Engine* e, Node* n, int mode) {   /* bonds.cpp:605-611 */
+    (void)mode;
+    SliceData* d = (SliceData*)n->data; Node* pos = parent(e, n, 0);
+    for (int na = 0; na < n->n_elem; ++na) for (int c = 0; c < n->elem_width; ++c) VA(n->output, c, na) = VA(pos->output, c, d->id[na]);
+}
+static void slice_deriv(Engine* e, Node* n) {   /* bonds.cpp:613-619 */
+    SliceData* d = (SliceData*)n->data; Node* pos = parent(e, n, 0);
+    for (int na = 0; na < n->n_elem; ++na) for (int c = 0; c < n->elem_width; ++c) VA(pos->sens, c, d->id[na]) += VA(n->sens, c, na);
+}
+
+typedef struct { int n_coeff; float offset, inv_dx; float* coeff; float* jac; } UniformTransformData;
+static void uniform_transform_value(Engine* e, Node* n, int mode) {   /* environment.cpp:180-188 */
+    (void)mode;
+    UniformTransformData* d = (UniformTransformData*)n->data; Node* in = parent(e, n, 0);
+    for (int ne = 0; ne < n->n_elem; ++ne) {
+        float v[2]; clamped_deBoor_vd_scalar(v, d->coeff, (VA(in->output, 0, ne) - d->offset) * d->inv_dx, d->n_coeff);
+        VA(n->output, 0, ne) = v[0];
+        d->jac[ne] = v[1] * d->inv_dx;
+    }
+}
+static void uniform_transform_deriv(Engine* e, Node* n) {   /* environment.cpp:190-194 */
+    UniformTransformData* d = (UniformTransformData*)n->data; Node* in = parent(e, n, 0);
+    for (int ne = 0; ne < n->n_elem; ++ne) VA(in->sens, 0, ne) += d->jac[ne] * VA(n->sens, 0, ne);
+}
+
+typedef struct { int n_coupling; float* couplings; int* types; int has_inact, inact_dim; } LinearCouplingData;
+static void linear_coupling_value(Engine* e, Node* n, int mode) {   /* environment.cpp:286-300 */
+    (void)mode;
+    LinearCouplingData* d = (LinearCouplingData*)n->data; Node* in = parent(e, n, 0);
+    Node* inact = d->has_inact ? parent(e, n, 1) : NULL;
+    float pot = 0.f;
+    for (int ne = 0; ne < in->n_elem; ++ne) {
+        float c = d->couplings[d->types[ne]];
+        float act = inact ? sqr(1.f - VA(inact->output, d->inact_dim, ne)) : 1.f;
+        float val = VA(in->output, 0, ne);
+        pot += c * val * act;
+        VA(in->sens, 0, ne) += c * act;
+        if (inact) VA(inact->sens, d->inact_dim, ne) -= c * val;
+    }
+    n->potential = pot;
+}
+
+/* spline.cpp:192-259 and spline.h:456-515 (LayeredClampedSpline1D<1>) */
+static void solve_clamped_1d_spline(int n, double* coefficients, const double* data, double* ts) {
+    double *a = ts, *b = ts + n, *c = ts + 2 * n, *solution = ts + 3 * n;
+    for (int i = 0; i < n; ++i) { a[i] = 1. / 6.; b[i] = 2. / 3.; c[i] = 1. / 6.; solution[i] = data[i]; }
+    a[n - 1] *= 2.; c[0] *= 2.;
+    solve_tridiagonal_system(n, solution, a + 1, b, c);
+    for (int i = 0; i < 4 * (n - 1); ++i) coefficients[i] = 0.;
+    for (int i = 0; i < n; ++i)
+        for (int inc = 0; inc < 4; ++inc) {
+            int idx = i + inc - 2;
+            if (idx < 0 || idx >= n - 1) continue;
+            for (int k = 0; k < 4; ++k) coefficients[idx * 4 + k] += solution[i] * bspline_coeffs[inc][k];
+        }
+    for (int k = 0; k < 4; ++k) coefficients[k] += solution[1] * bspline_coeffs[3][k];
+    for (int k = 0; k < 4; ++k) coefficients[(n - 2) * 4 + k] += solution[n - 2] * bspline_coeffs[0][k];
+}
+typedef struct { int n_layer, nx; float* coeff; float* left; float* right; } ClampedSpline1D;
+static void clamped1d_fit(ClampedSpline1D* s, const double* data) {
+    s->coeff = (float*)xcalloc((size_t)s->n_layer * (s->nx - 1) * 4, sizeof(float));
+    s->left = (float*)xcalloc(s->n_layer, sizeof(float)); s->right = (float*)xcalloc(s->n_layer, sizeof(float));
+    double* ct = (double*)xcalloc((size_t)(s->nx - 1) * 4, sizeof(double)); double* ts = (double*)xcalloc((size_t)4 * s->nx, sizeof(double));
+    for (int il = 0; il < s->n_layer; ++il) {
+        s->left[il] = (float)data[il * s->nx]; s->right[il] = (float)data[il * s->nx + s->nx - 1];
+        solve_clamped_1d_spline(s->nx, ct, data + (size_t)il * s->nx, ts);
+        for (int i = 0; i < (s->nx - 1) * 4; ++i) s->coeff[(size_t)il * (s->nx - 1) * 4 + i] = (float)ct[i];
+    }
+    free(ct); free(ts);
+}
+static void clamped1d_eval(const ClampedSpline1D* s, float result[2], int layer, float x) {   /* result = (deriv, value) */
+    if (x >= s->nx - 1) { result[0] = 0.f; result[1] = s->right[layer]; }
+    else if (x <= 0) { result[0] = 0.f; result[1] = s->left[layer]; }
+    else {
+        int x_bin = (int)x; float fx = x - x_bin, fx2 = fx * fx, fx3 = fx * fx2;
+        const float* c = s->coeff + ((size_t)layer * (s->nx - 1) + x_bin) * 4;
+        result[0] = c[1] + 2.f * fx * c[2] + 3.f * fx2 * c[3];
+        result[1] = c[0] + fx * c[1] + fx2 * c[2] + fx3 * c[3];
+    }
+}
+typedef struct {
+    int n_elem, n_donor, n_acceptor; int *cb_index, *env_index, *restype; float *cov_midpoint, *cov_sharpness;
+    ClampedSpline1D cb, uhb; float cb_z_shift, cb_z_scale, uhb_z_shift, uhb_z_scale;
+} MembraneData;
+static void membrane_value(Engine* e, Node* n, int mode) {   /* membrane_potential.cpp:104-151 */
+    (void)mode;
+    MembraneData* d = (MembraneData*)n->data;
+    Node* cb = parent(e, n, 0); Node* env = parent(e, n, 1); Node* hb = parent(e, n, 2);
+    float pot = 0.f;
+    for (int nr = 0; nr < d->n_elem; ++nr) {
+        float r[2]; clamped1d_eval(&d->cb, r, d->restype[nr], (VA(cb->output, 2, d->cb_index[nr]) + d->cb_z_shift) * d->cb_z_scale);
+        float spline_value = r[1], spline_deriv = r[0] * d->cb_z_scale;
+        float sg[2]; compact_sigmoid(sg, VA(env->output, 0, d->env_index[nr]) - d->cov_midpoint[d->restype[nr]], d->cov_sharpness[d->restype[nr]]);
+        pot += spline_value * sg[0];
+        VA(cb->sens, 2, d->cb_index[nr]) += spline_deriv * sg[0];
+        VA(env->sens, 0, d->env_index[nr]) += spline_value * sg[1];
+    }
+    for (int nv = 0; nv < d->n_donor + d->n_acceptor; ++nv) {
+        float r[2]; clamped1d_eval(&d->uhb, r, nv >= d->n_donor, (VA(hb->output, 2, nv) + d->uhb_z_shift) * d->uhb_z_scale);
+        float spline_value = r[1], spline_deriv = r[0] * d->uhb_z_scale, uhb_prob = 1.f - VA(hb->output, 6, nv);
+        pot += spline_value * sqr(uhb_prob);
+        VA(hb->sens, 2, nv) += spline_deriv * sqr(uhb_prob);
+        VA(hb->sens, 6, nv) += -2.f * spline_value * uhb_prob;
+    }
+    n->potential = pot;
+}
+
 /* ---- backbone_pairs (backbone_steric.cpp) ---- */
 typedef struct { int n_res; int* residue; int* id; int* n_atom; float* ref_pos; float dist_cutoff; } BackboneData;
 static float nonbonded_kernel(int return_deriv, float r_mag2) {   /* backbone_steric.cpp:18-30 */
@@ -1651,6 +1818,77 @@ static int build_node(Engine* e, Node* n, hid_t grp, const char* name) {
         n->data = d; n->compute_value = w == 2 ? dist_spring_value : (w == 3 ? angle_spring_value : dihedral_spring_value);
         return 0;
     }
+    if (is_prefix("atom_pos_spring", name) || is_prefix("tension", name) || is_prefix("AFM", name) || is_prefix("z_flat_bottom", name)) {
+        PointData* d = (PointData*)xcalloc(1, sizeof(*d));
+        d->kind = is_prefix("atom_pos_spring", name) ? 0 : is_prefix("tension", name) ? 1 : is_prefix("AFM", name) ? 2 : 3;
+        d->id = h5_read_i(grp, d->kind == 0 ? "id" : "atom", 1, dims); if (!d->id) return -1; d->n = (int)dims[0];
+        if (d->kind == 0) { d->x0 = h5_read_f(grp, "x0", 2, dims); d->k = h5_read_f(grp, "spring_const", 1, dims); if (!d->x0 || !d->k) return -1; }
+        else if (d->kind == 1) { d->v3 = h5_read_f(grp, "tension_coeff", 2, dims); if (!d->v3) return -1; }
+        else if (d->kind == 2) {
+            d->k = h5_read_f(grp, "spring_const", 1, dims); d->x0 = h5_read_f(grp, "starting_tip_pos", 2, dims); d->v3 = h5_read_f(grp, "pulling_vel", 2, dims);
+            if (!d->k || !d->x0 || !d->v3) return -1;
+            d->time_initial = h5_attr_f(grp, "pulling_vel", "time_initial"); d->time_step = h5_attr_f(grp, "pulling_vel", "time_step");
+        } else {
+            d->a = h5_read_f(grp, "z0", 1, dims); d->b = h5_read_f(grp, "radius", 1, dims); d->k = h5_read_f(grp, "spring_constant", 1, dims);
+            if (!d->a || !d->b || !d->k) return -1;
+        }
+        n->data = d; n->compute_value = point_potential_value; return 0;
+    }
+    if (is_prefix("contact", name)) {
+        ContactData* d = (ContactData*)xcalloc(1, sizeof(*d));
+        d->id = h5_read_i(grp, "id", 2, dims); if (!d->id || dims[1] != 2) return -1; d->n = (int)dims[0];
+        d->energy = h5_read_f(grp, "energy", 1, dims); d->dist = h5_read_f(grp, "distance", 1, dims); d->scale = h5_read_f(grp, "width", 1, dims);
+        if (!d->energy || !d->dist || !d->scale) return -1;
+        d->cutoff = (float*)xcalloc(d->n, sizeof(float));
+        for (int i = 0; i < d->n; ++i) { d->scale[i] = 1.f / d->scale[i]; d->cutoff[i] = d->dist[i] + 1.f / d->scale[i]; }   /* sidechain_radial.cpp:170-171 */
+        n->data = d; n->compute_value = contact_value; return 0;
+    }
+    if (is_prefix("constant", name)) {
+        ConstantData* d = (ConstantData*)xcalloc(1, sizeof(*d));
+        d->value = h5_read_f(grp, "value", 2, dims); if (!d->value) return -1;
+        coord_node(n, (int)dims[0], (int)dims[1]); n->data = d; n->compute_value = constant_value; n->propagate_deriv = no_deriv; return 0;
+    }
+    if (is_prefix("slice", name)) {
+        SliceData* d = (SliceData*)xcalloc(1, sizeof(*d));
+        d->id = h5_read_i(grp, "id", 1, dims); if (!d->id) return -1;
+        coord_node(n, (int)dims[0], e->nodes[n->parents[0]].elem_width); n->data = d; n->compute_value = slice_value; n->propagate_deriv = slice_deriv; return 0;
+    }
+    if (is_prefix("uniform_transform", name)) {
+        UniformTransformData* d = (UniformTransformData*)xcalloc(1, sizeof(*d));
+        d->coeff = h5_read_f(grp, "bspline_coeff", 1, dims); if (!d->coeff) return -1; d->n_coeff = (int)dims[0];
+        d->offset = h5_attr_f(grp, "bspline_coeff", "spline_offset"); d->inv_dx = h5_attr_f(grp, "bspline_coeff", "spline_inv_dx");
+        int ne = e->nodes[n->parents[0]].n_elem;
+        d->jac = (float*)xcalloc(ne, sizeof(float));
+        coord_node(n, ne, 1); n->data = d; n->compute_value = uniform_transform_value; n->propagate_deriv = uniform_transform_deriv; return 0;
+    }
+    if (is_prefix("linear_coupling_uniform", name) || is_prefix("linear_coupling_with_inactivation", name)) {
+        LinearCouplingData* d = (LinearCouplingData*)xcalloc(1, sizeof(*d));
+        d->has_inact = is_prefix("linear_coupling_with_inactivation", name);
+        if (d->has_inact) d->inact_dim = h5_attr_i(grp, ".", "inactivation_dim", 0);
+        d->couplings = h5_read_f(grp, "couplings", 1, dims); if (!d->couplings) return -1; d->n_coupling = (int)dims[0];
+        d->types = h5_read_i(grp, "coupling_types", 1, dims); if (!d->types) return -1;
+        n->data = d; n->compute_value = linear_coupling_value; return 0;
+    }
+    if (is_prefix("membrane_potential", name)) {
+        MembraneData* d = (MembraneData*)xcalloc(1, sizeof(*d));
+        d->cb_index = h5_read_i(grp, "cb_index", 1, dims); if (!d->cb_index) return -1; d->n_elem = (int)dims[0];
+        d->env_index = h5_read_i(grp, "env_index", 1, dims); d->restype = h5_read_i(grp, "residue_type", 1, dims);
+        d->cov_midpoint = h5_read_f(grp, "cov_midpoint", 1, dims); d->cov_sharpness = h5_read_f(grp, "cov_sharpness", 1, dims);
+        if (!d->env_index || !d->restype || !d->cov_midpoint || !d->cov_sharpness) return -1;
+        if (h5_dims(grp, "donor_residue_ids", 1, dims)) return -1;
+        d->n_donor = (int)dims[0];
+        if (h5_dims(grp, "acceptor_residue_ids", 1, dims)) return -1;
+        d->n_acceptor = (int)dims[0];
+        double* cbe = h5_read_d(grp, "cb_energy", 2, dims); if (!cbe) return -1;
+        d->cb.n_layer = (int)dims[0]; d->cb.nx = (int)dims[1]; clamped1d_fit(&d->cb, cbe); free(cbe);
+        double* uhe = h5_read_d(grp, "uhb_energy", 2, dims); if (!uhe || dims[0] != 2) return -1;
+        d->uhb.n_layer = 2; d->uhb.nx = (int)dims[1]; clamped1d_fit(&d->uhb, uhe); free(uhe);
+        d->cb_z_shift = -h5_attr_f(grp, "cb_energy", "z_min");
+        d->cb_z_scale = (d->cb.nx - 1) / (h5_attr_f(grp, "cb_energy", "z_max") + d->cb_z_shift);
+        d->uhb_z_shift = -h5_attr_f(grp, "uhb_energy", "z_min");
+        d->uhb_z_scale = (d->uhb.nx - 1) / (h5_attr_f(grp, "uhb_energy", "z_max") + d->uhb_z_shift);
+        n->data = d; n->compute_value = membrane_value; return 0;
+    }
     if (is_prefix("cavity_radial", name)) {
         CavityData* d = (CavityData*)xcalloc(1, sizeof(*d));
         d->id = h5_read_i(grp, "id", 1, dims); if (!d->id) return -1; d->n = (int)dims[0];
@@ -1952,6 +2190,8 @@ int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_
     else if (is_prefix("hbond_energy", n->name)) expected = 1;
     else if (is_prefix("nonlinear_coupling", n->name)) { NonlinearData* d = (NonlinearData*)n->data; expected = d->n_restype * d->n_coeff; }
     else if (is_prefix("placement_fixed", n->name)) { PlacementData* d = (PlacementData*)n->data; expected = d->n_layer * d->n_pos_dim; }
+    else if (is_prefix("linear_coupling", n->name)) expected = ((LinearCouplingData*)n->data)->n_coupling;
+    else if (is_prefix("uniform_transform", n->name)) expected = 2 + ((UniformTransformData*)n->data)->n_coeff;
     if (n_param != expected) { fprintf(stderr, "ERROR: Wrong number of parameters, expected %i but got %i\n", expected, n_param); return 1; }
     if (g) igraph_param_deriv(g, deriv);
     else if (is_prefix("hbond_energy", n->name)) deriv[0] = ((HBondEnergyData*)n->data)->n_hbond;       /* hbond.cpp:447-448 */
@@ -1962,6 +2202,24 @@ int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_
             int sb; float result[4];
             clamped_deBoor_coeff_deriv(&sb, result, (VA(in->output, 0, ne) - d->offset) * d->inv_dx, d->n_coeff);
             for (int k = 0; k < 4; ++k) deriv[d->types[ne] * d->n_coeff + sb + k] += result[k];
+        }
+    } else if (is_prefix("linear_coupling", n->name)) {                                                  /* environment.cpp:301-312 */
+        LinearCouplingData* d = (LinearCouplingData*)n->data; Node* in = &e->nodes[n->parents[0]];
+        Node* inact = d->has_inact ? &e->nodes[n->parents[1]] : NULL;
+        for (int k = 0; k < expected; ++k) deriv[k] = 0.f;
+        for (int ne = 0; ne < in->n_elem; ++ne) {
+            float act = inact ? 1.f - VA(inact->output, d->inact_dim, ne) : 1.f;   /* sic: not squared there */
+            deriv[d->types[ne]] += VA(in->output, 0, ne) * act;
+        }
+    } else if (is_prefix("uniform_transform", n->name)) {                                                /* environment.cpp:205-221 */
+        UniformTransformData* d = (UniformTransformData*)n->data; Node* in = &e->nodes[n->parents[0]];
+        for (int k = 0; k < expected; ++k) deriv[k] = 0.f;
+        for (int ne = 0; ne < in->n_elem; ++ne) {
+            float coord = (VA(in->output, 0, ne) - d->offset) * d->inv_dx;
+            float v[2]; clamped_deBoor_vd_scalar(v, d->coeff, coord, d->n_coeff);
+            int sb; float result[4]; clamped_deBoor_coeff_deriv(&sb, result, coord, d->n_coeff);
+            deriv[0] += v[1]; deriv[1] += v[1] * (VA(in->output, 0, ne) - d->offset);
+            for (int k = 0; k < 4; ++k) deriv[2 + sb + k] += result[k];
         }
     } else if (is_prefix("placement_fixed", n->name)) memcpy(deriv, ((PlacementData*)n->data)->param_deriv, sizeof(float) * (size_t)expected);   /* placement.cpp:156-160 */
     return 0;

@@ -101,13 +101,20 @@ def canonical_sort(edges):
     return e[order]
 
 
-def evaluate_all(up, pos):
+# the optional restraint / external-field nodes of the fixture proteinG56_restraints (tools/make_fixtures.py)
+RESTRAINT_POTENTIALS = ['z_flat_bottom', 'tension', 'AFM', 'atom_pos_spring', 'contact', 'membrane_potential',
+                        'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env',
+                        'atom_pos_spring_on_slice']
+RESTRAINT_COORDS = ['placement_fixed_point_only_CB', 'slice_hbond_for_coupling', 'slice_pos_for_spring']
+
+
+def evaluate_all(up, pos, extra_coords=(), extra_potentials=()):
     """energy, deriv and every node's output/sens through the C-ABI."""
     res = dict(energy=np.float32(up.energy(pos)), deriv=up.deriv(pos))
-    for nm in COORD_NODES:
+    for nm in COORD_NODES + list(extra_coords):
         res['out/' + nm] = up.get_output(nm)
         res['sens/' + nm] = up.get_sens(nm)
-    for nm in POTENTIAL_NODES:
+    for nm in POTENTIAL_NODES + list(extra_potentials):
         res['pot/' + nm] = up.get_output(nm)[0, 0]
     return res
 

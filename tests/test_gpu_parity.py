@@ -123,6 +123,35 @@ def test_param_derivs_match_reference_golden(hip, name):
     up.close()
 
 
+def test_optional_restraint_nodes_match_oracle_and_reference(hip):
+    """the optional restraint / external-field nodes (z_flat_bottom, tension, AFM, atom_pos_spring, contact,
+    membrane_potential, linear_coupling_uniform / _with_inactivation, slice, placement_fixed_point_only): energies,
+    forces, node outputs and sensitivities against the oracle (1e-5) and the reference's golden vectors"""
+    name = 'proteinG56_restraints'
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    act = P.evaluate_all(up, g['pos'], P.RESTRAINT_COORDS, P.RESTRAINT_POTENTIALS)
+    ref = P.evaluate_all(orc, g['pos'], P.RESTRAINT_COORDS, P.RESTRAINT_POTENTIALS)
+    keys = [k for k in ref if k != 'energy']
+    assert_close(ref, act, keys=keys)
+    scale = sum(abs(float(ref['pot/' + k])) for k in P.POTENTIAL_NODES + P.RESTRAINT_POTENTIALS)
+    assert abs(float(ref['energy']) - float(act['energy'])) < RTOL * scale
+    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4                       # the reference's own spread, as above
+    for k in g:
+        if k.startswith('pot/') and k[4:] in P.RESTRAINT_POTENTIALS:
+            assert abs(float(g[k]) - float(act[k])) < RTOL * max(1., abs(float(g[k]))), k
+        if k.startswith('param_deriv/'):
+            assert P.rel_rms(g[k], up.get_param_deriv(g[k].shape, k.split('/', 1)[1])) < RTOL, k
+    # a second structure, through the cached pair lists, oracle only
+    act2 = P.evaluate_all(up, g['pos'] + np.float32(0.05) * np.random.RandomState(3).normal(size=g['pos'].shape).astype('f4'),
+                          P.RESTRAINT_COORDS, P.RESTRAINT_POTENTIALS)
+    ref2 = P.evaluate_all(orc, g['pos'] + np.float32(0.05) * np.random.RandomState(3).normal(size=g['pos'].shape).astype('f4'),
+                          P.RESTRAINT_COORDS, P.RESTRAINT_POTENTIALS)
+    assert_close(ref2, act2, keys=keys)
+    up.close(); orc.close()
+
+
 def test_param_deriv_of_every_system(hip):
     """the batched extension returns each system's own derivative"""
     name = 'proteinG56_7A'
@@ -444,6 +473,38 @@ def test_upside_main_output_matches_reference(hip, tmp_path):
         assert np.array_equal(g_['replica_index'], r['replica_index']), (g_['replica_index'].ravel(), r['replica_index'].ravel())
         assert np.allclose(g_['temperature'], r['temperature'])
         assert P.rel_rms(r['pos'][1], g_['pos'][1]) < 1e-3
+
+
+def test_upside_main_with_restraint_nodes_matches_reference(hip, tmp_path):
+    """MD through `upside_main` on the configuration that carries every optional restraint / external-field node,
+    against the reference executable: same first frames.  The AFM tip moves with every force evaluation of the
+    integrator (bonds.cpp:150-151), which the logged potential of the later frames only matches if the node counts
+    the evaluations the way the reference does."""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'proteinG56_restraints'
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up')
+    shutil.copyfile(P.fixture(name), a); shutil.copyfile(P.fixture(name), b)
+    args = ['--duration', '1.08', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '11']   # 40 rounds, frame every 10
+    # z-dependent potentials refuse full recentring in both programs (main.cpp:548-556)
+    assert subprocess.run([ref_exe] + args + [a], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).returncode != 0
+    with pytest.raises(RuntimeError):
+        hip.in_process_upside(args + [b], verbose=False)
+    args += ['--disable-z-recentering']
+    subprocess.run([ref_exe] + args + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                   env=dict(os.environ, OMP_NUM_THREADS='1'))
+    hip.in_process_upside(args + [b], verbose=False)
+    ref, _ = _read_output(a)
+    got, _ = _read_output(b)
+    assert got['pos'].shape == ref['pos'].shape and np.array_equal(got['time'], ref['time'])
+    assert np.abs(got['pos'][0] - ref['pos'][0]).max() < 2e-5
+    assert P.rel_rms(ref['pos'][1], got['pos'][1]) < 1e-4
+    assert P.rel_rms(ref['pos'][2], got['pos'][2]) < 1e-3
+    for fr in (0, 1, 2):     # the AFM term alone moves by ~1 energy unit per frame on this fixture
+        assert abs(got['potential'][fr, 0] - ref['potential'][fr, 0]) < 2e-4 * abs(ref['potential'][fr, 0]), fr
 
 
 def test_upside_main_pivot_moves_match_reference(hip, tmp_path):

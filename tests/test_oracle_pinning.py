@@ -68,6 +68,28 @@ def test_oracle_param_derivs_match_reference_golden(oracle, name):
     up.close()
 
 
+def test_oracle_optional_nodes_match_reference_golden(oracle):
+    """z_flat_bottom, tension, AFM, atom_pos_spring, contact, membrane_potential, linear_coupling_uniform /
+    _with_inactivation, slice (bonds.cpp, environment.cpp, sidechain_radial.cpp, membrane_potential.cpp) on the
+    fixture that carries all of them, against the compiled reference"""
+    g = P.golden('proteinG56_restraints')
+    up = P.pkg.Upside(P.fixture('proteinG56_restraints'), library=oracle)
+    act = P.evaluate_all(up, g['pos'], P.RESTRAINT_COORDS, P.RESTRAINT_POTENTIALS)
+    assert P.rel_rms(g['deriv'], act['deriv']) < TOL_SENS
+    for k in sorted(g):
+        if k.startswith('pot/') and k[4:] in P.RESTRAINT_POTENTIALS:
+            assert abs(float(g[k]) - float(act[k])) < TOL_OUT * max(1., abs(float(g[k]))), k
+        elif k.startswith('out/'):
+            assert P.rel_rms(g[k], act[k]) < TOL_OUT, k
+        elif k.startswith('sens/'):
+            assert P.rel_rms(g[k], act[k]) < TOL_SENS, k
+        elif k.startswith('param_deriv/'):
+            assert P.rel_rms(g[k], up.get_param_deriv(g[k].shape, k.split('/', 1)[1])) < TOL_OUT, k
+    scale = sum(abs(float(act['pot/' + k])) for k in P.POTENTIAL_NODES + P.RESTRAINT_POTENTIALS)
+    assert abs(float(g['energy']) - float(act['energy'])) < TOL_OUT * 10 * scale
+    up.close()
+
+
 @pytest.mark.parametrize('name', FIXTURES)
 def test_oracle_pairlist_bit_exact(oracle, name):
     """pair-list indices in the reference's canonical order, exact (integer work)."""

@@ -9,6 +9,7 @@ and the canonical pair list.  Nothing here is needed at test time; tests read on
 
 usage: python tools/make_fixtures.py [name ...]
        python tools/make_fixtures.py --add-param-derivs [name ...]   (adds param_deriv/<node> to existing golden files)
+       python tools/make_fixtures.py --restraints                    (proteinG56_restraints: every optional node)
 """
 import os
 import subprocess
@@ -80,6 +81,58 @@ def add_param_derivs(name):
     up.close()
     np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
     print(name, dict((k, (v.shape, float(np.abs(v).max()))) for k, v in g.items() if k.startswith('param_deriv/')))
+
+
+RESTRAINT_NODES = ['z_flat_bottom', 'tension', 'AFM', 'atom_pos_spring', 'contact', 'membrane_potential',
+                   'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env', 'atom_pos_spring_on_slice']
+
+
+def restraint_spec(n_res, seed=5):
+    """synthetic parameters for every optional node (there is no membrane library under parameters/: smooth random
+    tables stand in for it -- the node only sees tables)"""
+    rs = np.random.RandomState(seed)
+    res = lambda k: rs.choice(n_res, k, replace=False)
+    z = np.linspace(-30., 30., 61)
+    cb = np.array([rs.normal() * np.tanh(z / rs.uniform(4, 9)) + 0.3 * rs.normal() * np.exp(-(z / 6.) ** 2) for _ in range(20)])
+    uhb = np.array([1.5 * np.exp(-(z / 9.) ** 2), 1.1 * np.exp(-((z - 2.) / 8.) ** 2)])
+    pairs = np.array([(i, j) for i in range(n_res) for j in range(i + 4, n_res)])
+    pairs = pairs[rs.choice(len(pairs), 40, replace=False)]
+    return dict(
+        z_flat_bottom=np.column_stack((res(6), rs.normal(0, 3, 6), rs.uniform(1, 4, 6), rs.uniform(0.5, 2, 6))),
+        tension=np.column_stack((res(3), rs.normal(0, 0.2, (3, 3)))),
+        afm=(np.column_stack((res(2), rs.uniform(0.05, 0.2, 2), rs.normal(0, 10, (2, 3)), rs.normal(0, 0.5, (2, 3)))), 7.5, 0.027),
+        pos_spring=np.column_stack((rs.choice(3 * n_res, 5, replace=True), rs.normal(0, 8, (5, 3)), rs.uniform(0.1, 1., 5))),
+        contacts=np.column_stack((pairs, rs.normal(-1., 1., 40), rs.uniform(5., 9., 40), rs.uniform(0.8, 2.5, 40))),
+        membrane=dict(cb_energy=cb, uhb_energy=uhb, z_min=z[0], z_max=z[-1], cov_midpoint=rs.normal(4., 1., 20),
+                      cov_sharpness=rs.uniform(0.2, 0.6, 20), residue_type=rs.randint(0, 20, n_res)),
+        slice_spring=rs.choice(3 * n_res, 12, replace=True))
+
+
+def make_restraints(base='proteinG56_7A', name='proteinG56_restraints'):
+    """a copy of an existing fixture with every optional restraint / external-field node added; golden vectors from
+    the compiled reference (two files: linear_coupling_uniform and linear_coupling_with_inactivation variants share it)"""
+    import shutil
+    variant = FIXTURES[base][1]
+    out = os.path.join(GOLD, name + '.up')
+    shutil.copyfile(os.path.join(GOLD, base + '.up'), out)
+    n_res = len(cfg.PROTEIN_G) if base.startswith('proteinG') else FIXTURES[base][0]
+    spec = restraint_spec(n_res)
+    cfg.add_restraints(out, linear_coupling=dict(couplings=np.random.RandomState(9).normal(0, 0.3, 20), inactivation=False), **spec)
+    cfg.add_restraints(out, linear_coupling=dict(couplings=np.random.RandomState(10).normal(0, 0.3, 20), inactivation=True))
+    lib = pkg.UpsideLibrary(os.path.join(REF, 'libupside_%s.so' % variant))
+    up = pkg.Upside(out, library=lib)
+    x = up.initial_pos.copy()
+    g = dict(pos=x, energy=np.float32(up.energy(x)), deriv=up.deriv(x))
+    for nm in RESTRAINT_NODES + POTENTIALS:
+        g['pot/' + nm] = up.get_output(nm)[0, 0]
+    for nm in NODES + ['placement_fixed_point_only_CB', 'slice_hbond_for_coupling', 'slice_pos_for_spring']:
+        g['out/' + nm] = up.get_output(nm)
+        g['sens/' + nm] = up.get_sens(nm)
+    for nm in ('linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env'):
+        g['param_deriv/' + nm] = up.get_param_deriv((20,), nm)
+    up.close()
+    np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
+    print(name, 'energy %.4f' % g['energy'], dict((k, float(v)) for k, v in g.items() if k.startswith('pot/') and k[4:] in RESTRAINT_NODES))
 
 
 def make(name):
@@ -159,6 +212,9 @@ def make(name):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--restraints']:            # the optional-node fixture (built on proteinG56_7A)
+        make_restraints()
+        sys.exit(0)
     if sys.argv[1:2] == ['--add-param-derivs']:      # extend the committed golden files without regenerating them
         for nm in sys.argv[2:] or list(FIXTURES):
             add_param_derivs(nm)

@@ -416,3 +416,93 @@ def add_jump_moves(path, atom_ranges, sigma_trans, sigma_rot):
         g.write('atom_range', np.asarray(atom_ranges, 'i4').reshape(-1, 2))
         g.write('sigma_trans', np.asarray(sigma_trans, 'f4').reshape(-1))
         g.write('sigma_rot', np.asarray(sigma_rot, 'f4').reshape(-1))
+
+
+def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=None, contacts=None, membrane=None,
+                   linear_coupling=None, slice_spring=None):
+    """add the optional restraint / external-field nodes of py/upside_config.py to an existing configuration, with
+    the dataset names and argument lists the reference's writers use:
+      z_flat_bottom: rows (residue, z0, radius, spring_constant)        upside_config.py:46-79  (CA atom = 3*res+1)
+      tension:       rows (residue, tx, ty, tz)                         upside_config.py:82-108
+      afm:           (rows (residue, k, tip xyz, vel xyz), time_initial, time_step)   upside_config.py:111-146
+      pos_spring:    rows (atom, x0 xyz, k)                             atom_pos_spring, src/bonds.cpp:9-50
+      contacts:      rows (res1, res2, energy, distance, width)         upside_config.py:814-853 (+ write_CB, :795-812)
+      membrane:      dict(cb_energy (n_restype,nz), uhb_energy (2,nz), z_min, z_max, cov_midpoint, cov_sharpness,
+                          residue_type (n_res))                         the datasets of upside_config.py:1137-1149
+      linear_coupling: dict(couplings (n_type), inactivation (bool))    linear_coupling_* on environment_coverage
+                                                                        (the commented-out writer, upside_config.py:274-285)
+      slice_spring:  atom ids: a `slice` of pos (src/bonds.cpp:589-621) feeding an `atom_pos_spring`
+    """
+    with h5lite.open_file(path, 'r+') as f:
+        inp = f.group('input')
+        pot = inp.group('potential')
+        n_atom = inp.shape('pos')[0]
+        n_res = n_atom // 3
+
+        def ca(rows):
+            res = np.asarray([int(r[0]) for r in rows])
+            assert ((0 <= res) & (res < n_res)).all()
+            return (res * 3 + 1).astype('i4')
+        if z_flat_bottom is not None:
+            r = np.asarray(z_flat_bottom, 'f8')
+            g = pot.create_group('z_flat_bottom'); _args(g, ['pos'])
+            g.write('atom', ca(r)); g.write('z0', r[:, 1]); g.write('radius', r[:, 2]); g.write('spring_constant', r[:, 3])
+        if tension is not None:
+            r = np.asarray(tension, 'f8')
+            g = pot.create_group('tension'); _args(g, ['pos'])
+            g.write('atom', ca(r)); g.write('tension_coeff', r[:, 1:4])
+        if afm is not None:
+            rows, time_initial, time_step = afm
+            r = np.asarray(rows, 'f8')
+            g = pot.create_group('AFM'); _args(g, ['pos'])
+            g.write('atom', ca(r)); g.write('spring_const', r[:, 1]); g.write('starting_tip_pos', r[:, 2:5]); g.write('pulling_vel', r[:, 5:8])
+            g.set_attr('time_initial', float(time_initial), 'pulling_vel'); g.set_attr('time_step', float(time_step), 'pulling_vel')
+        if pos_spring is not None:
+            r = np.asarray(pos_spring, 'f8')
+            g = pot.create_group('atom_pos_spring'); _args(g, ['pos'])
+            g.write('id', r[:, 0].astype('i4')); g.write('x0', r[:, 1:4]); g.write('spring_const', r[:, 4])
+        if (contacts is not None or membrane is not None) and 'placement_fixed_point_only_CB' not in pot:
+            g = pot.create_group('placement_fixed_point_only_CB'); _args(g, ['affine_alignment'])
+            ref = np.array([(-1.19280531, -0.83127186, 0.), (0., 0., 0.), (1.25222632, -0.87268266, 0.), (0., 0.94375626, 1.2068012)])
+            ref -= ref[:3].mean(axis=0, keepdims=True)
+            g.write('affine_residue', np.arange(n_res, dtype='i4')); g.write('layer_index', np.zeros(n_res, 'i4'))
+            g.write('placement_data', ref[3:4].copy())
+        if contacts is not None:
+            r = np.asarray(contacts, 'f8')
+            assert (r[:, 4] > 0).all()
+            g = pot.create_group('contact'); _args(g, ['placement_fixed_point_only_CB'])
+            g.write('id', r[:, :2].astype('i4')); g.write('energy', r[:, 2]); g.write('distance', r[:, 3]); g.write('width', r[:, 4])
+        if membrane is not None:
+            seq = [x.decode() for x in inp.read('sequence')]
+            g = pot.create_group('membrane_potential')
+            _args(g, ['placement_fixed_point_only_CB', 'environment_coverage', 'protein_hbond'])
+            donors = np.array([i for i in range(n_res) if i > 0 and seq[i] != 'PRO'], 'i4')       # upside_config.py:1058-1059
+            acceptors = np.array([i for i in range(n_res) if i < n_res - 1], 'i4')
+            g.write('cb_index', np.arange(n_res, dtype='i4')); g.write('env_index', np.arange(n_res, dtype='i4'))
+            g.write('residue_type', np.asarray(membrane['residue_type'], 'i4'))
+            g.write('cov_midpoint', np.asarray(membrane['cov_midpoint'], 'f8')); g.write('cov_sharpness', np.asarray(membrane['cov_sharpness'], 'f8'))
+            g.write('cb_energy', np.asarray(membrane['cb_energy'], 'f8')); g.write('uhb_energy', np.asarray(membrane['uhb_energy'], 'f8'))
+            g.write('donor_residue_ids', donors); g.write('acceptor_residue_ids', acceptors)
+            for nm in ('cb_energy', 'uhb_energy'):
+                g.set_attr('z_min', float(membrane['z_min']), nm); g.set_attr('z_max', float(membrane['z_max']), nm)
+        if linear_coupling is not None:
+            types = pot.group('nonlinear_coupling_environment').read('coupling_types', 'i4')
+            name = 'linear_coupling_with_inactivation_env' if linear_coupling.get('inactivation') else 'linear_coupling_uniform_env'
+            g = pot.create_group(name)
+            if linear_coupling.get('inactivation'):
+                # one residue per environment element; the burial of a residue is switched off by the hydrogen-bond
+                # probability (component 6) of a protein_hbond row -- a synthetic pairing, only to exercise the node
+                _args(g, ['environment_coverage', 'slice_hbond_for_coupling'])
+                g.set_attr('inactivation_dim', 6)
+                sg = pot.create_group('slice_hbond_for_coupling'); _args(sg, ['protein_hbond'])
+                n_hb = pot.group('protein_hbond').shape('index1')[0] + pot.group('protein_hbond').shape('index2')[0]
+                sg.write('id', (np.arange(len(types)) % n_hb).astype('i4'))
+            else:
+                _args(g, ['environment_coverage'])
+            g.write('couplings', np.asarray(linear_coupling['couplings'], 'f8')); g.write('coupling_types', types)
+        if slice_spring is not None:
+            ids = np.asarray(slice_spring, 'i4')
+            sg = pot.create_group('slice_pos_for_spring'); _args(sg, ['pos'])
+            sg.write('id', ids)
+            g = pot.create_group('atom_pos_spring_on_slice'); _args(g, ['slice_pos_for_spring'])
+            g.write('id', np.arange(len(ids), dtype='i4')); g.write('x0', np.zeros((len(ids), 3))); g.write('spring_const', np.full(len(ids), 0.3))

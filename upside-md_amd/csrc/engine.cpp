@@ -161,7 +161,7 @@ int DerivEngine::get_idx(const string& name, bool must_exist) {
 }
 
 void DerivEngine::finalize() {
-    for (auto& n : nodes) n.computation->finalize();
+    for (auto& n : nodes) { n.computation->finalize(); if (!n.computation->capturable()) graph_failed = true; }
     // Unroll the level-synchronous sweep of deriv_engine.cpp:124-169 once; the order of events is static.
     schedule.clear();
     for (auto& n : nodes) n.germ_exec_level = n.deriv_exec_level = -1;

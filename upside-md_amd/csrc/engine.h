@@ -99,6 +99,7 @@ struct DerivComputation {   // deriv_engine.h:48-80
     virtual std::vector<float> get_param_deriv(int system) { (void)system; return std::vector<float>(); }
     virtual std::vector<float> get_value_by_name(const char*) { throw std::string("No values implemented"); }
     virtual void finalize() {}   // called once after the whole graph exists (scatter plans, device pointer tables)
+    virtual bool capturable() const { return true; }   // false: kernel arguments change from step to step (no hipGraph replay)
     // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).
     // The engine enqueues it on a side stream as soon as the last parent is computed, so a straggling rebuild of a
     // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).
@@ -232,6 +233,20 @@ struct RegisterNodeType<NodeClass, -1> {
         add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
             if (!args.size()) throw std::string("Expected at least 1 arg");
             return new NodeClass(c, grp, args); });
+    }
+};
+template <typename NodeClass>
+struct RegisterNodeType<NodeClass, 0> {
+    RegisterNodeType(std::string name_prefix) {
+        add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
+            check_arguments_length(args, 0); return new NodeClass(c, grp); });
+    }
+};
+template <typename NodeClass>
+struct RegisterNodeType<NodeClass, 3> {
+    RegisterNodeType(std::string name_prefix) {
+        add_node_creation_function(name_prefix, [](DeviceCtx* c, hid_t_compat grp, const ArgList& args) {
+            check_arguments_length(args, 3); return new NodeClass(c, grp, *args[0], *args[1], *args[2]); });
     }
 };
 template <typename NodeClass>

@@ -305,6 +305,8 @@ extern "C" int upside_hip_mc_stats(DerivEngine* e, int sampler, int* stats, int 
 extern "C" int upside_hip_mc_loaded(DerivEngine* e, int sampler) { return e ? (sampler == 0 ? e->pivot.loaded : (sampler == 1 ? e->jump.loaded : 0)) : 0; }
 extern "C" int upside_hip_recenter(DerivEngine* e) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
+extern "C" int upside_hip_recenter_axes(DerivEngine* e, int xy_only) {
+    API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), xy_only ? 1 : 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 
 extern "C" int upside_hip_replica_swap_from(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
     API_TRY

@@ -1108,3 +1108,240 @@ extern "C" int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, in
     hipLaunchKernelGGL(k_column_sum, grid1(c.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), c, comp, system, out);
     return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optional restraint / external-field nodes of the reference (not part of the README force field; per element).
+
+// single-atom potentials on `pos`: par is [n][8]
+//   kind 0 atom_pos_spring (bonds.cpp:36-48)  par = x0[3], k
+//   kind 1 tension         (bonds.cpp:73-88)  par = tension_coeff[3]
+//   kind 2 AFM             (bonds.cpp:147-166) par = k, starting_tip_pos[3], pulling_vel[3];  time = time_estimate
+//   kind 3 z_flat_bottom   (bonds.cpp:406-425) par = z0, radius, k
+__global__ void k_point_potential(int kind, upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ par, int n, float time,
+                                  float* __restrict__ contrib, long contrib_stride, float* __restrict__ pot_terms) {
+    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt >= n) return;
+    const int s = blockIdx.y;
+    const f3 x = ld3(C_OUT(pos, s) + (size_t)id[nt] * pos.stride);
+    const float* p = par + (size_t)nt * 8;
+    float pot = 0.f; f3 d = mk3(0.f, 0.f, 0.f);
+    if (kind == 0) {
+        const f3 disp = x - mk3(p[0], p[1], p[2]);
+        pot = 0.5f * p[3] * mag2(disp);
+        d = p[3] * disp;
+    } else if (kind == 1) {
+        const f3 c = mk3(p[0], p[1], p[2]);
+        pot = -dot(x, c);
+        d = mk3(-c.x, -c.y, -c.z);
+    } else if (kind == 2) {
+        const f3 tip = mk3(p[1], p[2], p[3]) + time * mk3(p[4], p[5], p[6]);
+        const f3 diff = x - tip;
+        pot = 0.5f * p[0] * mag2(diff);
+        d = p[0] * diff;
+    } else {
+        const float dz = x.z - p[0];
+        const float excess = dz > p[1] ? dz - p[1] : (dz < -p[1] ? dz + p[1] : 0.f);
+        pot = 0.5f * p[2] * sqr(excess);
+        d = mk3(0.f, 0.f, p[2] * excess);
+    }
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)nt * 3;
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
+    if (pot_terms) pot_terms[(size_t)s * n + nt] = pot;
+}
+extern "C" int upk_point_potential(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* par, int n, float time,
+                                   float* contrib, long contrib_stride, float* pot_terms) {
+    hipLaunchKernelGGL(k_point_potential, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), kind, pos, id, par, n, time, contrib,
+                       contrib_stride, pot_terms);
+    return launch_status();
+}
+
+// contact (sidechain_radial.cpp:187-204): par is [n][4] = energy, dist, scale (1/width), cutoff
+__global__ void k_contact(upk_coord_t bead, const int* __restrict__ id, const float* __restrict__ par, int n, float* __restrict__ contrib,
+                          long contrib_stride, float* __restrict__ pot_terms) {
+    const int nc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nc >= n) return;
+    const int s = blockIdx.y;
+    const float* x = C_OUT(bead, s);
+    const f3 disp = ld3(x + (size_t)id[nc * 2] * bead.stride) - ld3(x + (size_t)id[nc * 2 + 1] * bead.stride);
+    const float* p = par + (size_t)nc * 4;
+    const float dist = sqrtf(mag2(disp));
+    float pot = 0.f; f3 d = mk3(0.f, 0.f, 0.f);
+    if (!(dist >= p[3])) {
+        float v, dv;
+        compact_sigmoid(v, dv, dist - p[1], p[2]);
+        pot = p[0] * v;
+        d = (p[0] * dv * rcp(dist)) * disp;
+    }
+    float* o = contrib + (size_t)s * contrib_stride + (size_t)nc * 6;
+    o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = -d.x; o[4] = -d.y; o[5] = -d.z;
+    if (pot_terms) pot_terms[(size_t)s * n + nc] = pot;
+}
+extern "C" int upk_contact(const upk_launch_t* L, upk_coord_t bead, const int* id, const float* par, int n, float* contrib,
+                           long contrib_stride, float* pot_terms) {
+    hipLaunchKernelGGL(k_contact, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), bead, id, par, n, contrib, contrib_stride, pot_terms);
+    return launch_status();
+}
+
+// constant (bonds.cpp:550-587): the same values in every system;  slice (bonds.cpp:589-621)
+__global__ void k_broadcast_rows(const float* __restrict__ value, upk_coord_t out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out.n_elem * out.width) return;
+    const int ne = i / out.width, d = i - ne * out.width;
+    C_OUT(out, blockIdx.y)[(size_t)ne * out.stride + d] = value[i];
+}
+extern "C" int upk_broadcast_rows(const upk_launch_t* L, const float* value, upk_coord_t out) {
+    hipLaunchKernelGGL(k_broadcast_rows, grid1(out.n_elem * out.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), value, out);
+    return launch_status();
+}
+__global__ void k_slice_fwd(upk_coord_t in, const int* __restrict__ id, upk_coord_t out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out.n_elem * out.width) return;
+    const int s = blockIdx.y, na = i / out.width, d = i - na * out.width;
+    C_OUT(out, s)[(size_t)na * out.stride + d] = C_OUT(in, s)[(size_t)id[na] * in.stride + d];
+}
+extern "C" int upk_slice_fwd(const upk_launch_t* L, upk_coord_t in, const int* id, upk_coord_t out) {
+    hipLaunchKernelGGL(k_slice_fwd, grid1(out.n_elem * out.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, id, out);
+    return launch_status();
+}
+// the slice's sensitivity rows become one contribution each of the sliced node
+__global__ void k_slice_bwd(upk_coord_t self, float* __restrict__ contrib, long contrib_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= self.n_elem * self.width) return;
+    const int s = blockIdx.y, na = i / self.width, d = i - na * self.width;
+    contrib[(size_t)s * contrib_stride + i] = C_SENS(self, s)[(size_t)na * self.stride + d];
+}
+extern "C" int upk_slice_bwd(const upk_launch_t* L, upk_coord_t self, float* contrib, long contrib_stride) {
+    hipLaunchKernelGGL(k_slice_bwd, grid1(self.n_elem * self.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, contrib, contrib_stride);
+    return launch_status();
+}
+
+// uniform_transform (environment.cpp:158-235): clamped spline of a 1-wide input, element for element
+__global__ void k_uniform_transform_fwd(upk_coord_t in, const float* __restrict__ coeff, int n_coeff, float offset, float inv_dx,
+                                        upk_coord_t out, float* __restrict__ jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_elem) return;
+    const int s = blockIdx.y;
+    float v, dv;
+    clamped_deBoor_vd_scalar(v, dv, coeff, (C_OUT(in, s)[(size_t)i * in.stride] - offset) * inv_dx, n_coeff);
+    C_OUT(out, s)[(size_t)i * out.stride] = v;
+    jac[(size_t)s * in.n_elem + i] = dv * inv_dx;
+}
+extern "C" int upk_uniform_transform_fwd(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset, float inv_dx,
+                                         upk_coord_t out, float* jac) {
+    hipLaunchKernelGGL(k_uniform_transform_fwd, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, coeff, n_coeff, offset, inv_dx, out, jac);
+    return launch_status();
+}
+__global__ void k_uniform_transform_bwd(upk_coord_t in, upk_coord_t self, const float* __restrict__ jac) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_elem) return;
+    const int s = blockIdx.y;
+    C_SENS(in, s)[(size_t)i * in.stride] += jac[(size_t)s * in.n_elem + i] * C_SENS(self, s)[(size_t)i * self.stride];
+}
+extern "C" int upk_uniform_transform_bwd(const upk_launch_t* L, upk_coord_t in, upk_coord_t self, const float* jac) {
+    hipLaunchKernelGGL(k_uniform_transform_bwd, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, self, jac);
+    return launch_status();
+}
+// d(potential)/d(offset, inv_dx, coefficients) of uniform_transform (environment.cpp:205-221), one system
+__global__ void k_uniform_transform_param_deriv(upk_coord_t in, const float* __restrict__ coeff, int n_coeff, float offset, float inv_dx,
+                                                int s, float* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_elem) return;
+    const float x0 = C_OUT(in, s)[(size_t)i * in.stride] - offset, x = x0 * inv_dx;
+    float v, dv;
+    clamped_deBoor_vd_scalar(v, dv, coeff, x, n_coeff);
+    int bin; float w[4];
+    if (x <= 1.f) { bin = 0; w[0] = 1.f / 6.f; w[1] = 2.f / 3.f; w[2] = 1.f / 6.f; w[3] = 0.f; }
+    else if (x >= (float)(n_coeff - 2)) { bin = n_coeff - 4; w[0] = 0.f; w[1] = 1.f / 6.f; w[2] = 2.f / 3.f; w[3] = 1.f / 6.f; }
+    else {
+        const int x_bin = (int)x; bin = x_bin - 1;
+        const float excess = x - (float)x_bin; float der;
+        uniform_deBoor(w[0], der, 1.f, 0.f, 0.f, 0.f, excess); uniform_deBoor(w[1], der, 0.f, 1.f, 0.f, 0.f, excess);
+        uniform_deBoor(w[2], der, 0.f, 0.f, 1.f, 0.f, excess); uniform_deBoor(w[3], der, 0.f, 0.f, 0.f, 1.f, excess);
+    }
+    atomicAdd(table, dv); atomicAdd(table + 1, dv * x0);
+    for (int k = 0; k < 4; ++k) atomicAdd(table + 2 + bin + k, w[k]);
+}
+extern "C" int upk_uniform_transform_param_deriv(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset,
+                                                 float inv_dx, int system, float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_uniform_transform_param_deriv, grid1(in.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), in, coeff, n_coeff, offset, inv_dx, system, table);
+    return launch_status();
+}
+
+// linear_coupling_uniform / _with_inactivation (environment.cpp:286-300)
+__global__ void k_linear_coupling(upk_coord_t in, const int* __restrict__ types, const float* __restrict__ couplings, upk_coord_t inact,
+                                  int has_inact, int inact_dim, float* __restrict__ pot_terms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_elem) return;
+    const int s = blockIdx.y;
+    const float c = couplings[types[i]];
+    const float act = has_inact ? sqr(1.f - C_OUT(inact, s)[(size_t)i * inact.stride + inact_dim]) : 1.f;
+    const float val = C_OUT(in, s)[(size_t)i * in.stride];
+    C_SENS(in, s)[(size_t)i * in.stride] += c * act;
+    if (has_inact) C_SENS(inact, s)[(size_t)i * inact.stride + inact_dim] -= c * val;
+    if (pot_terms) pot_terms[(size_t)s * in.n_elem + i] = c * val * act;
+}
+extern "C" int upk_linear_coupling(const upk_launch_t* L, upk_coord_t in, const int* types, const float* couplings, upk_coord_t inact,
+                                   int has_inact, int inact_dim, float* pot_terms) {
+    hipLaunchKernelGGL(k_linear_coupling, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, types, couplings, inact, has_inact,
+                       inact_dim, pot_terms);
+    return launch_status();
+}
+// environment.cpp:301-312 (note: act = 1 - inactivation there, not its square)
+__global__ void k_linear_coupling_param_deriv(upk_coord_t in, const int* __restrict__ types, upk_coord_t inact, int has_inact, int inact_dim,
+                                              int s, float* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_elem) return;
+    const float act = has_inact ? 1.f - C_OUT(inact, s)[(size_t)i * inact.stride + inact_dim] : 1.f;
+    atomicAdd(table + types[i], C_OUT(in, s)[(size_t)i * in.stride] * act);
+}
+extern "C" int upk_linear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t in, const int* types, upk_coord_t inact, int has_inact,
+                                               int inact_dim, int system, float* table) {
+    if (system < 0 || system >= L->n_system) return 9101;
+    hipLaunchKernelGGL(k_linear_coupling_param_deriv, grid1(in.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), in, types, inact, has_inact, inact_dim, system, table);
+    return launch_status();
+}
+
+// membrane_potential (membrane_potential.cpp:104-151).  Clamped cubic tables in monomial form (spline.h:496-515).
+__device__ __forceinline__ void clamped_spline1d(float& value, float& deriv, const float* __restrict__ coeff, const float* __restrict__ table,
+                                                 int layer, int nx, float x) {
+    if (x >= (float)(nx - 1)) { deriv = 0.f; value = table[(size_t)layer * nx + nx - 1]; }
+    else if (x <= 0.f) { deriv = 0.f; value = table[(size_t)layer * nx]; }
+    else {
+        const int x_bin = (int)x; const float fx = x - (float)x_bin, fx2 = fx * fx, fx3 = fx * fx2;
+        const float* c = coeff + ((size_t)layer * (nx - 1) + x_bin) * 4;
+        deriv = c[1] + 2.f * fx * c[2] + 3.f * fx2 * c[3];
+        value = c[0] + fx * c[1] + fx2 * c[2] + fx3 * c[3];
+    }
+}
+__global__ void k_membrane(upk_membrane_t M, upk_coord_t cb, upk_coord_t env, upk_coord_t hb, float* __restrict__ pot_terms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    const int n_term = M.n_res + hb.n_elem;
+    if (i >= n_term) return;
+    float pot;
+    if (i < M.n_res) {          // residue burial term: cb_index and env_index are injective (checked on the host)
+        const int ci = M.cb_index[i], ei = M.env_index[i], rt = M.restype[i];
+        float v, dv, sg, dsg;
+        clamped_spline1d(v, dv, M.cb_coeff, M.cb_table, rt, M.cb_nx, (C_OUT(cb, s)[(size_t)ci * cb.stride + 2] + M.cb_z_shift) * M.cb_z_scale);
+        compact_sigmoid(sg, dsg, C_OUT(env, s)[(size_t)ei * env.stride] - M.cov_midpoint[rt], M.cov_sharpness[rt]);
+        pot = v * sg;
+        C_SENS(cb, s)[(size_t)ci * cb.stride + 2] += dv * M.cb_z_scale * sg;
+        C_SENS(env, s)[(size_t)ei * env.stride] += v * dsg;
+    } else {                    // unpaired backbone hydrogen-bond sites
+        const int nv = i - M.n_res;
+        const float* h = C_OUT(hb, s) + (size_t)nv * hb.stride;
+        float v, dv;
+        clamped_spline1d(v, dv, M.uhb_coeff, M.uhb_table, nv >= M.n_donor ? 1 : 0, M.uhb_nx, (h[2] + M.uhb_z_shift) * M.uhb_z_scale);
+        const float uhb = 1.f - h[6];
+        pot = v * sqr(uhb);
+        float* hs = C_SENS(hb, s) + (size_t)nv * hb.stride;
+        hs[2] += dv * M.uhb_z_scale * sqr(uhb);
+        hs[6] += -2.f * v * uhb;
+    }
+    if (pot_terms) pot_terms[(size_t)s * n_term + i] = pot;
+}
+extern "C" int upk_membrane(const upk_launch_t* L, const upk_membrane_t* M, upk_coord_t cb, upk_coord_t env, upk_coord_t hb, float* pot_terms) {
+    hipLaunchKernelGGL(k_membrane, grid1(M->n_res + hb.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *M, cb, env, hb, pot_terms);
+    return launch_status();
+}

@@ -127,7 +127,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     double duration = -1., frame_interval = -1., time_step = 0.009, thermostat_timescale = 5., thermostat_interval = -1., replica_interval = 0., mc_interval = 0.;
     string temperature_str = "1.0";
     unsigned long seed = 42;
-    bool recenter = true, write_output = true;
+    bool recenter = true, write_output = true, xy_recenter_only = false;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -143,7 +143,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--swap-set") swap_sets.push_back(need("--swap-set"));
         else if (a == "--disable-recentering") recenter = false;
         else if (a == "--no-output") write_output = false;       // extension: leave the configuration files untouched
-        else if (a == "--re-raise-signal" || a == "--disable-z-recentering") {}
+        else if (a == "--disable-z-recentering") xy_recenter_only = true;   // main.cpp:358-360, 416
+        else if (a == "--re-raise-signal") {}
         else if (a == "--monte-carlo-interval") mc_interval = stod(need("--monte-carlo-interval"));
         else if (a == "--log-level" || a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
@@ -185,6 +186,15 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     DerivEngine* e = upside_hip_construct(n_atom, files[0].c_str(), n_system, !verbose);
     if (!e) throw string("unable to construct the engine: ") + upside_hip_last_error();
     struct Guard { DerivEngine* e; ~Guard() { delete e; } } guard{e};
+    // main.cpp:548-564: recentring would fight a potential that is not translation invariant
+    for (auto& n : e->nodes) {
+        auto pre = [&](const char* p) { return n.name == string(p).substr(0, n.name.size()); };   // is_prefix(n.name, p), deriv_engine.cpp:72-74
+        if (recenter && !xy_recenter_only && (pre("membrane_potential") || pre("z_flat_bottom") || pre("tension") || pre("AFM")))
+            throw string("You have z-centering and a z-dependent potential turned on.  This is not what you want.  "
+                         "Consider --disable-z-recentering or --disable-recentering.");
+        if (recenter && pre("cavity_radial"))
+            throw string("You have re-centering and a radial potential turned on.  This is not what you want.  Consider --disable-recentering.");
+    }
     if (upside_hip_set_pos(e, all_pos.data())) throw string(upside_hip_last_error());
     if (upside_hip_init_md(e, temps.data(), base_seed, (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
 
@@ -230,7 +240,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // pivots before the frame of the same round, never at t = 0 (main.cpp:626-630)
         if (have_mc && rnd && !(rnd % mc_rounds)) if (upside_hip_mc_step(e, rnd)) throw string(upside_hip_last_error());
         if (!(rnd % frame_rounds)) {   // main.cpp:633-654: recenter, energy, log, print -- before the round is integrated
-            if (recenter) upside_hip_recenter(e);
+            if (recenter) upside_hip_recenter_axes(e, xy_recenter_only);
             if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
             if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
             if (have_pivot && upside_hip_mc_stats(e, 0, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame

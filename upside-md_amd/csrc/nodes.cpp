@@ -670,6 +670,233 @@ struct NonlinearCoupling : public PotentialNode {
 RegisterNodeType<NonlinearCoupling, 1> nonlinear_coupling_node("nonlinear_coupling");
 
 // ---------------------------------------------------------------------------------------------------
+// Optional restraint / external-field nodes (not emitted for the README force field)
+
+// atom_pos_spring (bonds.cpp:9-50), tension (:53-90), AFM (:93-168), z_flat_bottom (:377-427): one atom per term
+struct PointPotential : public PotentialNode {
+    int kind, n_term; CoordNode& pos; DevBuf<int> id; DevBuf<float> par; int src;
+    float time_initial = 0.f, time_step = 0.f; int round_num = 0;     // AFM only
+    PointPotential(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_, int kind_) : PotentialNode(c), kind(kind_), pos(pos_) {
+        check_elem_width_lower_bound(pos, 3);
+        const char* id_name = kind == 0 ? "id" : "atom";
+        auto ids = read<int>(H(grp), id_name, 1);
+        n_term = (int)ids.size();
+        for (int x : ids) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
+        vector<float> p((size_t)n_term * 8, 0.f);
+        auto col = [&](const char* name, int off) {
+            check_size(H(grp), name, {(size_t)n_term});
+            auto v = read<float>(H(grp), name, 1);
+            for (int i = 0; i < n_term; ++i) p[(size_t)i * 8 + off] = v[i]; };
+        auto vec3 = [&](const char* name, int off) {
+            check_size(H(grp), name, {(size_t)n_term, 3});
+            auto v = read<float>(H(grp), name, 2);
+            for (int i = 0; i < n_term; ++i) for (int d = 0; d < 3; ++d) p[(size_t)i * 8 + off + d] = v[(size_t)i * 3 + d]; };
+        if (kind == 0) { vec3("x0", 0); col("spring_const", 3); }
+        else if (kind == 1) vec3("tension_coeff", 0);
+        else if (kind == 2) {
+            col("spring_const", 0); vec3("starting_tip_pos", 1); vec3("pulling_vel", 4);
+            time_initial = attr<float>(H(grp), "pulling_vel", "time_initial"); time_step = attr<float>(H(grp), "pulling_vel", "time_step");
+        } else { col("z0", 0); col("radius", 1); col("spring_constant", 2); }
+        id.upload(ids); par.upload(p);
+        src = pos.scatter.add_source(n_term, 1, 3, ids);
+        alloc_terms(n_term);
+    }
+    bool capturable() const override { return kind != 2; }   // the AFM tip position travels as a kernel argument
+    void compute_value(ComputeMode mode) override {
+        float time = 0.f;
+        if (kind == 2) {                                   // bonds.cpp:150-151: the tip advances on every DerivMode evaluation
+            if (mode == DerivMode) round_num += 1;
+            time = time_initial + time_step * round_num;
+        }
+        upk_check(upk_point_potential(&ctx->L, kind, pos.coord(), id.p, par.p, n_term, time, pos.scatter.source_ptr(src), pos.scatter.arena_size,
+                                      mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "point_potential");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+struct PosSpring : PointPotential { PosSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 0) {} };
+struct TensionPotential : PointPotential { TensionPotential(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 1) {} };
+struct AFMPotential : PointPotential { AFMPotential(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 2) {} };
+struct ZFlatBottom : PointPotential { ZFlatBottom(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 3) {} };
+RegisterNodeType<PosSpring, 1> pos_spring_node("atom_pos_spring");
+RegisterNodeType<TensionPotential, 1> tension_node("tension");
+RegisterNodeType<AFMPotential, 1> AFM_node("AFM");
+RegisterNodeType<ZFlatBottom, 1> z_flat_bottom_node("z_flat_bottom");
+
+// contact: sidechain_radial.cpp:139-205
+struct ContactEnergy : public PotentialNode {
+    int n_contact; CoordNode& bead_pos; DevBuf<int> id; DevBuf<float> par; int src;
+    ContactEnergy(DeviceCtx* c, hid_t_compat grp, CoordNode& bead_pos_) : PotentialNode(c), bead_pos(bead_pos_) {
+        check_elem_width_lower_bound(bead_pos, 3);
+        vector<hsize_t> dims;
+        auto ids = read<int>(H(grp), "id", 2, &dims);
+        n_contact = (int)dims[0];
+        if ((int)dims[1] != 2) throw string("wrong width for id");
+        for (int x : ids) if (x < 0 || x >= bead_pos.n_elem) throw string("contact index out of range");
+        check_size(H(grp), "energy", {(size_t)n_contact}); check_size(H(grp), "distance", {(size_t)n_contact}); check_size(H(grp), "width", {(size_t)n_contact});
+        auto en = read<float>(H(grp), "energy", 1), dist = read<float>(H(grp), "distance", 1), width = read<float>(H(grp), "width", 1);
+        vector<float> p((size_t)n_contact * 4);
+        for (int i = 0; i < n_contact; ++i) {
+            const float scale = 1.f / width[i];
+            p[(size_t)i * 4] = en[i]; p[(size_t)i * 4 + 1] = dist[i]; p[(size_t)i * 4 + 2] = scale; p[(size_t)i * 4 + 3] = dist[i] + 1.f / scale;   // :171
+        }
+        id.upload(ids); par.upload(p);
+        src = bead_pos.scatter.add_source(n_contact, 2, 3, ids);
+        alloc_terms(n_contact);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_contact(&ctx->L, bead_pos.coord(), id.p, par.p, n_contact, bead_pos.scatter.source_ptr(src), bead_pos.scatter.arena_size,
+                              mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "contact");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+RegisterNodeType<ContactEnergy, 1> contact_node("contact");
+
+// constant: bonds.cpp:550-587
+struct ConstantCoord : public CoordNode {
+    vector<float> value; DevBuf<float> d_value;
+    static int dim(hid_t_compat grp, int k) { return (int)dset_size(2, H(grp), "value")[k]; }
+    ConstantCoord(DeviceCtx* c, hid_t_compat grp) : CoordNode(c, dim(grp, 0), dim(grp, 1)) {
+        value = read<float>(H(grp), "value", 2); d_value.upload(value);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_broadcast_rows(&ctx->L, d_value.p, coord()), "constant"); }
+    void propagate_deriv() override {}
+    vector<float> get_param() const override { return value; }
+    void set_param(const vector<float>& p) override {
+        if (p.size() != value.size()) throw string("invalid size to set_param");
+        value = p; hip_check(hipMemcpy(d_value.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    }
+};
+RegisterNodeType<ConstantCoord, 0> constant_coord_node("constant");
+
+// slice: bonds.cpp:589-621
+struct Slice : public CoordNode {
+    CoordNode& pos; DevBuf<int> id; int src;
+    Slice(DeviceCtx* c, hid_t_compat grp, CoordNode& pos_) : CoordNode(c, (int)dset_size(1, H(grp), "id")[0], pos_.elem_width), pos(pos_) {
+        auto ids = read<int>(H(grp), "id", 1);
+        for (int x : ids) if (x < 0 || x >= pos.n_elem) throw string("slice index out of range");
+        id.upload(ids);
+        src = pos.scatter.add_source(n_elem, 1, elem_width, ids);
+    }
+    void compute_value(ComputeMode) override { upk_check(upk_slice_fwd(&ctx->L, pos.coord(), id.p, coord()), "slice_fwd"); }
+    void propagate_deriv() override { upk_check(upk_slice_bwd(&ctx->L, coord(), pos.scatter.source_ptr(src), pos.scatter.arena_size), "slice_bwd"); }
+};
+RegisterNodeType<Slice, 1> slice_node("slice");
+
+// uniform_transform: environment.cpp:158-235
+struct UniformTransform : public CoordNode {
+    CoordNode& input; int n_coeff; float spline_offset, spline_inv_dx;
+    vector<float> coeff; DevBuf<float> d_coeff, jac;
+    UniformTransform(DeviceCtx* c, hid_t_compat grp, CoordNode& input_) : CoordNode(c, input_.n_elem, 1), input(input_) {
+        check_elem_width(input, 1);
+        coeff = read<float>(H(grp), "bspline_coeff", 1); n_coeff = (int)coeff.size();
+        spline_offset = attr<float>(H(grp), "bspline_coeff", "spline_offset"); spline_inv_dx = attr<float>(H(grp), "bspline_coeff", "spline_inv_dx");
+        d_coeff.upload(coeff); jac.alloc((size_t)c->n_system * n_elem);
+    }
+    void compute_value(ComputeMode) override {
+        upk_check(upk_uniform_transform_fwd(&ctx->L, input.coord(), d_coeff.p, n_coeff, spline_offset, spline_inv_dx, coord(), jac.p), "uniform_transform_fwd"); }
+    void propagate_deriv() override { upk_check(upk_uniform_transform_bwd(&ctx->L, input.coord(), coord(), jac.p), "uniform_transform_bwd"); }
+    vector<float> get_param() const override {                     // environment.cpp:197-203
+        vector<float> r(2 + n_coeff); r[0] = spline_offset; r[1] = spline_inv_dx; copy(coeff.begin(), coeff.end(), r.begin() + 2); return r; }
+    vector<float> get_param_deriv(int system) override {           // environment.cpp:205-221
+        return param_deriv_table(ctx, 2 + n_coeff, [&](float* t) {
+            upk_check(upk_uniform_transform_param_deriv(&ctx->L, input.coord(), d_coeff.p, n_coeff, spline_offset, spline_inv_dx, system, t), "uniform_transform param_deriv"); });
+    }
+    void set_param(const vector<float>& p) override {              // environment.cpp:223-233
+        if (p.size() < size_t(2 + 4)) throw string("too small of size for spline");
+        n_coeff = (int)p.size() - 2; spline_offset = p[0]; spline_inv_dx = p[1];
+        coeff.assign(p.begin() + 2, p.end()); d_coeff.upload(coeff);
+    }
+};
+RegisterNodeType<UniformTransform, 1> uniform_transform_node("uniform_transform");
+
+// linear_coupling_uniform / linear_coupling_with_inactivation: environment.cpp:237-321
+struct LinearCoupling : public PotentialNode {
+    CoordNode& input; CoordNode* inactivation; int inactivation_dim = 0;
+    vector<float> couplings; DevBuf<float> d_couplings; DevBuf<int> types;
+    LinearCoupling(DeviceCtx* c, hid_t_compat grp, CoordNode& input_, CoordNode* inact_) : PotentialNode(c), input(input_), inactivation(inact_) {
+        check_elem_width(input, 1);
+        if (inactivation) {
+            inactivation_dim = attr<int>(H(grp), ".", "inactivation_dim");
+            if (input.n_elem != inactivation->n_elem) throw string("Inactivation size must match input size");
+            check_elem_width_lower_bound(*inactivation, inactivation_dim + 1);
+        }
+        couplings = read<float>(H(grp), "couplings", 1);
+        check_size(H(grp), "coupling_types", {(size_t)input.n_elem});
+        auto t = read<int>(H(grp), "coupling_types", 1);
+        for (int i : t) if (i < 0 || i >= (int)couplings.size()) throw string("invalid coupling type");
+        d_couplings.upload(couplings); types.upload(t);
+        alloc_terms(input.n_elem);
+    }
+    upk_coord_t inact_coord() const { upk_coord_t z; memset(&z, 0, sizeof(z)); return inactivation ? inactivation->coord() : z; }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_linear_coupling(&ctx->L, input.coord(), types.p, d_couplings.p, inact_coord(), inactivation != nullptr, inactivation_dim,
+                                      mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "linear_coupling");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+    vector<float> get_param() const override { return couplings; }
+    vector<float> get_param_deriv(int system) override {           // environment.cpp:301-312
+        return param_deriv_table(ctx, couplings.size(), [&](float* t) {
+            upk_check(upk_linear_coupling_param_deriv(&ctx->L, input.coord(), types.p, inact_coord(), inactivation != nullptr, inactivation_dim, system, t), "linear_coupling param_deriv"); });
+    }
+    void set_param(const vector<float>& p) override {
+        if (p.size() != couplings.size()) throw string("attempting to change size of couplings vector on set_param");
+        couplings = p; hip_check(hipMemcpy(d_couplings.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    }
+};
+struct LinearCouplingUniform : LinearCoupling { LinearCouplingUniform(DeviceCtx* c, hid_t_compat g, CoordNode& in) : LinearCoupling(c, g, in, nullptr) {} };
+struct LinearCouplingInactivation : LinearCoupling {
+    LinearCouplingInactivation(DeviceCtx* c, hid_t_compat g, CoordNode& in, CoordNode& inact) : LinearCoupling(c, g, in, &inact) {} };
+RegisterNodeType<LinearCouplingUniform, 1> linear_coupling_node1("linear_coupling_uniform");
+RegisterNodeType<LinearCouplingInactivation, 2> linear_coupling_node2("linear_coupling_with_inactivation");
+
+// membrane_potential: membrane_potential.cpp:13-155
+struct MembranePotential : public PotentialNode {
+    CoordNode &res_pos, &environment_coverage, &protein_hbond;
+    upk_membrane_t M;
+    DevBuf<int> cb_index, env_index, restype; DevBuf<float> cov_midpoint, cov_sharpness, cb_coeff, cb_table, uhb_coeff, uhb_table;
+    MembranePotential(DeviceCtx* c, hid_t_compat grp, CoordNode& res_pos_, CoordNode& env_, CoordNode& hb_)
+        : PotentialNode(c), res_pos(res_pos_), environment_coverage(env_), protein_hbond(hb_) {
+        memset(&M, 0, sizeof(M));
+        check_elem_width_lower_bound(res_pos, 3); check_elem_width_lower_bound(environment_coverage, 1); check_elem_width(protein_hbond, 7);
+        auto ci = read<int>(H(grp), "cb_index", 1);
+        M.n_res = (int)ci.size();
+        check_size(H(grp), "env_index", {(size_t)M.n_res}); check_size(H(grp), "residue_type", {(size_t)M.n_res});
+        auto ei = read<int>(H(grp), "env_index", 1), rt = read<int>(H(grp), "residue_type", 1);
+        vector<hsize_t> dims;
+        auto cb_e = read<double>(H(grp), "cb_energy", 2, &dims);
+        const int n_restype = (int)dims[0]; M.cb_nx = (int)dims[1];
+        auto uhb_e = read<double>(H(grp), "uhb_energy", 2, &dims);
+        if ((int)dims[0] != 2) throw string("uhb_energy must have 2 rows (unpaired donor, unpaired acceptor)");
+        M.uhb_nx = (int)dims[1];
+        check_size(H(grp), "cov_midpoint", {(size_t)n_restype}); check_size(H(grp), "cov_sharpness", {(size_t)n_restype});
+        const int n_donor = (int)dset_size(1, H(grp), "donor_residue_ids")[0], n_acceptor = (int)dset_size(1, H(grp), "acceptor_residue_ids")[0];
+        if (n_donor + n_acceptor != protein_hbond.n_elem) throw string("membrane_potential: donor/acceptor counts do not match protein_hbond");
+        M.n_donor = n_donor;
+        for (int x : rt) if (x < 0 || x >= n_restype) throw string("residue_type out of range");
+        require_injective(ci, res_pos.n_elem, "membrane_potential cb_index");
+        require_injective(ei, environment_coverage.n_elem, "membrane_potential env_index");
+        M.cb_z_shift = -attr<float>(H(grp), "cb_energy", "z_min");
+        M.cb_z_scale = (M.cb_nx - 1) / (attr<float>(H(grp), "cb_energy", "z_max") + M.cb_z_shift);
+        M.uhb_z_shift = -attr<float>(H(grp), "uhb_energy", "z_min");
+        M.uhb_z_scale = (M.uhb_nx - 1) / (attr<float>(H(grp), "uhb_energy", "z_max") + M.uhb_z_shift);
+        cb_index.upload(ci); env_index.upload(ei); restype.upload(rt);
+        cov_midpoint.upload(read<float>(H(grp), "cov_midpoint", 1)); cov_sharpness.upload(read<float>(H(grp), "cov_sharpness", 1));
+        cb_coeff.upload(fit_layered_clamped_spline1d(cb_e, n_restype, M.cb_nx)); uhb_coeff.upload(fit_layered_clamped_spline1d(uhb_e, 2, M.uhb_nx));
+        cb_table.upload(vector<float>(cb_e.begin(), cb_e.end())); uhb_table.upload(vector<float>(uhb_e.begin(), uhb_e.end()));
+        M.cb_index = cb_index.p; M.env_index = env_index.p; M.restype = restype.p;
+        M.cov_midpoint = cov_midpoint.p; M.cov_sharpness = cov_sharpness.p;
+        M.cb_coeff = cb_coeff.p; M.cb_table = cb_table.p; M.uhb_coeff = uhb_coeff.p; M.uhb_table = uhb_table.p;
+        alloc_terms(M.n_res + protein_hbond.n_elem);
+    }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_membrane(&ctx->L, &M, res_pos.coord(), environment_coverage.coord(), protein_hbond.coord(),
+                               mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "membrane_potential");
+        if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+};
+RegisterNodeType<MembranePotential, 3> membrane_potential_node("membrane_potential");
+
+// ---------------------------------------------------------------------------------------------------
 // rotamer: rotamer.cpp:581-1082
 struct RotamerSidechain : public PotentialNode {
     vector<CoordNode*> prob_nodes;

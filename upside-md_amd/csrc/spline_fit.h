@@ -76,7 +76,36 @@ inline void solve_clamped_1d_spline_for_bsplines(int n_coeff, double* coefficien
     coefficients[n_coeff - 1] = coefficients[n_coeff - 3];
 }
 
+// spline.cpp:192-259: clamped (zero end-slope) interpolating cubic through n points on the integer grid, as monomial
+// coefficients of its n-1 intervals
+inline void solve_clamped_1d_spline(int n, double* coefficients, const double* data, double* ts) {
+    double *a = ts, *b = ts + n, *c = ts + 2 * n, *solution = ts + 3 * n;
+    for (int i = 0; i < n; ++i) { a[i] = 1. / 6.; b[i] = 2. / 3.; c[i] = 1. / 6.; solution[i] = data[i]; }
+    a[n - 1] *= 2.; c[0] *= 2.;
+    solve_tridiagonal_system(n, solution, a + 1, b, c);
+    for (int i = 0; i < 4 * (n - 1); ++i) coefficients[i] = 0.;
+    for (int i = 0; i < n; ++i)
+        for (int inc = 0; inc < 4; ++inc) {
+            const int idx = i + inc - 2;
+            if (idx < 0 || idx >= n - 1) continue;
+            for (int k = 0; k < 4; ++k) coefficients[idx * 4 + k] += solution[i] * kBsplineMonomial[inc][k];
+        }
+    for (int k = 0; k < 4; ++k) coefficients[k] += solution[1] * kBsplineMonomial[3][k];                      // left wing
+    for (int k = 0; k < 4; ++k) coefficients[(n - 2) * 4 + k] += solution[n - 2] * kBsplineMonomial[0][k];    // right wing
+}
+
 }  // namespace splinefit
+
+// spline.h:456-493 LayeredClampedSpline1D<1>::fit_spline: data (n_layer,nx) -> fp32 (n_layer,nx-1,4)
+inline std::vector<float> fit_layered_clamped_spline1d(const std::vector<double>& data, int n_layer, int nx) {
+    std::vector<float> out((size_t)n_layer * (nx - 1) * 4);
+    std::vector<double> coeff((size_t)(nx - 1) * 4), ts((size_t)4 * nx);
+    for (int il = 0; il < n_layer; ++il) {
+        splinefit::solve_clamped_1d_spline(nx, coeff.data(), data.data() + (size_t)il * nx, ts.data());
+        for (size_t i = 0; i < coeff.size(); ++i) out[(size_t)il * (nx - 1) * 4 + i] = (float)coeff[i];
+    }
+    return out;
+}
 
 // data (n_layer,nx,ny,ndim) -> fp32 bicubic patch coefficients (n_layer,nx,ny,ndim,16)
 inline std::vector<float> fit_layered_periodic_spline2d(const std::vector<double>& data, int n_layer, int nx, int ny, int ndim) {
