@@ -188,6 +188,7 @@ typedef struct {
     const int *bead_node, *bead_rot;     /* [n_bead] */
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     float* bead_pack;                    /* [S][n_bead][8] packed bead rows for systems whose beads do not fit LDS (else NULL) */
+    int one_bead_per_state;              /* every (residue, rotamer state) owns exactly one bead: each pair-matrix entry has a single writer */
     const int *node_bead_start, *node_bead_list;   /* CSR (node*6+rot) -> beads of that rotamer state */
     int n_prob; const float* const* prob_out; float* const* prob_sens; const int* prob_stride;   /* 1-body parents (device arrays of device ptrs) */
     const long* prob_sys_stride;

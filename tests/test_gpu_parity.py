@@ -380,6 +380,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_IG_WGS': '4096'},           # many thin workgroups per pair kernel
     {'UPSIDE_HIP_ROT_UNSTAGED': '1'},        # rotamer pair kernels with bead rows in global memory (large systems)
     {'UPSIDE_HIP_GRAPH': '1'},               # MD loop replayed from a captured hipGraph
+    {'UPSIDE_HIP_ROTAMER_ATOMIC': '1'},      # pair matrices accumulated with atomics (libraries with several beads per state)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes

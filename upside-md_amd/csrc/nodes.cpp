@@ -948,6 +948,9 @@ struct RotamerSidechain : public PotentialNode {
         vector<int> nb_start(n_node * 6 + 1, 0), nb_list;
         for (int k = 0; k < n_node * 6; ++k) { nb_start[k] = (int)nb_list.size(); nb_list.insert(nb_list.end(), beads_of[k].begin(), beads_of[k].end()); }
         nb_start[n_node * 6] = (int)nb_list.size();
+        one_bead_per_state = true;           // then every pair-matrix entry has a single contributing bead pair
+        for (auto& b : beads_of) if (b.size() > 1u) one_bead_per_state = false;
+        if (env_int("UPSIDE_HIP_ROTAMER_ATOMIC", 0)) one_bead_per_state = false;   // tests: the general accumulation path
         const int S = c->n_system;
         d_node_nrot.upload(node_nrot); d_bead_node.upload(bead_node); d_bead_rot.upload(bead_rot); d_nb_start.upload(nb_start); d_nb_list.upload(nb_list);
         vector<int> bead_meta(n_bead);
@@ -978,8 +981,10 @@ struct RotamerSidechain : public PotentialNode {
         d_prob_out.upload(po); d_prob_sens.upload(ps); d_prob_stride.upload(st); d_prob_sys_stride.upload(ss);
         fill_struct();
     }
+    bool one_bead_per_state = false;
     void fill_struct() {
         R.G = ig.G;
+        R.one_bead_per_state = one_bead_per_state ? 1 : 0;
         R.n_node = n_node; R.n_node1 = n1; R.n_node3 = n3;
         R.node_nrot = d_node_nrot.p; R.bead_node = d_bead_node.p; R.bead_rot = d_bead_rot.p;
         R.node_bead_start = d_nb_start.p; R.node_bead_list = d_nb_list.p;
