@@ -148,6 +148,7 @@ typedef struct {
     /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
        (mark_n x mark_n bytes, pre-cleared by upk_rotamer_clear_slots) is set to 1 for every cached pair */
     unsigned char* mark_table; const int* mark_node; int mark_n, mark_stride;   /* mark_stride: bytes per system (multiple of 16) */
+    int mark_start3, mark_start6;        /* node of a bead id (rotamer.cpp:812-816): (id >> 8) + {0, mark_start3, mark_start6} by its state count */
 } upk_igraph_t;
 
 /* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): regenerates the raw material of profiles/ under
+# gpurun_out/prof/.  Each rocprofv3 pass profiles the program itself (no shell hop after --), PMC passes are separate
+# from each other and carry no trace domains beyond the kernel trace.
+set -u
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof
+rm -rf "$OUT"; mkdir -p "$OUT"
+for R in 1 64 256 1024; do
+  st=100; [ $R -le 64 ] && st=300
+  python3 bench.py --replicas $R --steps $st --warmup 30 2>"$OUT/bench_R$R.err" | tail -1 > "$OUT/bench_R$R.json"
+done
+CMD="python3 bench.py --steps 60 --warmup 15 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS -d "$OUT/sq" -o sq -- $CMD > "$OUT/sq.log" 2>&1
+for t in trace fetch write sq; do
+  db=$(find "$OUT/$t" -name "*.db" | head -1)
+  [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" "$OUT/${t}_summary.txt"
+done
+fdb=$(find "$OUT/fetch" -name "*.db" | head -1); wdb=$(find "$OUT/write" -name "*.db" | head -1)
+python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 1024 "$OUT/hbm_traffic.json" > "$OUT/hbm_traffic.txt" 2>&1
+# keep the merge small: drop the databases
+find "$OUT" -name "*.db" -delete
+ls -la "$OUT"

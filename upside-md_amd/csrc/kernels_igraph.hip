@@ -198,16 +198,28 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
 // whole other side (16 bytes per element) in LDS and serves PLB_ROWS rows; one wavefront per row tests 64
 // candidates at a time and compacts hits with a ballot + popcount prefix, so each row comes out in ascending order.
 #define PLB_ROWS 64
-template <bool STAGED>
+// IT: pair functor (compile time, so the id rule is straight-line code); the inner loop is written without
+// short-circuit tests: uniform branches and nested exec masks cost as much as the arithmetic here (measured: the
+// branchy form spent ~half of each 64-candidate trip in scalar control flow).  The staged copy is padded to a multiple
+// of 64 with far-away sentinels, so the trip needs no bounds test.
+template <int IT>
+__device__ __forceinline__ bool plb_id_ok(int id_row_side1, int id_other_side2) {
+    if (IT == UPK_IT_ROTAMER) return ((unsigned)(id_row_side1 ^ id_other_side2)) > 15u;     // different residue: ids differ above bit 4
+    if (IT == UPK_IT_HBOND_COVERAGE || IT == UPK_IT_ENVIRONMENT) { const int d = id_row_side1 - id_other_side2; return (d > 2) | (d < -2); }
+    return true;
+}
+template <bool STAGED, int IT>
 __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1) {
     extern __shared__ __attribute__((aligned(16))) float plb_lds[];
     float4* oth = (float4*)plb_lds;
+    constexpr bool SYM = IT == UPK_IT_ROTAMER;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
     const bool side1 = (int)blockIdx.x < blocks1;             // workgroups [0, blocks1) serve the side-1 rows
     const int rb = side1 ? blockIdx.x : blockIdx.x - blocks1;
     const int n_my = side1 ? G.n1 : G.n2, n_other = side1 ? G.n2 : G.n1;
+    const int n_pad = (n_other + 63) & ~63;
     const int cap = side1 ? G.cap1 : G.cap2;
     const float cut2 = G.cache_cutoff * G.cache_cutoff;
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
@@ -216,7 +228,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
         const float4* mine = (const float4*)((side1 ? G.cache_pos1 : G.cache_pos2) + (size_t)s * n_my * 4);
         if (STAGED) {
             __syncthreads();                                   // the previous system's copy is no longer read
-            for (int j = threadIdx.x; j < n_other; j += blockDim.x) oth[j] = src[j];
+            for (int j = threadIdx.x; j < n_pad; j += blockDim.x) oth[j] = j < n_other ? src[j] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
             __syncthreads();
         }
         for (int r = wave; r < PLB_ROWS; r += n_wave) {
@@ -226,24 +238,31 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
             const int my_id = __float_as_int(x.w);
             int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
             int count = 0;
-            for (int j0 = 0; j0 < n_other; j0 += 64) {
+            for (int j0 = 0; j0 < n_pad; j0 += 64) {
                 const int j = j0 + lane;
-                bool hit = false;
-                if (j < n_other) {
-                    const float4 y = STAGED ? oth[j] : src[j];
-                    const float d2 = dist2_exact(x.x, x.y, x.z, y.x, y.y, y.z);
-                    const int oid = __float_as_int(y.w);
-                    hit = (d2 < cut2) && (side1 ? acceptable_id_pair(G.itype, my_id, oid) : acceptable_id_pair(G.itype, oid, my_id));
-                    if (G.symmetric) hit = hit && (j != i);
-                }
+                float4 y;
+                if (STAGED) y = oth[j];
+                else y = j < n_other ? src[j] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
+                const float d2 = dist2_exact(x.x, x.y, x.z, y.x, y.y, y.z);
+                const int oid = __float_as_int(y.w);
+                bool hit = (d2 < cut2) & (side1 ? plb_id_ok<IT>(my_id, oid) : plb_id_ok<IT>(oid, my_id));
+                if (SYM) hit = hit & (j != i);
                 const unsigned long long b = __ballot(hit);
                 const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
-                if (hit && pos < cap) nbr[pos] = j;
+                if (hit & (pos < cap)) nbr[pos] = j;
                 count += __popcll(b);
-                if (G.mark_table && hit && j > i) {   // residue pairs owning a cached bead pair (rotamer slots); benign race
-                    unsigned char* mt = G.mark_table + (size_t)s * G.mark_stride;
-                    const int a = G.mark_node[i], bb = G.mark_node[j];
-                    mt[a * G.mark_n + bb] = 1; mt[bb * G.mark_n + a] = 1;
+                if (SYM && G.mark_table) {   // residue pairs owning a cached bead pair (rotamer slots); benign race.  Beads of one
+                                             // residue are adjacent: only the first hit lane of each residue run stores
+                    auto node_of = [&](int id) { const int nr = (id >> 4) & 15; return (id >> 8) + (nr == 6 ? G.mark_start6 : (nr == 3 ? G.mark_start3 : 0)); };
+                    const bool up = hit & (j > i);
+                    const int bb = node_of(oid);
+                    const int bb_prev = __shfl_up(bb, 1, UP_WAVE);
+                    const bool up_prev = __shfl_up((int)up, 1, UP_WAVE) != 0;
+                    if (up & !((lane > 0) & up_prev & (bb_prev == bb))) {
+                        unsigned char* mt = G.mark_table + (size_t)s * G.mark_stride;
+                        const int a = node_of(my_id);
+                        mt[a * G.mark_n + bb] = 1; mt[bb * G.mark_n + a] = 1;
+                    }
                 }
             }
             if (lane == 0) {
@@ -253,14 +272,24 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
         }
     }
 }
+template <int IT>
+static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, size_t lds, bool staged, int blocks1) {
+    if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1);
+    else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1);
+}
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
     const int blocks1 = (G->n1 + PLB_ROWS - 1) / PLB_ROWS;
     const int blocks2 = G->symmetric ? 0 : (G->n2 + PLB_ROWS - 1) / PLB_ROWS;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
-    const size_t lds = (size_t)n_max * 16;
+    const size_t lds = (size_t)((n_max + 63) & ~63) * 16;
     const dim3 grid(blocks1 + blocks2, UPK_FLAG_GRID(L->n_system));
-    if (lds <= 150 * 1024) hipLaunchKernelGGL((k_pairlist_build<true>), grid, dim3(1024), lds, ST(L), *G, blocks1);
-    else hipLaunchKernelGGL((k_pairlist_build<false>), grid, dim3(1024), 0, ST(L), *G, blocks1);
+    const bool staged = lds <= 150 * 1024;
+    switch (G->itype) {
+        case UPK_IT_ROTAMER: plb_launch<UPK_IT_ROTAMER>(L, G, grid, lds, staged, blocks1); break;
+        case UPK_IT_HBOND_COVERAGE: plb_launch<UPK_IT_HBOND_COVERAGE>(L, G, grid, lds, staged, blocks1); break;
+        case UPK_IT_ENVIRONMENT: plb_launch<UPK_IT_ENVIRONMENT>(L, G, grid, lds, staged, blocks1); break;
+        default: plb_launch<UPK_IT_PROTEIN_HBOND>(L, G, grid, lds, staged, blocks1); break;
+    }
     return launch_status();
 }
 

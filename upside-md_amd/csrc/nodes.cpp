@@ -354,8 +354,16 @@ struct IGraphHost {
                     if (p1[2 * G.n_knot_angular + k] != p2[2 * G.n_knot_angular + k]) throw string("incompatible parameters");
             }
         G.cutoff = cutoff;
-        G.cache_cutoff = cutoff + (1.0f + 0.2f * cutoff);
+        G.cache_cutoff = cutoff + skin_scale() * (1.0f + 0.2f * cutoff);
     }
+
+    // Width of the cached-list margin relative to the reference's 1 + 0.2*cutoff (interaction_graph.h:395): any margin
+    // gives the same in-range pairs, it only trades rebuild frequency against list length.  Here the residue-pair slots of
+    // the side-chain solve are cut from the cached list too, so a long list also makes every belief-propagation sweep
+    // longer.  Measured at 1024 x 300 residues, system-steps/s by scale: 1.8: 73 k, 1.4: 79 k, 1.0: 85.6 k, 0.8: 89.2 k,
+    // 0.6: 91.2 k, 0.45: 90.6 k (256 systems: 78.0 / 82.4 / 82.2 k at 1.0 / 0.6 / 0.45); with the straight-line list
+    // build 0.6: 92.3 k, 0.5: 93.8 k, 0.4: 93.4 k.
+    static float skin_scale() { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.5f); return v; }
 
     IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
         memset(&G, 0, sizeof(G));
@@ -970,6 +978,7 @@ struct RotamerSidechain : public PotentialNode {
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
         mark.alloc((size_t)S * ig.G.mark_stride);
         ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
+        ig.G.mark_start3 = n1; ig.G.mark_start6 = n1 + n3;
         node_prob.alloc((size_t)S * n_node * 6); node_off.alloc((size_t)S * n_node); nb_cur.alloc((size_t)S * n_node * 6);
         P.alloc((size_t)S * R.slot_cap * 36); marg.alloc((size_t)S * R.slot_cap * 36);
         msg_cur.alloc((size_t)S * R.slot_cap * 16);
