@@ -208,6 +208,11 @@ __device__ __forceinline__ bool plb_id_ok(int id_row_side1, int id_other_side2) 
     if (IT == UPK_IT_HBOND_COVERAGE || IT == UPK_IT_ENVIRONMENT) { const int d = id_row_side1 - id_other_side2; return (d > 2) | (d < -2); }
     return true;
 }
+// node of a side-chain bead from its id (rotamer.cpp:812-816), straight-line
+__device__ __forceinline__ int plb_node_of(const upk_igraph_t& G, int id) {
+    const int nr = (id >> 4) & 15;
+    return (id >> 8) + ((-(int)(nr == 6) & G.mark_start6) | (-(int)(nr == 3) & G.mark_start3));
+}
 template <bool STAGED, int IT>
 __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1) {
     extern __shared__ __attribute__((aligned(16))) float plb_lds[];
@@ -238,6 +243,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
             const int my_id = __float_as_int(x.w);
             int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
             int count = 0;
+            const int my_node = SYM ? plb_node_of(G, my_id) : 0;
             for (int j0 = 0; j0 < n_pad; j0 += 64) {
                 const int j = j0 + lane;
                 float4 y;
@@ -253,15 +259,12 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
                 count += __popcll(b);
                 if (SYM && G.mark_table) {   // residue pairs owning a cached bead pair (rotamer slots); benign race.  Beads of one
                                              // residue are adjacent: only the first hit lane of each residue run stores
-                    auto node_of = [&](int id) { const int nr = (id >> 4) & 15; return (id >> 8) + (nr == 6 ? G.mark_start6 : (nr == 3 ? G.mark_start3 : 0)); };
                     const bool up = hit & (j > i);
-                    const int bb = node_of(oid);
-                    const int bb_prev = __shfl_up(bb, 1, UP_WAVE);
-                    const bool up_prev = __shfl_up((int)up, 1, UP_WAVE) != 0;
-                    if (up & !((lane > 0) & up_prev & (bb_prev == bb))) {
+                    const int key = up ? plb_node_of(G, oid) : -1;                 // -1: no mark from this lane
+                    const int key_prev = __builtin_amdgcn_update_dpp(-1, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    if (up & (key_prev != key)) {
                         unsigned char* mt = G.mark_table + (size_t)s * G.mark_stride;
-                        const int a = node_of(my_id);
-                        mt[a * G.mark_n + bb] = 1; mt[bb * G.mark_n + a] = 1;
+                        mt[my_node * G.mark_n + key] = 1; mt[key * G.mark_n + my_node] = 1;
                     }
                 }
             }
