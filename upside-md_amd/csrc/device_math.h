@@ -39,29 +39,35 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, UP_WAVE);
     return v;
 }
-// sum 8 per-lane values over the wavefront with 10 shuffles instead of 48: three halving exchanges leave one
+// sum 8 per-lane values over the wavefront in 10 cross-lane steps instead of 48: three halving exchanges leave one
 // partial value per lane, three butterflies finish it.  Returns the total of v[(lane >> 3) & 7] (the same in the
 // 8 lanes of a group), i.e. lane 8*c holds the sum of component c.
+// All ten steps are VALU cross-lane operations of gfx950 (v_permlane32_swap / v_permlane16_swap for the half- and
+// row-exchanges, DPP row_mirror / row_half_mirror / quad_perm inside a row): no ds_bpermute, nothing on the LDS pipe.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
     float a[4], b[2], c;
-    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+    const bool h8 = lane & 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = h32 ? v[i + 4] : v[i], send = h32 ? v[i] : v[i + 4];
-        a[i] = keep + __shfl_xor(send, 32, UP_WAVE);
+    for (int i = 0; i < 4; ++i) {      // lanes 0-31 end up with components 0-3, lanes 32-63 with 4-7
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = h16 ? a[i + 2] : a[i], send = h16 ? a[i] : a[i + 2];
-        b[i] = keep + __shfl_xor(send, 16, UP_WAVE);
+    for (int i = 0; i < 2; ++i) {      // even 16-lane rows keep the lower pair of components, odd rows the upper pair
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 2]), false, false);
+        b[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
     {
         const float keep = h8 ? b[1] : b[0], send = h8 ? b[0] : b[1];
-        c = keep + __shfl_xor(send, 8, UP_WAVE);
+        c = keep + dpp_mov<0x140>(send);        // row_mirror: lane L hears from 15-L, which sits in the other half of the row
     }
-    c += __shfl_xor(c, 4, UP_WAVE);
-    c += __shfl_xor(c, 2, UP_WAVE);
-    c += __shfl_xor(c, 1, UP_WAVE);
+    c += dpp_mov<0x141>(c);                     // row_half_mirror: L <-> 7-L
+    c += dpp_mov<0x4E>(c);                      // quad_perm [2,3,0,1]
+    c += dpp_mov<0xB1>(c);                      // quad_perm [1,0,3,2]
     return c;
 }
 __device__ __forceinline__ float wave_max(float v) {
