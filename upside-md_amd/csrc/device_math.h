@@ -34,20 +34,36 @@ __device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float
 }
 
 // ---- wavefront reductions (64 lanes) -----------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, UP_WAVE);
+// Cross-lane steps as VALU operations of gfx950 (nothing on the LDS pipe, unlike the ds_bpermute behind __shfl_*):
+// DPP quad_perm / row_half_mirror / row_mirror inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across
+// rows and wave halves.  dpp_xor<1|2> are true lane^1 / lane^2 exchanges; the mirrors pair a lane with one in the
+// other half of its 8 / 16 lanes, which is all a butterfly reduction needs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+#define UP_DPP_XOR1 0xB1         /* quad_perm [1,0,3,2] */
+#define UP_DPP_XOR2 0x4E         /* quad_perm [2,3,0,1] */
+#define UP_DPP_HALF_MIRROR 0x141 /* L <-> 7-L   */
+#define UP_DPP_ROW_MIRROR 0x140  /* L <-> 15-L  */
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {       // every lane ends with the reduction of all 64
+    v = op(v, dpp_mov<UP_DPP_XOR1>(v));
+    v = op(v, dpp_mov<UP_DPP_XOR2>(v));
+    v = op(v, dpp_mov<UP_DPP_HALF_MIRROR>(v));
+    v = op(v, dpp_mov<UP_DPP_ROW_MIRROR>(v));
+    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = op(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = op(__uint_as_float(r[0]), __uint_as_float(r[1])); }
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
 // sum 8 per-lane values over the wavefront in 10 cross-lane steps instead of 48: three halving exchanges leave one
 // partial value per lane, three butterflies finish it.  Returns the total of v[(lane >> 3) & 7] (the same in the
 // 8 lanes of a group), i.e. lane 8*c holds the sum of component c.
 // All ten steps are VALU cross-lane operations of gfx950 (v_permlane32_swap / v_permlane16_swap for the half- and
 // row-exchanges, DPP row_mirror / row_half_mirror / quad_perm inside a row): no ds_bpermute, nothing on the LDS pipe.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
 __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
     float a[4], b[2], c;
     const bool h8 = lane & 8;
@@ -70,11 +86,7 @@ __device__ __forceinline__ float wave_sum8(const float v[8], int lane) {
     c += dpp_mov<0xB1>(c);                      // quad_perm [1,0,3,2]
     return c;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, UP_WAVE));
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ---- B-splines: /root/reference/src/spline.h:136-174 (uniform de Boor), 228-242, 275-310 ----------
 __device__ __forceinline__ void uniform_deBoor(float& val, float& der, float c00, float c01, float c02,

@@ -206,7 +206,7 @@ __device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __rest
     int nq = 0;
     const int my_cnt = lane < ce - cb ? cnt_arr[cb + lane] : 0;       // the chunk's list lengths in one load
     for (int row = cb; row < ce; ++row) {
-        const int cnt = __shfl(my_cnt, row - cb, UP_WAVE);
+        const int cnt = __builtin_amdgcn_readlane(my_cnt, row - cb);      // wave-uniform lane index: v_readlane, not a shuffle
         const int* __restrict__ nbr = nbr_base + (size_t)row * cap;
         float x[3];
         row_xyz(row, x);
@@ -250,7 +250,7 @@ template <int N>
 __device__ __forceinline__ void seg_accumulate(float* acc, int rl, bool valid, const float v[8], int lane) {
     unsigned long long pending = __ballot(valid);
     while (pending) {
-        const int r0 = __shfl(rl, __builtin_ctzll(pending), UP_WAVE);
+        const int r0 = __builtin_amdgcn_readlane(rl, __builtin_ctzll(pending));
         const bool mine = valid && rl == r0;
         if (N == 1) {
             const float t = wave_sum(mine ? v[0] : 0.f);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void workgroup_row_range(int n_rows, int chunk, int& 
 __device__ __forceinline__ int next_chunk(int* counter, int lane) {
     int c = 0;
     if (lane == 0) c = atomicAdd(counter, 1);
-    return __shfl(c, 0, UP_WAVE);
+    return __builtin_amdgcn_readfirstlane(c);
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp

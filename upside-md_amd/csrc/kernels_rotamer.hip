@@ -821,11 +821,19 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
                     }
                 }
             }
-#pragma unroll
-            for (int off = BP_GROUP / 2; off > 0; off >>= 1) {
+            static_assert(BP_GROUP == 4, "the combine below is the lane^2, lane^1 butterfly of a quad");
+            {
                 float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { bb[r] *= __shfl_xor(bb[r], off, UP_WAVE); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                for (int r = 0; r < 6; ++r) { bb[r] *= dpp_mov<UP_DPP_XOR2>(bb[r]); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+            }
+            {
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { bb[r] *= dpp_mov<UP_DPP_XOR1>(bb[r]); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
                 const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
