@@ -1053,7 +1053,7 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
 // a lane loops over its share of the slots like the one-workgroup kernel does -- any C works; used for mid-size
 // batches that leave CUs idle under the one-workgroup solve.
 template <bool RESIDENT>
-__global__ void __launch_bounds__(RESIDENT ? BPC_BLOCK : BP_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
+__global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t R, int want_energy, int C, int sys0, int n_sys, int p_cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x >= n_sys) return;
     const int s = sys0 + blockIdx.x, c = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -1358,7 +1358,7 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
             for (int s0 = 0; s0 < L->n_system; s0 += chunk) {
                 const int n = L->n_system - s0 < chunk ? L->n_system - s0 : chunk;
                 if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
-                else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BP_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
+                else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BPC_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
             hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds_base, ST(L), *R, want_energy, 1, 0);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
             return launch_status();

@@ -1053,11 +1053,12 @@ struct RotamerSidechain : public PotentialNode {
         // The cluster solves trade HBM traffic for two device-scope barriers per sweep.  Resident form: wins while the
         // whole batch fits ONE cluster launch (CUs / C systems; measured 0.20 vs 0.53 ms at 1 system, 0.46 vs 0.75 ms
         // at 32).  Beyond that, while at least four CUs per system are free, the split form spreads each system over
-        // the CUs the one-workgroup solve would leave idle (measured 0.68 vs 0.83 ms at 48 systems, 0.88 vs 0.92 at 64;
-        // with two workgroups per system it loses: 1.16 vs 0.98 ms at 96); once every CU has its own system the
-        // one-workgroup solve is best (3.9 vs 1.6 ms at 256).
+        // the CUs the one-workgroup solve would leave idle (512 lanes per workgroup keep its three slot states in
+        // registers: 0.48 vs 0.61 ms for two resident launches at 48 systems, 0.55 vs 0.70 at 64, but 0.50 vs 0.41 at 40;
+        // with two workgroups per system it loses to the one-workgroup solve: 0.74 vs 0.54 ms at 96, 0.85 vs 0.59 at
+        // 128); once every CU has its own system the one-workgroup solve is best.
         const int n_cu = upk_device_cu_count();
-        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 32)) {
+        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 40)) {
             C = 1;
             const int split_max = env_int("UPSIDE_HIP_BP_SPLIT_MAX_SYSTEMS", n_cu / 4);
             if (ctx->n_system <= split_max) { C = min(8, n_cu / ctx->n_system); R.bp_resident = 0; if (C < 2 || n_node - R.n_node1 < C) C = 1; }
