@@ -24,3 +24,9 @@ python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 1024 "$OUT/hbm_traffic.jso
 # keep the merge small: drop the databases
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT"
+# other BASELINE configurations
+for w in trpcage20_7A proteinG56_7A syn150_10A syn300_7A syn300_10A; do
+for R in 1 8 64 512; do
+  st=300; [ $R -ge 64 ] && st=150
+  python3 bench.py --workload $w --replicas $R --steps $st --warmup 40 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', $R, round(d['value']))"
+done; done > "$OUT/other_configs.txt"
