@@ -286,7 +286,9 @@ extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) 
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     const size_t lds = (size_t)((n_max + 63) & ~63) * 16;
     const dim3 grid(blocks1 + blocks2, UPK_FLAG_GRID(L->n_system));
-    const bool staged = lds <= 150 * 1024;
+    static int force_unstaged = -1;   // UPSIDE_HIP_PLB_UNSTAGED=1 exercises the path of systems whose elements do not fit LDS
+    if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_PLB_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
+    const bool staged = lds <= 150 * 1024 && !force_unstaged;
     switch (G->itype) {
         case UPK_IT_ROTAMER: plb_launch<UPK_IT_ROTAMER>(L, G, grid, lds, staged, blocks1); break;
         case UPK_IT_HBOND_COVERAGE: plb_launch<UPK_IT_HBOND_COVERAGE>(L, G, grid, lds, staged, blocks1); break;
