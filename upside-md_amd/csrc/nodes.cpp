@@ -1050,19 +1050,20 @@ struct RotamerSidechain : public PotentialNode {
         if (want > 1) C = want;
         if (C > 16 || n_node - R.n_node1 < C) C = 1;             // too large for a co-resident cluster: one-workgroup solve
         R.bp_resident = 1;
-        // The cluster solves trade HBM traffic for two device-scope barriers per sweep.  Resident form: wins while the
-        // whole batch fits ONE cluster launch (CUs / C systems; measured 0.20 vs 0.53 ms at 1 system, 0.46 vs 0.75 ms
-        // at 32).  Beyond that, while at least four CUs per system are free, the split form spreads each system over
-        // the CUs the one-workgroup solve would leave idle (512 lanes per workgroup keep its three slot states in
-        // registers: 0.48 vs 0.61 ms for two resident launches at 48 systems, 0.55 vs 0.70 at 64, but 0.50 vs 0.41 at 40;
-        // with two workgroups per system it loses to the one-workgroup solve: 0.74 vs 0.54 ms at 96, 0.85 vs 0.59 at
-        // 128); once every CU has its own system the one-workgroup solve is best.
+        // The cluster solve trades HBM/L2 traffic for two device-scope barriers per sweep.  Re-measured after the
+        // one-workgroup kernel got its batched loads and the short list margin (BP ms, cluster vs one workgroup):
+        //   300 residues / 10 A (C = 8):  1 system 0.19 vs 0.31, 8: 0.23 vs 0.35, 32: 0.35 vs 0.43, 48 (two launches or the
+        //                                 split form): 0.63 vs 0.47, 64: 0.56 vs 0.48
+        //   300 residues / 7 A, 150 residues / 10 A (C = 3..4): 0.22 vs 0.19 at 1 system, 0.31 vs 0.24 at 32
+        //   56 and 20 residues (C = 1): the one-workgroup solve by construction
+        // so the resident cluster is used when the pair matrices need many workgroups (C >= 6) and the batch fits one
+        // launch (CUs / C systems) or a quarter more; everything else takes the one-workgroup solve.  The split form
+        // (cluster over global-memory matrices) no longer wins anywhere; UPSIDE_HIP_BP_SPLIT keeps it testable.
         const int n_cu = upk_device_cu_count();
-        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", 40)) {
-            C = 1;
-            const int split_max = env_int("UPSIDE_HIP_BP_SPLIT_MAX_SYSTEMS", n_cu / 4);
-            if (ctx->n_system <= split_max) { C = min(8, n_cu / ctx->n_system); R.bp_resident = 0; if (C < 2 || n_node - R.n_node1 < C) C = 1; }
-        }
+        int per_launch = C > 1 ? n_cu / C : 0;
+        if (per_launch >= 8) per_launch &= ~7;
+        const int resident_limit = C >= env_int("UPSIDE_HIP_BP_CLUSTER_MIN_C", 6) ? per_launch + per_launch / 4 : 0;
+        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", resident_limit)) C = 1;
         if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
     }
