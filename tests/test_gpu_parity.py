@@ -152,6 +152,38 @@ def test_optional_restraint_nodes_match_oracle_and_reference(hip):
     up.close(); orc.close()
 
 
+@pytest.mark.parametrize('name', ['edge_gly5', 'edge_pro6', 'edge_awa3'])
+def test_degenerate_sequences(hip, name):
+    """empty interaction classes and tiny systems: all-glycine (belief propagation without a single edge), all-proline
+    (one donor site), three residues; force pass against the oracle and the reference's golden vectors, pair lists
+    bit-exact, then a short batched MD run that must stay finite"""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    ref = P.evaluate_all(orc, g['pos']); act = P.evaluate_all(up, g['pos'])
+    assert_close(ref, act, keys=[k for k in ref if k != 'energy' and np.asarray(ref[k]).size])
+    scale = sum(abs(float(ref['pot/' + k])) for k in P.POTENTIAL_NODES)
+    assert abs(float(ref['energy']) - float(act['energy'])) <= RTOL * scale
+    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4
+    assert abs(float(g['energy']) - float(act['energy'])) < 1e-4 * max(1., scale)
+    for node in IGRAPH_NODES:
+        assert np.array_equal(hip_pairlist(up, node), P.oracle_pairlist(orc, node)), node
+    up.close(); orc.close()
+    c = hip.calc
+    n_atom = g['pos'].shape[0]
+    e = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 5, True)
+    x = np.tile(g['pos'][None], (5, 1, 1)).astype('f4')
+    assert c.upside_hip_set_pos(e, x.ctypes.data) == 0
+    temps = np.full(5, 0.8, 'f4')
+    assert c.upside_hip_init_md(e, temps.ctypes.data, 3, 5.0, 0.009, 1) == 0
+    assert c.upside_hip_run_md(e, 200) == 0
+    assert c.upside_hip_get_pos(e, x.ctypes.data) == 0
+    assert np.isfinite(x).all() and np.abs(x).max() < 100.
+    en = np.zeros(5, 'f4')
+    assert c.upside_hip_compute(e, en.ctypes.data, None) == 0 and np.isfinite(en).all()
+    c.free_deriv_engine(ct.c_void_p(e))
+
+
 def test_param_deriv_of_every_system(hip):
     """the batched extension returns each system's own derivative"""
     name = 'proteinG56_7A'

@@ -90,6 +90,24 @@ def test_oracle_optional_nodes_match_reference_golden(oracle):
     up.close()
 
 
+@pytest.mark.parametrize('name', ['edge_gly5', 'edge_pro6', 'edge_awa3'])
+def test_oracle_degenerate_sequences_match_reference_golden(oracle, name):
+    """all-glycine (no belief-propagation edges at all), all-proline (one hydrogen-bond donor), three residues (every
+    group of four SIMD lanes padded): energy, forces, node outputs and per-node potentials against the reference"""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name), library=oracle)
+    act = P.evaluate_all(up, g['pos'])
+    assert P.rel_rms(g['deriv'], act['deriv']) < TOL_SENS
+    scale = sum(abs(float(act['pot/' + k])) for k in P.POTENTIAL_NODES)
+    assert abs(float(g['energy']) - float(act['energy'])) < TOL_OUT * 10 * scale
+    for k in g:
+        if k.startswith('out/') and g[k].size:     # five-element arrays of nearly cancelling sums: no averaging in the RMS
+            assert P.rel_rms(g[k], act[k]) < 5 * TOL_OUT, k
+        if k.startswith('pot/'):
+            assert abs(float(g[k]) - float(act[k])) < TOL_OUT * 10 * max(1., abs(float(g[k]))), k
+    up.close()
+
+
 @pytest.mark.parametrize('name', FIXTURES)
 def test_oracle_pairlist_bit_exact(oracle, name):
     """pair-list indices in the reference's canonical order, exact (integer work)."""

@@ -10,6 +10,7 @@ and the canonical pair list.  Nothing here is needed at test time; tests read on
 usage: python tools/make_fixtures.py [name ...]
        python tools/make_fixtures.py --add-param-derivs [name ...]   (adds param_deriv/<node> to existing golden files)
        python tools/make_fixtures.py --restraints                    (proteinG56_restraints: every optional node)
+       python tools/make_fixtures.py --edge-cases                    (edge_*: degenerate sequences)
 """
 import os
 import subprocess
@@ -135,6 +136,36 @@ def make_restraints(base='proteinG56_7A', name='proteinG56_restraints'):
     print(name, 'energy %.4f' % g['energy'], dict((k, float(v)) for k, v in g.items() if k.startswith('pot/') and k[4:] in RESTRAINT_NODES))
 
 
+EDGE_CASES = {'edge_gly5': ['GLY'] * 5,            # one-state side chains only: the belief-propagation graph has no edges
+              'edge_pro6': ['PRO'] * 6,            # no backbone N-H donors after the first residue
+              'edge_awa3': ['ALA', 'TRP', 'ALA']}  # three residues: every group of four lanes is padded
+
+
+def make_edge_cases():
+    """degenerate sequences (empty interaction classes, padded SIMD groups); helix geometry with 0.05 A of seeded noise
+    (an exactly planar, axis-aligned first residue gives the alignment eigen-solver exact zeros, on which the reference's
+    -ffast-math build and an IEEE build take different branches)"""
+    rama_ref = cfg.load_rama_reference(os.path.join(PARAM, 'common', 'rama_reference.pkl'))
+    lib = pkg.UpsideLibrary(os.path.join(REF, 'libupside_7A.so'))
+    for i, (name, seq) in enumerate(sorted(EDGE_CASES.items())):
+        fasta = np.array(seq)
+        pos = cfg.helix_chain(len(seq)) + 0.05 * np.random.RandomState(40 + i).normal(size=(3 * len(seq), 3))
+        out = os.path.join(GOLD, name + '.up')
+        cfg.write_config(out, fasta, pos, sidechain_lib=os.path.join(PARAM, 'ff_1/sidechain.h5'),
+                         environment_lib=os.path.join(PARAM, 'ff_1', 'environment.h5'), rama_ref=rama_ref, hbond_energy=HBOND,
+                         rama_seed=1)
+        up = pkg.Upside(out, library=lib)
+        x = up.initial_pos.copy()
+        g = dict(pos=x, energy=np.float32(up.energy(x)), deriv=up.deriv(x))
+        for nm in NODES:
+            g['out/' + nm] = up.get_output(nm)
+        for nm in POTENTIALS:
+            g['pot/' + nm] = up.get_output(nm)[0, 0]
+        up.close()
+        np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
+        print(name, 'energy %.5f' % g['energy'], 'size %.2f MB' % (os.path.getsize(out) / 1e6))
+
+
 def make(name):
     seq, variant, sclib, r_cavity, seed, per_res = FIXTURES[name]
     fasta = cfg.fasta_from_one_letter(seq) if isinstance(seq, str) else cfg.random_fasta(seq, seed)
@@ -212,6 +243,9 @@ def make(name):
 
 
 if __name__ == '__main__':
+    if sys.argv[1:2] == ['--edge-cases']:
+        make_edge_cases()
+        sys.exit(0)
     if sys.argv[1:2] == ['--restraints']:            # the optional-node fixture (built on proteinG56_7A)
         make_restraints()
         sys.exit(0)

@@ -9,7 +9,8 @@ using namespace up;
 
 #define UPK_BLOCK 256
 #define ST(L) ((hipStream_t)(L)->stream)
-static inline dim3 grid1(int n, int S) { return dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)S, 1); }
+// (an empty node -- e.g. a sequence without hydrogen-bond donors -- still gets one workgroup: a zero grid is a launch error)
+static inline dim3 grid1(int n, int S) { return dim3((unsigned)(n > 0 ? (n + UPK_BLOCK - 1) / UPK_BLOCK : 1), (unsigned)S, 1); }
 static inline int launch_status() { return (int)hipGetLastError(); }
 
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)

@@ -19,6 +19,7 @@ using namespace up;
 #define ROWS_PER_BLOCK 4
 #define IG_BLOCK (ROWS_PER_BLOCK * UP_WAVE)
 static inline int launch_status() { return (int)hipGetLastError(); }
+static inline unsigned rows_grid(int n_rows) { return n_rows > 0 ? (unsigned)((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) : 1u; }   // an empty side still needs a non-zero grid
 
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
@@ -345,7 +346,7 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
 static int igraph_rowsum_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
                                  int out_stride, int out_comp, int out_row0, float* own_grad) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
-    hipLaunchKernelGGL(k_igraph_rowsum, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
+    hipLaunchKernelGGL(k_igraph_rowsum, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
                        out, out_sys_stride, out_stride, out_comp, out_row0, own_grad);
     return launch_status();
 }
@@ -405,7 +406,7 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
 static int igraph_grad_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                                const float* sens2, long sens_sys_stride, int sens_stride) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
-    hipLaunchKernelGGL(k_igraph_grad, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
+    hipLaunchKernelGGL(k_igraph_grad, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
                        sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
     return launch_status();
 }
@@ -649,7 +650,7 @@ __global__ void k_igraph_inrange(upk_igraph_t G, unsigned char* __restrict__ fla
     }
 }
 extern "C" int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags) {
-    hipLaunchKernelGGL(k_igraph_inrange, dim3((G->n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, flags);
+    hipLaunchKernelGGL(k_igraph_inrange, dim3(rows_grid(G->n1), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, flags);
     return launch_status();
 }
 
@@ -691,7 +692,7 @@ extern "C" int upk_igraph_param_deriv(const upk_launch_t* L, const upk_igraph_t*
                                       const float* sens2, long sens_sys_stride, int sens_stride, float* table) {
     if (system < 0 || system >= L->n_system) return 9101;
     if (G->itype == UPK_IT_ROTAMER) return 9102;   // upk_rotamer_param_deriv owns the pair sensitivities of that graph
-    hipLaunchKernelGGL(k_igraph_param_deriv, dim3((G->n1 + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(IG_BLOCK), 0, ST(L), *G, system,
+    hipLaunchKernelGGL(k_igraph_param_deriv, dim3(rows_grid(G->n1)), dim3(IG_BLOCK), 0, ST(L), *G, system,
                        sens_mode, sens1, sens2, sens_sys_stride, sens_stride, table);
     return launch_status();
 }
