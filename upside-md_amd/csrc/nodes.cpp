@@ -942,6 +942,8 @@ struct RotamerSidechain : public PotentialNode {
             n_elem_rot[n_rot] = max(n_elem_rot[n_rot], (int)id + 1);
         }
         n1 = n_elem_rot[1]; n3 = n_elem_rot[3]; n6 = n_elem_rot[6]; n_node = n1 + n3 + n6;
+        if (n_node > 1024)   // one lane per node in the slot numbering and the one-workgroup solve (kernels_rotamer.hip)
+            throw string("rotamer: ") + to_string(n_node) + " side-chain nodes, but the device belief-propagation solve handles at most 1024";
         const int start[7] = {0, 0, 0, n1, 0, 0, n1 + n3};
         node_nrot.assign(n_node, 0);
         for (int g = 0; g < n_node; ++g) node_nrot[g] = g < n1 ? 1 : (g < n1 + n3 ? 3 : 6);
