@@ -61,10 +61,21 @@ __global__ void k_gather_contrib(const float* __restrict__ arena, long arena_str
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.f;
     const int e0 = csr_start[t], e1 = csr_start[t + 1];
-    for (int e = e0; e < e1; ++e) {
-        const float* p = a + csr_entry[e];
+    // four contributions per trip: their offsets, then their rows, are fetched as independent loads before the adds
+    // (same summation order as one at a time)
+    for (int e = e0; e < e1; e += 4) {
+        int off[4]; float v[4][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) if (c < width) acc[c] += p[c];
+        for (int u = 0; u < 4; ++u) off[u] = csr_entry[e + u < e1 ? e + u : e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[u][c] = c < width ? a[off[u] + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e + u < e1)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c < width) acc[c] += v[u][c];
     }
     float* sens = C_SENS(target, s) + (size_t)t * target.stride + comp_offset;
 #pragma unroll
