@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Build a `.up` configuration for a real structure (python3 stand-in for PDB_to_initial_structure.py + the README call
+of upside_config.py; needs the reference's parameter directory, so it runs where /root/reference is available).
+
+    python tools/make_config.py --pdb 1abc.pdb --chains A --out 1abc.up [--param-dir /root/reference/parameters]
+                                [--cutoff 7|10] [--cavity-radius R] [--contacts table] [--z-flat-bottom table] ...
+
+The Ramachandran maps are the synthetic per-residue maps of config.synthetic_rama_maps around the shipped reference
+state (the README's rama.dat library is not part of the parameter directory here)."""
+import argparse
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def table(path):
+    rows = [ln.split() for ln in open(path) if ln.strip()]
+    return np.array([[float(x) for x in r] for r in rows[1:]])     # first line = header, as in upside_config.py
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--pdb'); ap.add_argument('--chains', default='')
+    ap.add_argument('--model', type=int, default=None)
+    ap.add_argument('--allow-unexpected-chain-breaks', action='store_true')
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--param-dir', default='/root/reference/parameters')
+    ap.add_argument('--cutoff', choices=['7', '10'], default='7')
+    ap.add_argument('--cavity-radius', type=float, default=0.)
+    ap.add_argument('--contacts'); ap.add_argument('--z-flat-bottom'); ap.add_argument('--tension')
+    ap.add_argument('--pivot-moves', action='store_true', help='also write /input/pivot_moves (Monte-Carlo)')
+    a = ap.parse_args()
+    pkg = load_package(); cfg = pkg.config
+    if not a.pdb:
+        ap.error('--pdb is required')
+    fasta, pos, first = cfg.read_pdb_backbone(a.pdb, chains=[c for c in a.chains.split(',') if c] or None, model=a.model,
+                                              allow_unexpected_chain_breaks=a.allow_unexpected_chain_breaks)
+    if first:
+        print('note: chains are concatenated; first residues of later chains: %s (bonded terms across them are kept)' % first)
+    P = a.param_dir
+    sclib = 'ff_1/sidechain.h5' if a.cutoff == '7' else 'packing/sidechain_10A_cutoff.h5'
+    info = cfg.write_config(a.out, fasta, pos, sidechain_lib=os.path.join(P, sclib),
+                            environment_lib=os.path.join(P, 'ff_1', 'environment.h5'),
+                            rama_ref=cfg.load_rama_reference(os.path.join(P, 'common', 'rama_reference.pkl')),
+                            hbond_energy=float(open(os.path.join(P, 'ff_1', 'hbond')).read()), cavity_radius=a.cavity_radius)
+    extra = {}
+    if a.contacts: extra['contacts'] = table(a.contacts)
+    if a.z_flat_bottom: extra['z_flat_bottom'] = table(a.z_flat_bottom)
+    if a.tension: extra['tension'] = table(a.tension)
+    if extra:
+        cfg.add_restraints(a.out, **extra)
+    if a.pivot_moves:
+        cfg.add_pivot_moves(a.out)
+    print('%s: %i residues, %i side-chain beads' % (a.out, info['n_res'], info['n_bead']))
+
+
+if __name__ == '__main__':
+    main()

@@ -506,3 +506,92 @@ def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=
             sg.write('id', ids)
             g = pot.create_group('atom_pos_spring_on_slice'); _args(g, ['slice_pos_for_spring'])
             g.write('id', np.arange(len(ids), dtype='i4')); g.write('x0', np.zeros((len(ids), 3))); g.write('spring_const', np.full(len(ids), 0.3))
+
+
+# --- real structures: the main path of py/PDB_to_initial_structure.py without ProDy ---------------------------------
+def _dihedral(x1, x2, x3, x4):
+    b1, b2, b3 = x2 - x1, x3 - x2, x4 - x3
+    b2b3 = np.cross(b2, b3)
+    return np.arctan2(np.sqrt((b2 ** 2).sum()) * (b1 * b2b3).sum(), (np.cross(b1, b2) * b2b3).sum())
+
+
+def read_pdb_backbone(path, chains=None, model=None, recenter=True, allow_unexpected_chain_breaks=False):
+    """N, CA, C coordinates and the sequence of a PDB file, as py/PDB_to_initial_structure.py:104-186 prepares them:
+    residues with a complete backbone only, MSE read as MET (:26-28), unknown residue types skipped (:58-60), a proline
+    after a cis peptide bond named CPR (:88), chains concatenated in file order with an error for a chain break inside a
+    chain (N more than 2 A from the previous C, :147-153), centre of mass moved to the origin unless recenter=False.
+    Alternate locations other than the first are ignored; `model` selects one MODEL of an NMR file (default: the first).
+    Returns (fasta: array of three-letter codes, pos: (3*n_res, 3) float64, chain_first_residue: list of indices)."""
+    standard = set(x for x in ('ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL').split())
+    wanted = set(chains) if chains else None
+    residues = []          # [chain, resid, restype, {atom: xyz}]
+    cur_model = None
+    for ln in open(path):
+        rec = ln[:6]
+        if rec.startswith('MODEL'):
+            cur_model = int(ln.split()[1])
+            continue
+        if rec.startswith('ENDMDL') and (model is None or cur_model == model) and residues:
+            break
+        if rec not in ('ATOM  ', 'HETATM'):
+            continue
+        if model is not None and cur_model is not None and cur_model != model:
+            continue
+        altloc, chain = ln[16], ln[21]
+        if wanted is not None and chain not in wanted:
+            continue
+        name, resname, resid = ln[12:16].strip(), ln[17:20].strip(), ln[22:27]
+        resname = {'MSE': 'MET'}.get(resname, resname)
+        if resname not in standard:
+            continue
+        key = (chain, resid)
+        if not residues or residues[-1][:2] != list(key):
+            residues.append([chain, resid, resname, {}, altloc])
+        if altloc not in (' ', residues[-1][4]) and residues[-1][4] != ' ':
+            continue
+        if altloc != ' ' and residues[-1][4] == ' ':
+            residues[-1][4] = altloc
+        residues[-1][3].setdefault(name, np.array([float(ln[30:38]), float(ln[38:46]), float(ln[46:54])]))
+    if wanted is not None:
+        missing = wanted.difference(r[0] for r in residues)
+        if missing:
+            raise ValueError('missing chain %s' % ','.join(sorted(missing)))
+    residues = [r for r in residues if all(a in r[3] for a in ('N', 'CA', 'C'))]
+    if not residues:
+        raise ValueError('no residue with a complete backbone in %s' % path)
+    fasta, coords, chain_first, unexpected = [], [], [], []
+    for i, (chain, resid, resname, atoms, _) in enumerate(residues):
+        new_chain = i > 0 and chain != residues[i - 1][0]
+        if coords:
+            dist = float(np.sqrt(((atoms['N'] - coords[-1]) ** 2).sum()))
+            if dist > 2.:
+                if new_chain:
+                    chain_first.append(len(fasta))
+                else:
+                    unexpected.append((len(fasta), dist))
+            if resname == 'PRO' and dist <= 2.:
+                omega = _dihedral(coords[-2], coords[-1], atoms['N'], atoms['CA'])
+                if abs(omega) < 0.5 * np.pi:
+                    resname = 'CPR'
+        fasta.append(resname)
+        coords.extend([atoms['N'], atoms['CA'], atoms['C']])
+    if unexpected and not allow_unexpected_chain_breaks:
+        raise ValueError('unexpected chain break(s) at residue(s) %s (probably residues missing from the structure)'
+                         % ', '.join('%i (%.1f A)' % u for u in unexpected))
+    pos = np.array(coords, dtype='f8')
+    if recenter:
+        pos -= pos.mean(axis=0)
+    return np.array(fasta), pos, chain_first
+
+
+def write_pdb_backbone(path, fasta, pos, chain='A'):
+    """the inverse, for round trips and for looking at structures: N, CA, C records only"""
+    with open(path, 'w') as f:
+        k = 1
+        for i, aa in enumerate(fasta):
+            for j, (nm, el) in enumerate((('N', 'N'), ('CA', 'C'), ('C', 'C'))):
+                x = pos[3 * i + j]
+                f.write('ATOM  %5i  %-3s %3s %1s%4i    %8.3f%8.3f%8.3f  1.00  0.00          %2s\n'
+                        % (k, nm, 'PRO' if aa == 'CPR' else aa, chain, i + 1, x[0], x[1], x[2], el))
+                k += 1
+        f.write('END\n')
