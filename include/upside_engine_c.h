@@ -108,6 +108,10 @@ int upside_hip_replica_swap(DerivEngine* engine, int n_pair, const int* pairs, u
  * draw0 = accepted[n_pair] returned for the previous set; accepted has n_pair+1 entries here. */
 int upside_hip_replica_swap_from(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
                                  uint64_t round, int draw0, int* accepted);
+/* a later swap set of the SAME attempt without a new force evaluation: in a temperature-only exchange the accepted pairs
+ * of the earlier sets merely traded their energies (the reference re-evaluates, main.cpp:251-259, and gets the same numbers) */
+int upside_hip_replica_swap_next(DerivEngine* engine, int n_pair, const int* pairs, uint32_t base_seed,
+                                 uint64_t round, int draw0, int* accepted);
 
 /* Replica exchange ACROSS engines / GPUs.  Each rank all-gathers one energy per system
  * (upside_hip_compute), every rank then calls upside_replica_decide on the identical global arrays: host arithmetic
@@ -121,6 +125,8 @@ int upside_replica_decide(int n_pair, const int* pairs, const float* beta, const
 int upside_hip_get_system_pos(DerivEngine* engine, int system, float* pos);        /* host (n_atom,3) */
 int upside_hip_set_system_pos(DerivEngine* engine, int system, const float* pos);
 int upside_hip_swap_systems(DerivEngine* engine, int system1, int system2);
+/* the same for n_pair disjoint pairs (pairs: host array (n_pair,2)) in one launch: the accepted on-GPU pairs of a swap set */
+int upside_hip_swap_system_pairs(DerivEngine* engine, int n_pair, const int* pairs);
 
 /* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */
 int upside_hip_rebuild_flags(DerivEngine* engine, const char* node_name, int* flags);

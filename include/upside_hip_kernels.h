@@ -307,6 +307,8 @@ int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_c
  * one receives the generator position after this set. */
 int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const float* energy, const float* beta, int n_pair,
                      const int* pairs, uint32_t seed, uint64_t round, int draw0, int* accepted);
+/* swap the coordinates of n_pair disjoint (s1, s2) pairs of systems; pairs is a device array */
+int upk_swap_system_pairs(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* pairs);
 
 #ifdef __cplusplus
 }

@@ -369,6 +369,40 @@ def test_replica_exchange_swap(hip):
     c.free_deriv_engine(ct.c_void_p(eng))
 
 
+def test_replica_swap_next_reuses_energies(hip):
+    """the later swap sets of one attempt: `upside_hip_replica_swap_next` (no new force evaluation, energies of accepted
+    pairs traded) gives the verdicts, generator position and coordinates of `upside_hip_replica_swap_from` (which
+    re-evaluates, like main.cpp:251-259)"""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    for f in (c.upside_hip_replica_swap_from, c.upside_hip_replica_swap_next):
+        f.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    rs = np.random.RandomState(4)
+    pos = np.stack([g['pos'] + np.float32(0.03 * k) * rs.normal(size=g['pos'].shape).astype('f4') for k in range(6)]).astype('f4')
+    temps = np.array([0.7, 0.74, 0.78, 0.82, 0.86, 0.9], 'f4')
+    sets = [np.array([[0, 1], [2, 3], [4, 5]], 'i4'), np.array([[1, 2], [3, 4]], 'i4')]
+    results = []
+    for later in (c.upside_hip_replica_swap_from, c.upside_hip_replica_swap_next):
+        eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 6, True)
+        c.upside_hip_set_pos(eng, pos.ctypes.data)
+        c.upside_hip_init_md(eng, temps.ctypes.data, 5, 5.0, 0.009, 1)
+        verdicts = []
+        for rnd in range(1, 9):
+            draw = 0
+            for k, pairs in enumerate(sets):
+                acc = np.zeros(len(pairs) + 1, 'i4')
+                fn = c.upside_hip_replica_swap_from if k == 0 else later
+                assert fn(eng, len(pairs), pairs.ctypes.data, 11, rnd, draw, acc.ctypes.data) == 0
+                draw = int(acc[-1]); verdicts.append(acc.copy())
+        out = np.zeros_like(pos); c.upside_hip_get_pos(eng, out.ctypes.data)
+        results.append((np.concatenate(verdicts), out))
+        c.free_deriv_engine(ct.c_void_p(eng))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    v = results[0][0]
+    assert 0 < v[v < 2].sum() < len(v)            # both accepted and rejected swaps occurred (entries > 1 are draw counters)
+
+
 def test_ensemble_exchange_matches_device_swap(hip):
     """The cross-rank replica-exchange path (host verdicts from gathered energies + per-system coordinate moves,
     upside-md_amd/replicas.py) and the single-engine device kernel must agree: same accepted pairs, same final

@@ -167,14 +167,21 @@ def _exchange_worker(rank, world, port, out_dir):
         beta = (1.0 / rep.geometric_ladder(0.5, 2.0, n)).astype('f4')
         lo, hi = rep.weak_shard(per_rank, world, rank)
         ens = _FakeEnsemble(all_pos[lo:hi])
+        ens2 = _FakeEnsemble(all_pos[lo:hi])                 # one energy evaluation per attempt, energies traded between sets
         ref = _FakeEnsemble(all_pos)                         # the same run in one process
         for round_num in range(6):
-            draw = draw_ref = 0
+            draw = draw_ref = draw2 = 0
+            energy = rep.all_gather_f32(dist, ens2.energies())
             for pairs in rep.neighbour_swap_sets(n):         # set 1 has the cross-rank pair (3,4)
                 acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, 5, round_num, draw)
                 acc_ref, draw_ref = rep.exchange_swap_set(None, ref, pairs, beta, 5, round_num, draw_ref)
+                acc2, draw2 = rep.exchange_swap_set(dist, ens2, pairs, beta, 5, round_num, draw2, energy_global=energy)
+                energy = rep.swap_energies(energy, pairs, acc2)
                 assert np.array_equal(acc, acc_ref) and draw == draw_ref
+                assert np.array_equal(acc2, acc_ref) and draw2 == draw_ref
+                assert np.array_equal(energy, ref.energies())
             assert np.array_equal(ens.pos, ref.pos[lo:hi]), 'sharded exchange must equal the single-process one'
+            assert np.array_equal(ens2.pos, ref.pos[lo:hi])
         moved = not np.array_equal(ref.pos, all_pos)
         with open(os.path.join(out_dir, 'x%d' % rank), 'w') as f:
             f.write('%d' % moved)

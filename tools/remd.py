@@ -63,8 +63,10 @@ def main():
         ens.run_rounds(n)
         done += n
         draw = 0
+        energy = rep.all_gather_f32(dist, ens.energies(), device)      # one force evaluation per attempt ...
         for k, pairs in enumerate(swap_sets):
-            acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, args.seed, done, draw, device)
+            acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, args.seed, done, draw, device, energy_global=energy)
+            energy = rep.swap_energies(energy, pairs, acc)               # ... the later sets see the traded energies
             n_attempt[k] += len(pairs); n_success[k] += int(acc.sum())
             for (s1, s2), ok in zip(pairs, acc):
                 if ok:

@@ -193,6 +193,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     // included, and replayed.  Invalidated by anything that changes a kernel argument.
     hipGraph_t md_graph = nullptr; hipGraphExec_t md_graph_exec = nullptr;
     bool md_graph_ready = false; int md_graph_parity = 0; uint64_t steps_done = 0, n_compute = 0;
+    std::vector<float> swap_energy;   // energies seen by the last replica-swap set, accepted pairs already traded (upside_hip_replica_swap_next)
     bool graph_failed = false;   // capture was refused once: stay on plain launches
     void invalidate_graph();
     bool capture_md_graph();

@@ -308,21 +308,35 @@ extern "C" int upside_hip_recenter(DerivEngine* e) {
 extern "C" int upside_hip_recenter_axes(DerivEngine* e, int xy_only) {
     API_TRY upk_check(upk_recenter(&e->ctx.L, e->pos->coord(), xy_only ? 1 : 0), "recenter"); e->sync(); return 0; API_CATCH(1) }
 
-extern "C" int upside_hip_replica_swap_from(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
-    API_TRY
+static int replica_swap_impl(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted, bool reuse_energy) {
     const int S = e->ctx.n_system;
     for (int i = 0; i < 2 * n_pair; ++i) if (pairs[i] < 0 || pairs[i] >= S) throw string("invalid system");
-    e->compute(PotentialAndDerivMode);
-    e->fetch_potentials();
+    if (reuse_energy) {
+        if ((int)e->swap_energy.size() != S) throw string("upside_hip_replica_swap_next needs a preceding upside_hip_replica_swap(_from) of the same attempt");
+    } else {
+        e->compute(PotentialAndDerivMode);
+        e->fetch_potentials();
+        e->swap_energy = e->potential;
+    }
     vector<float> beta(S);
     for (int s = 0; s < S; ++s) beta[s] = 1.f / e->temperature[s];
-    DevBuf<float> d_en, d_beta; d_en.upload(e->potential); d_beta.upload(beta);
+    DevBuf<float> d_en, d_beta; d_en.upload(e->swap_energy); d_beta.upload(beta);
     DevBuf<int> d_pairs, d_acc; d_pairs.upload(vector<int>(pairs, pairs + 2 * n_pair)); d_acc.alloc(n_pair + 1);
     upk_check(upk_replica_swap(&e->ctx.L, e->pos->coord(), d_en.p, d_beta.p, n_pair, d_pairs.p, base_seed, round, draw0, d_acc.p), "replica_swap");
     e->sync();
     auto acc = d_acc.download();
     for (int i = 0; i <= n_pair; ++i) accepted[i] = acc[i];   // accepted[n_pair] = generator position for the next set
+    for (int i = 0; i < n_pair; ++i) if (acc[i]) swap(e->swap_energy[pairs[2 * i]], e->swap_energy[pairs[2 * i + 1]]);   // the coordinates traded places
     return 0;
+}
+extern "C" int upside_hip_replica_swap_from(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
+    API_TRY
+    return replica_swap_impl(e, n_pair, pairs, base_seed, round, draw0, accepted, false);
+    API_CATCH(1)
+}
+extern "C" int upside_hip_replica_swap_next(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
+    API_TRY
+    return replica_swap_impl(e, n_pair, pairs, base_seed, round, draw0, accepted, true);
     API_CATCH(1)
 }
 extern "C" int upside_hip_replica_swap(DerivEngine* e, int n_pair, const int* pairs, uint32_t base_seed, uint64_t round, int* accepted) {
@@ -396,6 +410,22 @@ extern "C" int upside_hip_set_system_pos(DerivEngine* e, int sys, const float* p
     for (int a = 0; a < na; ++a) for (int d = 0; d < 3; ++d) buf[(size_t)a * st + d] = pos[a * 3 + d];
     e->sync();
     hip_check(hipMemcpy(e->pos->output.p + (size_t)sys * na * st, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_swap_system_pairs(DerivEngine* e, int n_pair, const int* pairs) {
+    API_TRY
+    const int S = e->ctx.n_system;
+    if (n_pair <= 0) return 0;
+    vector<char> used(S, 0);
+    for (int i = 0; i < 2 * n_pair; ++i) {
+        if (pairs[i] < 0 || pairs[i] >= S) throw string("invalid system");
+        if (used[pairs[i]]) throw string("Overlapping indices in swap set.");
+        used[pairs[i]] = 1;
+    }
+    DevBuf<int> d; d.upload(vector<int>(pairs, pairs + 2 * n_pair));
+    upk_check(upk_swap_system_pairs(&e->ctx.L, e->pos->coord(), n_pair, d.p), "swap_system_pairs");
+    e->sync();
     return 0;
     API_CATCH(1)
 }

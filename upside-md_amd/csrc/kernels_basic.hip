@@ -1051,6 +1051,20 @@ extern "C" int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const fl
     return launch_status();
 }
 
+// exchange the coordinates of disjoint pairs of systems in one launch (the accepted on-GPU pairs of a swap set)
+__global__ void k_swap_system_pairs(upk_coord_t pos, const int* __restrict__ pairs) {
+    const int p = blockIdx.y;
+    float* a = C_OUT(pos, pairs[p * 2]); float* b = C_OUT(pos, pairs[p * 2 + 1]);
+    const int n = pos.n_elem * pos.stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float t = a[i]; a[i] = b[i]; b[i] = t; }
+}
+extern "C" int upk_swap_system_pairs(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* pairs) {
+    if (n_pair <= 0) return 0;
+    const int n = pos.n_elem * pos.stride;
+    hipLaunchKernelGGL(k_swap_system_pairs, dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)n_pair), dim3(UPK_BLOCK), 0, ST(L), pos, pairs);
+    return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Parameter derivatives of the per-element nodes, for ONE system, into a zeroed table (the reference's
 // get_param_deriv under PARAM_DERIV).  Off the MD path: global atomics.

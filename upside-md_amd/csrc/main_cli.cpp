@@ -268,7 +268,9 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             int draw = 0;
             for (size_t k = 0; k < sets.size(); ++k) {
                 vector<int> acc(sets[k].size() / 2 + 1);
-                if (upside_hip_replica_swap_from(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, draw, acc.data())) throw string(upside_hip_last_error());
+                // one force evaluation per attempt: the later sets see the energies the accepted pairs traded
+                if ((k == 0 ? upside_hip_replica_swap_from : upside_hip_replica_swap_next)(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, draw, acc.data()))
+                    throw string(upside_hip_last_error());
                 draw = acc.back();
                 for (size_t i = 0; i < sets[k].size() / 2; ++i) {
                     n_attempt[k]++; n_success[k] += acc[i];

@@ -243,6 +243,7 @@ class Ensemble(object):
         c.upside_hip_get_system_pos.argtypes = [vp, i32, vp]
         c.upside_hip_set_system_pos.argtypes = [vp, i32, vp]
         c.upside_hip_swap_systems.argtypes = [vp, i32, i32]
+        c.upside_hip_swap_system_pairs.argtypes = [vp, i32, vp]
         c.upside_hip_last_error.restype = ct.c_char_p
         c._ensemble_bound = True
 
@@ -280,6 +281,11 @@ class Ensemble(object):
 
     def swap_systems(self, s1, s2):
         self._check(self.calc.upside_hip_swap_systems(self.engine, int(s1), int(s2)), 'swap_systems')
+
+    def swap_system_pairs(self, pairs):
+        p = np.ascontiguousarray(np.asarray(pairs, 'i4').reshape(-1, 2))
+        if len(p):
+            self._check(self.calc.upside_hip_swap_system_pairs(self.engine, int(len(p)), p.ctypes.data), 'swap_system_pairs')
 
     # -- force pass / MD ------------------------------------------------------------------------
     def energies(self):

@@ -87,7 +87,8 @@ def all_gather_f32(dist, local, device='cpu'):
     return torch.cat(out).cpu().numpy()
 
 
-def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, draw0=0, device='cpu', decide=None):
+def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, draw0=0, device='cpu', decide=None,
+                      energy_global=None):
     """One swap set of a replica-exchange attempt over systems spread across ranks (weak shard: rank r owns the
     global systems [r*n, (r+1)*n), n = ensemble.n_system).
 
@@ -98,6 +99,8 @@ def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, 
        send/recv of 3*n_atom floats per pair.  Momenta and temperatures stay where they are (main.cpp:244-247).
 
     `ensemble` needs n_system, energies(), get_system_pos(i), set_system_pos(i, x), swap_systems(i, j).
+    `energy_global`: the gathered energies if the caller already has them (in a temperature-only exchange the later
+    swap sets of one attempt need no new force evaluation: accepted pairs just trade their energies, `swap_energies`).
     Returns (accepted bool array over `pairs`, next draw index)."""
     import numpy as np
     import torch
@@ -107,15 +110,15 @@ def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, 
     n = ensemble.n_system
     lo = rank * n
     pairs = np.asarray(pairs, dtype='i4').reshape(-1, 2)
-    energy = all_gather_f32(dist, ensemble.energies(), device)
+    energy = all_gather_f32(dist, ensemble.energies(), device) if energy_global is None else np.asarray(energy_global, 'f4')
     accepted, draw = decide(pairs, beta_global, energy, base_seed, round_num, draw0)
-    ops, incoming = [], []
+    ops, incoming, local = [], [], []
     for (s1, s2), ok in zip(pairs.tolist(), accepted.tolist()):
         if not ok:
             continue
         r1, r2 = s1 // n, s2 // n
         if r1 == rank and r2 == rank:
-            ensemble.swap_systems(s1 - lo, s2 - lo)
+            local.append((s1 - lo, s2 - lo))
         elif rank in (r1, r2):
             mine, peer = (s1, r2) if r1 == rank else (s2, r1)
             out = torch.from_numpy(np.ascontiguousarray(ensemble.get_system_pos(mine - lo))).to(device)
@@ -123,12 +126,29 @@ def exchange_swap_set(dist, ensemble, pairs, beta_global, base_seed, round_num, 
             ops.append(dist.P2POp(dist.isend, out, peer))
             ops.append(dist.P2POp(dist.irecv, inc, peer))
             incoming.append((mine - lo, inc))
+    if local:       # all on-rank pairs of the set in one device launch
+        if hasattr(ensemble, 'swap_system_pairs'):
+            ensemble.swap_system_pairs(local)
+        else:
+            for a, b in local:
+                ensemble.swap_systems(a, b)
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for sys_local, inc in incoming:
             ensemble.set_system_pos(sys_local, inc.cpu().numpy())
     return accepted, draw
+
+
+def swap_energies(energy_global, pairs, accepted):
+    """energies after a swap set of a temperature-only exchange: the coordinates of an accepted pair changed places,
+    so did their (Hamiltonian-independent) energies"""
+    import numpy as np
+    e = np.array(energy_global, dtype='f4', copy=True)
+    for (s1, s2), ok in zip(np.asarray(pairs).reshape(-1, 2).tolist(), np.asarray(accepted).tolist()):
+        if ok:
+            e[s1], e[s2] = e[s2], e[s1]
+    return e
 
 
 def geometric_ladder(t_low, t_high, n):
