@@ -177,7 +177,7 @@ int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int 
 int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags);
 
 /* ---- rotamer (src/rotamer.cpp) ------------------------------------------------------------------- */
-/* grid.y of the rebuild kernels: enough slices that the systems flagged in one step (about one in three with the
+/* grid.y of the rebuild kernels: enough slices that the systems flagged in one step (about one in five with the
  * short list margin) are rebuilt side by side, few enough that a quiet step retires almost no idle workgroups
  * (measured at 1024 systems, same box: S/8 91.8 k, S/4 92.8 k, S/2 92.5 k system-steps/s) */
 #define UPK_FLAG_DIV_DEFAULT 4
