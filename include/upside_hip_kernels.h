@@ -22,6 +22,7 @@ typedef struct { float* out; float* sens; int n_elem; int width; int stride; } u
 /* ---- generic ---------------------------------------------------------------------------------- */
 /* out[s] (+)= sum_i in[s][i]; one workgroup per system, fixed tree order (deterministic).            */
 int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate);
+int upk_scale(const upk_launch_t* L, float* x, int n, float factor);   /* x[i] *= factor */
 /* zero n_buf device buffers (float counts in sizes[], 16-byte aligned) in one launch:
  * the per-node "zero sensitivity" of deriv_engine.cpp:147-151 for the whole graph */
 int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf);
@@ -123,7 +124,8 @@ int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residu
                        float* pot_terms);
 
 /* ---- interaction graph (src/interaction_graph.h) ---------------------------------------------------- */
-enum { UPK_IT_ROTAMER = 0, UPK_IT_HBOND_COVERAGE = 1, UPK_IT_ENVIRONMENT = 2, UPK_IT_PROTEIN_HBOND = 3 };
+enum { UPK_IT_ROTAMER = 0, UPK_IT_HBOND_COVERAGE = 1, UPK_IT_ENVIRONMENT = 2, UPK_IT_PROTEIN_HBOND = 3,
+       UPK_IT_RADIAL = 4 /* symmetric, sidechain_radial.cpp:16-79 */, UPK_IT_HBOND_SC_RADIAL = 5 /* the same functor between two nodes */ };
 
 typedef struct {
     int itype, symmetric;
@@ -171,6 +173,7 @@ int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int 
 /* K8 backward: for every row of `side`, sum over in-range neighbours of sens(pair) * d(value)/d(row coords),
  * added to the source node's sens at loc[row] (interaction_graph.h:525-555 in gather form).
  * Pair sensitivity: sens_mode 1: sens1[s][i1*sens_stride]; 2: sens2[s][i2*sens_stride]; 3: sens1[i1]+sens2[i2]. */
+/* sens_mode 0: every pair has sensitivity 1 (potentials summed over edges, sidechain_radial.cpp:94-96) */
 int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                     const float* sens2, long sens_sys_stride, int sens_stride);
 /* parity/diagnostic: flags[s][i][k] = 1 where cached neighbour k of row i is in range this step */

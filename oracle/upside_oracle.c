@@ -719,7 +719,7 @@ static void infer_deriv(Engine* e, Node* n) {
 /* ============================================================================================
  * interaction graph  (src/interaction_graph.h)
  * ========================================================================================== */
-enum { IT_ROTAMER = 0, IT_HBOND_COVERAGE = 1, IT_ENVIRONMENT = 2, IT_PROTEIN_HBOND = 3 };
+enum { IT_ROTAMER = 0, IT_HBOND_COVERAGE = 1, IT_ENVIRONMENT = 2, IT_PROTEIN_HBOND = 3, IT_RADIAL = 4, IT_HBOND_SC_RADIAL = 5 };
 
 typedef struct {
     int itype, symmetric;
@@ -741,6 +741,7 @@ static int acceptable_id_pair(int itype, int id1, int id2) {
     switch (itype) {
         case IT_ROTAMER: return ((unsigned)id1 >> N_BIT_ROTAMER) != ((unsigned)id2 >> N_BIT_ROTAMER);   /* bead_interaction.h:195-197 */
         case IT_HBOND_COVERAGE:                                                                           /* hbond.cpp:254-259 */
+        case IT_RADIAL: case IT_HBOND_SC_RADIAL:                                                          /* sidechain_radial.cpp:41-44 */
         case IT_ENVIRONMENT: return (2 < id1 - id2) || (2 < id2 - id1);                                   /* environment.cpp:22-25 */
         default: return 1;                                                                                /* hbond.cpp:162-164 */
     }
@@ -751,6 +752,7 @@ static float igraph_type_cutoff(const IGraph* g, const float* p) {
         case IT_ROTAMER: case IT_HBOND_COVERAGE:
             return (float)((g->n_knot - 2 - 1e-6) / g->inv_dx);         /* bead_interaction.h:191-193, hbond.cpp:250-252 */
         case IT_ENVIRONMENT: return p[0] + 1.f / p[1];                  /* environment.cpp:18-20, vector_math.h:660-666 */
+        case IT_RADIAL: case IT_HBOND_SC_RADIAL: return (float)((16 - 2 - 1e-6) / p[0]);   /* sidechain_radial.cpp:31-34 */
         default: return sqrtf(3.5f * 3.5f);                             /* hbond.cpp:124,158-160 */
     }
 }
@@ -763,7 +765,7 @@ static void igraph_update_cutoffs(IGraph* g) {   /* interaction_graph.h:383-398 
 
 static int igraph_init(IGraph* g, hid_t grp, int itype) {   /* interaction_graph.h:305-381 */
     memset(g, 0, sizeof(*g));
-    g->itype = itype; g->symmetric = (itype == IT_ROTAMER);
+    g->itype = itype; g->symmetric = (itype == IT_ROTAMER || itype == IT_RADIAL);
     hsize_t dims[3];
     g->param = h5_read_f(grp, "interaction_param", 3, dims);
     if (!g->param) return -1;
@@ -773,6 +775,7 @@ static int igraph_init(IGraph* g, hid_t grp, int itype) {   /* interaction_graph
         case IT_HBOND_COVERAGE: g->n_dim1 = 7; g->n_dim2 = 6; break;
         case IT_ENVIRONMENT: g->n_dim1 = 6; g->n_dim2 = 4; if (g->n_param != 4) return -1; break;
         case IT_PROTEIN_HBOND: g->n_dim1 = 6; g->n_dim2 = 6; if (g->n_param != 8) return -1; break;
+        case IT_RADIAL: case IT_HBOND_SC_RADIAL: g->n_dim1 = 3; g->n_dim2 = 3; if (g->n_param != 17) return -1; break;
     }
     if (itype == IT_ROTAMER || itype == IT_HBOND_COVERAGE) {
         /* compile-time knot counts of the reference become run-time: n_param = 2*ka + 2*k
@@ -840,6 +843,17 @@ static float quadspline(const IGraph* g, float* d1, float* d2, const float* p, c
     float coverage = wide[0] + angular_weight * narrow[0];
     for (int c = 0; c < 3; ++c) { d1[c] = -d_displace.v[c]; d1[3 + c] = d_rvec1.v[c]; d2[c] = d_displace.v[c]; d2[3 + c] = d_rvec2.v[c]; }
     return coverage;
+}
+
+/* sidechain_radial.cpp:46-61 */
+static float radial_edge(float* d1, float* d2, const float* p, const float* x1, const float* x2) {
+    float inv_dx = p[0];
+    f3 disp = f3_make(x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]);
+    float dist2 = f3_mag2(disp), inv_dist = rsqrtf_(dist2 + 1e-7f);
+    float dist_coord = dist2 * (inv_dist * inv_dx);
+    float en[2]; clamped_deBoor_vd(en, p + 1, dist_coord, 16);
+    for (int c = 0; c < 3; ++c) { d1[c] = disp.v[c] * (inv_dist * inv_dx * en[1]); d2[c] = -d1[c]; }
+    return en[0];
 }
 
 /* hbond.cpp:261-276 */
@@ -947,6 +961,7 @@ static void igraph_compute_edges(IGraph* g, Node* n1, Node* n2) {
                 case IT_ROTAMER: g->edge_value[e] = quadspline(g, d1, d2, p, x1, x2); break;
                 case IT_HBOND_COVERAGE: g->edge_value[e] = hbond_coverage_edge(g, d1, d2, p, x1, x2); break;
                 case IT_ENVIRONMENT: g->edge_value[e] = environment_edge(d1, d2, p, x1, x2); break;
+                case IT_RADIAL: case IT_HBOND_SC_RADIAL: g->edge_value[e] = radial_edge(d1, d2, p, x1, x2); break;
                 default: g->edge_value[e] = protein_hbond_edge(d1, d2, p, x1, x2, group_active); break;
             }
         }
@@ -1011,6 +1026,14 @@ static void igraph_param_deriv(IGraph* g, float* out) {
                 for (int d = 0; d < g->n_param; ++d) dp[d] *= prefactor;
             } break;
             case IT_ENVIRONMENT: for (int d = 0; d < g->n_param; ++d) dp[d] = 0.f; break;        /* environment.cpp:62-65 */
+            case IT_RADIAL: case IT_HBOND_SC_RADIAL: {                                            /* sidechain_radial.cpp:63-77 */
+                for (int d = 0; d < g->n_param; ++d) dp[d] = 0.f;
+                float dist = sqrtf(sqr(x1[0] - x2[0]) + sqr(x1[1] - x2[1]) + sqr(x1[2] - x2[2]));
+                float r[2]; clamped_deBoor_vd_scalar(r, p + 1, p[0] * dist, 16);
+                dp[0] = r[1] * dist;
+                int sb; float w[4]; clamped_deBoor_coeff_deriv(&sb, w, p[0] * dist, 16);
+                for (int k = 0; k < 4; ++k) dp[1 + sb + k] = w[k];
+            } break;
             default: for (int d = 0; d < g->n_param; ++d) dp[d] = -1.f; break;                   /* hbond.cpp:232-235 */
         }
         for (int d = 0; d < g->n_param; ++d) out[t * g->n_param + d] += g->edge_sens[e] * dp[d];
@@ -1078,6 +1101,15 @@ static void environment_coverage_deriv(Engine* e, Node* n) {
 }
 
 /* ---- hbond_energy (hbond.cpp:417-456) ---- */
+/* radial (sidechain_radial.cpp:81-104) and hbond_sc_radial (:107-136): unit edge sensitivities, potential = sum of edge values */
+static void radial_pairs_value(Engine* e, Node* n, int mode) {
+    IGraph* g = (IGraph*)n->data; Node* n1 = parent(e, n, 0); Node* n2 = g->symmetric ? NULL : parent(e, n, 1);
+    igraph_compute_edges(g, n1, n2);
+    for (int ne = 0; ne < g->n_edge; ++ne) g->edge_sens[ne] = 1.f;
+    igraph_propagate(g, n1, n2);
+    if (mode == PotentialAndDerivMode) { float pot = 0.f; for (int ne = 0; ne < g->n_edge; ++ne) pot += g->edge_value[ne]; n->potential = pot; }
+}
+
 typedef struct { float E_protein; float n_hbond; } HBondEnergyData;
 static void hbond_energy_value(Engine* e, Node* n, int mode) {
     (void)mode;
@@ -1834,6 +1866,11 @@ static int build_node(Engine* e, Node* n, hid_t grp, const char* name) {
         }
         n->data = d; n->compute_value = point_potential_value; return 0;
     }
+    if (is_prefix("radial", name) || is_prefix("hbond_sc_radial", name)) {
+        IGraph* g = (IGraph*)xcalloc(1, sizeof(*g));
+        if (igraph_init(g, grp, is_prefix("radial", name) ? IT_RADIAL : IT_HBOND_SC_RADIAL)) return -1;
+        n->data = g; n->compute_value = radial_pairs_value; return 0;
+    }
     if (is_prefix("contact", name)) {
         ContactData* d = (ContactData*)xcalloc(1, sizeof(*d));
         d->id = h5_read_i(grp, "id", 2, dims); if (!d->id || dims[1] != 2) return -1; d->n = (int)dims[0];
@@ -2162,7 +2199,7 @@ int set_param(int n_param, const float* param, DerivEngine* e, const char* node_
     Node* n = &e->nodes[i];
     IGraph* g = NULL;
     if (is_prefix("rotamer", n->name)) g = &((RotamerData*)n->data)->g;
-    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name)) g = (IGraph*)n->data;
+    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name) || is_prefix("hbond_sc_radial", n->name)) g = (IGraph*)n->data;
     if (!g || n_param != g->n_type1 * g->n_type2 * g->n_param) { fprintf(stderr, "ERROR: Bad param size\n"); return 1; }
     memcpy(g->param, param, sizeof(float) * n_param); igraph_update_cutoffs(g);
     return 0;
@@ -2172,7 +2209,7 @@ int get_param(int n_param, float* param, DerivEngine* e, const char* node_name) 
     Node* n = &e->nodes[i];
     IGraph* g = NULL;
     if (is_prefix("rotamer", n->name)) g = &((RotamerData*)n->data)->g;
-    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name)) g = (IGraph*)n->data;
+    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name) || is_prefix("hbond_sc_radial", n->name)) g = (IGraph*)n->data;
     if (!g || n_param != g->n_type1 * g->n_type2 * g->n_param) { fprintf(stderr, "ERROR: Wrong number of parameters\n"); return 1; }
     memcpy(param, g->param, sizeof(float) * n_param);
     return 0;
@@ -2185,7 +2222,7 @@ int get_param_deriv(int n_param, float* deriv, DerivEngine* e, const char* node_
     int expected = 0;
     IGraph* g = NULL;
     if (is_prefix("rotamer", n->name)) g = &((RotamerData*)n->data)->g;                                  /* rotamer.cpp:1064-1066 */
-    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name)) g = (IGraph*)n->data;   /* hbond.cpp:401-402, environment.cpp:104-105 */
+    else if (is_prefix("hbond_coverage", n->name) || is_prefix("environment_coverage", n->name) || is_prefix("hbond_sc_radial", n->name)) g = (IGraph*)n->data;   /* hbond.cpp:401-402, environment.cpp:104-105, sidechain_radial.cpp:131-135 */
     if (g) expected = g->n_type1 * g->n_type2 * g->n_param;
     else if (is_prefix("hbond_energy", n->name)) expected = 1;
     else if (is_prefix("nonlinear_coupling", n->name)) { NonlinearData* d = (NonlinearData*)n->data; expected = d->n_restype * d->n_coeff; }

@@ -104,7 +104,7 @@ def canonical_sort(edges):
 # the optional restraint / external-field nodes of the fixture proteinG56_restraints (tools/make_fixtures.py)
 RESTRAINT_POTENTIALS = ['z_flat_bottom', 'tension', 'AFM', 'atom_pos_spring', 'contact', 'membrane_potential',
                         'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env',
-                        'atom_pos_spring_on_slice']
+                        'atom_pos_spring_on_slice', 'radial', 'hbond_sc_radial']
 RESTRAINT_COORDS = ['placement_fixed_point_only_CB', 'slice_hbond_for_coupling', 'slice_pos_for_spring']
 
 

@@ -85,7 +85,8 @@ def add_param_derivs(name):
 
 
 RESTRAINT_NODES = ['z_flat_bottom', 'tension', 'AFM', 'atom_pos_spring', 'contact', 'membrane_potential',
-                   'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env', 'atom_pos_spring_on_slice']
+                   'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env', 'atom_pos_spring_on_slice',
+                   'radial', 'hbond_sc_radial']
 
 
 def restraint_spec(n_res, seed=5):
@@ -106,7 +107,9 @@ def restraint_spec(n_res, seed=5):
         contacts=np.column_stack((pairs, rs.normal(-1., 1., 40), rs.uniform(5., 9., 40), rs.uniform(0.8, 2.5, 40))),
         membrane=dict(cb_energy=cb, uhb_energy=uhb, z_min=z[0], z_max=z[-1], cov_midpoint=rs.normal(4., 1., 20),
                       cov_sharpness=rs.uniform(0.2, 0.6, 20), residue_type=rs.randint(0, 20, n_res)),
-        slice_spring=rs.choice(3 * n_res, 12, replace=True))
+        slice_spring=rs.choice(3 * n_res, 12, replace=True),
+        radial=cfg.radial_spline_params(np.random.RandomState(seed + 1), 20, 20, True),
+        hbond_sc_radial=cfg.radial_spline_params(np.random.RandomState(seed + 2), 2, 20, False))
 
 
 def make_restraints(base='proteinG56_7A', name='proteinG56_restraints'):
@@ -131,6 +134,7 @@ def make_restraints(base='proteinG56_7A', name='proteinG56_restraints'):
         g['sens/' + nm] = up.get_sens(nm)
     for nm in ('linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env'):
         g['param_deriv/' + nm] = up.get_param_deriv((20,), nm)
+    g['param_deriv/hbond_sc_radial'] = up.get_param_deriv((2, 20, 17), 'hbond_sc_radial')
     up.close()
     np.savez_compressed(os.path.join(GOLD, name + '.golden.npz'), **g)
     print(name, 'energy %.4f' % g['energy'], dict((k, float(v)) for k, v in g.items() if k.startswith('pot/') and k[4:] in RESTRAINT_NODES))

@@ -418,8 +418,20 @@ def add_jump_moves(path, atom_ranges, sigma_trans, sigma_rot):
         g.write('sigma_rot', np.asarray(sigma_rot, 'f4').reshape(-1))
 
 
+def radial_spline_params(rs, n_type1, n_type2, symmetric, inv_dx=1.5, scale=0.3):
+    """interaction_param (n_type1, n_type2, 17) obeying the four conditions of sidechain_radial.cpp:23-27: p[0] = 1/dx,
+    p[1] == p[3] (flat at the origin), p[-3] == p[-1] and zero value at the cut-off"""
+    c = scale * rs.normal(size=(n_type1, n_type2, 16))
+    c[..., 2] = c[..., 0]
+    c[..., 15] = c[..., 13]
+    c[..., 14] = -0.5 * c[..., 13]              # (1/6) c13 + (2/3) c14 + (1/6) c15 = 0
+    if symmetric:
+        c = 0.5 * (c + c.transpose(1, 0, 2))
+    return np.concatenate((np.full((n_type1, n_type2, 1), inv_dx), c), axis=2)
+
+
 def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=None, contacts=None, membrane=None,
-                   linear_coupling=None, slice_spring=None):
+                   linear_coupling=None, slice_spring=None, radial=None, hbond_sc_radial=None):
     """add the optional restraint / external-field nodes of py/upside_config.py to an existing configuration, with
     the dataset names and argument lists the reference's writers use:
       z_flat_bottom: rows (residue, z0, radius, spring_constant)        upside_config.py:46-79  (CA atom = 3*res+1)
@@ -432,6 +444,10 @@ def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=
       linear_coupling: dict(couplings (n_type), inactivation (bool))    linear_coupling_* on environment_coverage
                                                                         (the commented-out writer, upside_config.py:274-285)
       slice_spring:  atom ids: a `slice` of pos (src/bonds.cpp:589-621) feeding an `atom_pos_spring`
+      radial:        interaction_param (n_type, n_type, 17), types = the residue types of nonlinear_coupling_environment:
+                     the CB-CB pair potential of upside_config.py:866-883 (`radial`, src/sidechain_radial.cpp:81-104)
+      hbond_sc_radial: interaction_param (2, n_type, 17): the same functor between the inferred H / O sites (type 0 / 1)
+                     and the CB points (src/sidechain_radial.cpp:107-136; no writer in upside_config.py)
     """
     with h5lite.open_file(path, 'r+') as f:
         inp = f.group('input')
@@ -461,7 +477,8 @@ def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=
             r = np.asarray(pos_spring, 'f8')
             g = pot.create_group('atom_pos_spring'); _args(g, ['pos'])
             g.write('id', r[:, 0].astype('i4')); g.write('x0', r[:, 1:4]); g.write('spring_const', r[:, 4])
-        if (contacts is not None or membrane is not None) and 'placement_fixed_point_only_CB' not in pot:
+        if (contacts is not None or membrane is not None or radial is not None or hbond_sc_radial is not None) \
+                and 'placement_fixed_point_only_CB' not in pot:
             g = pot.create_group('placement_fixed_point_only_CB'); _args(g, ['affine_alignment'])
             ref = np.array([(-1.19280531, -0.83127186, 0.), (0., 0., 0.), (1.25222632, -0.87268266, 0.), (0., 0.94375626, 1.2068012)])
             ref -= ref[:3].mean(axis=0, keepdims=True)
@@ -500,6 +517,22 @@ def add_restraints(path, z_flat_bottom=None, tension=None, afm=None, pos_spring=
             else:
                 _args(g, ['environment_coverage'])
             g.write('couplings', np.asarray(linear_coupling['couplings'], 'f8')); g.write('coupling_types', types)
+        if radial is not None or hbond_sc_radial is not None:
+            restype = pot.group('nonlinear_coupling_environment').read('coupling_types', 'i4')
+            res = np.arange(n_res, dtype='i4')
+        if radial is not None:
+            g = pot.create_group('radial'); _args(g, ['placement_fixed_point_only_CB'])
+            g.write('index', res); g.write('type', restype); g.write('id', res)
+            g.write('interaction_param', np.asarray(radial, 'f8'))
+        if hbond_sc_radial is not None:
+            ph = pot.group('protein_hbond')
+            id1, id2 = ph.read('id1', 'i4'), ph.read('id2', 'i4')
+            g = pot.create_group('hbond_sc_radial'); _args(g, ['infer_H_O', 'placement_fixed_point_only_CB'])
+            g.write('index1', np.arange(len(id1) + len(id2), dtype='i4'))
+            g.write('type1', np.concatenate((np.zeros(len(id1), 'i4'), np.ones(len(id2), 'i4'))))
+            g.write('id1', np.concatenate((id1, id2)))
+            g.write('index2', res); g.write('type2', restype); g.write('id2', res)
+            g.write('interaction_param', np.asarray(hbond_sc_radial, 'f8'))
         if slice_spring is not None:
             ids = np.asarray(slice_spring, 'i4')
             sg = pot.create_group('slice_pos_for_spring'); _args(sg, ['pos'])

@@ -51,6 +51,15 @@ extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, flo
     return launch_status();
 }
 
+__global__ void k_scale(float* __restrict__ x, int n, float f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= f;
+}
+extern "C" int upk_scale(const upk_launch_t* L, float* x, int n, float factor) {
+    hipLaunchKernelGGL(k_scale, grid1(n, 1), dim3(UPK_BLOCK), 0, ST(L), x, n, factor);
+    return launch_status();
+}
+
 __global__ void k_gather_contrib(const float* __restrict__ arena, long arena_stride, const int* __restrict__ csr_start,
                                  const int* __restrict__ csr_entry, upk_coord_t target, int width, int comp_offset) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -125,9 +125,24 @@ __device__ __forceinline__ float protein_hbond_edge(const float* __restrict__ p,
     return hb_log;
 }
 
+// sidechain_radial.cpp:46-61: clamped cubic spline of the distance; p[0] = 1/dx, 16 coefficients follow
+__device__ __forceinline__ float radial_edge(const float* __restrict__ p, const float* x1, const float* x2, float* d1, float* d2) {
+    const float inv_dx = p[0];
+    const f3 disp = mk3(x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]);
+    const float dist2 = mag2(disp), inv_dist = rsqrt_(dist2 + 1e-7f);
+    const float dist_coord = dist2 * (inv_dist * inv_dx);
+    float v, dv;
+    clamped_deBoor_vd(v, dv, p + 1, dist_coord, 16);
+    const float k = inv_dist * inv_dx * dv;
+    d1[0] = disp.x * k; d1[1] = disp.y * k; d1[2] = disp.z * k;
+    d2[0] = -d1[0]; d2[1] = -d1[1]; d2[2] = -d1[2];
+    return v;
+}
+
 __device__ __forceinline__ float pair_eval(const upk_igraph_t& G, const float* __restrict__ p, const float* x1, const float* x2,
                                            float* d1, float* d2) {
     switch (G.itype) {
+        case UPK_IT_RADIAL: case UPK_IT_HBOND_SC_RADIAL: return radial_edge(p, x1, x2, d1, d2);
         case UPK_IT_HBOND_COVERAGE: return hbond_coverage_edge(G, p, x1, x2, d1, d2);
         case UPK_IT_ENVIRONMENT: return environment_edge(p, x1, x2, d1, d2);
         case UPK_IT_PROTEIN_HBOND: return protein_hbond_edge(p, x1, x2, d1, d2);
@@ -139,6 +154,7 @@ __device__ __forceinline__ bool acceptable_id_pair(int itype, int id1, int id2) 
     switch (itype) {
         case UPK_IT_ROTAMER: return ((unsigned)id1 >> 4) != ((unsigned)id2 >> 4);      // bead_interaction.h:195-197
         case UPK_IT_HBOND_COVERAGE:                                                    // hbond.cpp:254-259
+        case UPK_IT_RADIAL: case UPK_IT_HBOND_SC_RADIAL:                               // sidechain_radial.cpp:41-44
         case UPK_IT_ENVIRONMENT: return (2 < id1 - id2) || (2 < id2 - id1);            // environment.cpp:22-25
         default: return true;                                                          // hbond.cpp:162-164
     }
@@ -206,7 +222,7 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
 template <int IT>
 __device__ __forceinline__ bool plb_id_ok(int id_row_side1, int id_other_side2) {
     if (IT == UPK_IT_ROTAMER) return ((unsigned)(id_row_side1 ^ id_other_side2)) > 15u;     // different residue: ids differ above bit 4
-    if (IT == UPK_IT_HBOND_COVERAGE || IT == UPK_IT_ENVIRONMENT) { const int d = id_row_side1 - id_other_side2; return (d > 2) | (d < -2); }
+    if (IT == UPK_IT_HBOND_COVERAGE || IT == UPK_IT_ENVIRONMENT || IT == UPK_IT_RADIAL || IT == UPK_IT_HBOND_SC_RADIAL) { const int d = id_row_side1 - id_other_side2; return (d > 2) | (d < -2); }
     return true;
 }
 // node of a side-chain bead from its id (rotamer.cpp:812-816), straight-line
@@ -218,7 +234,7 @@ template <bool STAGED, int IT>
 __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1) {
     extern __shared__ __attribute__((aligned(16))) float plb_lds[];
     float4* oth = (float4*)plb_lds;
-    constexpr bool SYM = IT == UPK_IT_ROTAMER;
+    constexpr bool SYM = IT == UPK_IT_ROTAMER || IT == UPK_IT_RADIAL;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
@@ -294,6 +310,8 @@ extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) 
         case UPK_IT_ROTAMER: plb_launch<UPK_IT_ROTAMER>(L, G, grid, lds, staged, blocks1); break;
         case UPK_IT_HBOND_COVERAGE: plb_launch<UPK_IT_HBOND_COVERAGE>(L, G, grid, lds, staged, blocks1); break;
         case UPK_IT_ENVIRONMENT: plb_launch<UPK_IT_ENVIRONMENT>(L, G, grid, lds, staged, blocks1); break;
+        case UPK_IT_RADIAL: plb_launch<UPK_IT_RADIAL>(L, G, grid, lds, staged, blocks1); break;
+        case UPK_IT_HBOND_SC_RADIAL: plb_launch<UPK_IT_HBOND_SC_RADIAL>(L, G, grid, lds, staged, blocks1); break;
         default: plb_launch<UPK_IT_PROTEIN_HBOND>(L, G, grid, lds, staged, blocks1); break;
     }
     return launch_status();
@@ -386,7 +404,8 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
             const float* p = G.param + (size_t)(t1 * G.n_type2 + t2) * G.n_param;
             if (side == 1) pair_eval(G, p, xr, xo, d1, d2); else pair_eval(G, p, xo, xr, d1, d2);
             float ps;
-            if (sens_mode == 1) ps = side == 1 ? srow : S1[(size_t)j * sens_stride];
+            if (sens_mode == 0) ps = 1.f;
+            else if (sens_mode == 1) ps = side == 1 ? srow : S1[(size_t)j * sens_stride];
             else if (sens_mode == 2) ps = side == 2 ? srow : S2[(size_t)j * sens_stride];
             else ps = srow + (side == 1 ? S2[(size_t)j * sens_stride] : S1[(size_t)j * sens_stride]);
             const float* dr = side == 1 ? d1 : d2;
@@ -676,7 +695,7 @@ __global__ void k_igraph_param_deriv(upk_igraph_t G, int s, int sens_mode, const
             float xo[8];
             load_elem(xo, G.node2, s, G.loc2[j], G.dim2);
             if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;
-            float ps = 0.f;
+            float ps = sens_mode == 0 ? 1.f : 0.f;
             if (sens_mode == 1 || sens_mode == 3) ps += S1[(size_t)row * sens_stride];
             if (sens_mode == 2 || sens_mode == 3) ps += S2[(size_t)j * sens_stride];
             const size_t prow = (size_t)(t1 * G.n_type2 + G.type2[j]) * G.n_param;
@@ -684,6 +703,19 @@ __global__ void k_igraph_param_deriv(upk_igraph_t G, int s, int sens_mode, const
             if (G.itype == UPK_IT_HBOND_COVERAGE) {                      // hbond.cpp:278-283
                 const float one_m = 1.f - xr[6];
                 quadspline_param_accum(Q, G.param + prow, xr, xo, ps * (one_m * one_m), out);
+            } else if (G.itype == UPK_IT_RADIAL || G.itype == UPK_IT_HBOND_SC_RADIAL) {   // sidechain_radial.cpp:63-77
+                if (G.symmetric && j <= row) continue;                                  // each pair once (i1 < i2)
+                const float* p = G.param + prow;
+                const float dist = sqrtf(sqr(xr[0] - xo[0]) + sqr(xr[1] - xo[1]) + sqr(xr[2] - xo[2]));
+                const float x = p[0] * dist;
+                float v, dv;
+                clamped_deBoor_vd_scalar(v, dv, p + 1, x, 16);
+                atomicAdd(out, ps * dv * dist);
+                int bin; float w[4];
+                if (x <= 1.f) { bin = 0; w[0] = 1.f / 6.f; w[1] = 2.f / 3.f; w[2] = 1.f / 6.f; w[3] = 0.f; }
+                else if (x >= 14.f) { bin = 12; w[0] = 0.f; w[1] = 1.f / 6.f; w[2] = 2.f / 3.f; w[3] = 1.f / 6.f; }
+                else { const int xb = (int)x; bin = xb - 1; float db[4]; bspline_basis(x - (float)xb, w, db); }
+                for (int k = 0; k < 4; ++k) atomicAdd(out + 1 + bin + k, ps * w[k]);
             }   // environment.cpp:62-65: "not implemented" = zeros; protein_hbond has no get_param_deriv in the reference
         }
     }

@@ -336,6 +336,7 @@ struct IGraphHost {
     float type_cutoff(const float* p) const {
         switch (G.itype) {
             case UPK_IT_ROTAMER: case UPK_IT_HBOND_COVERAGE: return (float)((G.n_knot - 2 - 1e-6) / G.inv_dx);
+            case UPK_IT_RADIAL: case UPK_IT_HBOND_SC_RADIAL: return (float)((16 - 2 - 1e-6) / p[0]);   // sidechain_radial.cpp:31-34
             case UPK_IT_ENVIRONMENT: return p[0] + 1.f / p[1];
             default: return sqrtf(3.5f * 3.5f);
         }
@@ -367,12 +368,13 @@ struct IGraphHost {
 
     IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
         memset(&G, 0, sizeof(G));
-        G.itype = itype; G.symmetric = itype == UPK_IT_ROTAMER;
+        G.itype = itype; G.symmetric = itype == UPK_IT_ROTAMER || itype == UPK_IT_RADIAL;
         if (!(G.symmetric ^ bool(n2))) throw string("second node must be null iff symmetric interaction");
         switch (itype) {
             case UPK_IT_ROTAMER: G.dim1 = 6; G.dim2 = 6; break;
             case UPK_IT_HBOND_COVERAGE: G.dim1 = 7; G.dim2 = 6; break;
             case UPK_IT_ENVIRONMENT: G.dim1 = 6; G.dim2 = 4; break;
+            case UPK_IT_RADIAL: case UPK_IT_HBOND_SC_RADIAL: G.dim1 = 3; G.dim2 = 3; break;
             default: G.dim1 = 6; G.dim2 = 6; break;
         }
         check_elem_width_lower_bound(*node1, G.dim1);
@@ -392,6 +394,11 @@ struct IGraphHost {
             else if (G.n_param == 40) { G.n_knot_angular = 8; G.n_knot = 12; G.inv_dx = 1.f; }
             else if (G.n_param == 54) { G.n_knot_angular = 15; G.n_knot = 12; G.inv_dx = 2.f; }
             else throw string("unsupported interaction_param width ") + to_string(G.n_param) + " for hbond_coverage";
+        } else if (itype == UPK_IT_RADIAL || itype == UPK_IT_HBOND_SC_RADIAL) {
+            if (G.n_param != 17) throw string("radial pair potential expects 1 + 16 parameters per type pair");
+            if (itype == UPK_IT_RADIAL)      // is_compatible, sidechain_radial.cpp:36-39
+                for (int t1 = 0; t1 < G.n_type1; ++t1) for (int t2 = 0; t2 < G.n_type2; ++t2) for (int k = 0; k < 17; ++k)
+                    if (param[(size_t)(t1 * G.n_type2 + t2) * 17 + k] != param[(size_t)(t2 * G.n_type2 + t1) * 17 + k]) throw string("incompatible parameters");
         } else if (itype == UPK_IT_ENVIRONMENT) { if (G.n_param != 4) throw string("environment_coverage expects 4 parameters");
         } else if (G.n_param != 8) throw string("protein_hbond expects 8 parameters");
         G.inv_dtheta = (G.n_knot_angular - 3) / 2.f;
@@ -758,6 +765,37 @@ struct ContactEnergy : public PotentialNode {
     }
 };
 RegisterNodeType<ContactEnergy, 1> contact_node("contact");
+
+// radial (symmetric, sidechain_radial.cpp:81-104) and hbond_sc_radial (two nodes, :107-136): the sum over in-range pairs of
+// a clamped spline of their distance; every pair has sensitivity 1.  Old-style potentials without shipped parameters:
+// they run on the generic per-row kernels (`k_igraph_rowsum` / `k_igraph_grad`), not on the LDS-staged ones.
+struct RadialPairs : public PotentialNode {
+    IGraphHost ig;
+    RadialPairs(DeviceCtx* c, hid_t_compat grp, CoordNode& a, CoordNode* b)
+        : PotentialNode(c), ig(c, H(grp), b ? UPK_IT_HBOND_SC_RADIAL : UPK_IT_RADIAL, &a, b) { alloc_terms(ig.G.n1); }
+    bool has_prepare() const override { return true; }
+    void prepare() override { ig.update_lists(); }
+    void compute_value(ComputeMode mode) override {
+        upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 0, nullptr, nullptr, 0, 0), "radial grad side 1");
+        if (!ig.G.symmetric) upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 0, nullptr, nullptr, 0, 0), "radial grad side 2");
+        if (mode == PotentialAndDerivMode) {
+            upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, pot_terms.p, ig.G.n1, 1, 0, 0, nullptr), "radial rowsum");
+            reduce_terms();
+            if (ig.G.symmetric) upk_check(upk_scale(&ctx->L, potential_dev.p, ctx->n_system, 0.5f), "radial halve");   // a row sum sees each pair from both ends
+        }
+    }
+    vector<float> get_param() const override { return ig.G.symmetric ? vector<float>() : ig.param; }     // sidechain_radial.cpp:131-135: the two-node form only
+    void set_param(const vector<float>& p) override { if (!ig.G.symmetric) ig.set_param(p); }
+    vector<float> get_param_deriv(int system) override {
+        if (ig.G.symmetric) return vector<float>();
+        return param_deriv_table(ctx, ig.param.size(), [&](float* t) {
+            upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 0, nullptr, nullptr, 0, 0, t), "hbond_sc_radial param_deriv"); });
+    }
+};
+struct SidechainRadialPairs : RadialPairs { SidechainRadialPairs(DeviceCtx* c, hid_t_compat g, CoordNode& a) : RadialPairs(c, g, a, nullptr) {} };
+struct HBondSidechainRadialPairs : RadialPairs { HBondSidechainRadialPairs(DeviceCtx* c, hid_t_compat g, CoordNode& a, CoordNode& b) : RadialPairs(c, g, a, &b) {} };
+RegisterNodeType<SidechainRadialPairs, 1> radial_node("radial");
+RegisterNodeType<HBondSidechainRadialPairs, 2> hbond_sc_radial_node("hbond_sc_radial");
 
 // constant: bonds.cpp:550-587
 struct ConstantCoord : public CoordNode {
