@@ -184,6 +184,30 @@ def test_degenerate_sequences(hip, name):
     c.free_deriv_engine(ct.c_void_p(e))
 
 
+@pytest.mark.parametrize('name', ['trpcage20_7A', 'proteinG56_7A', 'syn300_10A'])
+def test_rotamer_named_values(hip, name):
+    """get_value_by_name of the side-chain node (rotamer.cpp:675-773): node energies with the 1-state partners folded in,
+    per-residue free energies and belief-weighted 1-body energies, against the reference's golden values (tolerances of
+    tests/test_oracle_pinning.py) and the oracle; the read-out must leave the engine state intact."""
+    g = P.golden(name)
+    up = P.pkg.Upside(P.fixture(name))
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    e0 = up.energy(g['pos']); orc.energy(g['pos'])
+    n = int(g['rotamer/n_node'])
+    ne = up.get_value_by_name((n, 6), 'rotamer', 'node_energy')
+    m = g['rotamer/node_energy'] < 1e4
+    assert np.abs(ne - g['rotamer/node_energy'])[m].max() < 5e-4 and np.array_equal(ne[~m], g['rotamer/node_energy'][~m])
+    assert np.abs(ne - orc.get_value_by_name((n, 6), 'rotamer', 'node_energy'))[m].max() < 2e-5
+    fe = up.get_value_by_name((n,), 'rotamer', 'rotamer_free_energy')
+    assert np.abs(fe - g['rotamer/rotamer_free_energy']).max() < 2e-4
+    assert np.abs(fe - orc.get_value_by_name((n,), 'rotamer', 'rotamer_free_energy')).max() < 5e-5
+    e1 = up.get_value_by_name((n, 3), 'rotamer', 'rotamer_1body_energy')
+    assert np.abs(e1 - g['rotamer/rotamer_1body_energy']).max() < 2e-4
+    assert abs(float(fe.sum()) - float(up.get_output('rotamer')[0, 0])) < 1e-3 * max(1., np.abs(fe).sum())   # the parts add up to the node's potential
+    assert up.energy(g['pos']) == e0 and np.array_equal(up.deriv(g['pos']), up.deriv(g['pos']))              # state left clean
+    up.close(); orc.close()
+
+
 def test_param_deriv_of_every_system(hip):
     """the batched extension returns each system's own derivative"""
     name = 'proteinG56_7A'

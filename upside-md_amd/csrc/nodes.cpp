@@ -1126,14 +1126,78 @@ struct RotamerSidechain : public PotentialNode {
         return param_deriv_table(ctx, ig.param.size(), [&](float* t) { upk_check(upk_rotamer_param_deriv(&ctx->L, &R, system, t), "rotamer param_deriv"); });
     }
 
+    template <typename T> static vector<T> head(const DevBuf<T>& b, size_t n) {   // the first n elements = system 0's share
+        vector<T> v(min(n, b.n));
+        if (!v.empty()) hip_check(hipMemcpy(v.data(), b.p, v.size() * sizeof(T), hipMemcpyDeviceToHost), "D2H");
+        return v;
+    }
+    // per-node values -> the reference's residue order: nodes in the order their first bead appears (rotamer.cpp:928-953)
+    vector<float> arrange_by_residue(const vector<float>& per_node, int width) const {
+        vector<float> out; out.reserve(per_node.size());
+        vector<char> seen(n_node, 0);
+        for (int i = 0; i < ig.G.n1; ++i) {
+            const int g = bead_node[i];
+            if (bead_rot[i] != 0 || seen[g]) continue;
+            seen[g] = 1;
+            for (int k = 0; k < width; ++k) out.push_back(per_node[(size_t)g * width + k]);
+        }
+        if ((int)out.size() != n_node * width) throw string("wrong number of residues");
+        return out;
+    }
     vector<float> get_value_by_name(const char* log_name) override {   // rotamer.cpp:675-773 (system 0)
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
         if (!strcmp(log_name, "n_node")) return vector<float>(1, (float)n_node);
         if (!strcmp(log_name, "count_edges_by_type")) return ig.count_edges_by_type(0);
-        if (!strcmp(log_name, "node_energy")) {
-            // before folding of 1-state partners this is exactly -log(prob); the reference reports the folded prob,
-            // which is what the BP kernel keeps in LDS only.  Report the unfolded 1-body part plus folded partners.
-            throw string("Value node_energy not implemented on the device engine");
+        if (!strcmp(log_name, "rotamer_1body_energy")) {   // rotamer.cpp:904-926: belief-weighted 1-body energy per residue and parent
+            const int np = (int)prob_nodes.size();
+            auto nb = head(nb_cur, (size_t)n_node * 6);
+            vector<float> per_node((size_t)n_node * np, 0.f);
+            for (int ip = 0; ip < np; ++ip) {
+                auto out = head(prob_nodes[ip]->output, (size_t)prob_nodes[ip]->n_elem * prob_nodes[ip]->stride);
+                for (int i = 0; i < ig.G.n1; ++i)
+                    per_node[(size_t)bead_node[i] * np + ip] += nb[bead_node[i] * 6 + bead_rot[i]] * out[(size_t)ig.loc1[i] * prob_nodes[ip]->stride];
+            }
+            return arrange_by_residue(per_node, np);
+        }
+        if (!strcmp(log_name, "node_energy") || !strcmp(log_name, "rotamer_free_energy")) {
+            // Diagnostics, assembled on the host from device results (like edge_marginal_in_graph_order below): the pair
+            // energies of the current structure are produced once more by the pair-energy kernel (the solve clears them),
+            // read back for system 0, and cleared again.  rotamer.cpp:697-711 (node_energy), :868-902 (free energies).
+            upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
+            hip_check(hipStreamSynchronize(ctx->stream), "sync");
+            const size_t cap = R.slot_cap;
+            auto E = head(P, cap * 36); auto act = head(slot_active, cap); auto sa = head(slot_a, cap), sb = head(slot_b, cap);
+            auto cs = head(class_start, 6); auto pr0 = head(node_prob, (size_t)n_node * 6); auto off = head(node_off, (size_t)n_node);
+            auto nb = head(nb_cur, (size_t)n_node * 6); auto mg = head(marg, cap * 36);
+            hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");                     // restore "accumulators clean"
+            hip_check(hipMemsetAsync(slot_active.p, 0, slot_active.n * sizeof(int), ctx->stream), "memset");
+            hip_check(hipStreamSynchronize(ctx->stream), "sync");
+            vector<float> prob(pr0);
+            // classes in slot order: 3x3, 3x6, 6x6, 1x1, 1xN (kernels_rotamer.hip); a < b in node order, so a 1xN slot has a = the 1-state node
+            for (int sl = cs[4]; sl < cs[5]; ++sl) if (act[sl])                                           // move_edge_prob_to_node2, rotamer.cpp:378-385
+                for (int r = 0; r < node_nrot[sb[sl]]; ++r) prob[sb[sl] * 6 + r] *= expf(-E[(size_t)r * cap + sl]);
+            if (!strcmp(log_name, "node_energy")) {
+                vector<float> ne((size_t)n_node * 6);
+                for (int g = 0; g < n_node; ++g) for (int r = 0; r < 6; ++r) ne[g * 6 + r] = r < node_nrot[g] ? -logf(prob[g * 6 + r]) : 1e5f;
+                return ne;
+            }
+            vector<float> fe(n_node, 0.f);
+            for (int g = 0; g < n_node; ++g) {                                                            // node_free_energy, rotamer.cpp:292-302
+                float e = off[g];
+                for (int r = 0; r < node_nrot[g]; ++r) { const float b = nb[g * 6 + r]; e += b * logf((1e-10f + b) / (1e-10f + prob[g * 6 + r])); }
+                fe[g] += e;
+            }
+            for (int sl = cs[3]; sl < cs[4]; ++sl) if (act[sl]) { const float en = E[sl]; fe[sa[sl]] += 0.5f * en; fe[sb[sl]] += 0.5f * en; }   // -log(prob) of a 1x1 edge
+            for (int sl = cs[0]; sl < cs[3]; ++sl) if (act[sl]) {                                          // edge_free_energy, rotamer.cpp:431-451
+                const int a = sa[sl], b = sb[sl];
+                float en = 0.f;
+                for (int i = 0; i < node_nrot[a]; ++i) for (int j = 0; j < node_nrot[b]; ++j) {
+                    const float p = mg[(size_t)(i * 6 + j) * cap + sl], pr = expf(-E[(size_t)(i * 6 + j) * cap + sl]);
+                    en += p * logf((1e-10f + p) / (1e-10f + pr * nb[a * 6 + i] * nb[b * 6 + j]));
+                }
+                fe[a] += 0.5f * en; fe[b] += 0.5f * en;
+            }
+            return arrange_by_residue(fe, 1);
         }
         if (!strcmp(log_name, "edge_marginal_in_graph_order")) {
             auto nb = nb_cur.download(); auto mg = marg.download(); auto sa = slot_a.download(); auto sb = slot_b.download();
