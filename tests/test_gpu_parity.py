@@ -203,6 +203,11 @@ def test_rotamer_named_values(hip, name):
     assert np.abs(fe - orc.get_value_by_name((n,), 'rotamer', 'rotamer_free_energy')).max() < 5e-5
     e1 = up.get_value_by_name((n, 3), 'rotamer', 'rotamer_1body_energy')
     assert np.abs(e1 - g['rotamer/rotamer_1body_energy']).max() < 2e-4
+    if n <= 60:
+        ee = up.get_value_by_name((n, n, 6, 6), 'rotamer', 'edge_energy')
+        eo = orc.get_value_by_name((n, n, 6, 6), 'rotamer', 'edge_energy')
+        assert np.array_equal(ee != 0, eo != 0) and np.abs(ee - eo).max() < 2e-5 * max(1., np.abs(eo).max())
+    assert int(up.get_value_by_name((1,), 'rotamer', 'read n_bad_solve and reset')[0]) == 0
     assert abs(float(fe.sum()) - float(up.get_output('rotamer')[0, 0])) < 1e-3 * max(1., np.abs(fe).sum())   # the parts add up to the node's potential
     assert up.energy(g['pos']) == e0 and np.array_equal(up.deriv(g['pos']), up.deriv(g['pos']))              # state left clean
     up.close(); orc.close()

@@ -1131,6 +1131,16 @@ struct RotamerSidechain : public PotentialNode {
         if (!v.empty()) hip_check(hipMemcpy(v.data(), b.p, v.size() * sizeof(T), hipMemcpyDeviceToHost), "D2H");
         return v;
     }
+    // Pair energies of system 0 for the current structure (diagnostics): the solve clears its accumulators, so the
+    // pair-energy kernel produces them once more; read back, then cleared again for every system.
+    void pair_energies_of_system0(vector<float>& E, vector<int>& act) {
+        upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
+        hip_check(hipStreamSynchronize(ctx->stream), "sync");
+        E = head(P, (size_t)R.slot_cap * 36); act = head(slot_active, (size_t)R.slot_cap);
+        hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");
+        hip_check(hipMemsetAsync(slot_active.p, 0, slot_active.n * sizeof(int), ctx->stream), "memset");
+        hip_check(hipStreamSynchronize(ctx->stream), "sync");
+    }
     // per-node values -> the reference's residue order: nodes in the order their first bead appears (rotamer.cpp:928-953)
     vector<float> arrange_by_residue(const vector<float>& per_node, int width) const {
         vector<float> out; out.reserve(per_node.size());
@@ -1163,15 +1173,12 @@ struct RotamerSidechain : public PotentialNode {
             // Diagnostics, assembled on the host from device results (like edge_marginal_in_graph_order below): the pair
             // energies of the current structure are produced once more by the pair-energy kernel (the solve clears them),
             // read back for system 0, and cleared again.  rotamer.cpp:697-711 (node_energy), :868-902 (free energies).
-            upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
-            hip_check(hipStreamSynchronize(ctx->stream), "sync");
             const size_t cap = R.slot_cap;
-            auto E = head(P, cap * 36); auto act = head(slot_active, cap); auto sa = head(slot_a, cap), sb = head(slot_b, cap);
+            vector<float> E; vector<int> act;
+            pair_energies_of_system0(E, act);
+            auto sa = head(slot_a, cap), sb = head(slot_b, cap);
             auto cs = head(class_start, 6); auto pr0 = head(node_prob, (size_t)n_node * 6); auto off = head(node_off, (size_t)n_node);
             auto nb = head(nb_cur, (size_t)n_node * 6); auto mg = head(marg, cap * 36);
-            hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");                     // restore "accumulators clean"
-            hip_check(hipMemsetAsync(slot_active.p, 0, slot_active.n * sizeof(int), ctx->stream), "memset");
-            hip_check(hipStreamSynchronize(ctx->stream), "sync");
             vector<float> prob(pr0);
             // classes in slot order: 3x3, 3x6, 6x6, 1x1, 1xN (kernels_rotamer.hip); a < b in node order, so a 1xN slot has a = the 1-state node
             for (int sl = cs[4]; sl < cs[5]; ++sl) if (act[sl])                                           // move_edge_prob_to_node2, rotamer.cpp:378-385
@@ -1199,18 +1206,24 @@ struct RotamerSidechain : public PotentialNode {
             }
             return arrange_by_residue(fe, 1);
         }
-        if (!strcmp(log_name, "edge_marginal_in_graph_order")) {
-            auto nb = nb_cur.download(); auto mg = marg.download(); auto sa = slot_a.download(); auto sb = slot_b.download();
-            auto act = slot_active_last.download(); int ns = n_slot.download()[0];
+        if (!strcmp(log_name, "edge_marginal_in_graph_order") || !strcmp(log_name, "edge_energy")) {   // rotamer.cpp:712-763
+            const bool do_marginal = !strcmp(log_name, "edge_marginal_in_graph_order");
+            const size_t cap = R.slot_cap;
+            auto nb = head(nb_cur, (size_t)n_node * 6); auto sa = head(slot_a, cap), sb = head(slot_b, cap);
+            int ns = head(n_slot, 1)[0];
+            vector<float> mg; vector<int> act;
+            if (do_marginal) { mg = head(marg, cap * 36); act = head(slot_active_last, cap); }
+            else pair_energies_of_system0(mg, act);            // -log(prob) of an edge entry is its pair energy
             vector<float> ev((size_t)n_node * n_node * 36, 0.f);
-            for (int i1 = 0; i1 < n_node; ++i1) for (int i2 = 0; i2 < n_node; ++i2) for (int r1 = 0; r1 < 6; ++r1) for (int r2 = 0; r2 < 6; ++r2)
-                ev[(((size_t)i1 * n_node + i2) * 6 + r1) * 6 + r2] = (i1 == i2) ? nb[i1 * 6 + r1] * (r1 == r2) : nb[i1 * 6 + r1] * nb[i2 * 6 + r2];
+            if (do_marginal)
+                for (int i1 = 0; i1 < n_node; ++i1) for (int i2 = 0; i2 < n_node; ++i2) for (int r1 = 0; r1 < 6; ++r1) for (int r2 = 0; r2 < 6; ++r2)
+                    ev[(((size_t)i1 * n_node + i2) * 6 + r1) * 6 + r2] = (i1 == i2) ? nb[i1 * 6 + r1] * (r1 == r2) : nb[i1 * 6 + r1] * nb[i2 * 6 + r2];
             for (int sl = 0; sl < ns; ++sl) {
                 if (!act[sl]) continue;
                 int a = sa[sl], b = sb[sl];
                 if (node_nrot[a] == 1 && node_nrot[b] != 1) continue;   // 1-3 / 1-6 edges are not listed (rotamer.cpp:745)
                 for (int r1 = 0; r1 < node_nrot[a]; ++r1) for (int r2 = 0; r2 < node_nrot[b]; ++r2) {
-                    float v = node_nrot[b] == 1 ? 1.f : mg[(size_t)(r1 * 6 + r2) * R.slot_cap + sl];
+                    float v = (do_marginal && node_nrot[b] == 1) ? 1.f : mg[(size_t)(r1 * 6 + r2) * R.slot_cap + sl];
                     ev[(((size_t)a * n_node + b) * 6 + r1) * 6 + r2] = v;
                     ev[(((size_t)b * n_node + a) * 6 + r2) * 6 + r1] = v;
                 }
@@ -1222,6 +1235,7 @@ struct RotamerSidechain : public PotentialNode {
             auto t = bp_trace.download(); return vector<float>(t.begin(), t.begin() + 16);
         }
         if (!strcmp(log_name, "read n_bad_solve")) return vector<float>(1, float(n_bad_solve));
+        if (!strcmp(log_name, "read n_bad_solve and reset")) { vector<float> r(1, float(n_bad_solve)); n_bad_solve = 0; return r; }
         throw string("Value ") + log_name + string(" not implemented");
     }
 };
