@@ -215,6 +215,7 @@ typedef struct {
                                           * receiving node, 4 floats per message to a 3-state node, 8 to a 6-state node */
     float damping, tol; int max_iter, chunk;
     int* iters;                          /* [S] sweeps of the last solve */
+    int* n_bad;                          /* [S] solves that ran into max_iter (rotamer.cpp:784-785), counted on the device */
     long long* bp_trace;                 /* [S][16] 100 MHz phase clocks of the last solve, or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */

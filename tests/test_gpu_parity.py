@@ -213,6 +213,28 @@ def test_rotamer_named_values(hip, name):
     up.close(); orc.close()
 
 
+def test_truncated_solve_is_counted_and_matches_oracle(hip, tmp_path):
+    """a belief-propagation solve cut off by max_iter: same forces as the oracle's equally truncated solve, and the
+    node counts it (rotamer.cpp:784-785, `read n_bad_solve`)"""
+    import shutil
+    from upside_md_amd import h5lite
+    name = 'proteinG56_7A'
+    f = str(tmp_path / 'short.up')
+    shutil.copyfile(P.fixture(name), f)
+    with h5lite.open_file(f, 'r+') as h:
+        h.group('input/potential/rotamer').set_attr('max_iter', 6)
+    g = P.golden(name)
+    up = P.pkg.Upside(f); orc = P.pkg.Upside(f, library=P.oracle_library())
+    for k in range(3):
+        assert P.rel_rms(orc.deriv(g['pos']), up.deriv(g['pos'])) < RTOL
+    it = np.zeros(1, 'i4'); up.calc.upside_hip_rotamer_iterations(up.engine, it.ctypes.data)
+    assert int(it[0]) == 6 == orc.calc.oracle_rotamer_iterations(orc.engine)
+    assert int(up.get_value_by_name((1,), 'rotamer', 'read n_bad_solve')[0]) == 3
+    assert int(up.get_value_by_name((1,), 'rotamer', 'read n_bad_solve and reset')[0]) == 3
+    assert int(up.get_value_by_name((1,), 'rotamer', 'read n_bad_solve')[0]) == 0
+    up.close(); orc.close()
+
+
 def test_param_deriv_of_every_system(hip):
     """the batched extension returns each system's own derivative"""
     name = 'proteinG56_7A'

@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         }
         float* t = nb_old; nb_old = nb_cur; nb_cur = t;                // rotamer.cpp:1040-1044
     }
-    if (tid == 0) R.iters[s] = iter;
+    if (tid == 0) { R.iters[s] = iter; if (iter >= R.max_iter - R.chunk - 1) R.n_bad[s] += 1; }
     if (trace) tr_loop = wall_clock64();
 
     // ---- marginals (rotamer.cpp:1053-1059)
@@ -1264,7 +1264,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
             }
         }
     }
-    if (c == 0 && tid == 0) R.iters[s] = iter;
+    if (c == 0 && tid == 0) { R.iters[s] = iter; if (iter >= R.max_iter - R.chunk - 1) R.n_bad[s] += 1; }
 
     // ---- marginals (rotamer.cpp:1053-1059): own nodes normalise, everyone reloads
     float* out_nb = R.nb_cur + (size_t)s * NN * 6;

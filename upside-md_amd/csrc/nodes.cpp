@@ -957,7 +957,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
-    long n_bad_solve = 0;
+    DevBuf<int> n_bad;
 
     RotamerSidechain(DeviceCtx* c, hid_t_compat grp, const ArgList& args)
         : PotentialNode(c), prob_nodes(args.begin() + 1, args.end()),
@@ -1013,7 +1013,7 @@ struct RotamerSidechain : public PotentialNode {
         R.adj_cap = min(max(n_node, 1), env_int("UPSIDE_HIP_ADJ_CAP", 256));
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
-        iters.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
+        iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); nbr_slot.alloc((size_t)S * ig.G.n1 * ig.G.cap1); slot_active_last.alloc((size_t)S * R.slot_cap);
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
         mark.alloc((size_t)S * ig.G.mark_stride);
@@ -1044,7 +1044,7 @@ struct RotamerSidechain : public PotentialNode {
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.marg = marg.p;
-        R.iters = iters.p; R.energy = energy.p;
+        R.iters = iters.p; R.n_bad = n_bad.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
         if (ig.G.n1 >= 65536 || ig.G.cap1 > 4096) throw string("rotamer pair kernels pack (bead, list position) into 16 + 12 bits: UPSIDE_HIP_NBR_CAP <= 4096");
@@ -1234,8 +1234,11 @@ struct RotamerSidechain : public PotentialNode {
             if (!R.bp_trace) throw string("set UPSIDE_HIP_BP_TRACE=1 before constructing the engine");
             auto t = bp_trace.download(); return vector<float>(t.begin(), t.begin() + 16);
         }
-        if (!strcmp(log_name, "read n_bad_solve")) return vector<float>(1, float(n_bad_solve));
-        if (!strcmp(log_name, "read n_bad_solve and reset")) { vector<float> r(1, float(n_bad_solve)); n_bad_solve = 0; return r; }
+        if (!strcmp(log_name, "read n_bad_solve") || !strcmp(log_name, "read n_bad_solve and reset")) {   // rotamer.cpp:764-770
+            vector<float> r(1, float(head(n_bad, 1)[0]));
+            if (strstr(log_name, "reset")) n_bad.fill_bytes(0);
+            return r;
+        }
         throw string("Value ") + log_name + string(" not implemented");
     }
 };

@@ -73,6 +73,7 @@ def lib():
         ("H5Aread", C.c_int, [hid, hid, C.c_void_p]),
         ("H5Aopen", hid, [hid, C.c_char_p, hid]),
         ("H5Aexists", C.c_int, [hid, C.c_char_p]),
+        ("H5Adelete", C.c_int, [hid, C.c_char_p]),
         ("H5Aget_type", hid, [hid]),
         ("H5Aget_space", hid, [hid]),
         ("H5Aclose", C.c_int, [hid]),
@@ -256,6 +257,8 @@ class Node(object):
         L = lib()
         oid, close = self._open_obj(obj)
         try:
+            if L.H5Aexists(oid, name.encode()) > 0:        # overwrite = delete + create
+                _chk(L.H5Adelete(oid, name.encode()), "H5Adelete " + name)
             if isinstance(value, (list, tuple, np.ndarray)) and len(value) and isinstance(
                     np.asarray(value).flat[0], (str, bytes, np.str_, np.bytes_)):
                 arr = np.ascontiguousarray(np.asarray(value).astype("S"))
