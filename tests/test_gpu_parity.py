@@ -570,6 +570,17 @@ def test_upside_main_output_matches_reference(hip, tmp_path):
     assert np.abs(got['pos'][0] - ref['pos'][0]).max() < 2e-5                 # recentred initial structure
     assert abs(got['potential'][0, 0] - ref['potential'][0, 0]) < 1e-4 * max(1., abs(ref['potential'][0, 0]))
     assert abs(got['kinetic'][0, 0] - ref['kinetic'][0, 0]) < 1e-5 * ref['kinetic'][0, 0]   # same Threefry/Box-Muller draws
+    # every dataset the reference writes at its default log level exists here with the same shape and type, and frame 0
+    # (same structure in both programs) holds the same numbers: rama, hbond, nonbonded_spring_energy, rama_map_potential,
+    # nonlinear_coupling, rotamer_free_energy, rotamer_1body_energy0-2, rotamer_bad_solves_cumulative
+    assert set(ref) <= set(got), sorted(set(ref) - set(got))
+    for k in sorted(ref):
+        assert got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype, (k, got[k].shape, ref[k].shape, got[k].dtype, ref[k].dtype)
+        if k in ('pos', 'kinetic', 'potential', 'time', 'temperature'):
+            continue
+        r0, g0 = np.asarray(ref[k][0], 'f8'), np.asarray(got[k][0], 'f8')
+        assert np.abs(r0 - g0).max() < 3e-4 * max(1., np.abs(r0).max()), (k, np.abs(r0 - g0).max())
+        assert np.abs(np.asarray(ref[k][1], 'f8') - np.asarray(got[k][1], 'f8')).max() < 2e-2 * max(1., np.abs(r0).max()), k   # 30 steps later
     # 30 and 60 MD steps later: the two fp32 trajectories are still the same trajectory
     assert P.rel_rms(ref['pos'][1], got['pos'][1]) < 1e-4
     assert P.rel_rms(ref['pos'][2], got['pos'][2]) < 1e-3

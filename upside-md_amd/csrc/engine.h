@@ -84,6 +84,12 @@ struct ScatterPlan {
     void finalize(int n_target, int n_system);
 };
 
+// one named per-frame quantity of a node in the /output group (the reference's default_logger->add_logger calls)
+struct LogValue {
+    std::string name; std::vector<size_t> dims; bool as_long = false; int level = 1;   // 0 basic, 1 detailed, 2 extensive
+    std::function<void(int system, float* buffer)> fill;                              // as_long: values are written as int64
+};
+
 struct DerivComputation {   // deriv_engine.h:48-80
     const bool potential_term;
     DeviceCtx* ctx = nullptr;
@@ -99,6 +105,10 @@ struct DerivComputation {   // deriv_engine.h:48-80
     virtual std::vector<float> get_param_deriv(int system) { (void)system; return std::vector<float>(); }
     virtual std::vector<float> get_value_by_name(const char*) { throw std::string("No values implemented"); }
     virtual void finalize() {}   // called once after the whole graph exists (scatter plans, device pointer tables)
+    // /output loggers of this node (state_logger.h add_logger); begin/end bracket the frame's read-outs of all systems
+    virtual void add_loggers(std::vector<LogValue>&) {}
+    virtual void begin_log_frame() {}
+    virtual void end_log_frame() {}
     virtual bool capturable() const { return true; }   // false: kernel arguments change from step to step (no hipGraph replay)
     // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).
     // The engine enqueues it on a side stream as soon as the last parent is computed, so a straggling rebuild of a

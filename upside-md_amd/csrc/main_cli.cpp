@@ -88,6 +88,28 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
         log_jump = with_jump;
         if (log_jump) jump_stats.create(group, "jump_stats", H5T_NATIVE_INT, 4, {2});
     }
+    // the nodes' own per-frame quantities (default_logger->add_logger in the reference's node constructors)
+    vector<EArray> extra; vector<LogValue> extra_spec;
+    void add_node_loggers(const vector<LogValue>& specs) {
+        for (auto& l : specs) {
+            if (H5Lexists(group, l.name.c_str(), H5P_DEFAULT) > 0) continue;      // a second node of the same kind: first one wins
+            vector<hsize_t> row(l.dims.begin(), l.dims.end());
+            extra.emplace_back();
+            if (l.as_long) extra.back().create(group, l.name.c_str(), H5T_NATIVE_LONG, sizeof(long), row);
+            else extra.back().create(group, l.name.c_str(), H5T_NATIVE_FLOAT, 4, row);
+            extra_spec.push_back(l);
+        }
+    }
+    void sample_node_loggers(int system) {
+        vector<float> buf; vector<long> lbuf;
+        for (size_t i = 0; i < extra.size(); ++i) {
+            size_t n = 1; for (auto d : extra_spec[i].dims) n *= d;
+            buf.assign(n, 0.f);
+            extra_spec[i].fill(system, buf.data());
+            if (extra_spec[i].as_long) { lbuf.assign(buf.begin(), buf.end()); extra[i].push(lbuf.data()); }
+            else extra[i].push(buf.data());
+        }
+    }
     void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc, const int* mcj) {
         pos.push(x); kinetic.push(&kin); potential.push(&pot); time.push(&t); temperature.push(&temp);
         if (log_replica) replica_index.push(&rep);
@@ -99,11 +121,13 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
         pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) replica_index.flush();
         if (log_pivot) pivot_stats.flush();
         if (log_jump) jump_stats.flush();
+        for (auto& x : extra) x.flush();
         if (file >= 0) H5Fflush(file, H5F_SCOPE_LOCAL);
     }
     void close() {
         if (file < 0) return;
         pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); pivot_stats.close(); jump_stats.close();
+        for (auto& x : extra) x.close();
         H5Gclose(group); H5Fclose(file); file = group = -1;
     }
     ~OutputLogger() { try { close(); } catch (...) {} }
@@ -128,6 +152,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     string temperature_str = "1.0";
     unsigned long seed = 42;
     bool recenter = true, write_output = true, xy_recenter_only = false;
+    int log_level = 1;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -146,7 +171,12 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--disable-z-recentering") xy_recenter_only = true;   // main.cpp:358-360, 416
         else if (a == "--re-raise-signal") {}
         else if (a == "--monte-carlo-interval") mc_interval = stod(need("--monte-carlo-interval"));
-        else if (a == "--log-level" || a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
+        else if (a == "--log-level") {   // main.cpp:474-479: "" = detailed
+            const string v = need("--log-level");
+            if (v == "basic") log_level = 0; else if (v == "detailed" || v == "") log_level = 1; else if (v == "extensive") log_level = 2;
+            else throw string("Illegal value for --log-level");
+        }
+        else if (a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
         else files.push_back(a);
     }
@@ -230,6 +260,14 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     const bool have_pivot = have_mc && upside_hip_mc_loaded(e, 0), have_jump = have_mc && upside_hip_mc_loaded(e, 1);
     vector<int> mc_stats((size_t)n_system * 2, 0), mcj_stats((size_t)n_system * 2, 0);
     if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_pivot, have_jump);
+    vector<LogValue> node_loggers;      // in node order, filtered by --log-level (state_logger.h:17-27)
+    if (write_output) {
+        for (auto& n : e->nodes) {
+            vector<LogValue> v; n.computation->add_loggers(v);
+            for (auto& l : v) if (l.level <= log_level) node_loggers.push_back(l);
+        }
+        for (int ns = 0; ns < n_system; ++ns) loggers[ns].add_node_loggers(node_loggers);
+    }
     vector<int> replica_index(n_system);
     for (int ns = 0; ns < n_system; ++ns) replica_index[ns] = ns;
     vector<float> frame_pos((size_t)n_system * n_atom * 3), frame_mom((size_t)n_system * n_atom * 3);
@@ -245,6 +283,11 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
             if (have_pivot && upside_hip_mc_stats(e, 0, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame
             if (have_jump && upside_hip_mc_stats(e, 1, mcj_stats.data(), 1)) throw string(upside_hip_last_error());
+            if (write_output && !node_loggers.empty()) {
+                for (auto& n : e->nodes) n.computation->begin_log_frame();
+                for (int ns = 0; ns < n_system; ++ns) loggers[ns].sample_node_loggers(ns);
+                for (auto& n : e->nodes) n.computation->end_log_frame();
+            }
             for (int ns = 0; ns < n_system; ++ns) {
                 const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
                 double sum_kin = 0.;

@@ -45,7 +45,7 @@ struct SpringNode : public PotentialNode {
         if ((int)dims[1] != kind) throw string("wrong width for id");
         check_size(H(grp), "equil_dist", {(size_t)n_elem});
         check_size(H(grp), "spring_const", {(size_t)n_elem});
-        if (kind == 2) check_size(H(grp), "bonded_atoms", {(size_t)n_elem});
+        if (kind == 2) { check_size(H(grp), "bonded_atoms", {(size_t)n_elem}); bonded_atoms = read<int>(H(grp), "bonded_atoms", 1); }
         for (int x : ids) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
         id.upload(ids);
         equil.upload(read<float>(H(grp), "equil_dist", 1));
@@ -58,7 +58,10 @@ struct SpringNode : public PotentialNode {
                              mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "spring");
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
+    vector<int> bonded_atoms;
+    void add_loggers(vector<LogValue>& out) override;   // bonds.cpp:281-295 (dist_spring only)
 };
+// (SpringNode::add_loggers is defined after sys_slice)
 struct DistSpring : SpringNode { DistSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 2) {} };
 struct AngleSpring : SpringNode { AngleSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 3) {} };
 struct DihedralSpring : SpringNode { DihedralSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 4) {} };
@@ -106,6 +109,7 @@ struct RamaCoord : public CoordNode {
         src = pos.scatter.add_source(n_elem, 5, 3, a);
     }
     void compute_value(ComputeMode) override { upk_check(upk_rama_fwd(&ctx->L, pos.coord(), atom.p, dummy.p, n_elem, coord(), jac.p), "rama_fwd"); }
+    void add_loggers(vector<LogValue>& out) override;   // bonds.cpp:199-202
     void propagate_deriv() override {
         upk_check(upk_rama_bwd(&ctx->L, coord(), jac.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size), "rama_bwd"); }
 };
@@ -154,6 +158,38 @@ struct Infer_H_O : public CoordNode {
         upk_check(upk_infer_bwd(&ctx->L, coord(), bond_length.p, dfd.p, n_virtual, pos.scatter.source_ptr(src), pos.scatter.arena_size), "infer_bwd"); }
 };
 RegisterNodeType<Infer_H_O, 1> infer_node("infer_H_O");
+
+// elements [sys*n, (sys+1)*n) of a per-system device array
+template <typename T>
+static vector<T> sys_slice(const DevBuf<T>& b, int sys, size_t n) {
+    vector<T> v(n);
+    if ((size_t)(sys + 1) * n > b.n) throw string("system slice out of range");
+    if (n) hip_check(hipMemcpy(v.data(), b.p + (size_t)sys * n, n * sizeof(T), hipMemcpyDeviceToHost), "D2H");
+    return v;
+}
+
+// rows [0, n_elem) x columns [0, width) of one system's output
+static vector<float> output_rows(const CoordNode& n, int sys, int col0, int n_col) {
+    auto raw = sys_slice(n.output, sys, (size_t)n.n_elem * n.stride);
+    vector<float> v((size_t)n.n_elem * n_col);
+    for (int i = 0; i < n.n_elem; ++i) for (int c = 0; c < n_col; ++c) v[(size_t)i * n_col + c] = raw[(size_t)i * n.stride + col0 + c];
+    return v;
+}
+void RamaCoord::add_loggers(vector<LogValue>& out) {
+    LogValue l; l.name = "rama"; l.dims = {(size_t)n_elem, 2};
+    l.fill = [this](int sys, float* b) { auto v = output_rows(*this, sys, 0, 2); copy(v.begin(), v.end(), b); };
+    out.push_back(l);
+}
+void SpringNode::add_loggers(vector<LogValue>& out) {
+    if (kind != 2) return;
+    LogValue l; l.name = "nonbonded_spring_energy"; l.dims = {1};   // the frame's energy evaluation filled pot_terms
+    l.fill = [this](int sys, float* b) {
+        auto t = sys_slice(pot_terms, sys, (size_t)n_elem);
+        float pot = 0.f;
+        for (int i = 0; i < n_elem; ++i) if (!bonded_atoms[i]) pot += t[i];
+        b[0] = pot; };
+    out.push_back(l);
+}
 
 // get_param_deriv plumbing: a zeroed device table of the get_param() layout, filled by `launch` on the engine stream
 template <typename F>
@@ -281,6 +317,14 @@ struct RamaMapPot : public PotentialNode {
         residue.upload(res); map_id.upload(mid);
         coeff.upload(fit_layered_periodic_spline2d(raw, (int)dims[0], nx, nx, 1));
         alloc_terms(n_residue);
+        log_pot = attr<int>(H(grp), ".", "log_pot", 1) != 0;   // rama_map_pot.cpp:34
+    }
+    bool log_pot = true;
+    void add_loggers(vector<LogValue>& out) override {   // rama_map_pot.cpp:50-54
+        if (!log_pot) return;
+        LogValue l; l.name = "rama_map_potential"; l.dims = {(size_t)n_residue};
+        l.fill = [this](int sys, float* b) { auto t = sys_slice(pot_terms, sys, (size_t)n_residue); copy(t.begin(), t.end(), b); };
+        out.push_back(l);
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_rama_map_pot(&ctx->L, rama.coord(), residue.p, map_id.p, n_residue, coeff.p, nx,
@@ -531,6 +575,11 @@ struct ProteinHBond : public CoordNode {
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
+    void add_loggers(vector<LogValue>& out) override {   // hbond.cpp:306-310
+        LogValue l; l.name = "hbond"; l.dims = {(size_t)n_elem};
+        l.fill = [this](int sys, float* b) { auto v = output_rows(*this, sys, 6, 1); copy(v.begin(), v.end(), b); };
+        out.push_back(l);
+    }
     // no get_param_deriv: the reference's ProteinHBond does not override it either (hbond.cpp:290-368) -> empty
 };
 RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
@@ -672,6 +721,11 @@ struct NonlinearCoupling : public PotentialNode {
                                          mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "nonlinear_coupling");
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
+    void add_loggers(vector<LogValue>& out) override {   // environment.cpp:348-356
+        LogValue l; l.name = "nonlinear_coupling"; l.dims = {(size_t)input.n_elem};
+        l.fill = [this](int sys, float* b) { auto t = sys_slice(pot_terms, sys, (size_t)input.n_elem); copy(t.begin(), t.end(), b); };
+        out.push_back(l);
+    }
     vector<float> get_param() const override { return coeff; }
     vector<float> get_param_deriv(int system) override {   // environment.cpp:375-389
         return param_deriv_table(ctx, coeff.size(), [&](float* t) {
@@ -717,6 +771,17 @@ struct PointPotential : public PotentialNode {
         alloc_terms(n_term);
     }
     bool capturable() const override { return kind != 2; }   // the AFM tip position travels as a kernel argument
+    void add_loggers(vector<LogValue>& out) override {   // bonds.cpp:130-145 (AFM only, basic level)
+        if (kind != 2) return;
+        LogValue tip; tip.name = "tip_pos"; tip.dims = {(size_t)n_term, 3}; tip.level = 0;
+        tip.fill = [this](int, float* b) {
+            auto p = par.download(); const float t = time_initial + time_step * round_num;
+            for (int i = 0; i < n_term; ++i) for (int d = 0; d < 3; ++d) b[i * 3 + d] = p[(size_t)i * 8 + 1 + d] + p[(size_t)i * 8 + 4 + d] * t; };
+        out.push_back(tip);
+        LogValue te; te.name = "time_estimate"; te.dims = {1}; te.level = 0;
+        te.fill = [this](int, float* b) { b[0] = time_initial + time_step * round_num; };
+        out.push_back(te);
+    }
     void compute_value(ComputeMode mode) override {
         float time = 0.f;
         if (kind == 2) {                                   // bonds.cpp:150-151: the tip advances on every DerivMode evaluation
@@ -878,6 +943,13 @@ struct LinearCoupling : public PotentialNode {
         upk_check(upk_linear_coupling(&ctx->L, input.coord(), types.p, d_couplings.p, inact_coord(), inactivation != nullptr, inactivation_dim,
                                       mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "linear_coupling");
         if (mode == PotentialAndDerivMode) reduce_terms();
+    }
+    void add_loggers(vector<LogValue>& out) override {   // environment.cpp:271-279: coupling * input, without the inactivation factor
+        LogValue l; l.name = inactivation ? "linear_coupling_with_inactivation" : "linear_coupling_uniform"; l.dims = {(size_t)input.n_elem};
+        l.fill = [this](int sys, float* b) {
+            auto v = output_rows(input, sys, 0, 1); auto t = types.download();
+            for (int i = 0; i < input.n_elem; ++i) b[i] = couplings[t[i]] * v[i]; };
+        out.push_back(l);
     }
     vector<float> get_param() const override { return couplings; }
     vector<float> get_param_deriv(int system) override {           // environment.cpp:301-312
@@ -1126,20 +1198,89 @@ struct RotamerSidechain : public PotentialNode {
         return param_deriv_table(ctx, ig.param.size(), [&](float* t) { upk_check(upk_rotamer_param_deriv(&ctx->L, &R, system, t), "rotamer param_deriv"); });
     }
 
-    template <typename T> static vector<T> head(const DevBuf<T>& b, size_t n) {   // the first n elements = system 0's share
-        vector<T> v(min(n, b.n));
-        if (!v.empty()) hip_check(hipMemcpy(v.data(), b.p, v.size() * sizeof(T), hipMemcpyDeviceToHost), "D2H");
-        return v;
-    }
-    // Pair energies of system 0 for the current structure (diagnostics): the solve clears its accumulators, so the
-    // pair-energy kernel produces them once more; read back, then cleared again for every system.
-    void pair_energies_of_system0(vector<float>& E, vector<int>& act) {
+    template <typename T> static vector<T> head(const DevBuf<T>& b, size_t n) { return sys_slice(b, 0, n); }
+    // Pair energies of one system for the current structure (diagnostics / logging): the solve clears its accumulators,
+    // so the pair-energy kernel produces them once more; read back, then cleared again for every system.  Inside
+    // begin_log_frame / end_log_frame the kernel runs once for the read-outs of all systems.
+    bool log_frame_open = false;
+    void fill_pair_energies() {
         upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
-        E = head(P, (size_t)R.slot_cap * 36); act = head(slot_active, (size_t)R.slot_cap);
+    }
+    void clear_pair_energies() {
         hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");
         hip_check(hipMemsetAsync(slot_active.p, 0, slot_active.n * sizeof(int), ctx->stream), "memset");
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
+    }
+    void begin_log_frame() override { fill_pair_energies(); log_frame_open = true; }
+    void end_log_frame() override { if (log_frame_open) { clear_pair_energies(); log_frame_open = false; } }
+    void pair_energies(int sys, vector<float>& E, vector<int>& act) {
+        if (!log_frame_open) fill_pair_energies();
+        E = sys_slice(P, sys, (size_t)R.slot_cap * 36); act = sys_slice(slot_active, sys, (size_t)R.slot_cap);
+        if (!log_frame_open) clear_pair_energies();
+    }
+    void pair_energies_of_system0(vector<float>& E, vector<int>& act) { pair_energies(0, E, act); }
+    vector<float> one_body_energies(int sys) {   // rotamer.cpp:904-926: belief-weighted 1-body energy per node and parent
+        const int np = (int)prob_nodes.size();
+        auto nb = sys_slice(nb_cur, sys, (size_t)n_node * 6);
+        vector<float> per_node((size_t)n_node * np, 0.f);
+        for (int ip = 0; ip < np; ++ip) {
+            auto out = sys_slice(prob_nodes[ip]->output, sys, (size_t)prob_nodes[ip]->n_elem * prob_nodes[ip]->stride);
+            for (int i = 0; i < ig.G.n1; ++i)
+                per_node[(size_t)bead_node[i] * np + ip] += nb[bead_node[i] * 6 + bead_rot[i]] * out[(size_t)ig.loc1[i] * prob_nodes[ip]->stride];
+        }
+        return per_node;
+    }
+    // node energies with the 1-state partners folded in (rotamer.cpp:697-711) or per-node free energies (:868-902),
+    // assembled on the host from device results
+    vector<float> folded_or_free_energies(int sys, bool want_node_energy) {
+        const size_t cap = R.slot_cap;
+        vector<float> E; vector<int> act;
+        pair_energies(sys, E, act);
+        auto sa = sys_slice(slot_a, sys, cap), sb = sys_slice(slot_b, sys, cap);
+        auto cs = sys_slice(class_start, sys, 6); auto prob = sys_slice(node_prob, sys, (size_t)n_node * 6); auto off = sys_slice(node_off, sys, (size_t)n_node);
+        auto nb = sys_slice(nb_cur, sys, (size_t)n_node * 6); auto mg = sys_slice(marg, sys, cap * 36);
+        // classes in slot order: 3x3, 3x6, 6x6, 1x1, 1xN (kernels_rotamer.hip); a < b in node order, so a 1xN slot has a = the 1-state node
+        for (int sl = cs[4]; sl < cs[5]; ++sl) if (act[sl])                                           // move_edge_prob_to_node2, rotamer.cpp:378-385
+            for (int r = 0; r < node_nrot[sb[sl]]; ++r) prob[sb[sl] * 6 + r] *= expf(-E[(size_t)r * cap + sl]);
+        if (want_node_energy) {
+            vector<float> ne((size_t)n_node * 6);
+            for (int g = 0; g < n_node; ++g) for (int r = 0; r < 6; ++r) ne[g * 6 + r] = r < node_nrot[g] ? -logf(prob[g * 6 + r]) : 1e5f;
+            return ne;
+        }
+        vector<float> fe(n_node, 0.f);
+        for (int g = 0; g < n_node; ++g) {                                                            // node_free_energy, rotamer.cpp:292-302
+            float e = off[g];
+            for (int r = 0; r < node_nrot[g]; ++r) { const float b = nb[g * 6 + r]; e += b * logf((1e-10f + b) / (1e-10f + prob[g * 6 + r])); }
+            fe[g] += e;
+        }
+        for (int sl = cs[3]; sl < cs[4]; ++sl) if (act[sl]) { const float en = E[sl]; fe[sa[sl]] += 0.5f * en; fe[sb[sl]] += 0.5f * en; }   // -log(prob) of a 1x1 edge
+        for (int sl = cs[0]; sl < cs[3]; ++sl) if (act[sl]) {                                          // edge_free_energy, rotamer.cpp:431-451
+            const int a = sa[sl], b = sb[sl];
+            float en = 0.f;
+            for (int i = 0; i < node_nrot[a]; ++i) for (int j = 0; j < node_nrot[b]; ++j) {
+                const float p = mg[(size_t)(i * 6 + j) * cap + sl], pr = expf(-E[(size_t)(i * 6 + j) * cap + sl]);
+                en += p * logf((1e-10f + p) / (1e-10f + pr * nb[a * 6 + i] * nb[b * 6 + j]));
+            }
+            fe[a] += 0.5f * en; fe[b] += 0.5f * en;
+        }
+        return fe;
+    }
+    void add_loggers(vector<LogValue>& out) override {   // rotamer.cpp:657-672
+        LogValue bad; bad.name = "rotamer_bad_solves_cumulative"; bad.dims = {1}; bad.as_long = true;
+        bad.fill = [this](int sys, float* b) { b[0] = (float)sys_slice(n_bad, sys, 1)[0]; };
+        out.push_back(bad);
+        LogValue fe; fe.name = "rotamer_free_energy"; fe.dims = {(size_t)n_node};
+        fe.fill = [this](int sys, float* b) { auto v = arrange_by_residue(folded_or_free_energies(sys, false), 1); copy(v.begin(), v.end(), b); };
+        out.push_back(fe);
+        const int np = (int)prob_nodes.size();
+        for (int ip = 0; ip < np; ++ip) {
+            LogValue e1; e1.name = "rotamer_1body_energy" + to_string(ip); e1.dims = {(size_t)n_node};
+            e1.fill = [this, ip, np](int sys, float* b) {
+                auto v = arrange_by_residue(one_body_energies(sys), np);
+                for (int g = 0; g < n_node; ++g) b[g] = v[(size_t)g * np + ip]; };
+            out.push_back(e1);
+        }
     }
     // per-node values -> the reference's residue order: nodes in the order their first bead appears (rotamer.cpp:928-953)
     vector<float> arrange_by_residue(const vector<float>& per_node, int width) const {
@@ -1158,54 +1299,9 @@ struct RotamerSidechain : public PotentialNode {
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
         if (!strcmp(log_name, "n_node")) return vector<float>(1, (float)n_node);
         if (!strcmp(log_name, "count_edges_by_type")) return ig.count_edges_by_type(0);
-        if (!strcmp(log_name, "rotamer_1body_energy")) {   // rotamer.cpp:904-926: belief-weighted 1-body energy per residue and parent
-            const int np = (int)prob_nodes.size();
-            auto nb = head(nb_cur, (size_t)n_node * 6);
-            vector<float> per_node((size_t)n_node * np, 0.f);
-            for (int ip = 0; ip < np; ++ip) {
-                auto out = head(prob_nodes[ip]->output, (size_t)prob_nodes[ip]->n_elem * prob_nodes[ip]->stride);
-                for (int i = 0; i < ig.G.n1; ++i)
-                    per_node[(size_t)bead_node[i] * np + ip] += nb[bead_node[i] * 6 + bead_rot[i]] * out[(size_t)ig.loc1[i] * prob_nodes[ip]->stride];
-            }
-            return arrange_by_residue(per_node, np);
-        }
-        if (!strcmp(log_name, "node_energy") || !strcmp(log_name, "rotamer_free_energy")) {
-            // Diagnostics, assembled on the host from device results (like edge_marginal_in_graph_order below): the pair
-            // energies of the current structure are produced once more by the pair-energy kernel (the solve clears them),
-            // read back for system 0, and cleared again.  rotamer.cpp:697-711 (node_energy), :868-902 (free energies).
-            const size_t cap = R.slot_cap;
-            vector<float> E; vector<int> act;
-            pair_energies_of_system0(E, act);
-            auto sa = head(slot_a, cap), sb = head(slot_b, cap);
-            auto cs = head(class_start, 6); auto pr0 = head(node_prob, (size_t)n_node * 6); auto off = head(node_off, (size_t)n_node);
-            auto nb = head(nb_cur, (size_t)n_node * 6); auto mg = head(marg, cap * 36);
-            vector<float> prob(pr0);
-            // classes in slot order: 3x3, 3x6, 6x6, 1x1, 1xN (kernels_rotamer.hip); a < b in node order, so a 1xN slot has a = the 1-state node
-            for (int sl = cs[4]; sl < cs[5]; ++sl) if (act[sl])                                           // move_edge_prob_to_node2, rotamer.cpp:378-385
-                for (int r = 0; r < node_nrot[sb[sl]]; ++r) prob[sb[sl] * 6 + r] *= expf(-E[(size_t)r * cap + sl]);
-            if (!strcmp(log_name, "node_energy")) {
-                vector<float> ne((size_t)n_node * 6);
-                for (int g = 0; g < n_node; ++g) for (int r = 0; r < 6; ++r) ne[g * 6 + r] = r < node_nrot[g] ? -logf(prob[g * 6 + r]) : 1e5f;
-                return ne;
-            }
-            vector<float> fe(n_node, 0.f);
-            for (int g = 0; g < n_node; ++g) {                                                            // node_free_energy, rotamer.cpp:292-302
-                float e = off[g];
-                for (int r = 0; r < node_nrot[g]; ++r) { const float b = nb[g * 6 + r]; e += b * logf((1e-10f + b) / (1e-10f + prob[g * 6 + r])); }
-                fe[g] += e;
-            }
-            for (int sl = cs[3]; sl < cs[4]; ++sl) if (act[sl]) { const float en = E[sl]; fe[sa[sl]] += 0.5f * en; fe[sb[sl]] += 0.5f * en; }   // -log(prob) of a 1x1 edge
-            for (int sl = cs[0]; sl < cs[3]; ++sl) if (act[sl]) {                                          // edge_free_energy, rotamer.cpp:431-451
-                const int a = sa[sl], b = sb[sl];
-                float en = 0.f;
-                for (int i = 0; i < node_nrot[a]; ++i) for (int j = 0; j < node_nrot[b]; ++j) {
-                    const float p = mg[(size_t)(i * 6 + j) * cap + sl], pr = expf(-E[(size_t)(i * 6 + j) * cap + sl]);
-                    en += p * logf((1e-10f + p) / (1e-10f + pr * nb[a * 6 + i] * nb[b * 6 + j]));
-                }
-                fe[a] += 0.5f * en; fe[b] += 0.5f * en;
-            }
-            return arrange_by_residue(fe, 1);
-        }
+        if (!strcmp(log_name, "rotamer_1body_energy")) return arrange_by_residue(one_body_energies(0), (int)prob_nodes.size());
+        if (!strcmp(log_name, "node_energy")) return folded_or_free_energies(0, true);
+        if (!strcmp(log_name, "rotamer_free_energy")) return arrange_by_residue(folded_or_free_energies(0, false), 1);
         if (!strcmp(log_name, "edge_marginal_in_graph_order") || !strcmp(log_name, "edge_energy")) {   // rotamer.cpp:712-763
             const bool do_marginal = !strcmp(log_name, "edge_marginal_in_graph_order");
             const size_t cap = R.slot_cap;
