@@ -79,6 +79,8 @@ int upside_hip_init_md(DerivEngine* engine, const float* temperature, uint32_t b
  * Ornstein-Uhlenbeck thermostat (thermostat.cpp:9-18) every thermostat_interval rounds; everything
  * stays on the device, the call returns after the stream has drained. */
 int upside_hip_run_md(DerivEngine* engine, int n_round);
+/* change the thermostat temperature of every system between run_md calls (simulated annealing, main.cpp:436-442,658-660) */
+int upside_hip_set_temperature(DerivEngine* engine, const float* temperature);
 /* the same loop counted in MD steps (one force evaluation + one leapfrog stage each, the unit of the reference's
  * "steps/s", main.cpp:677-682); a cycle left unfinished is resumed by the next call. */
 int upside_hip_run_steps(DerivEngine* engine, int n_step);

@@ -638,6 +638,30 @@ def test_upside_main_with_restraint_nodes_matches_reference(hip, tmp_path):
         assert abs(got['potential'][fr, 0] - ref['potential'][fr, 0]) < 2e-4 * abs(ref['potential'][fr, 0]), fr
 
 
+def test_upside_main_annealing_matches_reference(hip, tmp_path):
+    """--anneal-factor / --anneal-duration (main.cpp:432-442, 658-660): the thermostat temperature follows the reference's
+    schedule (logged per frame) and the trajectory stays the reference's"""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'trpcage20_7A'
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up')
+    shutil.copyfile(P.fixture(name), a); shutil.copyfile(P.fixture(name), b)
+    args = ['--duration', '1.62', '--frame-interval', '0.27', '--temperature', '0.9', '--seed', '5', '--anneal-factor', '0.25',
+            '--anneal-duration', '1.08', '--thermostat-interval', '0.054']      # thermostat every 2 rounds, annealing over the last 40 of 60
+    subprocess.run([ref_exe] + args + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                   env=dict(os.environ, OMP_NUM_THREADS='1'))
+    hip.in_process_upside(args + [b], verbose=False)
+    ref, _ = _read_output(a); got, _ = _read_output(b)
+    assert got['temperature'].shape == ref['temperature'].shape
+    assert np.abs(got['temperature'] - ref['temperature']).max() < 1e-6, (got['temperature'].ravel(), ref['temperature'].ravel())
+    assert ref['temperature'][-1, 0] < 0.5 * ref['temperature'][0, 0]          # the schedule really ran
+    assert P.rel_rms(ref['pos'][1], got['pos'][1]) < 1e-4 and P.rel_rms(ref['pos'][3], got['pos'][3]) < 5e-3
+    assert abs(got['kinetic'][2, 0] - ref['kinetic'][2, 0]) < 5e-3 * ref['kinetic'][2, 0]
+
+
 def test_upside_main_pivot_moves_match_reference(hip, tmp_path):
     """Monte-Carlo pivot moves (monte_carlo_sampler.cpp) through `upside_main --monte-carlo-interval`: the same
     proposals (random stream 2), the same Metropolis verdicts and therefore the same `pivot_stats` and the same

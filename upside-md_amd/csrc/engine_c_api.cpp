@@ -238,6 +238,23 @@ static void thermostat_params(DerivEngine* e, float delta_t) {
     }
     e->mom_scale.upload(ms); e->noise_scale.upload(ns);
 }
+// thermostat temperature of every system from now on (System::set_temperature, main.cpp:107-110; used by simulated annealing)
+extern "C" int upside_hip_set_temperature(DerivEngine* e, const float* temperature) {
+    API_TRY
+    const int S = e->ctx.n_system;
+    if ((int)e->noise_scale.n != S) throw string("upside_hip_set_temperature needs upside_hip_init_md first");
+    const float delta_t = e->thermostat_interval * 3 * e->dt;
+    vector<float> ns(S);
+    for (int s = 0; s < S; ++s) {
+        e->temperature[s] = temperature[s];
+        const float ms = (float)exp(-delta_t / e->thermostat_timescale);
+        ns[s] = sqrtf(temperature[s] * (1 - ms * ms));
+    }
+    e->sync();
+    hip_check(hipMemcpy(e->noise_scale.p, ns.data(), S * sizeof(float), hipMemcpyHostToDevice), "H2D");
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_init_md(DerivEngine* e, const float* temperature, uint32_t base_seed, float thermostat_timescale, float dt,
                                   int thermostat_interval_rounds) {
     API_TRY

@@ -153,6 +153,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     unsigned long seed = 42;
     bool recenter = true, write_output = true, xy_recenter_only = false;
     int log_level = 1;
+    double anneal_factor = 1., anneal_duration = -1.;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -176,7 +177,9 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             if (v == "basic") log_level = 0; else if (v == "detailed" || v == "") log_level = 1; else if (v == "extensive") log_level = 2;
             else throw string("Illegal value for --log-level");
         }
-        else if (a == "--anneal-factor" || a == "--anneal-duration" || a == "--set-param") need(a.c_str());
+        else if (a == "--anneal-factor") anneal_factor = stod(need("--anneal-factor"));
+        else if (a == "--anneal-duration") anneal_duration = stod(need("--anneal-duration"));
+        else if (a == "--set-param") need(a.c_str());
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
         else files.push_back(a);
     }
@@ -198,6 +201,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     if (temps.size() != 1u && (int)temps.size() != n_system) throw string("Received ") + to_string(temps.size()) + " temperatures but have " + to_string(n_system) + " systems";
     if (temps.size() == 1u) temps.assign(n_system, temps[0]);
 
+    if (anneal_duration == -1.) anneal_duration = duration;      // main.cpp:434
+    const vector<float> initial_temps = temps;
     // all systems must share the topology of the first file; only /input/pos differs
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
     int n_atom = 0;
@@ -303,6 +308,19 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             fflush(stdout);
         }
         uint64_t next = min<uint64_t>(n_round, (rnd / frame_rounds + 1) * (uint64_t)frame_rounds);
+        if (anneal_factor != 1.) {   // main.cpp:436-442, 658-660: the temperature is reset before every thermostat application
+            if (!(rnd % thermo_rounds)) {
+                const double time = 3 * dt * (float)(rnd + 1);
+                const double fraction = max(0., (time - (duration - anneal_duration)) / anneal_duration);
+                for (int ns = 0; ns < n_system; ++ns) {
+                    const double T0 = initial_temps[ns], T1 = initial_temps[ns] * anneal_factor;
+                    const double r = sqrt(T0) * (1. - fraction) + sqrt(T1) * fraction;
+                    temps[ns] = (float)(r * r);
+                }
+                if (upside_hip_set_temperature(e, temps.data())) throw string(upside_hip_last_error());
+            }
+            next = min<uint64_t>(next, (rnd / thermo_rounds + 1) * (uint64_t)thermo_rounds);
+        }
         if (replica_rounds) next = min<uint64_t>(next, (rnd / replica_rounds + 1) * (uint64_t)replica_rounds);
         if (have_mc) next = min<uint64_t>(next, (rnd / mc_rounds + 1) * (uint64_t)mc_rounds);
         if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error());
