@@ -662,6 +662,31 @@ def test_upside_main_annealing_matches_reference(hip, tmp_path):
     assert abs(got['kinetic'][2, 0] - ref['kinetic'][2, 0]) < 5e-3 * ref['kinetic'][2, 0]
 
 
+def test_upside_main_set_param_matches_reference(hip, tmp_path):
+    """--set-param FILE (main.cpp:384-395,498-499): one 1-D dataset per node name, handed to that node's set_param"""
+    import shutil
+    import subprocess
+    from upside_md_amd import h5lite
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'trpcage20_7A'
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up'); pf = str(tmp_path / 'param.h5')
+    shutil.copyfile(P.fixture(name), a); shutil.copyfile(P.fixture(name), b)
+    with h5lite.open_file(pf, 'w') as h:
+        h.write('hbond_energy', np.array([-3.5], 'f4'))
+    base = ['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '2']
+    pots = {}
+    for tag, extra in (('plain', []), ('set', ['--set-param', pf])):
+        subprocess.run([ref_exe] + base + extra + [a], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS='1'))
+        hip.in_process_upside(base + extra + [b], verbose=False)
+        pots[tag] = (float(_read_output(a)[0]['potential'][0, 0]), float(_read_output(b)[0]['potential'][0, 0]))
+    assert abs(pots['plain'][0] - pots['set'][0]) > 0.1                      # the parameter matters
+    for tag in pots:
+        assert abs(pots[tag][0] - pots[tag][1]) < 1e-4 * max(1., abs(pots[tag][0])), (tag, pots[tag])
+
+
 def test_upside_main_pivot_moves_match_reference(hip, tmp_path):
     """Monte-Carlo pivot moves (monte_carlo_sampler.cpp) through `upside_main --monte-carlo-interval`: the same
     proposals (random stream 2), the same Metropolis verdicts and therefore the same `pivot_stats` and the same

@@ -154,6 +154,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     bool recenter = true, write_output = true, xy_recenter_only = false;
     int log_level = 1;
     double anneal_factor = 1., anneal_duration = -1.;
+    string set_param_file;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -179,7 +180,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
         else if (a == "--anneal-factor") anneal_factor = stod(need("--anneal-factor"));
         else if (a == "--anneal-duration") anneal_duration = stod(need("--anneal-duration"));
-        else if (a == "--set-param") need(a.c_str());
+        else if (a == "--set-param") set_param_file = need("--set-param");
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
         else files.push_back(a);
     }
@@ -221,6 +222,15 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     DerivEngine* e = upside_hip_construct(n_atom, files[0].c_str(), n_system, !verbose);
     if (!e) throw string("unable to construct the engine: ") + upside_hip_last_error();
     struct Guard { DerivEngine* e; ~Guard() { delete e; } } guard{e};
+    if (!set_param_file.empty()) {   // main.cpp:384-395, 498-499: one 1-D float dataset per node name
+        hid_t pf = H5Fopen(set_param_file.c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
+        if (pf < 0) throw string("unable to open ") + set_param_file;
+        h5u::Handle pfh(pf, H5Fclose);
+        for (const string& node_name : h5u::node_names_in_group(pf)) {
+            auto values = h5u::read<float>(pf, node_name, 1);
+            if (set_param((int)values.size(), values.data(), e, node_name.c_str())) throw string("--set-param: ") + upside_hip_last_error();
+        }
+    }
     // main.cpp:548-564: recentring would fight a potential that is not translation invariant
     for (auto& n : e->nodes) {
         auto pre = [&](const char* p) { return n.name == string(p).substr(0, n.name.size()); };   // is_prefix(n.name, p), deriv_engine.cpp:72-74
