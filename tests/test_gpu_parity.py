@@ -533,6 +533,20 @@ def test_alternate_code_paths_agree(tmp_path):
         assert P.rel_rms(base['md_pos'], alt['md_pos']) < 1e-5, env_extra
 
 
+def test_capacity_overflow_fails_loudly():
+    """a neighbour list that outgrows its row capacity (or the slot table) is reported by the evaluating call, not
+    silently truncated: run with a deliberately tiny capacity in a child process"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity_util as P\n"
+            "up = P.pkg.Upside(P.fixture('proteinG56_7A'))\n"
+            "try:\n    up.energy(up.initial_pos)\n    print('NO ERROR')\n"
+            "except RuntimeError as e:\n    print('RAISED', up.lib.calc.upside_hip_last_error())\n") % (P.ROOT, os.path.join(P.ROOT, 'tests'))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, UPSIDE_HIP_NBR_CAP='8'), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    assert 'RAISED' in out and 'capacity overflow' in out, out
+
+
 def _read_output(path):
     from upside_md_amd import h5lite
     with h5lite.open_file(path) as f:
