@@ -547,6 +547,47 @@ def test_capacity_overflow_fails_loudly():
     assert 'RAISED' in out and 'capacity overflow' in out, out
 
 
+def test_upside_main_stops_cleanly_on_sigint(hip, tmp_path):
+    """SIGINT during a run (main.cpp:24-92, 616, 669-674, 742-743): the run stops at the next chunk boundary, the frames
+    logged so far are in the file, "Received early termination signal" goes to stderr, the caller's handlers are back
+    and -- `in_process_upside` passes --re-raise-signal as py/upside_engine.py does -- Python sees KeyboardInterrupt."""
+    import shutil
+    import signal
+    import subprocess
+    cfg = str(tmp_path / 'sig.up')
+    shutil.copyfile(P.fixture('proteinG56_7A'), cfg)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity_util as P\n"
+            "lib = P.pkg.default_library()\n"
+            "try:\n"
+            "    lib.in_process_upside(['--duration', '1e7', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '1', %r])\n"
+            "    print('RETURNED', flush=True)\n"
+            "except KeyboardInterrupt:\n"
+            "    print('INTERRUPTED', flush=True)\n") % (P.ROOT, os.path.join(P.ROOT, 'tests'), cfg)
+    child = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    lines = []
+    try:
+        while True:                       # wait for a few progress lines: the run is inside its MD loop
+            ln = child.stdout.readline().decode()
+            assert ln, ''.join(lines)
+            lines.append(ln)
+            if sum('hbonds' in x for x in lines) >= 3:
+                break
+        child.send_signal(signal.SIGINT)
+        rest = child.communicate(timeout=120)[0].decode()
+    finally:
+        if child.poll() is None:
+            child.kill()
+    out = ''.join(lines) + rest
+    assert 'Received early termination signal' in out, out
+    assert 'INTERRUPTED' in out and 'RETURNED' not in out, out
+    assert child.returncode == 0
+    got, _ = _read_output(cfg)
+    n_frame = got['pos'].shape[0]
+    assert n_frame >= 3 and got['time'].shape == (n_frame,) and got['potential'].shape[0] == n_frame
+    assert np.isfinite(got['pos']).all()
+
+
 def _read_output(path):
     from upside_md_amd import h5lite
     with h5lite.open_file(path) as f:

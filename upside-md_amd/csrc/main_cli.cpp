@@ -12,6 +12,7 @@
 #include "engine.h"
 #include "h5util.h"
 #include <chrono>
+#include <csignal>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,21 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
 };
 }  // namespace
 
+// Orderly termination (main.cpp:24-92): SIGINT / SIGTERM stop the run at the next chunk boundary, the buffered frames
+// are written, the caller's handlers come back (RAII, the library may be running inside Python), and with
+// --re-raise-signal the signal is raised again for the caller.
+namespace {
+volatile sig_atomic_t g_received_signal = -1;
+void note_signal(int signum) { g_received_signal = signum; }
+struct SignalGuard {
+    int signum; void (*old_handler)(int);
+    explicit SignalGuard(int s) : signum(s), old_handler(signal(s, note_signal)) {
+        if (old_handler == SIG_ERR) fprintf(stderr, "Warning: problem installing signal handler. Does not affect correctness of simulation.\n");
+    }
+    ~SignalGuard() { if (old_handler != SIG_ERR) signal(signum, old_handler); }
+};
+}  // namespace
+
 static vector<string> split_string(const string& src, const string& sep) {
     vector<string> ret;
     size_t pos = 0;
@@ -155,6 +171,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     int log_level = 1;
     double anneal_factor = 1., anneal_duration = -1.;
     string set_param_file;
+    bool re_raise_signal = false;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -171,7 +188,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--disable-recentering") recenter = false;
         else if (a == "--no-output") write_output = false;       // extension: leave the configuration files untouched
         else if (a == "--disable-z-recentering") xy_recenter_only = true;   // main.cpp:358-360, 416
-        else if (a == "--re-raise-signal") {}
+        else if (a == "--re-raise-signal") re_raise_signal = true;
         else if (a == "--monte-carlo-interval") mc_interval = stod(need("--monte-carlo-interval"));
         else if (a == "--log-level") {   // main.cpp:474-479: "" = detailed
             const string v = need("--log-level");
@@ -289,7 +306,11 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
 
     auto tstart = chrono::high_resolution_clock::now();
     vector<long> n_attempt(sets.size(), 0), n_success(sets.size(), 0);
-    for (uint64_t rnd = 0; rnd < n_round;) {
+    g_received_signal = -1;
+    int stop_signal = -1;
+    {
+    SignalGuard on_int(SIGINT), on_term(SIGTERM);
+    for (uint64_t rnd = 0; rnd < n_round && g_received_signal == -1;) {
         // pivots before the frame of the same round, never at t = 0 (main.cpp:626-630)
         if (have_mc && rnd && !(rnd % mc_rounds)) if (upside_hip_mc_step(e, rnd)) throw string(upside_hip_last_error());
         if (!(rnd % frame_rounds)) {   // main.cpp:633-654: recenter, energy, log, print -- before the round is integrated
@@ -312,8 +333,15 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
                 for (int d = 0; d < 3; ++d) com[d] /= n_atom;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) rg += (x[i * 3 + d] - com[d]) * (x[i * 3 + d] - com[d]);
-                if (verbose) printf("%*.0f / %*.0f elapsed %2i system %.2f temp, Rg %5.1f A, potential % 8.2f\n", 8, rnd * 3 * double(dt), 8,
-                                    duration, ns, temps[ns], sqrt(rg / n_atom), energy[ns]);
+                if (verbose) {   // the line of main.cpp:649-654, hydrogen-bond count included (get_n_hbond, main.cpp:28-35)
+                    double n_hbond = 0.;
+                    for (auto& n : e->nodes) if (dynamic_cast<HBondCounter*>(n.computation.get())) {
+                        auto v = n.computation->get_param_deriv(ns);      // d(potential)/d(E_protein) = the count
+                        if (!v.empty()) n_hbond += v[0];
+                    }
+                    printf("%*.0f / %*.0f elapsed %2i system %.2f temp %5.1f hbonds, Rg %5.1f A, potential % 8.2f\n", 8, rnd * 3 * double(dt), 8,
+                           duration, ns, temps[ns], n_hbond, sqrt(rg / n_atom), energy[ns]);
+                }
             }
             fflush(stdout);
         }
@@ -351,10 +379,14 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
     }
     e->sync();
-    for (auto& lg : loggers) lg.close();
+    for (auto& lg : loggers) lg.close();          // buffered frames reach the files also after an early stop
+    stop_signal = g_received_signal;
+    }   // the caller's signal handlers are back
+    if (stop_signal != -1) fprintf(stderr, "Received early termination signal\n");
     double elapsed = chrono::duration<double>(chrono::high_resolution_clock::now() - tstart).count();
     printf("\n\nfinished in %.1f seconds (%.2f us/systems/step, %.1e simulation_time_unit/hour)\n", elapsed,
            elapsed * 1e6 / n_system / max<uint64_t>(n_round, 1) / 3, n_round * 3 * time_step / elapsed * 3600.);
     for (size_t k = 0; k < sets.size(); ++k) printf("swap set %zu: %ld / %ld accepted\n", k, n_success[k], n_attempt[k]);
+    if (re_raise_signal && stop_signal != -1) raise(stop_signal);     // main.cpp:742-743
     return 0;
 }
