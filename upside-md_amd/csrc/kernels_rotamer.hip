@@ -554,6 +554,18 @@ __device__ __forceinline__ void clear_class(float* P, int cap, int lo, int hi, i
         P[(size_t)((e / NB) * 6 + e % NB) * cap + lo + l] = 0.f;
     }
 }
+// end of a solve: zero the accumulator entries of the slots that were written this step and hand their flags on
+template <int NA, int NB>
+__device__ __forceinline__ void retire_class(float* P, int cap, int lo, int hi, int* __restrict__ active_w, int* __restrict__ active_last, int tid, int nt) {
+    for (int sl = lo + tid; sl < hi; sl += nt) {
+        const int act = active_w[sl];
+        active_last[sl] = act; active_w[sl] = 0;
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = 0.f;
+        }
+    }
+}
 __device__ __forceinline__ void clear_all_classes(float* P, int cap, const int* cls, int part, int n_part, int tid, int nt) {
     auto sub = [&](int c, int& lo, int& hi) { const int b = cls[c], n = cls[c + 1] - b; lo = b + (int)((long)n * part / n_part); hi = b + (int)((long)n * (part + 1) / n_part); };
     int lo, hi;
@@ -578,6 +590,50 @@ struct BpCtx {
 // L1 normalisation of 506-521), rewritten in place.  1-ulp hardware reciprocals: the reference itself uses the
 // 12-bit rcpps here (Float4.h:199-212).
 template <int NA, int NB, bool WT>   // WT: messages leave through 16-byte write-through stores (cluster solve)
+__device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int a, int b, const float (&P)[NA * NB], const float* __restrict__ nb_old,
+                                             __amdgpu_buffer_rsrc_t inbox_w) {
+    float* ma = C.msg(oa);
+    float* mb = C.msg(ob);
+    float va[NA], vb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) va[i] = nb_old[a * 6 + i] * fast_rcp(1e-10f + ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) vb[j] = nb_old[b * 6 + j] * fast_rcp(1e-10f + mb[j]);
+    float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) t += P[i * NB + j] * vb[j];
+        ta[i] = t; sa += t; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) t += va[i] * P[i * NB + j];
+        tb[j] = t; sb += t; }
+    const float ra = fast_rcp(sa), rb = fast_rcp(sb);
+    if (WT) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ta[i] *= ra;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) tb[j] *= rb;
+        st_wt16(inbox_w, oa, ta[0], ta[1], ta[2], NA == 6 ? ta[NA - 3] : 1.f);
+        if (NA == 6) st_wt16(inbox_w, oa + 4, ta[NA - 2], ta[NA - 1], 1.f, 1.f);
+        st_wt16(inbox_w, ob, tb[0], tb[1], tb[2], NB == 6 ? tb[NB - 3] : 1.f);
+        if (NB == 6) st_wt16(inbox_w, ob + 4, tb[NB - 2], tb[NB - 1], 1.f, 1.f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+    }
+}
+// the NA x NB entries of one slot, row-major, from the [36][cap] table
+template <int NA, int NB>
+__device__ __forceinline__ void bp_load_matrix(const BpCtx& C, int sl, float (&P)[NA * NB]) {
+#pragma unroll
+    for (int e = 0; e < NA * NB; ++e) P[e] = C.P[(size_t)((e / NB) * 6 + e % NB) * C.cap + sl];
+}
+template <int NA, int NB, bool WT>
 __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
                                                    __amdgpu_buffer_rsrc_t inbox_w) {
     // (measured and rejected: fetching the next slot's flag and message offsets one trip ahead.  In the 6x6 instance it
@@ -586,45 +642,9 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
     for (int sl = lo + tid; sl < hi; sl += nt) {
         const int act = C.active[sl], oa = C.slot_off[sl * 2], ob = C.slot_off[sl * 2 + 1];
         if (!act) continue;
-        const int a = C.slot_a[sl], b = C.slot_b[sl];
-        float* ma = C.msg(oa);
-        float* mb = C.msg(ob);
-        float P[NA][NB], va[NA], vb[NB];
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) P[i][j] = C.P[(size_t)(i * 6 + j) * C.cap + sl];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) va[i] = nb_old[a * 6 + i] * fast_rcp(1e-10f + ma[i]);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) vb[j] = nb_old[b * 6 + j] * fast_rcp(1e-10f + mb[j]);
-        float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) { float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) t += P[i][j] * vb[j];
-            ta[i] = t; sa += t; }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) t += va[i] * P[i][j];
-            tb[j] = t; sb += t; }
-        const float ra = fast_rcp(sa), rb = fast_rcp(sb);
-        if (WT) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ta[i] *= ra;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) tb[j] *= rb;
-            st_wt16(inbox_w, oa, ta[0], ta[1], ta[2], NA == 6 ? ta[NA - 3] : 1.f);
-            if (NA == 6) st_wt16(inbox_w, oa + 4, ta[NA - 2], ta[NA - 1], 1.f, 1.f);
-            st_wt16(inbox_w, ob, tb[0], tb[1], tb[2], NB == 6 ? tb[NB - 3] : 1.f);
-            if (NB == 6) st_wt16(inbox_w, ob + 4, tb[NB - 2], tb[NB - 1], 1.f, 1.f);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
-        }
+        float P[NA * NB];
+        bp_load_matrix<NA, NB>(C, sl, P);
+        bp_edge_slot<NA, NB, WT>(C, oa, ob, C.slot_a[sl], C.slot_b[sl], P, nb_old, inbox_w);
     }
 }
 template <int NA, int NB>
@@ -635,8 +655,9 @@ __device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, co
 // One slot per lane and trip: all NA*NB loads of the slot are issued before the first store, so a trip costs one
 // memory round trip instead of NA*NB dependent ones (the in-place update otherwise serialises load -> store -> load).
 template <int NA, int NB>
-__device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int tid, int nt) {
+__device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int tid, int nt, const int* __restrict__ active = nullptr) {
     for (int sl = lo + tid; sl < hi; sl += nt) {
+        if (active && !active[sl]) continue;      // untouched accumulators stay 0: nobody reads the matrix of an inactive slot
         float v[NA * NB];
 #pragma unroll
         for (int e = 0; e < NA * NB; ++e) v[e] = P[(size_t)((e / NB) * 6 + e % NB) * cap + sl];
@@ -647,43 +668,86 @@ __device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int
 
 // pair marginals and (optionally) their Bethe free-energy terms (rotamer.cpp:405-451)
 template <int NA, int NB>
+__device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa, int ob, int a, int b, const float (&P)[NA * NB],
+                                                  const float* __restrict__ nbm, bool want_energy) {
+    float en = 0.f;
+    const float* ma = C.msg(oa);
+    const float* mb = C.msg(ob);
+    // the unnormalised marginals are formed twice (sum, then store) rather than kept: 36 fewer live registers next
+    // to the resident matrices, and the products round identically both times
+    float bc1[NA], bc2[NB], sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) bc1[i] = nbm[a * 6 + i] * rcp(1e-10f + ma[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bc2[j] = nbm[b * 6 + j] * rcp(1e-10f + mb[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sum += P[i * NB + j] * bc1[i] * bc2[j];
+    const float rs = rcp(sum);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float pm = (P[i * NB + j] * bc1[i] * bc2[j]) * rs;
+            C.marg[(size_t)(i * 6 + j) * C.cap + sl] = pm;
+            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i * NB + j] * nbm[a * 6 + i] * nbm[b * 6 + j]));
+        }
+    return en;
+}
+template <int NA, int NB>
 __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nbm, int tid, int nt,
                                                    bool want_energy) {
     float en = 0.f;
     for (int sl = lo + tid; sl < hi; sl += nt) {
         if (!C.active[sl]) continue;
-        const int a = C.slot_a[sl], b = C.slot_b[sl];
-        const float* ma = C.msg(C.slot_off[sl * 2]);
-        const float* mb = C.msg(C.slot_off[sl * 2 + 1]);
-        float P[NA][NB], bc1[NA], bc2[NB], mg[NA][NB], sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) P[i][j] = C.P[(size_t)(i * 6 + j) * C.cap + sl];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) bc1[i] = nbm[a * 6 + i] * rcp(1e-10f + ma[i]);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bc2[j] = nbm[b * 6 + j] * rcp(1e-10f + mb[j]);
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) { mg[i][j] = P[i][j] * bc1[i] * bc2[j]; sum += mg[i][j]; }
-        const float rs = rcp(sum);
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const float pm = mg[i][j] * rs;
-                C.marg[(size_t)(i * 6 + j) * C.cap + sl] = pm;
-                if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i][j] * nbm[a * 6 + i] * nbm[b * 6 + j]));
-            }
+        float P[NA * NB];
+        bp_load_matrix<NA, NB>(C, sl, P);
+        en += bp_marginal_slot<NA, NB>(C, sl, C.slot_off[sl * 2], C.slot_off[sl * 2 + 1], C.slot_a[sl], C.slot_b[sl], P, nbm, want_energy);
     }
     return en;
 }
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
 
-__global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
+// Pair matrices pinned in registers for the whole solve.  The edge phase is bandwidth bound (at 1024 systems every CU
+// streams ~0.6 MB per sweep, half of it exp(-E) matrices that never change during the solve), and the register file
+// of a CU (512 KB) is three times its LDS: a workgroup of BP_BLOCK / 2 lanes may use 256 VGPRs per lane, enough to keep the
+// matrices of its first K trips through a class, their message offsets and node ids for all sweeps and the marginals.
+template <int NA, int NB, int K>
+struct BpResident {
+    float P[K > 0 ? K : 1][NA * NB];
+    int oa[K > 0 ? K : 1], ob[K > 0 ? K : 1], ab[K > 0 ? K : 1];     // ab = a | b << 16; -1: no active slot in this trip
+    __device__ __forceinline__ void load(const BpCtx& C, int lo, int hi, int tid, int nt) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int sl = lo + tid + k * nt;
+            ab[k] = -1; oa[k] = 0; ob[k] = 0;
+#pragma unroll
+            for (int e = 0; e < NA * NB; ++e) P[k][e] = 0.f;
+            if (sl < hi && C.active[sl]) {
+                bp_load_matrix<NA, NB>(C, sl, P[k]);
+                oa[k] = C.slot_off[sl * 2]; ob[k] = C.slot_off[sl * 2 + 1];
+                ab[k] = C.slot_a[sl] | (C.slot_b[sl] << 16);
+            }
+        }
+    }
+    __device__ __forceinline__ void edge(const BpCtx& C, const float* __restrict__ nb_old, __amdgpu_buffer_rsrc_t rs) const {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (ab[k] >= 0) bp_edge_slot<NA, NB, false>(C, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nb_old, rs);
+    }
+    __device__ __forceinline__ float marginal(const BpCtx& C, int lo, const float* __restrict__ nbm, int tid, int nt, bool want_energy) const {
+        float en = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (ab[k] >= 0) en += bp_marginal_slot<NA, NB>(C, lo + tid + k * nt, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nbm, want_energy);
+        return en;
+    }
+};
+
+template <int BLOCK, int K66, int K36, int K33>
+__global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
@@ -719,11 +783,11 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
 
     // energies -> probabilities for the entries each class uses (rotamer.cpp:835); 1xN rows carry up to 6 columns
     // (unused ones stay exp(0) = 1, never read)
-    exp_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], tid, nt);
-    exp_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], tid, nt);
-    exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt);
-    exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt);
-    exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt);
+    exp_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], tid, nt, C.active);
+    exp_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], tid, nt, C.active);
+    exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt, C.active);
+    exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt, C.active);
+    exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
     // the head of the inbox stays in LDS as far as it reaches: the 4-float rows to the 3-state nodes come first, then
@@ -767,6 +831,9 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     __syncthreads();
     for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
+    BpResident<3, 3, K33> r33; BpResident<3, 6, K36> r36; BpResident<6, 6, K66> r66;
+    r33.load(C, cls[CL33], cls[CL33 + 1], tid, nt); r36.load(C, cls[CL36], cls[CL36 + 1], tid, nt); r66.load(C, cls[CL66], cls[CL66 + 1], tid, nt);
+    const __amdgpu_buffer_rsrc_t inbox_rs = make_rsrc(C.inbox, 0u);
 
     float* nb_old = nb0; float* nb_cur = nb1;
     int iter = 0;
@@ -779,9 +846,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
         long long tr_a = 0, tr_b = 0;
         if (trace) tr_a = wall_clock64();
         // ---- edge phase: every residue pair rewrites its two messages in place from the old node beliefs
-        bp_edge_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
-        bp_edge_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_old, tid, nt);
-        bp_edge_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_old, tid, nt);
+        // (measured and rejected: dealing 64-slot chunks of all classes to the wavefronts round-robin, heavy classes first, to
+        // even out the trip counts -- 1 % slower: the phase is limited by bytes, not by trips)
+        r33.edge(C, nb_old, inbox_rs); r36.edge(C, nb_old, inbox_rs); r66.edge(C, nb_old, inbox_rs);
+        bp_edge_range<3, 3>(C, cls[CL33] + K33 * nt, cls[CL33 + 1], nb_old, tid, nt);
+        bp_edge_range<3, 6>(C, cls[CL36] + K36 * nt, cls[CL36 + 1], nb_old, tid, nt);
+        bp_edge_range<6, 6>(C, cls[CL66] + K66 * nt, cls[CL66 + 1], nb_old, tid, nt);
         __syncthreads();
         if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
@@ -881,9 +951,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     }
     __syncthreads();
     float en = 0.f;
-    en += bp_marginal_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_cur, tid, nt, want_energy);
-    en += bp_marginal_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
-    en += bp_marginal_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
+    en += r33.marginal(C, cls[CL33], nb_cur, tid, nt, want_energy);
+    en += r36.marginal(C, cls[CL36], nb_cur, tid, nt, want_energy);
+    en += r66.marginal(C, cls[CL66], nb_cur, tid, nt, want_energy);
+    en += bp_marginal_range<3, 3>(C, cls[CL33] + K33 * nt, cls[CL33 + 1], nb_cur, tid, nt, want_energy);
+    en += bp_marginal_range<3, 6>(C, cls[CL36] + K36 * nt, cls[CL36 + 1], nb_cur, tid, nt, want_energy);
+    en += bp_marginal_range<6, 6>(C, cls[CL66] + K66 * nt, cls[CL66 + 1], nb_cur, tid, nt, want_energy);
     if (want_energy) {
         for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
             if (C.active[sl]) en += -logf(C.P[sl]);
@@ -899,10 +972,15 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_bp(upk_rotamer_t R, int wa
     for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[i];
     __syncthreads();
     // leave the accumulators clean for the next force evaluation
-    clear_all_classes(C.P, C.cap, cls, 0, 1, tid, nt);
+    // (only the slots written this step: the others were left at 0 by the prologue); the flags move to active_last
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
-    for (int i = tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
+    retire_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], active_w, active_last, tid, nt);
+    retire_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], active_w, active_last, tid, nt);
+    retire_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], active_w, active_last, tid, nt);
+    retire_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], active_w, active_last, tid, nt);
+    retire_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], active_w, active_last, tid, nt);
+    for (int i = cls[N_CLASS] + tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }   // (no slot lies outside the classes)
     if (trace) {
         long long* T = R.bp_trace + (size_t)s * 16;
         T[0] = tr_pro - tr_t0; T[1] = tr_loop - tr_pro; T[2] = wall_clock64() - tr_loop; T[3] = tr_edge; T[4] = tr_node;
@@ -1334,6 +1412,23 @@ extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // fl
     const int fixed = R->n_node * 14 + 48;
     return (int)(156 * 1024 / sizeof(float)) - fixed;
 }
+// one-workgroup solve: BP_BLOCK lanes streaming every matrix, or BP_BLOCK / 2 lanes with the first trips of each class pinned in registers
+static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy, int only_fallback, size_t lds, int lds_msg_floats, int threads) {
+    // UPSIDE_HIP_BP_RESIDENT: 0 = always stream every matrix, 1 / 2 = always a register layout; unset: by batch size.  With
+    // fewer systems than CUs the solve is latency bound and the wider workgroup wins (64 systems: 48.1 k vs 46.0 k
+    // system-steps/s); from one system per CU on the sweep is byte bound and the pinned matrices win (256: 94.0 k vs
+    // 92.8 k, 1024: 104.5 k vs 103.0 k)
+    static int resident_env = -2;
+    if (resident_env == -2) { const char* e = getenv("UPSIDE_HIP_BP_RESIDENT"); resident_env = e ? atoi(e) : -1; }
+    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() ? 1 : 0);
+    const dim3 grid(1, L->n_system);
+    if (resident == 0 || threads != BP_BLOCK || only_fallback)
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else                      // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+}
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
     const size_t lds_base = ((size_t)R->n_node * 20 + 64 + 8) * sizeof(float);
     if (lds_base > 155 * 1024) return 9004;
@@ -1360,12 +1455,12 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
                 if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
                 else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BPC_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
-            hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(BP_BLOCK), lds_base, ST(L), *R, want_energy, 1, 0);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
+            bp_launch(L, R, want_energy, 1, lds_base, 0, BP_BLOCK);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
             return launch_status();
         }
     }
     static int bp_threads = 0;   // UPSIDE_HIP_BP_THREADS (experiments): lanes per one-workgroup solve
     if (!bp_threads) { const char* e = getenv("UPSIDE_HIP_BP_THREADS"); bp_threads = e ? atoi(e) : BP_BLOCK; if (bp_threads < 64 || bp_threads > BP_BLOCK) bp_threads = BP_BLOCK; }
-    hipLaunchKernelGGL(k_rotamer_bp, dim3(1, L->n_system), dim3(bp_threads), lds, ST(L), *R, want_energy, 0, lds_msg_floats);
+    bp_launch(L, R, want_energy, 0, lds, lds_msg_floats, bp_threads);
     return launch_status();
 }

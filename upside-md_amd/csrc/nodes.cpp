@@ -1383,6 +1383,17 @@ double engine_bp_bytes(DerivEngine& e) {
                 }
                 total += per_sweep * (it[s] + 1);
             }
+            if (getenv("UPSIDE_HIP_BP_STATS")) {   // diagnostics: slot occupancy of the last launch
+                long n_slot[6] = {0}, n_act[6] = {0}, sweeps = 0;
+                for (int s = 0; s < S; ++s) {
+                    sweeps += it[s];
+                    for (int c = 0; c < 5; ++c)
+                        for (int sl = cs[(size_t)s * 6 + c]; sl < cs[(size_t)s * 6 + c + 1]; ++sl) { n_slot[c]++; n_act[c] += act[(size_t)s * cap + sl] != 0; }
+                }
+                fprintf(stderr, "bp stats: %d systems, %.1f sweeps/solve; slots (active/all) per system:", S, sweeps / (double)S);
+                for (int c = 0; c < 5; ++c) fprintf(stderr, " c%d %.0f/%.0f", c, n_act[c] / (double)S, n_slot[c] / (double)S);
+                fprintf(stderr, "; nodes 1/3/6: %d/%d/%d\n", r->R.n_node1, n3, n6);
+            }
             return total;
         }
     return 0.;
