@@ -580,6 +580,7 @@ struct BpCtx {
     const int *slot_a, *slot_b, *active, *slot_off;
     float *P, *inbox, *marg;
     int cap;
+    const int4* rec = nullptr;     // one-workgroup solve: the active slots of each class, packed (see bp_pack_active)
     // the first lds_floats floats of the inbox (messages to the 3-state nodes come first) may live in LDS instead of
     // global memory: the one-workgroup solve re-reads and rewrites them every sweep
     float* inbox_lds = nullptr; int lds_floats = 0;
@@ -647,6 +648,42 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
         bp_edge_slot<NA, NB, WT>(C, oa, ob, C.slot_a[sl], C.slot_b[sl], P, nb_old, inbox_w);
     }
 }
+// Active slots of the multi-state classes, packed once per solve: the sweeps then read one 16-byte record per ACTIVE slot
+// instead of 20 bytes of flags, offsets and node ids per CACHED slot (a quarter of the cached residue pairs has no bead
+// pair in range on a given step), and trips and pinned registers are spent on active slots only.  Order-preserving (the
+// free-energy sum keeps its summation order from run to run): 64-slot chunks are counted by ballot, one barrier, then
+// every chunk finds its base as the sum of the counts before it in its class.  chunk_cnt: LDS scratch, one int per chunk.
+__device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict__ rec, const int* cls, int* n_act, int* chunk_cnt, int tid, int nt) {
+    const int lane = tid & 63, wave = tid >> 6, n_wave = nt >> 6;
+    const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int ch = wave; ch < nc0 + nc1 + nc2; ch += n_wave) {
+            const int c = ch < nc0 ? CL33 : (ch < nc0 + nc1 ? CL36 : CL66);
+            const int first = c == CL33 ? 0 : (c == CL36 ? nc0 : nc0 + nc1);          // first chunk of the class
+            const int sl = cls[c] + (ch - first) * 64 + lane;
+            const bool act = sl < cls[c + 1] && C.active[sl] != 0;
+            const unsigned long long b = __ballot(act);
+            if (pass == 0) { if (lane == 0) chunk_cnt[ch] = __popcll(b); continue; }
+            int before = 0;
+            for (int k = first + lane; k < ch; k += 64) before += chunk_cnt[k];
+            before = __builtin_amdgcn_readfirstlane((int)wave_sum((float)before));      // counts are < 2^24: exact in fp32
+            if (act) rec[cls[c] + before + __popcll(b & ((1ull << lane) - 1ull))] =
+                make_int4(C.slot_off[sl * 2], C.slot_off[sl * 2 + 1], C.slot_a[sl] | (C.slot_b[sl] << 16), sl);
+            if (lane == 0 && ch == first + (c == CL33 ? nc0 : (c == CL36 ? nc1 : nc2)) - 1) n_act[c] = before + __popcll(b);
+        }
+        __syncthreads();
+    }
+}
+template <int NA, int NB>
+__device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int end, const float* __restrict__ nb_old, int tid, int nt,
+                                               __amdgpu_buffer_rsrc_t rs) {
+    for (int idx = first + tid; idx < end; idx += nt) {
+        const int4 r = C.rec[idx];
+        float P[NA * NB];
+        bp_load_matrix<NA, NB>(C, r.w, P);
+        bp_edge_slot<NA, NB, false>(C, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nb_old, rs);
+    }
+}
 template <int NA, int NB>
 __device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
     bp_edge_range_impl<NA, NB, false>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
@@ -708,6 +745,18 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
     return en;
 }
 
+template <int NA, int NB>
+__device__ __forceinline__ float bp_marginal_packed(const BpCtx& C, int first, int end, const float* __restrict__ nbm, int tid, int nt, bool want_energy) {
+    float en = 0.f;
+    for (int idx = first + tid; idx < end; idx += nt) {
+        const int4 r = C.rec[idx];
+        float P[NA * NB];
+        bp_load_matrix<NA, NB>(C, r.w, P);
+        en += bp_marginal_slot<NA, NB>(C, r.w, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nbm, want_energy);
+    }
+    return en;
+}
+
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
 
 // Pair matrices pinned in registers for the whole solve.  The edge phase is bandwidth bound (at 1024 systems every CU
@@ -717,18 +766,18 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
 template <int NA, int NB, int K>
 struct BpResident {
     float P[K > 0 ? K : 1][NA * NB];
-    int oa[K > 0 ? K : 1], ob[K > 0 ? K : 1], ab[K > 0 ? K : 1];     // ab = a | b << 16; -1: no active slot in this trip
-    __device__ __forceinline__ void load(const BpCtx& C, int lo, int hi, int tid, int nt) {
+    int oa[K > 0 ? K : 1], ob[K > 0 ? K : 1], ab[K > 0 ? K : 1], sl[K > 0 ? K : 1];     // ab = a | b << 16; -1: no slot in this trip
+    __device__ __forceinline__ void load(const BpCtx& C, int first, int end, int tid, int nt) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int sl = lo + tid + k * nt;
-            ab[k] = -1; oa[k] = 0; ob[k] = 0;
+            const int idx = first + tid + k * nt;
+            ab[k] = -1; oa[k] = 0; ob[k] = 0; sl[k] = 0;
 #pragma unroll
             for (int e = 0; e < NA * NB; ++e) P[k][e] = 0.f;
-            if (sl < hi && C.active[sl]) {
-                bp_load_matrix<NA, NB>(C, sl, P[k]);
-                oa[k] = C.slot_off[sl * 2]; ob[k] = C.slot_off[sl * 2 + 1];
-                ab[k] = C.slot_a[sl] | (C.slot_b[sl] << 16);
+            if (idx < end) {
+                const int4 r = C.rec[idx];
+                bp_load_matrix<NA, NB>(C, r.w, P[k]);
+                oa[k] = r.x; ob[k] = r.y; ab[k] = r.z; sl[k] = r.w;
             }
         }
     }
@@ -737,11 +786,11 @@ struct BpResident {
         for (int k = 0; k < K; ++k)
             if (ab[k] >= 0) bp_edge_slot<NA, NB, false>(C, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nb_old, rs);
     }
-    __device__ __forceinline__ float marginal(const BpCtx& C, int lo, const float* __restrict__ nbm, int tid, int nt, bool want_energy) const {
+    __device__ __forceinline__ float marginal(const BpCtx& C, const float* __restrict__ nbm, bool want_energy) const {
         float en = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (ab[k] >= 0) en += bp_marginal_slot<NA, NB>(C, lo + tid + k * nt, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nbm, want_energy);
+            if (ab[k] >= 0) en += bp_marginal_slot<NA, NB>(C, sl[k], oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nbm, want_energy);
         return en;
     }
 };
@@ -759,6 +808,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     int* nrot = (int*)(lds + NN * 18 + 32);      // [NN]   state counts
     int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
     int* cls = bp_start + NN + 1;                // [N_CLASS+1]
+    int* n_act = cls + N_CLASS + 1;              // [3] active slots of the 3x3 / 3x6 / 6x6 classes
     const int n_slot = R.n_slot[s];
     long long tr_t0 = 0, tr_edge = 0, tr_node = 0, tr_pro = 0, tr_loop = 0;
     const bool trace = R.bp_trace != nullptr && tid == 0;
@@ -772,12 +822,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     C.P = R.P + (size_t)s * R.slot_cap * 36;
     C.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
     C.marg = R.marg + (size_t)s * R.slot_cap * 36;
-    C.inbox_lds = (float*)(((size_t)(cls + N_CLASS + 2) + 15) & ~(size_t)15);   // [lds_msg_floats], 16-byte aligned
+    C.inbox_lds = (float*)(((size_t)(cls + N_CLASS + 5) + 15) & ~(size_t)15);   // [lds_msg_floats], 16-byte aligned
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
     for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
+    if (tid < 3) n_act[tid] = 0;
     for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
 
@@ -788,6 +839,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt, C.active);
     exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt, C.active);
     exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
+    // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
+    constexpr bool PACK = K66 + K36 + K33 > 0;
+    if (PACK) {
+        int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
+        C.rec = rec;
+        bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt);     // (nb0 / nb1 are filled after the fold below)
+    }
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
     // the head of the inbox stays in LDS as far as it reaches: the 4-float rows to the 3-state nodes come first, then
@@ -832,7 +890,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
     BpResident<3, 3, K33> r33; BpResident<3, 6, K36> r36; BpResident<6, 6, K66> r66;
-    r33.load(C, cls[CL33], cls[CL33 + 1], tid, nt); r36.load(C, cls[CL36], cls[CL36 + 1], tid, nt); r66.load(C, cls[CL66], cls[CL66 + 1], tid, nt);
+    const int e33 = cls[CL33] + n_act[CL33], e36 = cls[CL36] + n_act[CL36], e66 = cls[CL66] + n_act[CL66];   // ends of the packed records
+    r33.load(C, cls[CL33], e33, tid, nt); r36.load(C, cls[CL36], e36, tid, nt); r66.load(C, cls[CL66], e66, tid, nt);
     const __amdgpu_buffer_rsrc_t inbox_rs = make_rsrc(C.inbox, 0u);
 
     float* nb_old = nb0; float* nb_cur = nb1;
@@ -849,9 +908,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // (measured and rejected: dealing 64-slot chunks of all classes to the wavefronts round-robin, heavy classes first, to
         // even out the trip counts -- 1 % slower: the phase is limited by bytes, not by trips)
         r33.edge(C, nb_old, inbox_rs); r36.edge(C, nb_old, inbox_rs); r66.edge(C, nb_old, inbox_rs);
-        bp_edge_range<3, 3>(C, cls[CL33] + K33 * nt, cls[CL33 + 1], nb_old, tid, nt);
-        bp_edge_range<3, 6>(C, cls[CL36] + K36 * nt, cls[CL36 + 1], nb_old, tid, nt);
-        bp_edge_range<6, 6>(C, cls[CL66] + K66 * nt, cls[CL66 + 1], nb_old, tid, nt);
+        if (PACK) {
+            bp_edge_packed<3, 3>(C, cls[CL33] + K33 * nt, e33, nb_old, tid, nt, inbox_rs);
+            bp_edge_packed<3, 6>(C, cls[CL36] + K36 * nt, e36, nb_old, tid, nt, inbox_rs);
+            bp_edge_packed<6, 6>(C, cls[CL66] + K66 * nt, e66, nb_old, tid, nt, inbox_rs);
+        } else {
+            bp_edge_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
+            bp_edge_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_old, tid, nt);
+            bp_edge_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_old, tid, nt);
+        }
         __syncthreads();
         if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
@@ -951,12 +1016,18 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     __syncthreads();
     float en = 0.f;
-    en += r33.marginal(C, cls[CL33], nb_cur, tid, nt, want_energy);
-    en += r36.marginal(C, cls[CL36], nb_cur, tid, nt, want_energy);
-    en += r66.marginal(C, cls[CL66], nb_cur, tid, nt, want_energy);
-    en += bp_marginal_range<3, 3>(C, cls[CL33] + K33 * nt, cls[CL33 + 1], nb_cur, tid, nt, want_energy);
-    en += bp_marginal_range<3, 6>(C, cls[CL36] + K36 * nt, cls[CL36 + 1], nb_cur, tid, nt, want_energy);
-    en += bp_marginal_range<6, 6>(C, cls[CL66] + K66 * nt, cls[CL66 + 1], nb_cur, tid, nt, want_energy);
+    en += r33.marginal(C, nb_cur, want_energy);
+    en += r36.marginal(C, nb_cur, want_energy);
+    en += r66.marginal(C, nb_cur, want_energy);
+    if (PACK) {
+        en += bp_marginal_packed<3, 3>(C, cls[CL33] + K33 * nt, e33, nb_cur, tid, nt, want_energy);
+        en += bp_marginal_packed<3, 6>(C, cls[CL36] + K36 * nt, e36, nb_cur, tid, nt, want_energy);
+        en += bp_marginal_packed<6, 6>(C, cls[CL66] + K66 * nt, e66, nb_cur, tid, nt, want_energy);
+    } else {
+        en += bp_marginal_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_cur, tid, nt, want_energy);
+        en += bp_marginal_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
+        en += bp_marginal_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
+    }
     if (want_energy) {
         for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
             if (C.active[sl]) en += -logf(C.P[sl]);

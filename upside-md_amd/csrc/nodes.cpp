@@ -1026,7 +1026,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<unsigned char> mark;
     DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack;
     bool bp_C_chosen = false;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     DevBuf<int> n_bad;
@@ -1085,6 +1085,7 @@ struct RotamerSidechain : public PotentialNode {
         R.adj_cap = min(max(n_node, 1), env_int("UPSIDE_HIP_ADJ_CAP", 256));
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
+        bp_rec.alloc((size_t)S * R.slot_cap * 4);
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); nbr_slot.alloc((size_t)S * ig.G.n1 * ig.G.cap1); slot_active_last.alloc((size_t)S * R.slot_cap);
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
@@ -1116,7 +1117,7 @@ struct RotamerSidechain : public PotentialNode {
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.marg = marg.p;
-        R.iters = iters.p; R.n_bad = n_bad.p; R.energy = energy.p;
+        R.iters = iters.p; R.n_bad = n_bad.p; R.bp_rec = bp_rec.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
         if (ig.G.n1 >= 65536 || ig.G.cap1 > 4096) throw string("rotamer pair kernels pack (bead, list position) into 16 + 12 bits: UPSIDE_HIP_NBR_CAP <= 4096");
