@@ -125,7 +125,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--replicas', type=int, default=int(os.environ.get('UPSIDE_BENCH_REPLICAS', '1024')),
+    ap.add_argument('--replicas', type=int, default=int(os.environ.get('UPSIDE_BENCH_REPLICAS', '4096')),
                     help='independent replicas resident per GPU')
     ap.add_argument('--workload', default='syn300_10A')
     ap.add_argument('--no-cpu-baseline', action='store_true')

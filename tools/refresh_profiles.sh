@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-for R in 1 64 256 1024; do
+for R in 1 64 256 1024 4096; do
   st=100; [ $R -le 64 ] && st=300
   python3 bench.py --replicas $R --steps $st --warmup 30 2>"$OUT/bench_R$R.err" | tail -1 > "$OUT/bench_R$R.json"
 done
@@ -20,7 +20,7 @@ for t in trace fetch write sq; do
   [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" "$OUT/${t}_summary.txt"
 done
 fdb=$(find "$OUT/fetch" -name "*.db" | head -1); wdb=$(find "$OUT/write" -name "*.db" | head -1)
-python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 1024 "$OUT/hbm_traffic.json" > "$OUT/hbm_traffic.txt" 2>&1
+python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 4096 "$OUT/hbm_traffic.json" > "$OUT/hbm_traffic.txt" 2>&1
 # keep the merge small: drop the databases
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT"

@@ -928,11 +928,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
                 const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
-                // four rows per trip are fetched before the first multiply (same operation order as one at a time)
-                for (int k0 = gl; k0 < deg; k0 += 4 * BP_GROUP) {
-                    float4 m0[4]; float2 m1[4];
+                // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
+                // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
+                constexpr int ROWS = BLOCK == BP_BLOCK ? 4 : 8;
+                for (int k0 = gl; k0 < deg; k0 += ROWS * BP_GROUP) {
+                    float4 m0[ROWS]; float2 m1[ROWS];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < ROWS; ++u) {
                         const int k = k0 + u * BP_GROUP;
                         m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
@@ -942,7 +944,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < ROWS; ++u) {
                         if (k0 + u * BP_GROUP >= deg) break;
                         bb[0] *= m0[u].x; bb[1] *= m0[u].y; bb[2] *= m0[u].z;
                         if (n == 6) { bb[3] *= m0[u].w; bb[4] *= m1[u].x; bb[5] *= m1[u].y; }
