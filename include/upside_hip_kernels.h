@@ -198,6 +198,8 @@ typedef struct {
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     float* bead_pack;                    /* [S][n_bead][8] packed bead rows for systems whose beads do not fit LDS (else NULL) */
     int one_bead_per_state;              /* every (residue, rotamer state) owns exactly one bead: each pair-matrix entry has a single writer */
+    int p_prob;                          /* the pair-energy kernel stores exp(-E) (resting value 1) instead of E (resting value 0): the
+                                            one-workgroup solve then has no exp pass.  Needs one_bead_per_state and bp_C <= 1 */
     const int *node_bead_start, *node_bead_list;   /* CSR (node*6+rot) -> beads of that rotamer state */
     int n_prob; const float* const* prob_out; float* const* prob_sens; const int* prob_stride;   /* 1-body parents (device arrays of device ptrs) */
     const long* prob_sys_stride;

@@ -500,6 +500,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_ROTAMER_ATOMIC': '1'},      # pair matrices accumulated with atomics (libraries with several beads per state)
     {'UPSIDE_HIP_PLB_UNSTAGED': '1'},        # list build reading the other side from global memory (very large systems)
     {'UPSIDE_HIP_SKIN_SCALE': '1.0'},        # the reference's cached-list margin
+    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '0'},      # one-workgroup BP of 1024 lanes streaming every pair matrix
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '1'},      # 512 lanes, two 6x6 trips of pair matrices pinned in registers (large batches)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '2'},      # the other register layout of the resident matrices

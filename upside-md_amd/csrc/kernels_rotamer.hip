@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, i
                 const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
                 // With one bead per rotamer state (every shipped side-chain library) an entry has a single writer and a plain
                 // store does; device-scope float atomics on scattered lines cost 0.56 ms of this kernel's 1.37 at 1024 systems.
-                if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = E;
+                if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = R.p_prob ? expf(-E) : E;
                 else atomicAdd(&P[PIDX(R, sl, idx)], E);
                 active[sl] = 1;
             });
@@ -556,13 +556,13 @@ __device__ __forceinline__ void clear_class(float* P, int cap, int lo, int hi, i
 }
 // end of a solve: zero the accumulator entries of the slots that were written this step and hand their flags on
 template <int NA, int NB>
-__device__ __forceinline__ void retire_class(float* P, int cap, int lo, int hi, int* __restrict__ active_w, int* __restrict__ active_last, int tid, int nt) {
+__device__ __forceinline__ void retire_class(float* P, int cap, int lo, int hi, int* __restrict__ active_w, int* __restrict__ active_last, int tid, int nt, float rest) {
     for (int sl = lo + tid; sl < hi; sl += nt) {
         const int act = active_w[sl];
         active_last[sl] = act; active_w[sl] = 0;
         if (act) {
 #pragma unroll
-            for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = 0.f;
+            for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = rest;
         }
     }
 }
@@ -834,11 +834,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
 
     // energies -> probabilities for the entries each class uses (rotamer.cpp:835); 1xN rows carry up to 6 columns
     // (unused ones stay exp(0) = 1, never read)
-    exp_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], tid, nt, C.active);
-    exp_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], tid, nt, C.active);
-    exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt, C.active);
-    exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt, C.active);
-    exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
+    if (!R.p_prob) {                           // (p_prob: the pair-energy kernel stored exp(-E) already)
+        exp_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], tid, nt, C.active);
+        exp_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], tid, nt, C.active);
+        exp_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], tid, nt, C.active);
+        exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt, C.active);
+        exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
+    }
     // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
     constexpr bool PACK = K66 + K36 + K33 > 0;
     if (PACK) {
@@ -1048,11 +1050,12 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // (only the slots written this step: the others were left at 0 by the prologue); the flags move to active_last
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
-    retire_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], active_w, active_last, tid, nt);
-    retire_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], active_w, active_last, tid, nt);
-    retire_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], active_w, active_last, tid, nt);
-    retire_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], active_w, active_last, tid, nt);
-    retire_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], active_w, active_last, tid, nt);
+    const float rest = R.p_prob ? 1.f : 0.f;
+    retire_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], active_w, active_last, tid, nt, rest);
+    retire_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], active_w, active_last, tid, nt, rest);
+    retire_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], active_w, active_last, tid, nt, rest);
+    retire_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], active_w, active_last, tid, nt, rest);
+    retire_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], active_w, active_last, tid, nt, rest);
     for (int i = cls[N_CLASS] + tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }   // (no slot lies outside the classes)
     if (trace) {
         long long* T = R.bp_trace + (size_t)s * 16;

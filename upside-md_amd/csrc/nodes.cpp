@@ -1148,7 +1148,7 @@ struct RotamerSidechain : public PotentialNode {
         bp_C_chosen = true;
         const int want = env_int("UPSIDE_HIP_BP_CLUSTER", -1);   // 1 disables, >1 forces
         R.bp_resident = 1;
-        if (want == 1) { R.bp_C = 1; return; }
+        if (want == 1) { R.bp_C = 1; set_matrix_form(); return; }
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
         auto cs = class_start.download();
         long need = 0, widest = 0;
@@ -1179,6 +1179,18 @@ struct RotamerSidechain : public PotentialNode {
         if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", resident_limit)) C = 1;
         if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
+        set_matrix_form();
+    }
+    // One-workgroup solve with single-writer matrices: the pair-energy kernel writes exp(-E) itself and the matrices rest at 1
+    // (= no interaction) between evaluations, which removes the solve's exp pass over every active matrix.  The cluster
+    // solves and the accumulating (several beads per state) path keep energies resting at 0.
+    void set_matrix_form() {
+        R.p_prob = (R.bp_C <= 1 && one_bead_per_state && !env_int("UPSIDE_HIP_BP_ENERGY_TABLE", 0)) ? 1 : 0;
+        rest_matrices();
+    }
+    void rest_matrices() {
+        if (R.p_prob) hip_check(hipMemsetD32Async((hipDeviceptr_t)P.p, 0x3f800000 /* 1.0f */, P.n, ctx->stream), "fill");
+        else hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");
     }
     void compute_value(ComputeMode mode) override {   // rotamer.cpp:779-789
         if (!bp_C_chosen) choose_bp_cluster();
@@ -1205,11 +1217,13 @@ struct RotamerSidechain : public PotentialNode {
     // begin_log_frame / end_log_frame the kernel runs once for the read-outs of all systems.
     bool log_frame_open = false;
     void fill_pair_energies() {
-        upk_check(upk_rotamer_pair_energy(&ctx->L, &R), "rotamer_pair_energy");
+        upk_rotamer_t Re = R;                      // energies wanted here, whatever form the solve keeps
+        if (R.p_prob) { Re.p_prob = 0; hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset"); }
+        upk_check(upk_rotamer_pair_energy(&ctx->L, &Re), "rotamer_pair_energy");
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
     }
     void clear_pair_energies() {
-        hip_check(hipMemsetAsync(P.p, 0, P.n * sizeof(float), ctx->stream), "memset");
+        rest_matrices();
         hip_check(hipMemsetAsync(slot_active.p, 0, slot_active.n * sizeof(int), ctx->stream), "memset");
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
     }
