@@ -1,5 +1,5 @@
 L=upside-md_amd/csrc
-python -m pytest tests -x -q -m gpu > gpurun_out/pytest_gpu.txt 2>&1; grep -E "passed|failed" gpurun_out/pytest_gpu.txt
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "alternate or forces or md or rotamer or bp" > gpurun_out/pytest_bp.txt 2>&1; grep -E "passed|failed" gpurun_out/pytest_bp.txt
 cp $L/libupside_hip.so $L/libupside_hip.new
 for i in 1 2; do
 for v in old new; do
