@@ -537,6 +537,18 @@ def test_alternate_code_paths_agree(tmp_path):
         assert P.rel_rms(base['md_pos'], alt['md_pos']) < 1e-5, env_extra
 
 
+def test_large_batch_solver_on_every_fixture():
+    """the belief-propagation variant of large batches (512 lanes, active slots packed, pair matrices pinned in
+    registers) is chosen by batch size; forced here for the small parity cases -- every fixture incl. the degenerate
+    sequences (empty slot classes), named values, truncated solves -- by re-running those tests in a child pytest"""
+    import subprocess
+    env = dict(os.environ, UPSIDE_HIP_BP_RESIDENT='1', UPSIDE_HIP_BP_CLUSTER='1')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                          '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200).stdout.decode()
+    assert ' passed' in out and 'failed' not in out and 'error' not in out.lower(), out[-3000:]
+
+
 def test_capacity_overflow_fails_loudly():
     """a neighbour list that outgrows its row capacity (or the slot table) is reported by the evaluating call, not
     silently truncated: run with a deliberately tiny capacity in a child process"""
