@@ -1491,12 +1491,12 @@ extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // fl
 // one-workgroup solve: BP_BLOCK lanes streaming every matrix, or BP_BLOCK / 2 lanes with the first trips of each class pinned in registers
 static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy, int only_fallback, size_t lds, int lds_msg_floats, int threads) {
     // UPSIDE_HIP_BP_RESIDENT: 0 = always stream every matrix, 1 / 2 = always a register layout; unset: by batch size.  With
-    // fewer systems than CUs the solve is latency bound and the wider workgroup wins (64 systems: 48.1 k vs 46.0 k
-    // system-steps/s); from one system per CU on the sweep is byte bound and the pinned matrices win (256: 94.0 k vs
-    // 92.8 k, 1024: 104.5 k vs 103.0 k)
+    // few systems per CU the solve is latency bound and the wider workgroup wins (64 systems on 256 CUs: 48.1 k vs 46.0 k
+    // system-steps/s); the pinned matrices and packed slots draw level at 3/8 system per CU (96: 51.6 k vs 51.4 k) and
+    // win from there on (128: 73.3 vs 72.7 k, 192: 77.6 vs 75.9 k, 256: 96 vs 93 k, 1024: 108 vs 103 k)
     static int resident_env = -2;
     if (resident_env == -2) { const char* e = getenv("UPSIDE_HIP_BP_RESIDENT"); resident_env = e ? atoi(e) : -1; }
-    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() ? 1 : 0);
+    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() * 3 / 8 ? 1 : 0);
     const dim3 grid(1, L->n_system);
     if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
