@@ -212,9 +212,12 @@ extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) 
 }
 
 // K2: rebuild the row lists of the flagged systems from the refreshed reference positions.  A workgroup stages the
-// whole other side (16 bytes per element) in LDS and serves PLB_ROWS rows; one wavefront per row tests 64
+// whole other side (16 bytes per element) in LDS and serves plb_rows() rows; one wavefront per row tests 64
 // candidates at a time and compacts hits with a ballot + popcount prefix, so each row comes out in ascending order.
-#define PLB_ROWS 64
+// rows per workgroup: every workgroup stages the whole other side first, so more rows per workgroup amortise that copy
+// (128 rows: +0.4 % of the benchmark at 4096 systems; 256 leaves too few workgroups per system: -0.4 %), while a small
+// batch wants its few rebuilds spread over many workgroups (64 rows: +1 % at 1 and 64 systems)
+static inline int plb_rows(int n_system) { return n_system >= upk_device_cu_count() ? 128 : 64; }
 // IT: pair functor (compile time, so the id rule is straight-line code); the inner loop is written without
 // short-circuit tests: uniform branches and nested exec masks cost as much as the arithmetic here (measured: the
 // branchy form spent ~half of each 64-candidate trip in scalar control flow).  The staged copy is padded to a multiple
@@ -231,7 +234,7 @@ __device__ __forceinline__ int plb_node_of(const upk_igraph_t& G, int id) {
     return (id >> 8) + ((-(int)(nr == 6) & G.mark_start6) | (-(int)(nr == 3) & G.mark_start3));
 }
 template <bool STAGED, int IT>
-__global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1) {
+__global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float plb_lds[];
     float4* oth = (float4*)plb_lds;
     constexpr bool SYM = IT == UPK_IT_ROTAMER || IT == UPK_IT_RADIAL;
@@ -253,8 +256,8 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
             for (int j = threadIdx.x; j < n_pad; j += blockDim.x) oth[j] = j < n_other ? src[j] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
             __syncthreads();
         }
-        for (int r = wave; r < PLB_ROWS; r += n_wave) {
-            const int i = rb * PLB_ROWS + r;
+        for (int r = wave; r < rows_per_wg; r += n_wave) {
+            const int i = rb * rows_per_wg + r;
             if (i >= n_my) break;
             const float4 x = mine[i];
             const int my_id = __float_as_int(x.w);
@@ -294,12 +297,14 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
 }
 template <int IT>
 static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, size_t lds, bool staged, int blocks1) {
-    if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1);
-    else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1);
+    const int rows = plb_rows(L->n_system);
+    if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1, rows);
+    else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1, rows);
 }
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
-    const int blocks1 = (G->n1 + PLB_ROWS - 1) / PLB_ROWS;
-    const int blocks2 = G->symmetric ? 0 : (G->n2 + PLB_ROWS - 1) / PLB_ROWS;
+    const int rows = plb_rows(L->n_system);
+    const int blocks1 = (G->n1 + rows - 1) / rows;
+    const int blocks2 = G->symmetric ? 0 : (G->n2 + rows - 1) / rows;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     const size_t lds = (size_t)((n_max + 63) & ~63) * 16;
     const dim3 grid(blocks1 + blocks2, UPK_FLAG_GRID(L->n_system));
