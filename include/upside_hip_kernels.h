@@ -151,7 +151,22 @@ typedef struct {
        (mark_n x mark_n bytes, pre-cleared by upk_rotamer_clear_slots) is set to 1 for every cached pair */
     unsigned char* mark_table; const int* mark_node; int mark_n, mark_stride;   /* mark_stride: bytes per system (multiple of 16) */
     int mark_start3, mark_start6;        /* node of a bead id (rotamer.cpp:812-816): (id >> 8) + {0, mark_start3, mark_start6} by its state count */
+    /* This step's in-range pairs ("hit lists", the refine of interaction_graph.h:201-257 done ONCE per step and side by
+       upk_pairlist_refine): for every row of side 1 (hit1) / side 2 (hit2) the cached neighbours with d2 < cutoff2, in list
+       order; hit[s][row][k] holds the list word unchanged, hcnt[s][row] their number (capacity per row = cap1 / cap2).
+       Symmetric graphs: hlo1[s][row] = hits whose partner index is BELOW the row (lists ascend, so the partners above the
+       row -- each pair once, i1 < i2 -- are the tail [hlo1, hcnt1) of the hit list).
+       ord1 / ord2 [s][row]: rows sorted by descending hit count (upk_pairlist_order), ord1u by descending count of partners
+       above the row: the pair passes hand 8 consecutive rows of that order to the 8 lane groups of a wavefront, so the
+       groups of a wavefront run the same number of trips.
+       The rotamer graph's list words carry the residue-pair slot above bit UPK_ROT_J_BITS. */
+    int *hit1, *hit2, *hcnt1, *hcnt2, *hlo1;
+    unsigned short *ord1, *ord2, *ord1u;
+    float *cur_pos1, *cur_pos2;          /* [S][n][4] this step's positions (x, y, z, -), written by upk_pairlist_check */
+    int nbr_j_bits;                      /* 0: a list word is the element index; else the index is its low nbr_j_bits bits */
 } upk_igraph_t;
+#define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8192 beads, < 2^19 - 1 slots */
+#define UPK_ROT_SLOT_NONE 0x7FFFF        /* slot field of a cached bead pair whose residue pair got no slot (capacity overflow) */
 
 /* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build
  * (interaction_graph.h:57-90) */
@@ -159,21 +174,31 @@ int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G);
 /* K2: where flag[s] is set rebuild the row lists with d < cache_cutoff and acceptable_id_pair
  * (interaction_graph.h:116-158); clears the flag */
 int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G);
-/* K3 forward: rowsum over in-range neighbours of the pair value.
- *   side = 1: out[s][i1] = sum_{i2} value   (environment_coverage, protein_hbond donors)
- *   side = 2: out[s][i2] = sum_{i1} value   (hbond_coverage, protein_hbond acceptors)
- * out has element stride out_stride, component out_comp, row offset out_row0. */
-int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
-                      int out_stride, int out_comp, int out_row0, float* own_grad);
-/* own_grad (may be NULL): [S][n_rows][8], receives the unweighted sum over neighbours of d(value)/d(row element).
- * When the pair sensitivity is the row element's own (coverage nodes), the backward pass of that side is the
- * per-element product below instead of a third pair pass. */
+/* K2b: this step's in-range pairs of every system for the rows of `side` (hit lists above), from the cached lists and
+ * cur_pos; then the rows of that side sorted by descending hit count (ord1 / ord2, and ord1u for symmetric graphs) */
+int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side);
+int upk_pairlist_order(const upk_launch_t* L, const upk_igraph_t* G, int side);
+/* Pair passes over the hit lists (LDS-staged; fall back to the list-walking forms below for systems too large for LDS).
+ * upk_igraph_rows: for every row of `side`
+ *   mode 0: out[s][(out_row0 + row)*out_stride + out_comp] = sum over the row's in-range partners of the pair value
+ *           (hbond.cpp:387-389, environment.cpp:85-91, hbond.cpp:316-319)
+ *   mode 1: the same, and own_grad[s][row][8] = the UNWEIGHTED sum of d(value)/d(row element): when the pair sensitivity
+ *           is the row element's own (coverage nodes), that side's backward pass is upk_igraph_apply_own_grad
+ *   mode 2: sens(pair) * d(value)/d(row element) summed over the partners and added to the source node's sens at
+ *           loc[row] (interaction_graph.h:525-555 as a per-row gather; no atomics, fixed summation order).
+ *           Pair sensitivity: sens_mode 1: sens1[s][i1*sens_stride]; 2: sens2[s][i2*sens_stride]; 3: sens1[i1]+sens2[i2].
+ * side = 3: the rows of side 1, then the rows of side 2, in one launch (protein_hbond; mode 0 writes side 2 at out_row0_2) */
+int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride, int out_stride,
+                    int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode, const float* sens1, const float* sens2,
+                    long sens_sys_stride, int sens_stride);
 int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
                               const float* sens, long sens_sys_stride, int sens_stride);
-/* K8 backward: for every row of `side`, sum over in-range neighbours of sens(pair) * d(value)/d(row coords),
- * added to the source node's sens at loc[row] (interaction_graph.h:525-555 in gather form).
- * Pair sensitivity: sens_mode 1: sens1[s][i1*sens_stride]; 2: sens2[s][i2*sens_stride]; 3: sens1[i1]+sens2[i2]. */
-/* sens_mode 0: every pair has sensitivity 1 (potentials summed over edges, sidechain_radial.cpp:94-96) */
+/* List-walking forms (no hit lists, no LDS staging; any system size): the radial potentials and the fallback of the two
+ * launchers above.  Row sums of the pair value over one side's cached lists ... */
+int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
+                      int out_stride, int out_comp, int out_row0, float* own_grad /* may be NULL; as mode 1 above */);
+/* ... and the per-row gather of sens(pair) * d(value)/d(row coords), added to the source node's sens at loc[row].
+ * sens_mode 0: every pair has sensitivity 1 (potentials summed over edges, sidechain_radial.cpp:94-96) */
 int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                     const float* sens2, long sens_sys_stride, int sens_stride);
 /* parity/diagnostic: flags[s][i][k] = 1 where cached neighbour k of row i is in range this step */
@@ -211,7 +236,6 @@ typedef struct {
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
     int *class_start;                    /* [S][6] slot ranges by class: 3x3, 3x6, 6x6, 1x1, 1xN */
-    int *nbr_slot;                       /* [S][n_bead][cap1] slot of every cached bead pair */
     int *slot_active_last;               /* [S][cap] activity flags of the last solve (diagnostics) */
     float *P, *msg_cur, *marg;           /* P, marg: SoA [S][36][cap]; msg_cur: inbox [S][cap][16] floats at most: message rows grouped by
                                           * receiving node, 4 floats per message to a 3-state node, 8 to a 6-state node */

@@ -134,8 +134,9 @@ DerivEngine::~DerivEngine() {
     invalidate_graph();
     for (auto& kv : side) {
         (void)hipStreamSynchronize(kv.second.stream);
-        (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); (void)hipStreamDestroy(kv.second.stream);
+        (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); (void)hipEventDestroy(kv.second.join_bwd);
     }
+    for (auto& kv : side) if (kv.second.owns_stream) (void)hipStreamDestroy(kv.second.stream);
     nodes.clear();
     if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
 }
@@ -223,26 +224,43 @@ void DerivEngine::finalize() {
         first.insert(first.end(), rest.begin(), rest.end());
         schedule.swap(first);
     }
+    // One upkeep stream per node (small batches: the rebuilds of different graphs run side by side), or ONE shared upkeep
+    // stream (large batches): the bandwidth-bound upkeep kernels then run in the order the main stream needs their results,
+    // beside the VALU-bound pair passes of the graphs whose lists are already done, instead of all at once in front of them.
+    const char* env_streams = getenv("UPSIDE_HIP_UPKEEP_STREAMS");
+    const bool shared_stream = env_streams ? atoi(env_streams) == 1 : ctx.n_system >= 128;
+    hipStream_t shared = nullptr;
     std::vector<Step> hoisted;
     std::vector<int> n_dep_left(nodes.size(), -1);
     for (size_t i = 0; i < nodes.size(); ++i) if (nodes[i].computation->has_prepare()) n_dep_left[i] = (int)deps_of[i].size();
     for (auto& st : schedule) {
         hoisted.push_back(st);
         if (st.backward) continue;
+        std::vector<size_t> ready;
         for (size_t c = 0; c < nodes.size(); ++c) {
             if (n_dep_left[c] <= 0 || !std::binary_search(begin(deps_of[c]), end(deps_of[c]), (size_t)st.node)) continue;
-            if (--n_dep_left[c] == 0) {
-                Step ps{(int)c, false}; ps.prepare = true; hoisted.push_back(ps);
-                Side sd;
-                hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
-                hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
-                hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
-                side[(int)c] = sd;
-                n_dep_left[c] = -1;
-            }
+            if (--n_dep_left[c] == 0) { ready.push_back(c); n_dep_left[c] = -1; }
+        }
+        // several nodes may become ready at once: upkeep in the order of their forward steps
+        std::sort(begin(ready), end(ready), [&](size_t a, size_t b) {
+            auto pos = [&](size_t n) { for (size_t k = 0; k < schedule.size(); ++k) if (!schedule[k].backward && schedule[k].node == (int)n) return k; return schedule.size(); };
+            return pos(a) < pos(b); });
+        for (size_t c : ready) {
+            Step ps{(int)c, false}; ps.prepare = true; hoisted.push_back(ps);
+            Side sd;
+            if (shared_stream) {
+                if (!shared) hip_check(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking), "hipStreamCreate");
+                sd.stream = shared; sd.owns_stream = side.empty();
+            } else hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&sd.join_bwd, hipEventDisableTiming), "hipEventCreate");
+            side[(int)c] = sd;
         }
     }
     schedule.swap(hoisted);
+    last_prepare_step = -1;
+    for (size_t k = 0; k < schedule.size(); ++k) if (schedule[k].prepare) last_prepare_step = (int)k;
     if (getenv("UPSIDE_HIP_PRINT_SCHEDULE"))
         for (auto& st : schedule) {
             auto& n = nodes[st.node];
@@ -258,29 +276,44 @@ void DerivEngine::compute(ComputeMode mode) {
     // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
     // node's sens before that node's own forward step
     upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
-    for (auto& st : schedule) {
+    auto on_stream = [&](hipStream_t st, const std::function<void()>& f) {
+        hipStream_t main_stream = ctx.stream;
+        ctx.stream = st; ctx.L.stream = (void*)st;
+        try { f(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
+        ctx.stream = main_stream; ctx.L.stream = (void*)main_stream;
+    };
+    for (size_t k = 0; k < schedule.size(); ++k) {
+        const Step& st = schedule[k];
         auto* c = nodes[st.node].computation.get();
         if (st.prepare) {   // fork: side stream waits for everything enqueued so far, runs the upkeep, records `join`
             Side& sd = side[st.node];
             hip_check(hipEventRecord(sd.fork, ctx.stream), "hipEventRecord");
             hip_check(hipStreamWaitEvent(sd.stream, sd.fork, 0), "hipStreamWaitEvent");
-            hipStream_t main_stream = ctx.stream;
-            ctx.stream = sd.stream; ctx.L.stream = (void*)sd.stream;
-            try { c->prepare(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
-            ctx.stream = main_stream; ctx.L.stream = (void*)main_stream;
+            on_stream(sd.stream, [&] { c->prepare(); });
             hip_check(hipEventRecord(sd.join, sd.stream), "hipEventRecord");
+            if ((int)k == last_prepare_step)   // the backward-side upkeep of every node, after all the forward-side upkeep
+                for (auto& kv : side) {
+                    auto* cb = nodes[kv.first].computation.get();
+                    if (!cb->has_prepare_backward()) continue;
+                    on_stream(kv.second.stream, [&] { cb->prepare_backward(); });
+                    hip_check(hipEventRecord(kv.second.join_bwd, kv.second.stream), "hipEventRecord");
+                }
             continue;
         }
         if (!st.backward) {
             if (c->has_prepare()) {
                 auto it = side.find(st.node);
                 if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent");
-                else c->prepare();
+                else { c->prepare(); if (c->has_prepare_backward()) c->prepare_backward(); }
             }
             c->compute_value(mode);
         } else if (!c->potential_term) {
             auto* cn = static_cast<CoordNode*>(c);
             cn->gather_contributions();
+            if (c->has_prepare_backward()) {
+                auto it = side.find(st.node);
+                if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join_bwd, 0), "hipStreamWaitEvent");
+            }
             c->propagate_deriv();
         }
     }

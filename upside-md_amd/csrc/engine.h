@@ -115,6 +115,10 @@ struct DerivComputation {   // deriv_engine.h:48-80
     // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).
     virtual bool has_prepare() const { return false; }
     virtual void prepare() {}
+    // second part of the upkeep, needed by propagate_deriv() only (the hit lists of the side the backward pass gathers
+    // over): enqueued after every node's prepare(), so it runs beside the forward passes instead of in front of them
+    virtual bool has_prepare_backward() const { return false; }
+    virtual void prepare_backward() {}
     std::vector<const DerivComputation*> prepare_deps;   // parents prepare() reads (empty = all of them)
 };
 
@@ -175,8 +179,9 @@ struct DerivEngine {   // deriv_engine.h:145-237
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
     struct Step { int node; bool backward; bool prepare = false; };
     std::vector<Step> schedule;
-    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_bwd = nullptr; bool owns_stream = true; };
     std::map<int, Side> side;                  // node index -> side stream of its prepare() (empty when disabled)
+    int last_prepare_step = -1;                // index in `schedule` of the last prepare step
     DevBuf<float*> zero_ptrs; DevBuf<long> zero_sizes; int n_zero = 0;   // every CoordNode's sens, cleared by one launch per force pass
 
     DerivEngine(int n_atom, int n_system);

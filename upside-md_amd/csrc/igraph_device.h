@@ -1,51 +1,29 @@
-// Device-side building blocks shared by the interaction-graph kernels (kernels_igraph.hip, kernels_rotamer.hip).
+// Device-side building blocks shared by the interaction-graph kernels (kernels_igraph.hip, kernels_pair.hip,
+// kernels_rotamer.hip).
 //
-// Work decomposition on gfx950:
-//   * one workgroup (up to 16 wavefronts) serves ONE system at a time; it first stages into LDS
-//       - the whole spline/parameter table of the graph (6-99 KB), and
-//       - the packed coordinates of every element of both sides (8 floats per element, <= ~60 KB),
-//     so the per-pair gathers (4 coefficient windows + neighbour coordinates) hit LDS instead of issuing
-//     64-line scattered global loads per wave instruction;
-//   * one wavefront owns a few consecutive rows of the cached Verlet list at a time; candidates are distance-tested
-//     64 at a time and the survivors of ALL its rows are compacted (ballot + popcount) into one small per-wave LDS
-//     queue, so that the expensive pair functor always runs with 64 busy lanes;
-//   * row results are recovered by a segmented wavefront reduction into LDS accumulators; nothing is scattered.
+// Work decomposition on gfx950 (round 2):
+//   * list upkeep (side streams): k_pairlist_check -> k_pairlist_build (flagged systems) -> k_pairlist_refine, which
+//     applies this step's `d2 < cutoff2` test to the cached lists ONCE per graph side and step and leaves the survivors as
+//     per-row "hit lists" in global memory (4 bytes per in-range pair, list order) -> k_pairlist_order, which sorts the
+//     rows of a system by hit count.  Every pair pass of the step then reads hit lists only: no distance test, no ballot
+//     compaction, no queue in the compute kernels;
+//   * pair passes: one workgroup serves one system; it stages the spline/parameter table, the packed elements of both
+//     sides (8 floats per element) and the sorted row order in LDS.  A wavefront claims a BATCH of 8 consecutive rows of
+//     the sorted order; each of its eight 8-lane groups owns one of them, strides over that row's hit list, and keeps the
+//     row sums in registers (3 DPP steps per component at the end of the batch instead of a segmented 64-lane reduction per
+//     64 pairs).  Rows of a batch have (nearly) the same length, so the groups run in lock step and the batch bookkeeping is
+//     uniform code, amortised over the batch's trips;
+//   * every pass is a gather with a fixed summation order: no floating-point atomics (LDS float atomics run at 3 cycles per
+//     LANE on gfx950 -- tools/ubench/lds_atomics.hip: 192 cycles per wave instruction against <= 20 for integer ones --
+//     which is what sank the one-visit backward pass that was tried first), so results are reproducible bit for bit.
 #pragma once
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <cstdlib>
-// total workgroups an LDS-staged pair kernel aims at (each re-stages its system, so fewer + fatter is cheaper;
-// 2 x 16-wave workgroups fill a CU)
-#define DR_CHUNK 8              // most rows per work item (accumulated in LDS, then flushed)
-#define DR_QUEUE 128
-#define DR_WAVE_LDS (DR_QUEUE + DR_CHUNK * 8)   // 32-bit words per wave
-// rows per work item: 1 for a single system (latency), a quarter of a wave's share as the chip fills up (~4096 waves
-// in flight) so that the LDS counter can still balance the waves, 6 at most: measured on the 300-residue benchmark,
-// system-steps/s at 1024 systems by rows per item: 1: 61.2 k, 2: 63.2 k, 4: 64.2 k, 6: 64.7 k, 8: 64.4 k, 16: 63.4 k
-static inline int dr_chunk_rows(int n_system, int n_rows) {
-    static int forced = -1;   // UPSIDE_HIP_DR_CHUNK=n pins it (experiments)
-    if (forced < 0) { const char* e = getenv("UPSIDE_HIP_DR_CHUNK"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) return forced > DR_CHUNK ? DR_CHUNK : forced;
-    long c = ((long)n_system * n_rows) / (4096 * 4);
-    return c < 1 ? 1 : (c > 6 ? 6 : (int)c);
-}
-static inline int ig_target_wgs() {
-    static int v = 0;
-    if (!v) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); v = e ? atoi(e) : 256; if (v < 1) v = 256; }
-    return v;
-}
 
 namespace up {
-
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS operations of one wavefront execute in order; this only stops the compiler from reordering them and
-    // makes the data written by other lanes of the SAME wave visible to subsequent reads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // uniform cubic B-spline in basis form: value and derivative from the 4-coefficient window starting at c[bin-1]
 // (same interpolant as spline.h:136-174; de Boor's recurrence re-associated into the 4 basis polynomials)
@@ -71,11 +49,13 @@ __device__ __forceinline__ void bspline_vd(float& val, float& der, P c, int bin,
 }
 
 struct QuadShape { int ka, k; float inv_dx, inv_dtheta; };
+__device__ __forceinline__ QuadShape quad_shape(const upk_igraph_t& G) { QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta; return Q; }
 
 // bead_interaction.h:30-84 with the B-splines in basis form and hardware rsqrt (1 ulp).
-// WANT_D: 0 value only, 1 derivative w.r.t. the first element, 2 w.r.t. the second.
+// WANT_D: 0 value only; 3: both elements' derivatives in compact form --
+//   d(value)/d(x1) = (-dd, g1),  d(value)/d(x2) = (dd, g2)      (positions, then direction vectors)
 template <int WANT_D, typename P>
-__device__ __forceinline__ float quadspline2(const QuadShape& Q, P p, const float* x1, const float* x2, float* d) {
+__device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const float* x1, const float* x2, float* dd, float* g1, float* g2) {
     const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
     const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
     const float dist2 = mag2(displace), inv_dist = rsqrtf(dist2);
@@ -117,14 +97,10 @@ __device__ __forceinline__ float quadspline2(const QuadShape& Q, P p, const floa
         const float angular_deriv2 = Q.inv_dtheta * a1 * da2 * narrow;
         const f3 rXX = angular_deriv1 * rvec1 - angular_deriv2 * rvec2;
         const f3 deriv_dir = inv_dist * (rXX - dot(u, rXX) * u);
-        const f3 dd = radial_deriv * u + deriv_dir;
-        if (WANT_D == 1) {
-            d[0] = -dd.x; d[1] = -dd.y; d[2] = -dd.z;
-            d[3] = angular_deriv1 * u.x; d[4] = angular_deriv1 * u.y; d[5] = angular_deriv1 * u.z;
-        } else {
-            d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
-            d[3] = -angular_deriv2 * u.x; d[4] = -angular_deriv2 * u.y; d[5] = -angular_deriv2 * u.z;
-        }
+        const f3 d = radial_deriv * u + deriv_dir;
+        dd[0] = d.x; dd[1] = d.y; dd[2] = d.z;
+        g1[0] = angular_deriv1 * u.x; g1[1] = angular_deriv1 * u.y; g1[2] = angular_deriv1 * u.z;
+        g2[0] = -angular_deriv2 * u.x; g2[1] = -angular_deriv2 * u.y; g2[2] = -angular_deriv2 * u.z;
     }
     return wide + angular_weight * narrow;
 }
@@ -164,6 +140,61 @@ __device__ __forceinline__ void quadspline_param_accum(const QuadShape& Q, P p, 
     }
 }
 
+// environment.cpp:27-60.  d1: CB frame (6), d2: weighted side-chain bead (x, y, z, probability)
+__device__ __forceinline__ float environment_edge(const float* __restrict__ p, const float* cb, const float* sc, float* d1, float* d2) {
+    const f3 displace = mk3(sc[0] - cb[0], sc[1] - cb[1], sc[2] - cb[2]);
+    const f3 rvec1 = mk3(cb[3], cb[4], cb[5]);
+    const float prob = sc[3];
+    const float dist2 = mag2(displace), inv_dist = rsqrt_(dist2), dist = dist2 * inv_dist;
+    const f3 u = inv_dist * displace;
+    const float dp = dot(u, rvec1);
+    float rs, drs, as, das;
+    compact_sigmoid(rs, drs, dist - p[0], p[1]);
+    compact_sigmoid(as, das, p[2] - dp, p[3]);
+    const f3 dd = prob * ((drs * as) * u - (rs * das * inv_dist) * (rvec1 - dp * u));
+    const float k = -prob * rs * das;
+    d1[3] = k * u.x; d1[4] = k * u.y; d1[5] = k * u.z;
+    d1[0] = -dd.x; d1[1] = -dd.y; d1[2] = -dd.z;
+    d2[0] = dd.x; d2[1] = dd.y; d2[2] = dd.z;
+    const float score = rs * as;
+    d2[3] = score;
+    return prob * score;
+}
+
+// hbond.cpp:128-148, 166-230.  The angular cut-off is applied per pair (the reference applies it per group of
+// 4 SIMD edges, which lets pairs outside the cone pick up a value below 1.3e-6).
+__device__ __forceinline__ float protein_hbond_edge(const float* __restrict__ p, const float* x1, const float* x2, float* d1, float* d2) {
+    const f3 H = mk3(x1[0], x1[1], x1[2]), O = mk3(x2[0], x2[1], x2[2]);
+    const f3 rHN = mk3(x1[3], x1[4], x1[5]), rOC = mk3(x2[3], x2[4], x2[5]);
+    const f3 HO = H - O;
+    const float magHO2 = mag2(HO) + 1e-6f, invHOmag = rsqrt_(magHO2), magHO = magHO2 * invHOmag;
+    const f3 rHO = invHOmag * HO;
+    const float dotHOC = dot(rHO, rOC), dotOHN = -dot(rHO, rHN);
+    f3 dH = mk3(0.f, 0.f, 0.f), drHN = dH, drOC = dH;
+    float hb = 0.f;
+    if ((0.f < dotHOC) && (0.f < dotOHN)) {
+        float os, dos, is, dis, g1, dg1, g2, dg2;
+        sigmoid(os, dos, (p[2] - magHO) * p[3]);
+        sigmoid(is, dis, (magHO - p[0]) * p[1]);
+        const float radial = os * is;
+        const float dradial = -p[3] * dos * is + p[1] * dis * os;
+        sigmoid(g1, dg1, (dotHOC - p[4]) * p[5]); dg1 *= p[5];
+        sigmoid(g2, dg2, (dotOHN - p[4]) * p[5]); dg2 *= p[5];
+        hb = radial * g1 * g2;
+        const float c0 = dradial * g1 * g2, c1 = radial * dg1 * g2, c2 = -radial * g1 * dg2;
+        drOC = c1 * rHO;
+        drHN = c2 * rHO;
+        dH = c0 * rHO + (c1 * invHOmag) * (rOC - dotHOC * rHO) + (c2 * invHOmag) * (rHN + dotOHN * rHO);
+    }
+    const float hb_log = (1.f <= hb) ? 100.f : -logf(1.f - hb);
+    const float pref = fminf(rcp(1.f - hb), 1e5f);
+    d1[0] = dH.x * pref; d1[1] = dH.y * pref; d1[2] = dH.z * pref;
+    d1[3] = drHN.x * pref; d1[4] = drHN.y * pref; d1[5] = drHN.z * pref;
+    d2[0] = -dH.x * pref; d2[1] = -dH.y * pref; d2[2] = -dH.z * pref;
+    d2[3] = drOC.x * pref; d2[4] = drOC.y * pref; d2[5] = drOC.z * pref;
+    return hb_log;
+}
+
 // cooperative staging of one system's packed elements: element i of `node` (gathered through `loc`) becomes the
 // 8-float LDS row  [0,dim) coordinates | [6] aux0 | [7] aux1  where the aux words carry per-element metadata so
 // that the pair loop never touches global memory for them:
@@ -184,105 +215,107 @@ __device__ __forceinline__ void stage_rows(float* lds, const upk_coord_t& node, 
         lds[t] = v;
     }
 }
-__device__ __forceinline__ void stage_coords(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim) {
-    stage_rows(lds, node, s, loc, n, dim, nullptr, nullptr, nullptr, 0);
-}
 __device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
 }
+__device__ __forceinline__ void load_row8(float* x, const float* p) {   // one 32-byte packed element
+    const float4 lo = *(const float4*)p, hi = *(const float4*)(p + 4);
+    x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+}
 
-// ---- dense-lane pair loop over a contiguous CHUNK of rows owned by one wavefront -----------------------------
-// A row has 10-90 in-range neighbours, so running the pair functor row by row leaves about half of the 64 lanes
-// idle (a 66-hit row costs two functor passes).  Here the hits of consecutive rows share one queue: the functor
-// always runs on 64 queued (row, neighbour) entries, whatever rows they belong to, and the per-row sums are
-// recovered by a segmented wave reduction into a small per-wave LDS accumulator (rows are contiguous in the queue,
-// a batch spans ~1-6 of them).  Per wave: DR_QUEUE queue words, DR_CHUNK x 8 floats.
+// ---- 8-lane groups ------------------------------------------------------------------------------------------
+#ifndef PG_LANES
+#define PG_LANES 8
+#endif
+#define PG_PER_WAVE (UP_WAVE / PG_LANES)
+// pair kernels run one 1024-lane workgroup per CU (LDS): 4 wavefronts per SIMD, so a lane may use 128 VGPRs -- tell the
+// register allocator, or it keeps to 64 in the hope of an occupancy the LDS footprint rules out
+#ifndef PG_WAVES_PER_EU
+#define PG_WAVES_PER_EU 4
+#endif
+#define PG_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(PG_WAVES_PER_EU, PG_WAVES_PER_EU)))
+#ifndef PG_CHUNK
+#define PG_CHUNK 1      // trips evaluated together; their list words are loaded one chunk ahead
+#endif
+// sum over the lanes of a group, left in all of them
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(PG_LANES == 4 || PG_LANES == 8 || PG_LANES == 16, "group_sum: DPP steps for groups of 4, 8 or 16 lanes");
+    if (PG_LANES == 16) v += dpp_mov<UP_DPP_ROW_MIRROR>(v);
+    if (PG_LANES >= 8) v += dpp_mov<UP_DPP_HALF_MIRROR>(v);
+    v += dpp_mov<UP_DPP_XOR2>(v);
+    v += dpp_mov<UP_DPP_XOR1>(v);
+    return v;
+}
 
-//   row_xyz(row, x[3]): position of the row element (wave-uniform; kept in registers while its list is scanned)
-//   test(x, row, k, j, payload&) -> is cached neighbour k (= element j) of `row` in range?  payload < 2^28
-//   batch(row_local, payload, valid): called with ALL lanes converged on 64 (or, at the end of the chunk, fewer) entries
-// One queue word per hit: row_local << 28 | payload (DR_CHUNK <= 16).
-template <typename RowFn, typename TestFn, typename BatchFn>
-__device__ __forceinline__ void dense_row_loop(int cb, int ce, const int* __restrict__ cnt_arr, const int* __restrict__ nbr_base, int cap,
-                                               int lane, int* q, RowFn row_xyz, TestFn test, BatchFn batch) {
-    int nq = 0;
-    const int my_cnt = lane < ce - cb ? cnt_arr[cb + lane] : 0;       // the chunk's list lengths in one load
-    for (int row = cb; row < ce; ++row) {
-        const int cnt = __builtin_amdgcn_readlane(my_cnt, row - cb);      // wave-uniform lane index: v_readlane, not a shuffle
-        const int* __restrict__ nbr = nbr_base + (size_t)row * cap;
-        float x[3];
-        row_xyz(row, x);
-        for (int k0 = 0; k0 < cnt; k0 += 256) {
-            // the list scan is a chain of dependent global loads per wave: keep four of them in flight
-            int jj[4];
+// Batches b = batch_first, batch_first + batch_step, ... of 8 consecutive rows of the sorted order `ord`, claimed by
+// the wavefronts of this workgroup through the LDS counter `counter` (zeroed and barrier-published by the caller).  Op provides
+//   begin(row)      -- load the row element, reset the row accumulators
+//   body(row, word, live) -- one hit-list word per lane; !live: the lane is past the end of its row (word 0), discard
+//   flush(row)      -- reduce over the group and write the row's results (also for rows without hits)
+// All control flow is wave-uniform except the predication of lanes past the end of their row.
+template <typename Op>
+__device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsigned short* __restrict__ ord, const int* __restrict__ hcnt,
+                                                 const int* __restrict__ hlo, const int* __restrict__ hit, int cap, int* counter,
+                                                 int batch_first, int batch_step) {
+    const int lane = threadIdx.x & 63, gl = lane & (PG_LANES - 1), g = lane / PG_LANES;
+    const int n_batch = (n_rows + PG_PER_WAVE - 1) / PG_PER_WAVE;
+    auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
+    // one batch = (row, list range, first chunk of list words) per group; the NEXT batch's is fetched while the current one
+    // is processed, so a batch switch waits neither for the claim nor for the first global loads
+    struct Batch { int row, n_mine; const int* hrow; int w[PG_CHUNK]; bool valid; };
+    auto fetch = [&](int i, Batch& B) -> bool {                   // returns false past the last batch (wave-uniform)
+        const int b = batch_first + i * batch_step;
+        if (b >= n_batch) return false;
+        const int ri = b * PG_PER_WAVE + g;
+        B.valid = ri < n_rows;
+        B.row = B.valid ? (int)ord[ri] : 0;
+        const int end = B.valid ? hcnt[B.row] : 0, first = (B.valid && hlo) ? hlo[B.row] : 0;   // the row's hits [first, end)
+
+        B.hrow = hit + (size_t)B.row * cap + first + gl;
+        B.n_mine = end - first - gl;                              // this lane's words sit at hrow[0], hrow[8], ...: k < n_mine
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int k = k0 + u * 64 + lane; jj[u] = k < cnt ? nbr[k] : -1; }
+        for (int u = 0; u < PG_CHUNK; ++u) B.w[u] = u * PG_LANES < B.n_mine ? B.hrow[u * PG_LANES] : 0;
+        return true;
+    };
+    Batch cur, nxt;
+    bool have = fetch(claim(), cur);
+    while (have) {
+        const bool have_next = fetch(claim(), nxt);
+        const int n_trip = __builtin_amdgcn_readfirstlane((cur.n_mine + PG_LANES - 1) / PG_LANES);   // lane 0: group 0 holds the batch's longest row
+        op.begin(cur.row);      // (groups past the last row take row 0: their lanes are never live, but evaluate like everyone else's)
+        for (int t0 = 0; t0 < n_trip; t0 += PG_CHUNK) {
+            int wn[PG_CHUNK];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k0 + u * 64 >= cnt) break;
-                const int k = k0 + u * 64 + lane;
-                int pay = 0; bool hit = false;
-                if (jj[u] >= 0) hit = test(x, row, k, jj[u], pay);
-                const unsigned long long m = __ballot(hit);
-                if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = ((row - cb) << 28) | pay;
-                nq += __popcll(m);
-                wave_lds_fence();
-                if (nq >= 64) {
-                    const int w = q[lane];
-                    const bool more = lane + 64 < nq;
-                    const int keep = more ? q[lane + 64] : 0;
-                    wave_lds_fence();
-                    batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, true);
-                    if (more) q[lane] = keep;
-                    nq -= 64;
-                    wave_lds_fence();
-                }
-            }
+            for (int u = 0; u < PG_CHUNK; ++u) { const int k = (t0 + PG_CHUNK + u) * PG_LANES; wn[u] = k < cur.n_mine ? cur.hrow[k] : 0; }
+            // Bodies are branch-free (a lane past the end of its row evaluates list word 0 and discards the result) and there is
+            // ONE code path: which copy of the functor a pair runs through depends only on its position in its row, never on
+            // what else is in the batch, so results do not depend on how rows of equal length were dealt to the wavefronts.
+            // (PG_CHUNK > 1 lets the scheduler interleave the evaluations of a chunk; measured no faster, and a short last
+            // chunk then runs dead trips.)
+#pragma unroll
+            for (int u = 0; u < PG_CHUNK; ++u) op.body(cur.row, cur.w[u], (t0 + u) * PG_LANES < cur.n_mine);
+#pragma unroll
+            for (int u = 0; u < PG_CHUNK; ++u) cur.w[u] = wn[u];
         }
-    }
-    if (nq > 0) {
-        const bool valid = lane < nq;
-        const int w = valid ? q[lane] : 0;
-        wave_lds_fence();
-        batch((int)((unsigned)w >> 28), w & 0x0FFFFFFF, valid);
+        if (cur.valid) op.flush(cur.row);
+        cur = nxt; have = have_next;
     }
 }
-// acc[rl*8 + c] += sum over the lanes of row rl of v[c]; lanes of one row are adjacent, invalid lanes carry nothing
-template <int N>
-__device__ __forceinline__ void seg_accumulate(float* acc, int rl, bool valid, const float v[8], int lane) {
-    unsigned long long pending = __ballot(valid);
-    while (pending) {
-        const int r0 = __builtin_amdgcn_readlane(rl, __builtin_ctzll(pending));
-        const bool mine = valid && rl == r0;
-        if (N == 1) {
-            const float t = wave_sum(mine ? v[0] : 0.f);
-            if (lane == 0) acc[r0 * 8] += t;
-        } else {
-            float w[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) w[c] = mine ? v[c] : 0.f;
-            const float t = wave_sum8(w, lane);           // lane 8*c holds component c
-            if ((lane & 7) == 0) acc[r0 * 8 + (lane >> 3)] += t;
-        }
-        pending &= ~__ballot(mine);
-    }
-    wave_lds_fence();
-}
-// Work distribution: the rows of a system are cut into chunks of DR_CHUNK; the workgroups of the system take
-// contiguous shares and, inside a workgroup, the waves pull chunks from an LDS counter (rows differ a lot in cost --
-// in the symmetric "partner index above the row" pass the first rows have all the work -- so a static split leaves
-// waves idle).  The result does not depend on which wave runs a chunk.
-__device__ __forceinline__ void workgroup_row_range(int n_rows, int chunk, int& g0, int& g1) {
-    const int n_chunk = (n_rows + chunk - 1) / chunk;
-    const int per_wg = (n_chunk + gridDim.x - 1) / gridDim.x;
-    g0 = blockIdx.x * per_wg * chunk; g1 = g0 + per_wg * chunk;
-    if (g1 > n_rows) g1 = n_rows;
-    if (g0 > g1) g0 = g1;
-}
-__device__ __forceinline__ int next_chunk(int* counter, int lane) {
-    int c = 0;
-    if (lane == 0) c = atomicAdd(counter, 1);
-    return __builtin_amdgcn_readfirstlane(c);
+
+// launch geometry of an LDS-staged pair pass: workgroups per system and lanes per workgroup.  A large batch runs one
+// 1024-lane workgroup (16 wavefronts = 128 rows in flight) per system; small batches spread a system over several smaller
+// workgroups (each stages the system again, so only as many as it takes to give every CU work).
+static inline void pair_geometry(int n_system, int n_rows, int& wgs_per_system, int& threads) {
+    static int target = 0;
+    if (!target) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+    int bps = (target + n_system - 1) / n_system;
+    const int max_bps = (n_rows + 31) / 32;                      // at least 32 rows (4 wavefronts' batches) each
+    if (bps > max_bps) bps = max_bps;
+    if (bps < 1) bps = 1;
+    const int rows_per_wg = (n_rows + bps - 1) / bps;
+    int t = ((rows_per_wg * PG_LANES / 2 + 63) / 64) * 64;       // about two batches per wavefront
+    threads = t < 256 ? 256 : (t > 1024 ? 1024 : t);
+    wgs_per_system = bps;
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp

@@ -9,8 +9,7 @@
 //     the reference, interaction_graph.h:294-296): ~150 flop against 100+ bytes of HBM traffic per edge.
 //   * `dist2 < cutoff2` is evaluated with explicitly rounded operations (device_math.h dist2_exact) so
 //     pair-list membership is bit-identical to the CPU oracle on identical coordinates.
-#include "device_math.h"
-#include "../../include/upside_hip_kernels.h"
+#include "igraph_device.h"
 #include <cstring>
 
 using namespace up;
@@ -68,61 +67,6 @@ __device__ __forceinline__ float hbond_coverage_edge(const upk_igraph_t& G, cons
     for (int c = 0; c < 6; ++c) { d1[c] *= prefactor; d2[c] *= prefactor; }
     d1[6] = -coverage * one_m * 2.f;
     return prefactor * coverage;
-}
-
-// environment.cpp:27-60
-__device__ __forceinline__ float environment_edge(const float* __restrict__ p, const float* cb, const float* sc, float* d1, float* d2) {
-    const f3 displace = mk3(sc[0] - cb[0], sc[1] - cb[1], sc[2] - cb[2]);
-    const f3 rvec1 = mk3(cb[3], cb[4], cb[5]);
-    const float prob = sc[3];
-    const float dist2 = mag2(displace), inv_dist = rsqrt_(dist2), dist = dist2 * inv_dist;
-    const f3 u = inv_dist * displace;
-    const float dp = dot(u, rvec1);
-    float rs, drs, as, das;
-    compact_sigmoid(rs, drs, dist - p[0], p[1]);
-    compact_sigmoid(as, das, p[2] - dp, p[3]);
-    const f3 dd = prob * ((drs * as) * u - (rs * das * inv_dist) * (rvec1 - dp * u));
-    const float k = -prob * rs * das;
-    d1[3] = k * u.x; d1[4] = k * u.y; d1[5] = k * u.z;
-    d1[0] = -dd.x; d1[1] = -dd.y; d1[2] = -dd.z;
-    d2[0] = dd.x; d2[1] = dd.y; d2[2] = dd.z;
-    const float score = rs * as;
-    d2[3] = score;
-    return prob * score;
-}
-
-// hbond.cpp:128-148, 166-230.  The angular cut-off is applied per pair (the reference applies it per group of
-// 4 SIMD edges, which lets pairs outside the cone pick up a value below 1.3e-6).
-__device__ __forceinline__ float protein_hbond_edge(const float* __restrict__ p, const float* x1, const float* x2, float* d1, float* d2) {
-    const f3 H = mk3(x1[0], x1[1], x1[2]), O = mk3(x2[0], x2[1], x2[2]);
-    const f3 rHN = mk3(x1[3], x1[4], x1[5]), rOC = mk3(x2[3], x2[4], x2[5]);
-    const f3 HO = H - O;
-    const float magHO2 = mag2(HO) + 1e-6f, invHOmag = rsqrt_(magHO2), magHO = magHO2 * invHOmag;
-    const f3 rHO = invHOmag * HO;
-    const float dotHOC = dot(rHO, rOC), dotOHN = -dot(rHO, rHN);
-    f3 dH = mk3(0.f, 0.f, 0.f), drHN = dH, drOC = dH;
-    float hb = 0.f;
-    if ((0.f < dotHOC) && (0.f < dotOHN)) {
-        float os, dos, is, dis, g1, dg1, g2, dg2;
-        sigmoid(os, dos, (p[2] - magHO) * p[3]);
-        sigmoid(is, dis, (magHO - p[0]) * p[1]);
-        const float radial = os * is;
-        const float dradial = -p[3] * dos * is + p[1] * dis * os;
-        sigmoid(g1, dg1, (dotHOC - p[4]) * p[5]); dg1 *= p[5];
-        sigmoid(g2, dg2, (dotOHN - p[4]) * p[5]); dg2 *= p[5];
-        hb = radial * g1 * g2;
-        const float c0 = dradial * g1 * g2, c1 = radial * dg1 * g2, c2 = -radial * g1 * dg2;
-        drOC = c1 * rHO;
-        drHN = c2 * rHO;
-        dH = c0 * rHO + (c1 * invHOmag) * (rOC - dotHOC * rHO) + (c2 * invHOmag) * (rHN + dotOHN * rHO);
-    }
-    const float hb_log = (1.f <= hb) ? 100.f : -logf(1.f - hb);
-    const float pref = fminf(rcp(1.f - hb), 1e5f);
-    d1[0] = dH.x * pref; d1[1] = dH.y * pref; d1[2] = dH.z * pref;
-    d1[3] = drHN.x * pref; d1[4] = drHN.y * pref; d1[5] = drHN.z * pref;
-    d2[0] = -dH.x * pref; d2[1] = -dH.y * pref; d2[2] = -dH.z * pref;
-    d2[3] = drOC.x * pref; d2[4] = drOC.y * pref; d2[5] = drOC.z * pref;
-    return hb_log;
 }
 
 // sidechain_radial.cpp:46-61: clamped cubic spline of the distance; p[0] = 1/dx, 16 coefficients follow
@@ -184,8 +128,11 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
         const upk_coord_t& node = side1 ? G.node1 : G.node2;
         const float* x = C_OUT(node, s) + (size_t)(side1 ? G.loc1[i] : G.loc2[i]) * node.stride;
         const float* c = (side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + (size_t)i * 4;
-        const float dx = x[0] - c[0], dy = x[1] - c[1], dz = x[2] - c[2];
+        const float x0 = x[0], x1 = x[1], x2 = x[2];
+        const float dx = x0 - c[0], dy = x1 - c[1], dz = x2 - c[2];
         m |= lim < dx * dx + dy * dy + dz * dz;
+        // this step's positions, packed: what upk_pairlist_refine tests against the cutoff (the same bits the pair passes read)
+        ((float4*)(side1 ? G.cur_pos1 + (size_t)s * G.n1 * 4 : G.cur_pos2 + (size_t)s * G.n2 * 4))[i] = make_float4(x0, x1, x2, 0.f);
     }
     if (m) moved = 1;   // benign race: every writer stores 1
     __syncthreads();
@@ -323,6 +270,151 @@ extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2b: this step's in-range pairs (the refine of interaction_graph.h:201-257, once per step and graph side).  A workgroup
+// stages the other side's positions (16 bytes per element) in LDS and serves rows_per_wg rows; one wavefront per row tests
+// 64 cached neighbours per trip and appends the survivors' list words to the row's hit list in list order (ballot +
+// popcount prefix).  Latency bound by design -- it runs on the upkeep streams next to the VALU-bound pair passes -- so a
+// wavefront fetches the positions and list lengths of ALL its rows with one load each and keeps the first list words of
+// PLR_AHEAD rows in flight.
+#define PLR_BLOCK 256
+#ifndef PLR_AHEAD
+#define PLR_AHEAD 4
+#endif
+template <bool SYM>
+__global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, int side, int rows_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float plr_lds[];
+    float4* oth = (float4*)plr_lds;
+    const int s = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const bool rows1 = side == 1;
+    const int n_rows = rows1 ? G.n1 : G.n2, n_other = rows1 ? G.n2 : G.n1;
+    const int cap = rows1 ? G.cap1 : G.cap2;
+    const float4* src = (const float4*)((rows1 ? G.cur_pos2 : G.cur_pos1) + (size_t)s * n_other * 4);
+    const float4* mine = (const float4*)((rows1 ? G.cur_pos1 : G.cur_pos2) + (size_t)s * n_rows * 4);
+    for (int j = threadIdx.x; j < n_other; j += blockDim.x) oth[j] = src[j];
+    __syncthreads();
+    const int* nbr_base = (rows1 ? G.nbr1 : G.nbr2) + (size_t)s * n_rows * cap;
+    const int* cnt_arr = (rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows;
+    int* hit_base = (rows1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap;
+    int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
+    int* hlo = SYM ? G.hlo1 + (size_t)s * n_rows : nullptr;
+    const float cut2 = G.cutoff * G.cutoff;
+    const int jmask = G.nbr_j_bits ? (1 << G.nbr_j_bits) - 1 : 0x7fffffff;
+    // this wavefront's rows: a contiguous run of at most 64 (lane r holds row r0 + r's position and list length)
+    const int per_wave = (rows_per_wg + n_wave - 1) / n_wave;     // <= 64 (launcher)
+    const int r0 = blockIdx.x * rows_per_wg + wave * per_wave;
+    int r1 = r0 + per_wave; { const int wg_end = (blockIdx.x + 1) * rows_per_wg; if (r1 > wg_end) r1 = wg_end; if (r1 > n_rows) r1 = n_rows; }
+    if (r0 >= r1) return;
+    const bool have = r0 + lane < r1;
+    const float4 my_x = have ? mine[r0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int my_cnt = have ? cnt_arr[r0 + lane] : 0;
+    int my_n = 0, my_lo = 0;                                      // results of row r0 + lane
+    int w0[PLR_AHEAD];                                            // first 64 list words of the next PLR_AHEAD rows
+#pragma unroll
+    for (int a = 0; a < PLR_AHEAD; ++a) {
+        const int cnt = __builtin_amdgcn_readlane(my_cnt, a);
+        w0[a] = (r0 + a < r1 && lane < cnt) ? nbr_base[(size_t)(r0 + a) * cap + lane] : 0;
+    }
+    for (int rb = r0; rb < r1; rb += PLR_AHEAD) {
+        int wcur[PLR_AHEAD];
+#pragma unroll
+        for (int a = 0; a < PLR_AHEAD; ++a) wcur[a] = w0[a];
+#pragma unroll
+        for (int a = 0; a < PLR_AHEAD; ++a) {                      // prefetch the block after this one
+            const int r = rb + PLR_AHEAD + a;
+            const int cnt = r < r1 ? __builtin_amdgcn_readlane(my_cnt, (r - r0) & 63) : 0;
+            w0[a] = lane < cnt ? nbr_base[(size_t)r * cap + lane] : 0;
+        }
+#pragma unroll
+        for (int a = 0; a < PLR_AHEAD; ++a) {
+            const int row = rb + a;
+            if (row >= r1) break;
+            const int rl = row - r0;
+            const int cnt = __builtin_amdgcn_readlane(my_cnt, rl);
+            const float xx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.x), rl)), xy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.y), rl)),
+                        xz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.z), rl));
+            const int* nbr = nbr_base + (size_t)row * cap;
+            int* out = hit_base + (size_t)row * cap;
+            int n = 0, lo = 0;
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int k = k0 + lane;
+                const int w = k0 == 0 ? wcur[a] : (k < cnt ? nbr[k] : 0);
+                bool hit = false;
+                const int j = w & jmask;
+                if (k < cnt) { const float4 y = oth[j]; hit = dist2_exact(xx, xy, xz, y.x, y.y, y.z) < cut2; }
+                const unsigned long long m = __ballot(hit);
+                if (hit) out[n + __popcll(m & ((1ull << lane) - 1ull))] = w;
+                n += __popcll(m);
+                if (SYM) lo += __popcll(__ballot(hit && j < row));
+            }
+            if (lane == rl) { my_n = n; my_lo = lo; }
+        }
+    }
+    if (have) { hcnt[r0 + lane] = my_n; if (SYM) hlo[r0 + lane] = my_lo; }
+}
+extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side) {
+    const bool rows1 = side == 1;
+    const int n_rows = rows1 ? G->n1 : G->n2, n_other = rows1 ? G->n2 : G->n1;
+    if (n_rows < 1) return 0;
+    const size_t lds = (size_t)(n_other > 0 ? n_other : 1) * 16;
+    if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
+    // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
+    const int rows_per_wg = L->n_system >= upk_device_cu_count() ? 256 : (L->n_system >= 16 ? 64 : 16);
+    const dim3 grid((n_rows + rows_per_wg - 1) / rows_per_wg, L->n_system);
+    if (G->symmetric) hipLaunchKernelGGL(k_pairlist_refine<true>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
+    else hipLaunchKernelGGL(k_pairlist_refine<false>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
+    return launch_status();
+}
+
+// K2c: rows of a system sorted by descending hit count (counting sort in LDS, one workgroup per system): the pair passes
+// give the 8 lane groups of a wavefront 8 consecutive rows of this order, so they run the same number of trips.  Rows of
+// equal length keep no particular order (it only decides which wavefront serves them).  Symmetric graphs get a second order
+// by the number of partners ABOVE the row (the pair-energy pass visits each pair once).
+#define PLO_BINS 1024
+template <typename KeyFn>
+__device__ __forceinline__ void order_rows(unsigned short* __restrict__ ord, int n_rows, KeyFn key, int* hist, int* scratch) {
+    hist[threadIdx.x] = 0;                                         // blockDim.x == PLO_BINS
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_rows; r += blockDim.x) atomicAdd(&hist[PLO_BINS - 1 - key(r)], 1);   // bin 0 = the longest rows
+    __syncthreads();
+    // exclusive scan of the histogram, one bin per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = hist[threadIdx.x];
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, UP_WAVE); if (lane >= off) incl += t; }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { const int t = scratch[w]; scratch[w] = acc; acc += t; } }
+    __syncthreads();
+    hist[threadIdx.x] = scratch[wave] + incl - v;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_rows; r += blockDim.x) ord[atomicAdd(&hist[PLO_BINS - 1 - key(r)], 1)] = (unsigned short)r;
+    __syncthreads();
+}
+__global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int side) {
+    __shared__ int hist[PLO_BINS], scratch[16];
+    const int s = blockIdx.x;
+    const bool rows1 = side == 1;
+    const int n_rows = rows1 ? G.n1 : G.n2;
+    const int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
+    order_rows((rows1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows,
+               [&](int r) { const int c = hcnt[r]; return c < PLO_BINS ? c : PLO_BINS - 1; }, hist, scratch);
+    if (G.symmetric) {
+        const int* hlo = G.hlo1 + (size_t)s * n_rows;
+        order_rows(G.ord1u + (size_t)s * n_rows, n_rows,
+                   [&](int r) { const int c = hcnt[r] - hlo[r]; return c < PLO_BINS ? c : PLO_BINS - 1; }, hist, scratch);
+    }
+}
+extern "C" int upk_pairlist_order(const upk_launch_t* L, const upk_igraph_t* G, int side) {
+    const int n_rows = side == 1 ? G->n1 : G->n2;
+    if (n_rows < 1) return 0;
+    if (n_rows > 65535) return 9009;   // (16-bit row ids; larger systems take the list-walking kernels, which need no order)
+    hipLaunchKernelGGL(k_pairlist_order, dim3(L->n_system), dim3(PLO_BINS), 0, ST(L), *G, side);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3 forward: row sums of the pair value
 __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ out, long out_sys_stride, int out_stride, int out_comp,
                                 int out_row0, float* __restrict__ own_grad) {
@@ -366,7 +458,7 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
         }
     }
 }
-static int igraph_rowsum_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
+extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
                                  int out_stride, int out_comp, int out_row0, float* own_grad) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_rowsum, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
@@ -427,7 +519,7 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
         }
     }
 }
-static int igraph_grad_v1(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
+extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                                const float* sens2, long sens_sys_stride, int sens_stride) {
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_grad, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
@@ -435,227 +527,6 @@ static int igraph_grad_v1(const upk_launch_t* L, const upk_igraph_t* G, int side
     return launch_status();
 }
 
-
-// ================================================================================================
-// LDS-staged kernels (the normal path): see igraph_device.h for the decomposition
-#include "igraph_device.h"
-
-__device__ __forceinline__ QuadShape quad_shape(const upk_igraph_t& G) { QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta; return Q; }
-
-// value and (optionally) the derivative w.r.t. the ROW element; x1 is always the side-1 element.
-// ROW_SIDE: 1 or 2.  GRAD: derivative wanted.  d has 8 entries.
-template <int IT, int ROW_SIDE, bool GRAD>
-__device__ __forceinline__ float pair_eval2(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
-                                            const float* x1, const float* x2, float* d) {
-    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
-    if (IT == UPK_IT_HBOND_COVERAGE) {
-        const float coverage = quadspline2<GRAD ? ROW_SIDE : 0>(Q, p, x1, x2, d);
-        const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
-        if (GRAD) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) d[c] *= prefactor;
-            if (ROW_SIDE == 1) d[6] = -coverage * one_m * 2.f;
-        }
-        return prefactor * coverage;
-    } else if (IT == UPK_IT_ENVIRONMENT) {
-        float d1[8], d2[8];
-        const float v = environment_edge(p, x1, x2, d1, d2);
-        if (GRAD) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) d[c] = ROW_SIDE == 1 ? (c < 6 ? d1[c] : 0.f) : (c < 4 ? d2[c] : 0.f);
-        }
-        return v;
-    } else {
-        float d1[8], d2[8];
-        const float v = protein_hbond_edge(p, x1, x2, d1, d2);
-        if (GRAD) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) d[c] = c < 6 ? (ROW_SIDE == 1 ? d1[c] : d2[c]) : 0.f;
-        }
-        return v;
-    }
-}
-
-struct Ig2Args {
-    float* out; long out_sys_stride; int out_stride, out_comp, out_row0;      // rowsum
-    float* own_grad;                                                          // rowsum: [S][n_rows][8] sum of d(value)/d(row element)
-    int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // grad
-    int tab_floats, chunk_rows;
-};
-
-// MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element) (so that a backward
-// pass whose pair sensitivity depends on the row element only is a per-element product, upk_igraph_apply_own_grad);
-// 2: sum of sens(pair) * d(value)/d(row element)
-template <int IT, int ROW_SIDE, int MODE>
-__global__ void __launch_bounds__(1024) k_ig2(upk_igraph_t G, Ig2Args A) {
-    constexpr bool GRAD = MODE == 2;
-    constexpr bool WANT_D = MODE != 0;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    float* tab = lds;
-    float* c1 = lds + ((A.tab_floats + 3) & ~3);
-    float* c2 = c1 + G.n1 * 8;
-    int* q = (int*)(c2 + G.n2 * 8) + wave * DR_WAVE_LDS; float* acc = (float*)(q + DR_QUEUE);
-    int* chunk_counter = (int*)(c2 + G.n2 * 8) + n_wave * DR_WAVE_LDS;
-    if (threadIdx.x == 0) *chunk_counter = 0;
-    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
-    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
-    stage_table(tab, G.param, A.tab_floats);
-    // rows: [0,dim) coordinates, [6] per-element pair sensitivity (sides with dim <= 6), [7] element type
-    stage_rows(c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (GRAD && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
-    stage_rows(c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (GRAD && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
-    __syncthreads();
-    const QuadShape Q = quad_shape(G);
-    const int n_rows = ROW_SIDE == 1 ? G.n1 : G.n2;
-    const float cut2 = G.cutoff * G.cutoff;
-    const float* crow = ROW_SIDE == 1 ? c1 : c2;
-    const float* coth = ROW_SIDE == 1 ? c2 : c1;
-    const int cap = ROW_SIDE == 1 ? G.cap1 : G.cap2;
-    const int* nbr_base = ROW_SIDE == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2;
-    const int* cnt_arr = ROW_SIDE == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2;
-    // pair sensitivity = (row part) + (other part); a part is 0 when that side does not contribute
-    const bool row_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == ROW_SIDE));
-    const bool oth_has = GRAD && ((A.sens_mode == 3) || (A.sens_mode == 3 - ROW_SIDE));
-    const int dim_row = ROW_SIDE == 1 ? G.dim1 : G.dim2;
-    const upk_coord_t& row_node = ROW_SIDE == 1 ? G.node1 : G.node2;
-    const int* row_loc = ROW_SIDE == 1 ? G.loc1 : G.loc2;
-    int g0, g1;
-    const int chunk = A.chunk_rows;
-    workgroup_row_range(n_rows, chunk, g0, g1);
-    for (;;) {
-        const int cb = g0 + next_chunk(chunk_counter, lane) * chunk;
-        if (cb >= g1) break;
-        const int ce = cb + chunk < g1 ? cb + chunk : g1;
-        for (int t = lane; t < DR_CHUNK * 8; t += 64) acc[t] = 0.f;
-        wave_lds_fence();
-        dense_row_loop(cb, ce, cnt_arr, nbr_base, cap, lane, q,
-            [&](int row, float* x) { const float* p = crow + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
-            [&](const float* x, int, int, int j, int& pay) {
-                const float* y = coth + j * 8;
-                pay = j;
-                return dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
-            },
-            [&](int rl, int j, bool valid) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = 0.f;
-                if (valid) {
-                    float xr[8], xo[8], d[8];
-                    const float* pr = crow + (cb + rl) * 8; const float* po = coth + j * 8;
-                    const float4 rlo = *(const float4*)pr, rhi = *(const float4*)(pr + 4), lo = *(const float4*)po, hi = *(const float4*)(po + 4);
-                    xr[0] = rlo.x; xr[1] = rlo.y; xr[2] = rlo.z; xr[3] = rlo.w; xr[4] = rhi.x; xr[5] = rhi.y; xr[6] = rhi.z; xr[7] = rhi.w;
-                    xo[0] = lo.x; xo[1] = lo.y; xo[2] = lo.z; xo[3] = lo.w; xo[4] = hi.x; xo[5] = hi.y; xo[6] = hi.z; xo[7] = hi.w;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) d[c] = 0.f;
-                    const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
-                    const float val = ROW_SIDE == 1 ? pair_eval2<IT, 1, WANT_D>(G, Q, tab, tr, to, xr, xo, d)
-                                                    : pair_eval2<IT, 2, WANT_D>(G, Q, tab, to, tr, xo, xr, d);
-                    if (MODE == 0) v[0] = val;
-                    if (MODE == 1) {
-#pragma unroll
-                        for (int c = 0; c < 7; ++c) v[c] = d[c];
-                        v[7] = val;
-                    }
-                    if (MODE == 2) {
-                        const float ps = (row_has ? xr[6] : 0.f) + (oth_has ? xo[6] : 0.f);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[c] = ps * d[c];
-                    }
-                }
-                seg_accumulate<MODE == 0 ? 1 : 8>(acc, rl, valid, v, lane);
-            });
-        wave_lds_fence();
-        // flush the chunk: lane = (row, component)
-        for (int t = lane; t < (ce - cb) * 8; t += 64) {
-            const int row = cb + (t >> 3), c = t & 7;
-            const float val = acc[t];
-            float* out_p = A.out + (size_t)s * A.out_sys_stride + (size_t)(A.out_row0 + row) * A.out_stride + A.out_comp;
-            if (MODE == 0) { if (c == 0) *out_p = val; }
-            else if (MODE == 1) { if (c == 7) *out_p = val; else A.own_grad[((size_t)s * n_rows + row) * 8 + c] = val; }
-            else if (c < dim_row) C_SENS(row_node, s)[(size_t)row_loc[row] * row_node.stride + c] += val;
-        }
-        wave_lds_fence();
-    }
-}
-
-static bool ig2_geometry(const upk_launch_t* L, const upk_igraph_t* G, int n_rows, int& tab_floats, int& chunk_rows, size_t& lds_bytes, dim3& grid, dim3& block) {
-    tab_floats = G->n_type1 * G->n_type2 * G->n_param;
-    chunk_rows = dr_chunk_rows(L->n_system, n_rows);
-    // a small graph (a few hundred rows) cannot feed 16 waves with several chunks each: smaller workgroups, more of
-    // them per CU (they overlap each other's staging and list latency)
-    const int n_chunk = (n_rows + chunk_rows - 1) / chunk_rows;
-    int waves = n_chunk / 4;
-    waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
-    lds_bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + (size_t)waves * DR_WAVE_LDS + 4) * sizeof(float);
-    static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
-    if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
-    if (lds_bytes > 158 * 1024 || force_unstaged) return false;
-    int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;   // workgroups in flight across systems
-    const int max_bps = (n_rows + waves * chunk_rows - 1) / (waves * chunk_rows);   // at least one chunk per wave
-    if (bps > max_bps) bps = max_bps;
-    if (bps < 1) bps = 1;
-    grid = dim3(bps, L->n_system); block = dim3(waves * 64);
-    return true;
-}
-
-template <int IT, int SIDE>
-static int ig2_launch(const upk_launch_t* L, const upk_igraph_t* G, int mode, const Ig2Args& A0) {
-    Ig2Args A = A0; size_t lds; dim3 grid, block;
-    if (!ig2_geometry(L, G, SIDE == 1 ? G->n1 : G->n2, A.tab_floats, A.chunk_rows, lds, grid, block)) return -1;
-    if (mode == 0) hipLaunchKernelGGL((k_ig2<IT, SIDE, 0>), grid, block, lds, ST(L), *G, A);
-    else if (mode == 1) hipLaunchKernelGGL((k_ig2<IT, SIDE, 1>), grid, block, lds, ST(L), *G, A);
-    else hipLaunchKernelGGL((k_ig2<IT, SIDE, 2>), grid, block, lds, ST(L), *G, A);
-    return launch_status();
-}
-static int ig2_dispatch(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, const Ig2Args& A) {
-    switch (G->itype) {
-        case UPK_IT_HBOND_COVERAGE: return side == 1 ? ig2_launch<UPK_IT_HBOND_COVERAGE, 1>(L, G, mode, A) : ig2_launch<UPK_IT_HBOND_COVERAGE, 2>(L, G, mode, A);
-        case UPK_IT_ENVIRONMENT: return side == 1 ? ig2_launch<UPK_IT_ENVIRONMENT, 1>(L, G, mode, A) : ig2_launch<UPK_IT_ENVIRONMENT, 2>(L, G, mode, A);
-        case UPK_IT_PROTEIN_HBOND: return side == 1 ? ig2_launch<UPK_IT_PROTEIN_HBOND, 1>(L, G, mode, A) : ig2_launch<UPK_IT_PROTEIN_HBOND, 2>(L, G, mode, A);
-        default: return -1;
-    }
-}
-
-extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
-                                 int out_stride, int out_comp, int out_row0, float* own_grad) {
-    Ig2Args A; memset(&A, 0, sizeof(A));
-    A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp; A.out_row0 = out_row0;
-    A.own_grad = own_grad;
-    const int r = ig2_dispatch(L, G, side, own_grad ? 1 : 0, A);
-    if (r >= 0) return r;
-    return igraph_rowsum_v1(L, G, side, out, out_sys_stride, out_stride, out_comp, out_row0, own_grad);   // system too large for LDS staging
-}
-
-// backward pass of the row side when the pair sensitivity is the row element's own: sens[row] * own_grad[row]
-__global__ void k_igraph_apply_own_grad(upk_igraph_t G, int side, const float* __restrict__ own_grad, const float* __restrict__ sens,
-                                        long sens_sys_stride, int sens_stride) {
-    const int s = blockIdx.y;
-    const int n_rows = side == 1 ? G.n1 : G.n2, dim = side == 1 ? G.dim1 : G.dim2;
-    const upk_coord_t& node = side == 1 ? G.node1 : G.node2;
-    const int* loc = side == 1 ? G.loc1 : G.loc2;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * 8; t += gridDim.x * blockDim.x) {
-        const int row = t >> 3, c = t & 7;
-        if (c >= dim) continue;
-        const float v = sens[(size_t)s * sens_sys_stride + (size_t)row * sens_stride] * own_grad[((size_t)s * n_rows + row) * 8 + c];
-        C_SENS(node, s)[(size_t)loc[row] * node.stride + c] += v;
-    }
-}
-extern "C" int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
-                                         const float* sens, long sens_sys_stride, int sens_stride) {
-    const int n_rows = side == 1 ? G->n1 : G->n2;
-    hipLaunchKernelGGL(k_igraph_apply_own_grad, dim3((n_rows * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side, own_grad,
-                       sens, sens_sys_stride, sens_stride);
-    return launch_status();
-}
-extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
-                               const float* sens2, long sens_sys_stride, int sens_stride) {
-    Ig2Args A; memset(&A, 0, sizeof(A));
-    A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
-    const int r = ig2_dispatch(L, G, side, 2, A);
-    if (r >= 0) return r;
-    return igraph_grad_v1(L, G, side, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
-}
 
 // parity / diagnostics: which cached neighbours of the side-1 rows are in range this step
 __global__ void k_igraph_inrange(upk_igraph_t G, unsigned char* __restrict__ flags) {
@@ -668,7 +539,8 @@ __global__ void k_igraph_inrange(upk_igraph_t G, unsigned char* __restrict__ fla
         const float* x = C_OUT(G.node1, s) + (size_t)G.loc1[row] * G.node1.stride;
         unsigned char* f = flags + ((size_t)s * G.n1 + row) * G.cap1;
         for (int k = lane; k < cnt; k += 64) {
-            const float* y = C_OUT(G.node2, s) + (size_t)G.loc2[nbr[k]] * G.node2.stride;
+            const int j = G.nbr_j_bits ? (nbr[k] & ((1 << G.nbr_j_bits) - 1)) : nbr[k];
+            const float* y = C_OUT(G.node2, s) + (size_t)G.loc2[j] * G.node2.stride;
             f[k] = dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2 ? 1 : 0;
         }
     }

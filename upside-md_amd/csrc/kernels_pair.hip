@@ -1,0 +1,225 @@
+// Pair passes of the asymmetric interaction graphs (hbond_coverage, environment_coverage, protein_hbond) over this
+// step's hit lists: replaces the compute_edges / propagate_derivatives loops of /root/reference/src/interaction_graph.h:443-556
+// together with the node-side accumulation loops of hbond.cpp:387-397, environment.cpp:85-101 and hbond.cpp:316-365.
+//
+// See igraph_device.h for the decomposition.  Every pass is a per-row gather over the row's in-range partners; pair
+// gradients are re-evaluated in the backward pass instead of being stored (the reference keeps 12-13 floats of edge_deriv per
+// edge, interaction_graph.h:294-296: ~150 flop against 100+ bytes of HBM traffic per edge).
+#include "igraph_device.h"
+#include <cstring>
+
+using namespace up;
+
+#define ST(L) ((hipStream_t)(L)->stream)
+static inline int launch_status() { return (int)hipGetLastError(); }
+#define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
+
+struct PairArgs {
+    float* out; long out_sys_stride; int out_stride, out_comp, out_row0, out_row0_2;        // modes 0, 1
+    float* own_grad;                                                                         // mode 1
+    int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // mode 2
+    int tab_floats;
+};
+
+// value of one pair and, if GRAD, its derivative w.r.t. the ROW element in d[0..8); x1 is always the side-1 element
+template <int IT, int ROW_SIDE, bool GRAD>
+__device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
+                                              const float* x1, const float* x2, float* d) {
+    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
+    if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
+        float dd[3], g1[3], g2[3];
+        const float coverage = quadspline_pair<GRAD ? 3 : 0>(Q, p, x1, x2, dd, g1, g2);
+        const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
+        if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                d[c] = ROW_SIDE == 1 ? -prefactor * dd[c] : prefactor * dd[c];
+                d[3 + c] = prefactor * (ROW_SIDE == 1 ? g1[c] : g2[c]);
+            }
+            d[6] = ROW_SIDE == 1 ? -coverage * one_m * 2.f : 0.f;
+        }
+        return prefactor * coverage;
+    } else {
+        float d1[8], d2[8];
+        const float v = IT == UPK_IT_ENVIRONMENT ? environment_edge(p, x1, x2, d1, d2) : protein_hbond_edge(p, x1, x2, d1, d2);
+        if (GRAD) {
+            constexpr int n = ROW_SIDE == 1 ? 6 : (IT == UPK_IT_ENVIRONMENT ? 4 : 6);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) d[c] = c < n ? (ROW_SIDE == 1 ? d1[c] : d2[c]) : 0.f;
+        }
+        return v;
+    }
+}
+
+struct PairLds { float *tab, *c1, *c2; int* counter; };
+__device__ __forceinline__ PairLds pair_lds(float* lds, const upk_igraph_t& G, int tab_floats) {
+    PairLds L;
+    L.tab = lds;
+    L.c1 = lds + ((tab_floats + 3) & ~3);
+    L.c2 = L.c1 + G.n1 * 8;
+    L.counter = (int*)(L.c2 + G.n2 * 8);
+    return L;
+}
+
+// MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element); 2: sum of sens(pair) * d(value)/d(row element)
+template <int IT, int ROW_SIDE, int MODE>
+struct RowOp {
+    static constexpr int NV = MODE == 0 ? 1 : 8;
+    const upk_igraph_t& G; const QuadShape Q; const PairLds& L; const PairArgs& A;
+    const int s; const bool row_has, oth_has;
+    float xr[8], acc[NV];
+    __device__ __forceinline__ RowOp(const upk_igraph_t& G_, const PairLds& L_, const PairArgs& A_, int s_)
+        : G(G_), Q(quad_shape(G_)), L(L_), A(A_), s(s_),
+          row_has(MODE == 2 && (A_.sens_mode == 3 || A_.sens_mode == ROW_SIDE)), oth_has(MODE == 2 && (A_.sens_mode == 3 || A_.sens_mode == 3 - ROW_SIDE)) {}
+    __device__ __forceinline__ void begin(int row) {
+        load_row8(xr, (ROW_SIDE == 1 ? L.c1 : L.c2) + row * 8);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) acc[c] = 0.f;
+    }
+    __device__ __forceinline__ void body(int, int j, bool live) {
+        float xo[8], d[8];
+        load_row8(xo, (ROW_SIDE == 1 ? L.c2 : L.c1) + j * 8);
+        const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
+        const float v = ROW_SIDE == 1 ? pair_functor<IT, 1, MODE != 0>(G, Q, L.tab, tr, to, xr, xo, d)
+                                      : pair_functor<IT, 2, MODE != 0>(G, Q, L.tab, to, tr, xo, xr, d);
+        if (MODE == 0) acc[0] += live ? v : 0.f;
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < 7; ++c) acc[c] += live ? d[c] : 0.f;
+            acc[7] += live ? v : 0.f;
+        }
+        if (MODE == 2) {   // pair sensitivity = (row part) + (other part); the parts ride in slot 6 of the staged rows
+            const float ps = (row_has ? xr[6] : 0.f) + (oth_has ? xo[6] : 0.f);
+#pragma unroll
+            for (int c = 0; c < 7; ++c) acc[c] = live ? fmaf(ps, d[c], acc[c]) : acc[c];
+        }
+    }
+    __device__ __forceinline__ void flush(int row) {
+        float t[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) t[c] = group_sum(acc[c]);
+        if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
+        const int n_rows = ROW_SIDE == 1 ? G.n1 : G.n2;
+        float* out_p = A.out + (size_t)s * A.out_sys_stride + (size_t)((ROW_SIDE == 1 ? A.out_row0 : A.out_row0_2) + row) * A.out_stride + A.out_comp;
+        if (MODE == 0) *out_p = t[0];
+        if (MODE == 1) {
+            *out_p = t[7];
+            float4* o = (float4*)(A.own_grad + ((size_t)s * n_rows + row) * 8);
+            o[0] = make_float4(t[0], t[1], t[2], t[3]); o[1] = make_float4(t[4], t[5], t[6], 0.f);
+        }
+        if (MODE == 2) {   // one writer per element in this launch: the no-return atomic is a fire-and-forget "+=" (nothing waits for the old value)
+            const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
+            const int dim = ROW_SIDE == 1 ? G.dim1 : G.dim2;
+            float* o = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1 : G.loc2)[row] * node.stride;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) if (c < dim) unsafeAtomicAdd(o + c, t[c]);
+        }
+    }
+};
+
+// SIDES: 1 or 2 = the rows of that side; 3 = side 1, then side 2 (protein_hbond: both row sets in one launch)
+template <int IT, int SIDES, int MODE>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t G, PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const PairLds L = pair_lds(lds, G, A.tab_floats);
+    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
+    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
+    stage_table(L.tab, G.param, A.tab_floats);
+    // rows: [0,dim) coordinates, [6] per-element pair sensitivity (mode 2, sides with dim <= 6), [7] element type
+    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (MODE == 2 && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
+    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (MODE == 2 && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
+    if (SIDES & 1) {
+        if (threadIdx.x == 0) *L.counter = 0;
+        __syncthreads();
+        RowOp<IT, 1, MODE> op(G, L, A, s);
+        group_batch_loop(op, G.n1, G.ord1 + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, nullptr, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1,
+                         L.counter, blockIdx.x, gridDim.x);
+    }
+    if (SIDES & 2) {
+        if (SIDES == 3) __syncthreads();
+        if (threadIdx.x == 0) *L.counter = 0;
+        __syncthreads();
+        RowOp<IT, 2, MODE> op(G, L, A, s);
+        group_batch_loop(op, G.n2, G.ord2 + (size_t)s * G.n2, G.hcnt2 + (size_t)s * G.n2, nullptr, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2,
+                         L.counter, blockIdx.x, gridDim.x);
+    }
+}
+
+// LDS bytes of a staged pair pass; false when the system does not fit (callers fall back to the list-walking kernels)
+static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes) {
+    tab_floats = G->n_type1 * G->n_type2 * G->n_param;
+    const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
+    bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + 4) * sizeof(float);
+    static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
+    if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
+    return bytes <= 158 * 1024 && !force_unstaged && n_max < 65536 && G->cap1 < 65536 && G->cap2 < 65536;
+}
+
+template <int IT, int SIDES>
+static void rows_launch(const upk_launch_t* L, const upk_igraph_t* G, int mode, dim3 grid, dim3 block, size_t lds, const PairArgs& A) {
+    if (mode == 0) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 0>), grid, block, lds, ST(L), *G, A);
+    else if (mode == 1) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 1>), grid, block, lds, ST(L), *G, A);
+    else hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 2>), grid, block, lds, ST(L), *G, A);
+}
+template <int IT>
+static void rows_launch_sides(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, dim3 grid, dim3 block, size_t lds, const PairArgs& A) {
+    if (side == 1) rows_launch<IT, 1>(L, G, mode, grid, block, lds, A);
+    else if (side == 2) rows_launch<IT, 2>(L, G, mode, grid, block, lds, A);
+    else rows_launch<IT, 3>(L, G, mode, grid, block, lds, A);
+}
+
+extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride,
+                               int out_stride, int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode,
+                               const float* sens1, const float* sens2, long sens_sys_stride, int sens_stride) {
+    if (side < 1 || side > 3 || mode < 0 || mode > 2 || (mode == 1 && (!own_grad || side == 3))) return 9007;
+    PairArgs A; memset(&A, 0, sizeof(A));
+    A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp;
+    A.out_row0 = side == 2 ? 0 : out_row0; A.out_row0_2 = side == 2 ? out_row0 : out_row0_2;
+    A.own_grad = own_grad;
+    A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
+    size_t lds;
+    if (!pair_lds_bytes(G, A.tab_floats, lds)) {      // list-walking kernels, one side at a time
+        int r = 0;
+        for (int sd = 1; sd <= 2 && !r; ++sd) {
+            if (!(side & sd)) continue;
+            const int row0 = sd == 1 ? A.out_row0 : A.out_row0_2;
+            if (mode == 2) r = upk_igraph_grad(L, G, sd, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
+            else r = upk_igraph_rowsum(L, G, sd, out, out_sys_stride, out_stride, out_comp, row0, mode == 1 ? own_grad : nullptr);
+        }
+        return r;
+    }
+    const int n_rows = side == 1 ? G->n1 : (side == 2 ? G->n2 : (G->n1 > G->n2 ? G->n1 : G->n2));
+    int bps, threads;
+    pair_geometry(L->n_system, n_rows, bps, threads);
+    const dim3 grid(bps, L->n_system), block(threads);
+    switch (G->itype) {
+        case UPK_IT_HBOND_COVERAGE: rows_launch_sides<UPK_IT_HBOND_COVERAGE>(L, G, side, mode, grid, block, lds, A); break;
+        case UPK_IT_ENVIRONMENT: rows_launch_sides<UPK_IT_ENVIRONMENT>(L, G, side, mode, grid, block, lds, A); break;
+        case UPK_IT_PROTEIN_HBOND: rows_launch_sides<UPK_IT_PROTEIN_HBOND>(L, G, side, mode, grid, block, lds, A); break;
+        default: return 9008;
+    }
+    return launch_status();
+}
+
+// backward pass of the row side when the pair sensitivity is the row element's own: sens[row] * own_grad[row]
+__global__ void k_igraph_apply_own_grad(upk_igraph_t G, int side, const float* __restrict__ own_grad, const float* __restrict__ sens,
+                                        long sens_sys_stride, int sens_stride) {
+    const int s = blockIdx.y;
+    const int n_rows = side == 1 ? G.n1 : G.n2, dim = side == 1 ? G.dim1 : G.dim2;
+    const upk_coord_t& node = side == 1 ? G.node1 : G.node2;
+    const int* loc = side == 1 ? G.loc1 : G.loc2;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * 8; t += gridDim.x * blockDim.x) {
+        const int row = t >> 3, c = t & 7;
+        if (c >= dim) continue;
+        const float v = sens[(size_t)s * sens_sys_stride + (size_t)row * sens_stride] * own_grad[((size_t)s * n_rows + row) * 8 + c];
+        C_SENS(node, s)[(size_t)loc[row] * node.stride + c] += v;
+    }
+}
+extern "C" int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
+                                         const float* sens, long sens_sys_stride, int sens_stride) {
+    const int n_rows = side == 1 ? G->n1 : G->n2;
+    hipLaunchKernelGGL(k_igraph_apply_own_grad, dim3((n_rows * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side, own_grad,
+                       sens, sens_sys_stride, sens_stride);
+    return launch_status();
+}

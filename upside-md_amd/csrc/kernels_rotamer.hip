@@ -8,7 +8,7 @@
 //     build marks a dense node x node table (replaces the EdgeLocator hash, rotamer.cpp:134-206), one workgroup
 //     per system then numbers the slots GROUPED BY CLASS (3x3, 3x6, 6x6, 1x1, 1xN) so that belief propagation
 //     runs divergence-free template instances over contiguous ranges, and every cached bead pair remembers its
-//     slot (nbr_slot) so the pair kernels need no table lookup;
+//     slot in the upper bits of its list word, so the pair kernels need no table lookup;
 //   * slot matrices are structure-of-arrays ([36][slot_cap]); BP messages live in an "inbox" grouped by receiving
 //     node so the node update streams them;
 //   * belief propagation is ONE persistent workgroup per system with node beliefs in LDS; the bead-pair kernels
@@ -203,7 +203,8 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     return launch_status();
 }
 
-// rebuild step 3: every cached bead pair remembers its slot
+// rebuild step 3: every cached bead pair remembers its slot, in the bits of its list word above the bead index
+// (one 4-byte word per cached pair instead of a second array; the pair passes read nothing else)
 __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
     const upk_igraph_t& G = R.G;
     const int* fl = UPK_FLAG_LIST(G);
@@ -217,7 +218,11 @@ __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
             const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
             const int cnt = G.cnt1[(size_t)s * G.n1 + row];
             const int a = R.bead_node[row];
-            for (int k = lane; k < cnt; k += 64) R.nbr_slot[base + k] = slot_of[a * NN + R.bead_node[G.nbr1[base + k]]];
+            for (int k = lane; k < cnt; k += 64) {
+                const int j = G.nbr1[base + k];                  // freshly built: a bare bead index
+                const int sl = slot_of[a * NN + R.bead_node[j]];
+                G.nbr1[base + k] = j | ((sl < 0 ? UPK_ROT_SLOT_NONE : sl) << UPK_ROT_J_BITS);
+            }
         }
     }
 }
@@ -259,28 +264,25 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// bead-pair kernels: table + all beads of the system in LDS.  Bead row: [0,6) pos+dir, [6] type | rot<<8 |
-// nrot<<12, [7] node id (raw int bits).
+// bead-pair passes over this step's hit lists (igraph_device.h): table + all beads of the system in LDS.  Bead row:
+// [0,6) pos+dir, [6] type | rot<<8 | nrot<<12, [7] node id (raw int bits).  A hit-list word is
+// partner bead | residue-pair slot << UPK_ROT_J_BITS.
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
-// written by k_rotamer_pack_beads; the table and the queues stay in LDS.
-struct RotLds { float* tab; const float* rows; int* q; int* chunk_counter; };
+// written by k_rotamer_pack_beads; the table stays in LDS.
+struct RotLds { float* tab; const float* rows; int* counter; };
 template <bool STAGED>
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
+    const upk_igraph_t& G = R.G;
     RotLds r;
     r.tab = lds;
-    float* lds_rows = lds + ((tab_floats + 3) & ~3);
-    stage_table(r.tab, R.G.param, tab_floats);
+    float* p = lds + ((tab_floats + 3) & ~3);
+    stage_table(r.tab, G.param, tab_floats);
     if (STAGED) {
-        r.rows = lds_rows;
-        r.q = (int*)(lds_rows + R.G.n1 * 8) + (threadIdx.x >> 6) * DR_WAVE_LDS;
-        r.chunk_counter = (int*)(lds_rows + R.G.n1 * 8) + (blockDim.x >> 6) * DR_WAVE_LDS;
-        stage_rows(lds_rows, R.G.node1, s, R.G.loc1, R.G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
-    } else {
-        r.rows = R.bead_pack + (size_t)s * R.G.n1 * 8;
-        r.q = (int*)lds_rows + (threadIdx.x >> 6) * DR_WAVE_LDS;
-        r.chunk_counter = (int*)lds_rows + (blockDim.x >> 6) * DR_WAVE_LDS;
-    }
-    if (threadIdx.x == 0) *r.chunk_counter = 0;
+        r.rows = p; p += G.n1 * 8;
+        stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
+    } else r.rows = R.bead_pack + (size_t)s * G.n1 * 8;
+    r.counter = (int*)p;
+    if (threadIdx.x == 0) *r.counter = 0;
     __syncthreads();
     return r;
 }
@@ -296,172 +298,137 @@ __global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
 }
 
 // bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
+struct RotEnergyOp {
+    const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
+    float* P; int* active;
+    float xr[8];
+    __device__ __forceinline__ RotEnergyOp(const upk_rotamer_t& R_, const RotLds& L_, int s)
+        : R(R_), Q(quad_shape(R_.G)), L(L_), P(R_.P + (size_t)s * R_.slot_cap * 36), active(R_.slot_active + (size_t)s * R_.slot_cap) {}
+    __device__ __forceinline__ void begin(int row) { load_row8(xr, L.rows + row * 8); }
+    __device__ __forceinline__ void body(int, int w, bool live) {
+        const int j = w & ((1 << UPK_ROT_J_BITS) - 1), sl = (int)((unsigned)w >> UPK_ROT_J_BITS);
+        float xo[8];
+        load_row8(xo, L.rows + j * 8);
+        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+        const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+        const float* p = L.tab + ((mr & 0xFF) * R.G.n_type2 + (mo & 0xFF)) * R.G.n_param;   // row < partner: types [type(i1)][type(i2)], i1 < i2
+        const float E = quadspline_pair<0>(Q, p, xr, xo, nullptr, nullptr, nullptr);
+        if (!live || sl == UPK_ROT_SLOT_NONE) return;         // (no slot: only after a capacity overflow, the error flag is set)
+        const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
+        const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
+        // With one bead per rotamer state (every shipped side-chain library) an entry has a single writer and a plain
+        // store does; device-scope float atomics on scattered lines cost 0.56 ms of this kernel's 1.37 at 1024 systems.
+        if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = R.p_prob ? expf(-E) : E;
+        else atomicAdd(&P[PIDX(R, sl, idx)], E);
+        active[sl] = 1;
+    }
+    __device__ __forceinline__ void flush(int) {}
+};
 template <bool STAGED>
-__global__ void __launch_bounds__(1024) k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats, int chunk) {
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
     const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
-    const float cut2 = G.cutoff * G.cutoff;
-    float* P = R.P + (size_t)s * R.slot_cap * 36;
-    int* active = R.slot_active + (size_t)s * R.slot_cap;
-    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
-    // hits of consecutive beads share the queue (igraph_device.h: dense_row_loop); payload = partner | list position << 16
-    const int* nbr_base = G.nbr1 + (size_t)s * G.n1 * G.cap1;
-    const int* nsl_base = R.nbr_slot + (size_t)s * G.n1 * G.cap1;
-    const int* cnt_arr = G.cnt1 + (size_t)s * G.n1;
-    int g0, g1;
-    workgroup_row_range(G.n1, chunk, g0, g1);
-    (void)wave; (void)n_wave;
-    for (;;) {
-        const int cb = g0 + next_chunk(L.chunk_counter, lane) * chunk;
-        if (cb >= g1) break;
-        const int ce = cb + chunk < g1 ? cb + chunk : g1;
-        dense_row_loop(cb, ce, cnt_arr, nbr_base, G.cap1, lane, L.q,
-            [&](int row, float* x) { const float* p = L.rows + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
-            [&](const float* x, int row, int k, int j, int& pay) {
-                // each pair once: only partners with a larger bead index (i1 < i2 as in the reference)
-                const float* y = L.rows + j * 8;
-                pay = j | (k << 16);
-                return j > row && dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
-            },
-            [&](int rl, int pay, bool valid) {
-                if (!valid) return;
-                const int row = cb + rl, j = pay & 0xFFFF, k = (int)((unsigned)pay >> 16);
-                const int sl = nsl_base[(size_t)row * G.cap1 + k];       // issued first: its latency hides behind the functor
-                float xr[8], xo[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
-                const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
-                const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-                const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
-                const float E = quadspline2<0>(Q, p, xr, xo, nullptr);
-                if (sl < 0) return;                           // only after a capacity overflow (error flag is set)
-                const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
-                const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
-                // With one bead per rotamer state (every shipped side-chain library) an entry has a single writer and a plain
-                // store does; device-scope float atomics on scattered lines cost 0.56 ms of this kernel's 1.37 at 1024 systems.
-                if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = R.p_prob ? expf(-E) : E;
-                else atomicAdd(&P[PIDX(R, sl, idx)], E);
-                active[sl] = 1;
-            });
-    }
+    RotEnergyOp op(R, L, s);
+    // each pair once: the partners above the row = the tail [hlo, hcnt) of the row's hits; rows ordered by that count
+    group_batch_loop(op, G.n1, G.ord1u + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, G.hlo1 + (size_t)s * G.n1, G.hit1 + (size_t)s * G.n1 * G.cap1,
+                     G.cap1, L.counter, blockIdx.x, gridDim.x);
 }
 
 // 1 = table + beads staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
-static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, int& chunk, size_t& lds_bytes, dim3& grid, dim3& block) {
+static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
-    const int waves = 16;
-    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + (size_t)waves * DR_WAVE_LDS + 4) * sizeof(float);
+    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     int staged = 1;
     lds_bytes = fixed + (size_t)R->G.n1 * 8 * sizeof(float);
     if (lds_bytes > 158 * 1024 || force_unstaged) { staged = 0; lds_bytes = fixed; }
     if (lds_bytes > 158 * 1024 || (!staged && !R->bead_pack)) return -1;
-    int bps = (ig_target_wgs() + L->n_system - 1) / L->n_system;
-    chunk = dr_chunk_rows(L->n_system, R->G.n1);
-    const int max_bps = (R->G.n1 + waves * chunk - 1) / (waves * chunk);
-    if (bps > max_bps) bps = max_bps;
-    if (bps < 1) bps = 1;
-    grid = dim3(bps, L->n_system); block = dim3(waves * 64);
+    int bps, threads;
+    pair_geometry(L->n_system, R->G.n1, bps, threads);
+    grid = dim3(bps, L->n_system); block = dim3(threads);
     return staged;
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int tab_floats, chunk; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, chunk, lds, grid, block);
+    int tab_floats; size_t lds; dim3 grid, block;
+    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;   // interaction table larger than LDS
-    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats, chunk);
+    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats);
     else {
         hipLaunchKernelGGL(k_rotamer_pack_beads, dim3((R->G.n1 * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);   // also serves upk_rotamer_grad
-        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats, chunk);
+        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats);
     }
     return launch_status();
 }
 
-// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather)
+// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather): every in-range partner of the
+// bead contributes pair sensitivity x d(pair energy)/d(bead), where the pair sensitivity is the pair marginal of the two
+// rotamer states (the node marginal when one side has a single state).  Each pair is visited from both ends.
+struct RotGradOp {
+    const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
+    const float* marg; const float* nbm; float* sens; int sens_stride; const int s;
+    float xr[8], acc[6];
+    __device__ __forceinline__ RotGradOp(const upk_rotamer_t& R_, const RotLds& L_, int s_)
+        : R(R_), Q(quad_shape(R_.G)), L(L_), marg(R_.marg + (size_t)s_ * R_.slot_cap * 36), nbm(R_.nb_cur + (size_t)s_ * R_.n_node * 6),
+          sens(C_SENS(R_.G.node1, s_)), sens_stride(R_.G.node1.stride), s(s_) {}
+    __device__ __forceinline__ void begin(int row) {
+        load_row8(xr, L.rows + row * 8);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[c] = 0.f;
+    }
+    __device__ __forceinline__ void body(int, int w, bool live) {
+        const int j = w & ((1 << UPK_ROT_J_BITS) - 1), sl = (int)((unsigned)w >> UPK_ROT_J_BITS);
+        float xo[8];
+        load_row8(xo, L.rows + j * 8);
+        const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
+        const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
+        const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
+        // the pair sensitivity is a gather from global memory: issued before the functor
+        float ps;
+        if (na == 1 && nb == 1) ps = 1.f;
+        else if (na == 1) ps = nbm[b * 6 + rb];
+        else if (nb == 1) ps = nbm[a * 6 + ra];
+        else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
+        // evaluated with the row bead as first element: the table is symmetric under exchanging the beads with their angular
+        // splines (is_compatible, bead_interaction.h:209-218, checked at load), so this is the pair's energy seen from the row
+        const float* p = L.tab + ((mr & 0xFF) * R.G.n_type2 + (mo & 0xFF)) * R.G.n_param;
+        float dd[3], g1[3], g2[3];
+        quadspline_pair<3>(Q, p, xr, xo, dd, g1, g2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { acc[c] = live ? fmaf(-ps, dd[c], acc[c]) : acc[c]; acc[3 + c] = live ? fmaf(ps, g1[c], acc[3 + c]) : acc[3 + c]; }
+    }
+    __device__ __forceinline__ void flush(int row) {
+        float t[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t[c] = group_sum(acc[c]);
+        if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
+        const int loc = R.G.loc1[row];
+        float* o = sens + (size_t)loc * sens_stride;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) unsafeAtomicAdd(o + c, t[c]);   // single writer per element: a fire-and-forget "+="
+        // the node marginal of the bead's rotamer state goes to the 1-body parents (rotamer.cpp:968-984)
+        const float mg = nbm[__float_as_int(xr[7]) * 6 + ((__float_as_int(xr[6]) >> 8) & 0xF)];
+        for (int k = 0; k < R.n_prob; ++k) unsafeAtomicAdd(R.prob_sens[k] + (size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k], mg);
+    }
+};
 template <bool STAGED>
-__global__ void __launch_bounds__(1024) k_rotamer_grad(upk_rotamer_t R, int tab_floats, int chunk) {
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
     const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
-    const int NN = R.n_node;
-    const float cut2 = G.cutoff * G.cutoff;
-    const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
-    const float* nbm = R.nb_cur + (size_t)s * NN * 6;
-    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
-    float* acc = (float*)(L.q + DR_QUEUE);
-    const int* nbr_base = G.nbr1 + (size_t)s * G.n1 * G.cap1;
-    const int* nsl_base = R.nbr_slot + (size_t)s * G.n1 * G.cap1;
-    const int* cnt_arr = G.cnt1 + (size_t)s * G.n1;
-    int g0, g1;
-    workgroup_row_range(G.n1, chunk, g0, g1);
-    (void)wave; (void)n_wave;
-    for (;;) {
-        const int cb = g0 + next_chunk(L.chunk_counter, lane) * chunk;
-        if (cb >= g1) break;
-        const int ce = cb + chunk < g1 ? cb + chunk : g1;
-        for (int t = lane; t < DR_CHUNK * 8; t += 64) acc[t] = 0.f;
-        wave_lds_fence();
-        dense_row_loop(cb, ce, cnt_arr, nbr_base, G.cap1, lane, L.q,
-            [&](int row, float* x) { const float* p = L.rows + row * 8; x[0] = p[0]; x[1] = p[1]; x[2] = p[2]; },
-            [&](const float* x, int, int k, int j, int& pay) {
-                const float* y = L.rows + j * 8;
-                pay = j | (k << 16);
-                return dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2;
-            },
-            [&](int rl, int pay, bool valid) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = 0.f;
-                if (valid) {
-                    const int row = cb + rl, j = pay & 0xFFFF, k = (int)((unsigned)pay >> 16);
-                    float xr[8], xo[8], d1[6];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) { xr[c] = L.rows[row * 8 + c]; xo[c] = L.rows[j * 8 + c]; }
-                    const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
-                    const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-                    const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
-                    // the pair sensitivity is two dependent gathers (slot, then marginal): issue them before the functor
-                    float ps;
-                    if (na == 1 && nb == 1) ps = 1.f;
-                    else if (na == 1) ps = nbm[b * 6 + rb];
-                    else if (nb == 1) ps = nbm[a * 6 + ra];
-                    else {
-                        const int sl = nsl_base[(size_t)row * G.cap1 + k];
-                        ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
-                    }
-                    const float* p = L.tab + ((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
-                    quadspline2<1>(Q, p, xr, xo, d1);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) v[c] = ps * d1[c];
-                }
-                seg_accumulate<8>(acc, rl, valid, v, lane);
-            });
-        wave_lds_fence();
-        // flush: lane = (bead, component); component 6 pushes the node marginal to the 1-body parents
-        for (int t = lane; t < (ce - cb) * 8; t += 64) {
-            const int row = cb + (t >> 3), c = t & 7;
-            const int loc = G.loc1[row];
-            if (c < 6) C_SENS(G.node1, s)[(size_t)loc * G.node1.stride + c] += acc[t];
-            else if (c == 6) {
-                const int mr = __float_as_int(L.rows[row * 8 + 6]), a = __float_as_int(L.rows[row * 8 + 7]);
-                const float mg = nbm[a * 6 + ((mr >> 8) & 0xF)];
-                for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
-            }
-        }
-        wave_lds_fence();
-    }
+    RotGradOp op(R, L, s);
+    group_batch_loop(op, G.n1, G.ord1 + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, nullptr, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1,
+                     L.counter, blockIdx.x, gridDim.x);
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int tab_floats, chunk; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, chunk, lds, grid, block);
+    int tab_floats; size_t lds; dim3 grid, block;
+    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;
-    if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats, chunk);
-    else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats, chunk);   // beads packed by upk_rotamer_pair_energy this step
+    if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
+    else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step
     return launch_status();
 }
 
@@ -475,10 +442,9 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
     const float* base = G.node1.out + (size_t)s * G.node1.n_elem * G.node1.stride;
     const float* marg = R.marg + (size_t)s * R.slot_cap * 36;
     const float* nbm = R.nb_cur + (size_t)s * R.n_node * 6;
-    QuadShape Q; Q.ka = G.n_knot_angular; Q.k = G.n_knot; Q.inv_dx = G.inv_dx; Q.inv_dtheta = G.inv_dtheta;
+    const QuadShape Q = quad_shape(G);
     for (int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * (blockDim.x >> 6)) {
         const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
-        const int* nsl = R.nbr_slot + ((size_t)s * G.n1 + row) * G.cap1;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
         float xr[6];
 #pragma unroll
@@ -486,7 +452,8 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
         const int mr = R.bead_meta[row], a = R.bead_node[row];
         const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF;
         for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
+            const int w = nbr[k];
+            const int j = w & ((1 << UPK_ROT_J_BITS) - 1), sl = (int)((unsigned)w >> UPK_ROT_J_BITS);
             if (j <= row) continue;
             float xo[6];
 #pragma unroll
@@ -498,7 +465,7 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
             if (na == 1 && nb == 1) ps = 1.f;
             else if (na == 1) ps = nbm[b * 6 + rb];
             else if (nb == 1) ps = nbm[a * 6 + ra];
-            else { const int sl = nsl[k]; ps = sl < 0 ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)]; }
+            else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
             const size_t prow = (size_t)((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
             quadspline_param_accum(Q, G.param + prow, xr, xo, ps, table + prow);
         }

@@ -375,7 +375,9 @@ struct IGraphHost {
     vector<int> loc1, loc2, type1, type2, id1, id2;
     vector<float> param;
     DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag, flagged;
-    DevBuf<float> d_param, cache_pos1, cache_pos2;
+    DevBuf<float> d_param, cache_pos1, cache_pos2, cur_pos1, cur_pos2;
+    DevBuf<int> hit1, hit2, hcnt1, hcnt2, hlo1;   // this step's in-range pairs per row (upk_pairlist_refine)
+    DevBuf<unsigned short> ord1, ord2, ord1u;   // rows sorted by hit count (upk_pairlist_order)
 
     float type_cutoff(const float* p) const {
         switch (G.itype) {
@@ -476,6 +478,18 @@ struct IGraphHost {
             cache_pos2.upload(vector<float>((size_t)S * G.n2 * 4, 1e10f));
         }
         rebuild_flag.alloc(S);
+        G.nbr_j_bits = itype == UPK_IT_ROTAMER ? UPK_ROT_J_BITS : 0;
+        if (G.nbr_j_bits && G.n1 > (1 << G.nbr_j_bits)) throw string("rotamer pair lists pack the bead index into ") + to_string(G.nbr_j_bits) + " bits: at most 8192 beads";
+        cur_pos1.alloc((size_t)S * G.n1 * 4);
+        if (!G.symmetric) cur_pos2.alloc((size_t)S * G.n2 * 4);
+        if (itype != UPK_IT_RADIAL && itype != UPK_IT_HBOND_SC_RADIAL) {   // (the radial potentials walk the cached lists themselves)
+            hit1.alloc((size_t)S * G.n1 * G.cap1); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
+            if (G.symmetric) { hlo1.alloc((size_t)S * G.n1); ord1u.alloc((size_t)S * G.n1); }
+            else { hit2.alloc((size_t)S * G.n2 * G.cap2); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
+        }
+        G.hit1 = hit1.p; G.hit2 = hit2.p; G.hcnt1 = hcnt1.p; G.hcnt2 = hcnt2.p; G.hlo1 = hlo1.p;
+        G.ord1 = ord1.p; G.ord2 = ord2.p; G.ord1u = ord1u.p;
+        G.cur_pos1 = cur_pos1.p; G.cur_pos2 = G.symmetric ? cur_pos1.p : cur_pos2.p;
         G.loc1 = d_loc1.p; G.type1 = d_type1.p; G.id1 = d_id1.p;
         G.loc2 = G.symmetric ? d_loc1.p : d_loc2.p; G.type2 = G.symmetric ? d_type1.p : d_type2.p; G.id2 = G.symmetric ? d_id1.p : d_id2.p;
         G.param = d_param.p;
@@ -486,10 +500,21 @@ struct IGraphHost {
         G.node1 = node1->coord(); G.node2 = node2->coord();
     }
     void begin_step() { G.parity ^= 1; }
-    void update_lists() {   // K1 + K2
+    // K1 + K2 + K2b/c for the rows of `sides` (bit 1: side 1, bit 2: side 2); the other side's hit lists follow in refine()
+    void update_lists(int sides = 3) {
         begin_step();
         upk_check(upk_pairlist_check(&ctx->L, &G), "pairlist_check");
         upk_check(upk_pairlist_build(&ctx->L, &G), "pairlist_build");
+        refine(G, sides);
+    }
+    // this step's in-range pairs + the row order of the pair passes (G_: the graph, possibly with a substituted source node)
+    void refine(const upk_igraph_t& G_, int sides = 3) {
+        if (!G_.hit1) return;
+        for (int side = 1; side <= (G_.symmetric ? 1 : 2); ++side) {
+            if (!(sides & side)) continue;
+            upk_check(upk_pairlist_refine(&ctx->L, &G_, side), "pairlist_refine");
+            upk_check(upk_pairlist_order(&ctx->L, &G_, side), "pairlist_order");
+        }
     }
     void set_param(const vector<float>& p) {
         if (p.size() != param.size()) throw string("Bad param size, got ") + to_string(p.size()) + " params, but expected " + to_string(param.size());
@@ -528,7 +553,7 @@ struct IGraphHost {
         for (int i = 0; i < G.n1; ++i)
             for (int k = 0; k < ct[(size_t)sys * G.n1 + i]; ++k) {
                 size_t idx = ((size_t)sys * G.n1 + i) * G.cap1 + k;
-                int j = nb[idx];
+                int j = G.nbr_j_bits ? (nb[idx] & ((1 << G.nbr_j_bits) - 1)) : nb[idx];
                 if (!f[idx]) continue;
                 if (G.symmetric && j <= i) continue;
                 out.emplace_back(i, j);
@@ -559,18 +584,14 @@ struct ProteinHBond : public CoordNode {
     bool has_prepare() const override { return true; }
     void prepare() override { ig.update_lists(); }
     void compute_value(ComputeMode) override {
-        { IGraphHost::Prof pr(ig, name, "igraph_fwd1", 0);
-          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 6, 0, nullptr), "protein_hbond rowsum donors"); }
-        { IGraphHost::Prof pr(ig, name, "igraph_fwd2", 0);
-          upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 6, n_donor, nullptr), "protein_hbond rowsum acceptors"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);   // donor rows, then acceptor rows, in one launch
+          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 3, 0, output.p, sys_stride(), stride, 6, 0, n_donor, nullptr, 0, nullptr, nullptr, 0, 0), "protein_hbond values"); }
         upk_check(upk_protein_hbond_finish(&ctx->L, infer.coord(), coord()), "protein_hbond_finish");
     }
     void propagate_deriv() override {
         upk_check(upk_protein_hbond_bwd_pre(&ctx->L, coord(), sens_scaled.p), "protein_hbond_bwd_pre");
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad donors"); }
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond grad acceptors"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);
+          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 3, 2, nullptr, 0, 0, 0, 0, 0, nullptr, 3, sens_scaled.p, sens_scaled.p + n_donor, n_elem, 1), "protein_hbond backward"); }
         upk_check(upk_protein_hbond_passthrough(&ctx->L, coord(), infer.coord(), ig.G.loc1, n_donor, ig.G.loc2, n_acceptor), "protein_hbond_passthrough");
     }
     vector<float> get_param() const override { return ig.param; }
@@ -603,21 +624,24 @@ struct HBondCoverage : public CoordNode {
     }
     const CoordNode* site_positions = nullptr;
     bool has_prepare() const override { return true; }
-    void prepare() override {
-        if (!site_positions) { ig.update_lists(); return; }
+    void prepare() override {   // lists + the hit lists of the bead rows (forward pass)
+        if (!site_positions) { ig.update_lists(2); return; }
         ig.begin_step();
         upk_igraph_t Gp = ig.G;
         Gp.node1 = site_positions->coord();
         upk_check(upk_pairlist_check(&ctx->L, &Gp), "pairlist_check");
         upk_check(upk_pairlist_build(&ctx->L, &Gp), "pairlist_build");
+        ig.refine(Gp, 2);
     }
-    void compute_value(ComputeMode) override {
+    bool has_prepare_backward() const override { return true; }
+    void prepare_backward() override { ig.refine(ig.G, 1); }   // the hit lists of the site rows (reads cur_pos only)
+    void compute_value(ComputeMode) override {   // rows = beads: coverage and its unweighted gradient w.r.t. the bead
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 2, output.p, sys_stride(), stride, 0, 0, own_grad.p), "hbond_coverage rowsum");
+        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 2, 1, output.p, sys_stride(), stride, 0, 0, 0, own_grad.p, 0, nullptr, nullptr, 0, 0), "hbond_coverage values");
     }
-    void propagate_deriv() override {
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd1", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 1, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites"); }
+    void propagate_deriv() override {   // pair sensitivity = the bead's (hbond.cpp:395-397)
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);   // rows = sites
+          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 1, 2, nullptr, 0, 0, 0, 0, 0, nullptr, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites"); }
         upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 2, own_grad.p, sens.p, sys_stride(), stride), "hbond_coverage grad beads");
     }
     vector<float> get_param() const override { return ig.param; }
@@ -642,15 +666,17 @@ struct EnvironmentCoverage : public CoordNode {
         own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
     }
     bool has_prepare() const override { return true; }
-    void prepare() override { ig.update_lists(); }
+    void prepare() override { ig.update_lists(1); }
+    bool has_prepare_backward() const override { return true; }
+    void prepare_backward() override { ig.refine(ig.G, 2); }
     void compute_value(ComputeMode) override {
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rowsum(&ctx->L, &ig.G, 1, output.p, sys_stride(), stride, 0, 0, own_grad.p), "environment_coverage rowsum");
+        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 1, 1, output.p, sys_stride(), stride, 0, 0, 0, own_grad.p, 0, nullptr, nullptr, 0, 0), "environment_coverage values");
     }
-    void propagate_deriv() override {
+    void propagate_deriv() override {   // pair sensitivity = the CB frame's (environment.cpp:93-101)
         upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 1, own_grad.p, sens.p, sys_stride(), stride), "environment_coverage grad cb");
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd2", 2);
-          upk_check(upk_igraph_grad(&ctx->L, &ig.G, 2, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc"); }
+        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);   // rows = weighted side-chain beads
+          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 2, 2, nullptr, 0, 0, 0, 0, 0, nullptr, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc"); }
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
@@ -1026,7 +1052,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<unsigned char> mark;
     DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack;
     bool bp_C_chosen = false;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, nbr_slot, slot_active_last, d_bead_meta, bp_rec;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     DevBuf<int> n_bad;
@@ -1087,7 +1113,7 @@ struct RotamerSidechain : public PotentialNode {
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
         bp_rec.alloc((size_t)S * R.slot_cap * 4);
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
-        class_start.alloc((size_t)S * 6); nbr_slot.alloc((size_t)S * ig.G.n1 * ig.G.cap1); slot_active_last.alloc((size_t)S * R.slot_cap);
+        class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
         mark.alloc((size_t)S * ig.G.mark_stride);
         ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
@@ -1115,15 +1141,15 @@ struct RotamerSidechain : public PotentialNode {
         R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p;
         R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p; R.mark = mark.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
-        R.class_start = class_start.p; R.nbr_slot = nbr_slot.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
+        R.class_start = class_start.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.marg = marg.p;
         R.iters = iters.p; R.n_bad = n_bad.p; R.bp_rec = bp_rec.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
         R.bp_bar = bp_bar.p; R.bp_fallback = bp_fallback.p; R.bp_nbx = bp_nbx.p; R.bp_dev = bp_dev.p; R.bp_en_part = bp_en_part.p;
-        if (ig.G.n1 >= 65536 || ig.G.cap1 > 4096) throw string("rotamer pair kernels pack (bead, list position) into 16 + 12 bits: UPSIDE_HIP_NBR_CAP <= 4096");
+        if (R.slot_cap >= UPK_ROT_SLOT_NONE) throw string("rotamer pair lists pack the residue-pair slot into 19 bits: lower UPSIDE_HIP_SLOT_FACTOR");
         R.bp_C = 1;
         R.bead_pack = nullptr;   // packed global bead rows: only when table + beads exceed the LDS budget of the pair kernels
-        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 8 + 16 * 256 + 4) * sizeof(float) > 158 * 1024 ||
+        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 10 + 8) * sizeof(float) > 158 * 1024 ||   // table + beads + row order
             env_int("UPSIDE_HIP_ROT_UNSTAGED", 0)) {
             bead_pack.alloc((size_t)ctx->n_system * ig.G.n1 * 8); R.bead_pack = bead_pack.p;
         }
@@ -1140,6 +1166,7 @@ struct RotamerSidechain : public PotentialNode {
         upk_check(upk_pairlist_build(&ctx->L, &ig.G), "pairlist_build");
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
         upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
+        ig.refine(ig.G);
     }
     // workgroups per system of the belief-propagation solve: enough that the exp(-E) matrices of the multi-state
     // residue pairs fit their LDS (15% slack for the fluctuation of the pair count; systems that outgrow it fall
