@@ -1,5 +1,5 @@
 L=upside-md_amd/csrc
-for lib in ilp1 ilp2; do
+for lib in c2b c4b; do
 cp $L/exp/$lib.so $L/libupside_hip.so
 for st in 0 1; do
   echo "== $lib UPKEEP_STREAMS=$st"

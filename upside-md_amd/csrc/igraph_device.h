@@ -235,7 +235,7 @@ __device__ __forceinline__ void load_row8(float* x, const float* p) {   // one 3
 #endif
 #define PG_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(PG_WAVES_PER_EU, PG_WAVES_PER_EU)))
 #ifndef PG_CHUNK
-#define PG_CHUNK 1      // trips evaluated together; their list words are loaded one chunk ahead
+#define PG_CHUNK 4      // trips whose list words are loaded together, one chunk ahead
 #endif
 // sum over the lanes of a group, left in all of them
 __device__ __forceinline__ float group_sum(float v) {
@@ -247,16 +247,26 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-// Batches b = batch_first, batch_first + batch_step, ... of 8 consecutive rows of the sorted order `ord`, claimed by
+// per-row hit range staged in LDS: first | end << 16 (list positions; the launchers check that capacities fit 16 bits), and
+// the sorted row order
+__device__ __forceinline__ void stage_ranges(int* lds_range, unsigned short* lds_ord, const int* __restrict__ hcnt, const int* __restrict__ hlo,
+                                             const unsigned short* __restrict__ ord, int n_rows) {
+    for (int t = threadIdx.x; t < n_rows; t += blockDim.x) {
+        lds_range[t] = (hlo ? hlo[t] : 0) | (hcnt[t] << 16);
+        lds_ord[t] = ord[t];
+    }
+}
+#define PG_WALK_LDS_WORDS(n_rows) ((n_rows) + ((n_rows) + 1) / 2)   // 32-bit words of LDS behind stage_ranges
+
+// Batches b = batch_first, batch_first + batch_step, ... of 8 consecutive rows of the sorted order `ord` (LDS), claimed by
 // the wavefronts of this workgroup through the LDS counter `counter` (zeroed and barrier-published by the caller).  Op provides
 //   begin(row)      -- load the row element, reset the row accumulators
 //   body(row, word, live) -- one hit-list word per lane; !live: the lane is past the end of its row (word 0), discard
 //   flush(row)      -- reduce over the group and write the row's results (also for rows without hits)
 // All control flow is wave-uniform except the predication of lanes past the end of their row.
 template <typename Op>
-__device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsigned short* __restrict__ ord, const int* __restrict__ hcnt,
-                                                 const int* __restrict__ hlo, const int* __restrict__ hit, int cap, int* counter,
-                                                 int batch_first, int batch_step) {
+__device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsigned short* ord, const int* range,
+                                                 const int* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step) {
     const int lane = threadIdx.x & 63, gl = lane & (PG_LANES - 1), g = lane / PG_LANES;
     const int n_batch = (n_rows + PG_PER_WAVE - 1) / PG_PER_WAVE;
     auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
@@ -269,7 +279,8 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
         const int ri = b * PG_PER_WAVE + g;
         B.valid = ri < n_rows;
         B.row = B.valid ? (int)ord[ri] : 0;
-        const int end = B.valid ? hcnt[B.row] : 0, first = (B.valid && hlo) ? hlo[B.row] : 0;   // the row's hits [first, end)
+        const int rg = B.valid ? range[B.row] : 0;
+        const int first = rg & 0xffff, end = (int)((unsigned)rg >> 16);                         // the row's hits [first, end)
 
         B.hrow = hit + (size_t)B.row * cap + first + gl;
         B.n_mine = end - first - gl;                              // this lane's words sit at hrow[0], hrow[8], ...: k < n_mine
@@ -287,13 +298,14 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
             int wn[PG_CHUNK];
 #pragma unroll
             for (int u = 0; u < PG_CHUNK; ++u) { const int k = (t0 + PG_CHUNK + u) * PG_LANES; wn[u] = k < cur.n_mine ? cur.hrow[k] : 0; }
-            // Bodies are branch-free (a lane past the end of its row evaluates list word 0 and discards the result) and there is
-            // ONE code path: which copy of the functor a pair runs through depends only on its position in its row, never on
+            // Bodies are branch-free (a lane past the end of its row evaluates list word 0 and discards the result); which of
+            // the PG_CHUNK unrolled copies of the functor a pair runs through depends only on its position in its row, never on
             // what else is in the batch, so results do not depend on how rows of equal length were dealt to the wavefronts.
-            // (PG_CHUNK > 1 lets the scheduler interleave the evaluations of a chunk; measured no faster, and a short last
-            // chunk then runs dead trips.)
 #pragma unroll
-            for (int u = 0; u < PG_CHUNK; ++u) op.body(cur.row, cur.w[u], (t0 + u) * PG_LANES < cur.n_mine);
+            for (int u = 0; u < PG_CHUNK; ++u) {
+                if (t0 + u >= n_trip) break;        // (wave-uniform)
+                op.body(cur.row, cur.w[u], (t0 + u) * PG_LANES < cur.n_mine);
+            }
 #pragma unroll
             for (int u = 0; u < PG_CHUNK; ++u) cur.w[u] = wn[u];
         }

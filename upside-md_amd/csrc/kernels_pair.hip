@@ -51,13 +51,16 @@ __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadS
     }
 }
 
-struct PairLds { float *tab, *c1, *c2; int* counter; };
+struct PairLds { float *tab, *c1, *c2; int* range; unsigned short* ord; int* counter; };
 __device__ __forceinline__ PairLds pair_lds(float* lds, const upk_igraph_t& G, int tab_floats) {
     PairLds L;
     L.tab = lds;
     L.c1 = lds + ((tab_floats + 3) & ~3);
     L.c2 = L.c1 + G.n1 * 8;
-    L.counter = (int*)(L.c2 + G.n2 * 8);
+    const int n_max = G.n1 > G.n2 ? G.n1 : G.n2;
+    L.range = (int*)(L.c2 + G.n2 * 8);
+    L.ord = (unsigned short*)(L.range + n_max);
+    L.counter = L.range + PG_WALK_LDS_WORDS(n_max);
     return L;
 }
 
@@ -131,18 +134,18 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (MODE == 2 && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
     if (SIDES & 1) {
         if (threadIdx.x == 0) *L.counter = 0;
+        stage_ranges(L.range, L.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
         __syncthreads();
         RowOp<IT, 1, MODE> op(G, L, A, s);
-        group_batch_loop(op, G.n1, G.ord1 + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, nullptr, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1,
-                         L.counter, blockIdx.x, gridDim.x);
+        group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
     }
     if (SIDES & 2) {
         if (SIDES == 3) __syncthreads();
         if (threadIdx.x == 0) *L.counter = 0;
+        stage_ranges(L.range, L.ord, G.hcnt2 + (size_t)s * G.n2, nullptr, G.ord2 + (size_t)s * G.n2, G.n2);
         __syncthreads();
         RowOp<IT, 2, MODE> op(G, L, A, s);
-        group_batch_loop(op, G.n2, G.ord2 + (size_t)s * G.n2, G.hcnt2 + (size_t)s * G.n2, nullptr, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2,
-                         L.counter, blockIdx.x, gridDim.x);
+        group_batch_loop(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, blockIdx.x, gridDim.x);
     }
 }
 
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
 static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes) {
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
-    bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + 4) * sizeof(float);
+    bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + PG_WALK_LDS_WORDS(n_max) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_IG_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     return bytes <= 158 * 1024 && !force_unstaged && n_max < 65536 && G->cap1 < 65536 && G->cap2 < 65536;

@@ -269,9 +269,9 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // partner bead | residue-pair slot << UPK_ROT_J_BITS.
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
 // written by k_rotamer_pack_beads; the table stays in LDS.
-struct RotLds { float* tab; const float* rows; int* counter; };
+struct RotLds { float* tab; const float* rows; int* range; unsigned short* ord; int* counter; };
 template <bool STAGED>
-__device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats) {
+__device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats, bool upper) {
     const upk_igraph_t& G = R.G;
     RotLds r;
     r.tab = lds;
@@ -281,7 +281,9 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
         r.rows = p; p += G.n1 * 8;
         stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
     } else r.rows = R.bead_pack + (size_t)s * G.n1 * 8;
-    r.counter = (int*)p;
+    r.range = (int*)p; r.ord = (unsigned short*)(r.range + G.n1); r.counter = r.range + PG_WALK_LDS_WORDS(G.n1);
+    // the pair-energy pass visits each pair once: partners above the row = the tail [hlo, hcnt) of the row's hits
+    stage_ranges(r.range, r.ord, G.hcnt1 + (size_t)s * G.n1, upper ? G.hlo1 + (size_t)s * G.n1 : nullptr, (upper ? G.ord1u : G.ord1) + (size_t)s * G.n1, G.n1);
     if (threadIdx.x == 0) *r.counter = 0;
     __syncthreads();
     return r;
@@ -329,17 +331,15 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy(upk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, true);
     RotEnergyOp op(R, L, s);
-    // each pair once: the partners above the row = the tail [hlo, hcnt) of the row's hits; rows ordered by that count
-    group_batch_loop(op, G.n1, G.ord1u + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, G.hlo1 + (size_t)s * G.n1, G.hit1 + (size_t)s * G.n1 * G.cap1,
-                     G.cap1, L.counter, blockIdx.x, gridDim.x);
+    group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
 }
 
 // 1 = table + beads staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
 static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
     tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
-    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + 4) * sizeof(float);
+    const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + PG_WALK_LDS_WORDS(R->G.n1) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     int staged = 1;
@@ -418,10 +418,9 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad(upk_rotame
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, false);
     RotGradOp op(R, L, s);
-    group_batch_loop(op, G.n1, G.ord1 + (size_t)s * G.n1, G.hcnt1 + (size_t)s * G.n1, nullptr, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1,
-                     L.counter, blockIdx.x, gridDim.x);
+    group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
