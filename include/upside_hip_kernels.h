@@ -222,6 +222,8 @@ typedef struct {
     const int *bead_node, *bead_rot;     /* [n_bead] */
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     float* bead_pack;                    /* [S][n_bead][8] packed bead rows for systems whose beads do not fit LDS (else NULL) */
+    unsigned long long* grad_acc;        /* [S][n_bead][6] exact fixed-point (x 2^32) gradient accumulators of the gradient pass when a system is
+                                            served by several workgroups or does not fit LDS; zero between evaluations */
     int one_bead_per_state;              /* every (residue, rotamer state) owns exactly one bead: each pair-matrix entry has a single writer */
     int p_prob;                          /* the pair-energy kernel stores exp(-E) (resting value 1) instead of E (resting value 0): the
                                             one-workgroup solve then has no exp pass.  Needs one_bead_per_state and bp_C <= 1 */

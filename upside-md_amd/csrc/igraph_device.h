@@ -54,8 +54,12 @@ __device__ __forceinline__ QuadShape quad_shape(const upk_igraph_t& G) { QuadSha
 // bead_interaction.h:30-84 with the B-splines in basis form and hardware rsqrt (1 ulp).
 // WANT_D: 0 value only; 3: both elements' derivatives in compact form --
 //   d(value)/d(x1) = (-dd, g1),  d(value)/d(x2) = (dd, g2)      (positions, then direction vectors)
+// off1 / off2: where the angular coefficients of x1 / x2 start in the parameter row (0 / ka as stored; ka / 0 when a row of
+// the type pair (t2, t1) is used for (t1, t2), see stage_table_sym)
 template <int WANT_D, typename P>
-__device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const float* x1, const float* x2, float* dd, float* g1, float* g2) {
+__device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const float* x1, const float* x2, float* dd, float* g1, float* g2,
+                                                 int off1 = 0, int off2 = -1) {
+    if (off2 < 0) off2 = Q.ka;
     const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
     const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
     const float dist2 = mag2(displace), inv_dist = rsqrtf(dist2);
@@ -67,11 +71,11 @@ __device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const 
     float a1, da1, a2, da2;
     {
         const float x = (cos1 + 1.f) * Q.inv_dtheta + 1.f; const int bin = (int)x;
-        bspline_basis(x - (float)bin, b, db); bspline_vd(a1, da1, p, bin, b, db);
+        bspline_basis(x - (float)bin, b, db); bspline_vd(a1, da1, p + off1, bin, b, db);
     }
     {
         const float x = (cos2 + 1.f) * Q.inv_dtheta + 1.f; const int bin = (int)x;
-        bspline_basis(x - (float)bin, b, db); bspline_vd(a2, da2, p + Q.ka, bin, b, db);
+        bspline_basis(x - (float)bin, b, db); bspline_vd(a2, da2, p + off2, bin, b, db);
     }
     // radial splines share one coordinate; clamped ends (spline.h:275-310)
     float wide, dwide, narrow, dnarrow;
@@ -218,6 +222,33 @@ __device__ __forceinline__ void stage_rows(float* lds, const upk_coord_t& node, 
 __device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
     for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
 }
+// A symmetric pair table ([nt][nt][n_param] with row (t2, t1) = row (t1, t2) with the two angular blocks exchanged --
+// is_compatible, bead_interaction.h:209-218, checked when the node is built) staged as its upper triangle only: half the LDS
+__device__ __forceinline__ int tri_row(int lo, int hi, int nt) { return lo * nt - ((lo * (lo - 1)) >> 1) + (hi - lo); }   // lo <= hi
+__device__ __forceinline__ void stage_table_sym(float* lds, const float* __restrict__ tab, int nt, int n_param) {
+    const int n = (nt * (nt + 1) / 2) * n_param;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int r = t / n_param, c = t - r * n_param;
+        // row r of the triangle -> (lo, hi): walk the row starts (nt <= a few dozen)
+        int lo = 0, start = 0;
+        while (start + (nt - lo) <= r) { start += nt - lo; ++lo; }
+        lds[t] = tab[(size_t)(lo * nt + lo + (r - start)) * n_param + c];
+    }
+}
+// exact fixed-point image of a float (|v| < 2^31): v * 2^32 as a 64-bit two's-complement integer.  Integer adds commute, so
+// sums accumulated through LDS atomics in any order are the EXACT sum of the contributions (and bit-reproducible); LDS integer
+// atomics run at full rate on gfx950, float ones at 3 cycles per lane (tools/ubench/lds_atomics.hip)
+__device__ __forceinline__ unsigned long long to_fixed32(float v) {
+    const float h = truncf(v);                                    // integer part; v - h keeps v's sign and is exact (Sterbenz)
+    const float f = (v - h) * 4294967296.f;                       // |f| < 2^32, exact
+    const unsigned long long hi = (unsigned long long)(unsigned)(int)h << 32, lo = (unsigned)fabsf(f);
+    return f < 0.f ? hi - lo : hi + lo;
+}
+__device__ __forceinline__ float from_fixed32(unsigned long long a) { return (float)((double)(long long)a * 2.3283064365386963e-10); }
+__device__ __forceinline__ void lds_add_fixed(unsigned long long* p, float v) {
+    __hip_atomic_fetch_add(p, to_fixed32(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void load_row8(float* x, const float* p) {   // one 32-byte packed element
     const float4 lo = *(const float4*)p, hi = *(const float4*)(p + 4);
     x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;

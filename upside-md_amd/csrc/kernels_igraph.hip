@@ -185,6 +185,8 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
     extern __shared__ __attribute__((aligned(16))) float plb_lds[];
     float4* oth = (float4*)plb_lds;
     constexpr bool SYM = IT == UPK_IT_ROTAMER || IT == UPK_IT_RADIAL;
+    constexpr bool UPPER = IT == UPK_IT_ROTAMER;   // each bead pair once (partner above the row, i1 < i2 as in the reference's edge list): the
+                                                   // rotamer passes visit a pair once and give both beads their share
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
             int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
             int count = 0;
             const int my_node = SYM ? plb_node_of(G, my_id) : 0;
-            for (int j0 = 0; j0 < n_pad; j0 += 64) {
+            for (int j0 = UPPER ? ((i + 1) & ~63) : 0; j0 < n_pad; j0 += 64) {
                 const int j = j0 + lane;
                 float4 y;
                 if (STAGED) y = oth[j];
@@ -219,7 +221,8 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
                 const float d2 = dist2_exact(x.x, x.y, x.z, y.x, y.y, y.z);
                 const int oid = __float_as_int(y.w);
                 bool hit = (d2 < cut2) & (side1 ? plb_id_ok<IT>(my_id, oid) : plb_id_ok<IT>(oid, my_id));
-                if (SYM) hit = hit & (j != i);
+                if (UPPER) hit = hit & (j > i);
+                else if (SYM) hit = hit & (j != i);
                 const unsigned long long b = __ballot(hit);
                 const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
                 if (hit & (pos < cap)) nbr[pos] = j;
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     const int* cnt_arr = (rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows;
     int* hit_base = (rows1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap;
     int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
-    int* hlo = SYM ? G.hlo1 + (size_t)s * n_rows : nullptr;
+    int* hlo = (SYM && G.hlo1) ? G.hlo1 + (size_t)s * n_rows : nullptr;
     const float cut2 = G.cutoff * G.cutoff;
     const int jmask = G.nbr_j_bits ? (1 << G.nbr_j_bits) - 1 : 0x7fffffff;
     // this wavefront's rows: a contiguous run of at most 64 (lane r holds row r0 + r's position and list length)
@@ -350,7 +353,7 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
             if (lane == rl) { my_n = n; my_lo = lo; }
         }
     }
-    if (have) { hcnt[r0 + lane] = my_n; if (SYM) hlo[r0 + lane] = my_lo; }
+    if (have) { hcnt[r0 + lane] = my_n; if (SYM && hlo) hlo[r0 + lane] = my_lo; }
 }
 extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side) {
     const bool rows1 = side == 1;
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int
     const int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
     order_rows((rows1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows,
                [&](int r) { const int c = hcnt[r]; return c < PLO_BINS ? c : PLO_BINS - 1; }, hist, scratch);
-    if (G.symmetric) {
+    if (G.symmetric && G.hlo1) {
         const int* hlo = G.hlo1 + (size_t)s * n_rows;
         order_rows(G.ord1u + (size_t)s * n_rows, n_rows,
                    [&](int r) { const int c = hcnt[r] - hlo[r]; return c < PLO_BINS ? c : PLO_BINS - 1; }, hist, scratch);

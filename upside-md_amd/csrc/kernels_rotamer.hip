@@ -266,27 +266,38 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // ------------------------------------------------------------------------------------------------
 // bead-pair passes over this step's hit lists (igraph_device.h): table + all beads of the system in LDS.  Bead row:
 // [0,6) pos+dir, [6] type | rot<<8 | nrot<<12, [7] node id (raw int bits).  A hit-list word is
-// partner bead | residue-pair slot << UPK_ROT_J_BITS.
+// partner bead | residue-pair slot << UPK_ROT_J_BITS; the lists hold each pair once (partner above the row).
+// The pair table is staged as its upper triangle (stage_table_sym): 34 instead of 64 KB for the 20 x 20 x 40 table, which is
+// what lets the gradient pass keep 48 bytes of exact accumulators per bead next to it.
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
-// written by k_rotamer_pack_beads; the table stays in LDS.
-struct RotLds { float* tab; const float* rows; int* range; unsigned short* ord; int* counter; };
+// written by k_rotamer_pack_beads and the gradient accumulates in global memory.
+struct RotLds { float* tab; const float* rows; unsigned long long* acc; int* range; unsigned short* ord; int* counter; };
 template <bool STAGED>
-__device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats, bool upper) {
+__device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats, bool want_acc) {
     const upk_igraph_t& G = R.G;
     RotLds r;
     r.tab = lds;
     float* p = lds + ((tab_floats + 3) & ~3);
-    stage_table(r.tab, G.param, tab_floats);
+    stage_table_sym(r.tab, G.param, G.n_type1, G.n_param);
+    r.acc = nullptr;
     if (STAGED) {
+        if (want_acc) { r.acc = (unsigned long long*)p; p += G.n1 * 12; for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) r.acc[t] = 0ull; }
         r.rows = p; p += G.n1 * 8;
         stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
     } else r.rows = R.bead_pack + (size_t)s * G.n1 * 8;
     r.range = (int*)p; r.ord = (unsigned short*)(r.range + G.n1); r.counter = r.range + PG_WALK_LDS_WORDS(G.n1);
-    // the pair-energy pass visits each pair once: partners above the row = the tail [hlo, hcnt) of the row's hits
-    stage_ranges(r.range, r.ord, G.hcnt1 + (size_t)s * G.n1, upper ? G.hlo1 + (size_t)s * G.n1 : nullptr, (upper ? G.ord1u : G.ord1) + (size_t)s * G.n1, G.n1);
+    stage_ranges(r.range, r.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
     if (threadIdx.x == 0) *r.counter = 0;
     __syncthreads();
     return r;
+}
+// parameter row of the bead pair (row type tr, partner type to) in the triangle table, and where the two beads' angular
+// coefficients start in it
+__device__ __forceinline__ const float* rot_param_row(const upk_rotamer_t& R, const float* tab, int tr, int to, int& off_row, int& off_oth) {
+    const bool sw = tr > to;
+    const int ka = R.G.n_knot_angular;
+    off_row = sw ? ka : 0; off_oth = sw ? 0 : ka;
+    return tab + tri_row(sw ? to : tr, sw ? tr : to, R.G.n_type1) * R.G.n_param;
 }
 __global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
     const int s = blockIdx.y, n = R.G.n1;
@@ -313,8 +324,9 @@ struct RotEnergyOp {
         load_row8(xo, L.rows + j * 8);
         const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
         const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
-        const float* p = L.tab + ((mr & 0xFF) * R.G.n_type2 + (mo & 0xFF)) * R.G.n_param;   // row < partner: types [type(i1)][type(i2)], i1 < i2
-        const float E = quadspline_pair<0>(Q, p, xr, xo, nullptr, nullptr, nullptr);
+        int o1, o2;
+        const float* p = rot_param_row(R, L.tab, mr & 0xFF, mo & 0xFF, o1, o2);   // row < partner: types [type(i1)][type(i2)], i1 < i2
+        const float E = quadspline_pair<0>(Q, p, xr, xo, nullptr, nullptr, nullptr, o1, o2);
         if (!live || sl == UPK_ROT_SLOT_NONE) return;         // (no slot: only after a capacity overflow, the error flag is set)
         const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
         const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
@@ -331,20 +343,21 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy(upk
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, true);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, false);
     RotEnergyOp op(R, L, s);
     group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
 }
 
-// 1 = table + beads staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
-static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
-    tab_floats = R->G.n_type1 * R->G.n_type2 * R->G.n_param;
+// 1 = table + beads (+ accumulators) staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
+static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want_acc, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+    const int nt = R->G.n_type1;
+    tab_floats = (nt * (nt + 1) / 2) * R->G.n_param;
     const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + PG_WALK_LDS_WORDS(R->G.n1) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     int staged = 1;
-    lds_bytes = fixed + (size_t)R->G.n1 * 8 * sizeof(float);
-    if (lds_bytes > 158 * 1024 || force_unstaged) { staged = 0; lds_bytes = fixed; }
+    lds_bytes = fixed + (size_t)R->G.n1 * (want_acc ? 20 : 8) * sizeof(float);
+    if (lds_bytes > 158 * 1024 || force_unstaged || R->bead_pack) { staged = 0; lds_bytes = fixed; }   // (a system whose gradient pass needs the packed copy uses it in both passes)
     if (lds_bytes > 158 * 1024 || (!staged && !R->bead_pack)) return -1;
     int bps, threads;
     pair_geometry(L->n_system, R->G.n1, bps, threads);
@@ -353,7 +366,7 @@ static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, int& tab_
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    const int staged = rot_geometry(L, R, false, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;   // interaction table larger than LDS
     if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats);
     else {
@@ -363,16 +376,22 @@ extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_
     return launch_status();
 }
 
-// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555 as a per-bead gather): every in-range partner of the
-// bead contributes pair sensitivity x d(pair energy)/d(bead), where the pair sensitivity is the pair marginal of the two
-// rotamer states (the node marginal when one side has a single state).  Each pair is visited from both ends.
+// derivative push (rotamer.cpp:956-985 + interaction_graph.h:525-555): ONE visit per in-range bead pair yields both beads'
+// gradients, weighted by the pair sensitivity = pair marginal of the two rotamer states (the node marginal when one side has
+// a single state).  The row bead's share accumulates in registers over its hits; the partner's goes through 64-bit integer
+// LDS atomics as exact fixed point (to_fixed32), so the per-bead totals do not depend on the order in which pairs arrive.
+template <bool STAGED>
 struct RotGradOp {
     const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
-    const float* marg; const float* nbm; float* sens; int sens_stride; const int s;
+    const float* marg; const float* nbm; unsigned long long* gacc;
     float xr[8], acc[6];
-    __device__ __forceinline__ RotGradOp(const upk_rotamer_t& R_, const RotLds& L_, int s_)
-        : R(R_), Q(quad_shape(R_.G)), L(L_), marg(R_.marg + (size_t)s_ * R_.slot_cap * 36), nbm(R_.nb_cur + (size_t)s_ * R_.n_node * 6),
-          sens(C_SENS(R_.G.node1, s_)), sens_stride(R_.G.node1.stride), s(s_) {}
+    __device__ __forceinline__ RotGradOp(const upk_rotamer_t& R_, const RotLds& L_, int s)
+        : R(R_), Q(quad_shape(R_.G)), L(L_), marg(R_.marg + (size_t)s * R_.slot_cap * 36), nbm(R_.nb_cur + (size_t)s * R_.n_node * 6),
+          gacc(R_.grad_acc + (size_t)s * R_.G.n1 * 6) {}
+    __device__ __forceinline__ void add(int bead, int c, float v) const {
+        if (STAGED) lds_add_fixed(L.acc + bead * 6 + c, v);
+        else atomicAdd(gacc + bead * 6 + c, to_fixed32(v));
+    }
     __device__ __forceinline__ void begin(int row) {
         load_row8(xr, L.rows + row * 8);
 #pragma unroll
@@ -385,32 +404,30 @@ struct RotGradOp {
         const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
         const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
         const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (mo >> 8) & 0xF, nb = (mo >> 12) & 0xF;
-        // the pair sensitivity is a gather from global memory: issued before the functor
-        float ps;
-        if (na == 1 && nb == 1) ps = 1.f;
-        else if (na == 1) ps = nbm[b * 6 + rb];
-        else if (nb == 1) ps = nbm[a * 6 + ra];
-        else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
-        // evaluated with the row bead as first element: the table is symmetric under exchanging the beads with their angular
-        // splines (is_compatible, bead_interaction.h:209-218, checked at load), so this is the pair's energy seen from the row
-        const float* p = L.tab + ((mr & 0xFF) * R.G.n_type2 + (mo & 0xFF)) * R.G.n_param;
+        // the pair sensitivity is a gather from global memory, issued before the functor: ONE unconditional load from a
+        // selected address (node marginal of the multi-state side, or the pair marginal)
+        const bool both1 = na == 1 && nb == 1, no_slot = na > 1 && nb > 1 && sl == UPK_ROT_SLOT_NONE;
+        const float* pp = na == 1 ? nbm + b * 6 + rb : (nb == 1 ? nbm + a * 6 + ra : marg + PIDX(R, no_slot ? 0 : sl, a < b ? ra * 6 + rb : rb * 6 + ra));
+        const float pv = *pp;
+        const float ps = both1 ? 1.f : (no_slot ? 0.f : pv);
+        int o1, o2;
+        const float* p = rot_param_row(R, L.tab, mr & 0xFF, mo & 0xFF, o1, o2);
         float dd[3], g1[3], g2[3];
-        quadspline_pair<3>(Q, p, xr, xo, dd, g1, g2);
+        quadspline_pair<3>(Q, p, xr, xo, dd, g1, g2, o1, o2);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { acc[c] = live ? fmaf(-ps, dd[c], acc[c]) : acc[c]; acc[3 + c] = live ? fmaf(ps, g1[c], acc[3 + c]) : acc[3 + c]; }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { add(j, c, ps * dd[c]); add(j, 3 + c, ps * g2[c]); }
+        }
     }
     __device__ __forceinline__ void flush(int row) {
         float t[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) t[c] = group_sum(acc[c]);
         if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
-        const int loc = R.G.loc1[row];
-        float* o = sens + (size_t)loc * sens_stride;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) unsafeAtomicAdd(o + c, t[c]);   // single writer per element: a fire-and-forget "+="
-        // the node marginal of the bead's rotamer state goes to the 1-body parents (rotamer.cpp:968-984)
-        const float mg = nbm[__float_as_int(xr[7]) * 6 + ((__float_as_int(xr[6]) >> 8) & 0xF)];
-        for (int k = 0; k < R.n_prob; ++k) unsafeAtomicAdd(R.prob_sens[k] + (size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k], mg);
+        for (int c = 0; c < 6; ++c) add(row, c, t[c]);
     }
 };
 template <bool STAGED>
@@ -418,16 +435,57 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad(upk_rotame
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, false);
-    RotGradOp op(R, L, s);
-    group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
+    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, true);
+    {
+        RotGradOp<STAGED> op(R, L, s);
+        group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
+    }
+    if (!STAGED) return;                   // accumulated in global memory: k_rotamer_grad_finish converts
+    __syncthreads();
+    float* sens = C_SENS(G.node1, s);
+    unsigned long long* gacc = R.grad_acc + (size_t)s * G.n1 * 6;
+    const bool alone = gridDim.x == 1;     // the system's only workgroup: its accumulators are the totals
+    for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) {
+        const unsigned long long a = L.acc[t];
+        if (!a) continue;
+        if (alone) { const int i = t / 6, c = t - i * 6; sens[(size_t)G.loc1[i] * G.node1.stride + c] += from_fixed32(a); }
+        else atomicAdd(gacc + t, a);       // several workgroups share the system: exact partial sums, k_rotamer_grad_finish converts
+    }
+    if (alone) {   // the node marginal of the bead's rotamer state goes to the 1-body parents (rotamer.cpp:968-984)
+        const float* nbm = R.nb_cur + (size_t)s * R.n_node * 6;
+        for (int i = threadIdx.x; i < G.n1; i += blockDim.x) {
+            const float mg = nbm[R.bead_node[i] * 6 + ((R.bead_meta[i] >> 8) & 0xF)];
+            const int loc = G.loc1[i];
+            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+        }
+    }
+}
+// global accumulators -> sens (and cleared for the next evaluation); the 1-body marginal push of the systems that took this path
+__global__ void k_rotamer_grad_finish(upk_rotamer_t R) {
+    const int s = blockIdx.y;
+    const upk_igraph_t& G = R.G;
+    float* sens = C_SENS(G.node1, s);
+    unsigned long long* gacc = R.grad_acc + (size_t)s * G.n1 * 6;
+    const float* nbm = R.nb_cur + (size_t)s * R.n_node * 6;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < G.n1 * 6; t += gridDim.x * blockDim.x) {
+        const int i = t / 6, c = t - i * 6;
+        const unsigned long long a = gacc[t];
+        const int loc = G.loc1[i];
+        if (a) { sens[(size_t)loc * G.node1.stride + c] += from_fixed32(a); gacc[t] = 0ull; }
+        if (c == 0) {
+            const float mg = nbm[R.bead_node[i] * 6 + ((R.bead_meta[i] >> 8) & 0xF)];
+            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+        }
+    }
 }
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
-    const int staged = rot_geometry(L, R, tab_floats, lds, grid, block);
+    const int staged = rot_geometry(L, R, true, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;
     if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
     else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step
+    if (!staged || grid.x > 1)
+        hipLaunchKernelGGL(k_rotamer_grad_finish, dim3((R->G.n1 * 6 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
     return launch_status();
 }
 
@@ -452,8 +510,7 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
         const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF;
         for (int k = lane; k < cnt; k += 64) {
             const int w = nbr[k];
-            const int j = w & ((1 << UPK_ROT_J_BITS) - 1), sl = (int)((unsigned)w >> UPK_ROT_J_BITS);
-            if (j <= row) continue;
+            const int j = w & ((1 << UPK_ROT_J_BITS) - 1), sl = (int)((unsigned)w >> UPK_ROT_J_BITS);   // (the list holds partners above the row only)
             float xo[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) xo[c] = base[(size_t)G.loc1[j] * G.node1.stride + c];

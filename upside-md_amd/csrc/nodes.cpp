@@ -484,7 +484,7 @@ struct IGraphHost {
         if (!G.symmetric) cur_pos2.alloc((size_t)S * G.n2 * 4);
         if (itype != UPK_IT_RADIAL && itype != UPK_IT_HBOND_SC_RADIAL) {   // (the radial potentials walk the cached lists themselves)
             hit1.alloc((size_t)S * G.n1 * G.cap1); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
-            if (G.symmetric) { hlo1.alloc((size_t)S * G.n1); ord1u.alloc((size_t)S * G.n1); }
+            if (G.symmetric) { /* (each pair once: the lists hold the partners above the row only) */ }
             else { hit2.alloc((size_t)S * G.n2 * G.cap2); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
         }
         G.hit1 = hit1.p; G.hit2 = hit2.p; G.hcnt1 = hcnt1.p; G.hcnt2 = hcnt2.p; G.hlo1 = hlo1.p;
@@ -1050,7 +1050,7 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
-    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
@@ -1149,7 +1149,8 @@ struct RotamerSidechain : public PotentialNode {
         if (R.slot_cap >= UPK_ROT_SLOT_NONE) throw string("rotamer pair lists pack the residue-pair slot into 19 bits: lower UPSIDE_HIP_SLOT_FACTOR");
         R.bp_C = 1;
         R.bead_pack = nullptr;   // packed global bead rows: only when table + beads exceed the LDS budget of the pair kernels
-        if (((size_t)ig.G.n_type1 * ig.G.n_type2 * ig.G.n_param + (size_t)ig.G.n1 * 10 + 8) * sizeof(float) > 158 * 1024 ||   // table + beads + row order
+        grad_acc.alloc((size_t)ctx->n_system * ig.G.n1 * 6); R.grad_acc = grad_acc.p;
+        if (((size_t)(ig.G.n_type1 * (ig.G.n_type1 + 1) / 2) * ig.G.n_param + (size_t)ig.G.n1 * 22 + 8) * sizeof(float) > 158 * 1024 ||   // triangle table + beads + accumulators + row order
             env_int("UPSIDE_HIP_ROT_UNSTAGED", 0)) {
             bead_pack.alloc((size_t)ctx->n_system * ig.G.n1 * 8); R.bead_pack = bead_pack.p;
         }
