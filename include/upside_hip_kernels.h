@@ -163,6 +163,8 @@ typedef struct {
     int *hit1, *hit2, *hcnt1, *hcnt2, *hlo1;
     unsigned short *ord1, *ord2, *ord1u;
     float *cur_pos1, *cur_pos2;          /* [S][n][4] this step's positions (x, y, z, -), written by upk_pairlist_check */
+    unsigned long long* gacc;            /* [S][n_other][8] exact fixed-point (x 2^32) gradient accumulators of upk_igraph_backward when several
+                                            workgroups serve one system (small batches); NULL: one workgroup per system; zero between evaluations */
     int nbr_j_bits;                      /* 0: a list word is the element index; else the index is its low nbr_j_bits bits */
 } upk_igraph_t;
 #define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8192 beads, < 2^19 - 1 slots */
@@ -193,6 +195,11 @@ int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int 
                     long sens_sys_stride, int sens_stride);
 int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
                               const float* sens, long sens_sys_stride, int sens_stride);
+/* Backward over the hit lists of side `row_side`, ONE visit per pair: sens(pair) * d(value)/d(element) is added to the source
+ * nodes' sens of BOTH elements (interaction_graph.h:525-555).  The row element's share accumulates in registers, the other
+ * element's through 64-bit integer LDS atomics as exact fixed point, so results do not depend on the order of the pairs. */
+int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
+                        const float* sens2, long sens_sys_stride, int sens_stride);
 /* List-walking forms (no hit lists, no LDS staging; any system size): the radial potentials and the fallback of the two
  * launchers above.  Row sums of the pair value over one side's cached lists ... */
 int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,

@@ -51,6 +51,27 @@ __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadS
     }
 }
 
+// value of one pair with BOTH elements' derivatives: d1[0..7) w.r.t. the side-1 element, d2[0..6) w.r.t. the side-2 element
+template <int IT>
+__device__ __forceinline__ float pair_functor_both(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
+                                                   const float* x1, const float* x2, float* d1, float* d2) {
+    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
+    if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
+        float dd[3], g1[3], g2[3];
+        const float coverage = quadspline_pair<3>(Q, p, x1, x2, dd, g1, g2);
+        const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d1[c] = -prefactor * dd[c]; d1[3 + c] = prefactor * g1[c]; d2[c] = prefactor * dd[c]; d2[3 + c] = prefactor * g2[c]; }
+        d1[6] = -coverage * one_m * 2.f;
+        return prefactor * coverage;
+    } else if (IT == UPK_IT_ENVIRONMENT) return environment_edge(p, x1, x2, d1, d2);
+    else return protein_hbond_edge(p, x1, x2, d1, d2);
+}
+template <int IT> struct PairDims;
+template <> struct PairDims<UPK_IT_HBOND_COVERAGE> { static constexpr int d1 = 7, d2 = 6; };
+template <> struct PairDims<UPK_IT_ENVIRONMENT>    { static constexpr int d1 = 6, d2 = 4; };
+template <> struct PairDims<UPK_IT_PROTEIN_HBOND>  { static constexpr int d1 = 6, d2 = 6; };
+
 struct PairLds { float *tab, *c1, *c2; int* range; unsigned short* ord; int* counter; };
 __device__ __forceinline__ PairLds pair_lds(float* lds, const upk_igraph_t& G, int tab_floats) {
     PairLds L;
@@ -149,6 +170,107 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
     }
 }
 
+// ---- backward, ONE visit per pair over the rows of side RS (the side the forward pass ran over): the row element's gradient
+// accumulates in registers; the other element's goes through 64-bit integer LDS atomics as exact fixed point (igraph_device.h:
+// to_fixed32), so its total does not depend on the order in which the pairs arrive -- results stay bit-reproducible
+template <int IT, int RS>
+struct BackwardOp {
+    static constexpr int DR = RS == 1 ? PairDims<IT>::d1 : PairDims<IT>::d2;     // components of the row / the other element
+    static constexpr int DO = RS == 1 ? PairDims<IT>::d2 : PairDims<IT>::d1;
+    const upk_igraph_t& G; const QuadShape Q; const PairLds& L; unsigned long long* oacc;
+    const bool row_has, oth_has;
+    float xr[8], acc[DR];
+    float* row_sens; const int* row_loc; int row_stride;
+    __device__ __forceinline__ BackwardOp(const upk_igraph_t& G_, const PairLds& L_, unsigned long long* oacc_, int sens_mode, int s)
+        : G(G_), Q(quad_shape(G_)), L(L_), oacc(oacc_), row_has(sens_mode == 3 || sens_mode == RS), oth_has(sens_mode == 3 || sens_mode == 3 - RS) {
+        const upk_coord_t& node = RS == 1 ? G.node1 : G.node2;
+        row_sens = C_SENS(node, s); row_loc = RS == 1 ? G.loc1 : G.loc2; row_stride = node.stride;
+    }
+    __device__ __forceinline__ void begin(int row) {
+        load_row8(xr, (RS == 1 ? L.c1 : L.c2) + row * 8);
+#pragma unroll
+        for (int c = 0; c < DR; ++c) acc[c] = 0.f;
+    }
+    __device__ __forceinline__ void body(int, int j, bool live) {
+        float xo[8], d1[8], d2[8];
+        load_row8(xo, (RS == 1 ? L.c2 : L.c1) + j * 8);
+        const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
+        if (RS == 1) pair_functor_both<IT>(G, Q, L.tab, tr, to, xr, xo, d1, d2);
+        else pair_functor_both<IT>(G, Q, L.tab, to, tr, xo, xr, d1, d2);
+        // pair sensitivity = (row part) + (other part); the parts ride in slot 6 of the staged rows
+        const float ps = (row_has ? xr[6] : 0.f) + (oth_has ? xo[6] : 0.f);
+        const float* dr = RS == 1 ? d1 : d2; const float* dv = RS == 1 ? d2 : d1;
+#pragma unroll
+        for (int c = 0; c < DR; ++c) acc[c] = live ? fmaf(ps, dr[c], acc[c]) : acc[c];
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < DO; ++c) lds_add_fixed(oacc + j * DO + c, ps * dv[c]);
+        }
+    }
+    __device__ __forceinline__ void flush(int row) {
+        float t[DR];
+#pragma unroll
+        for (int c = 0; c < DR; ++c) t[c] = group_sum(acc[c]);
+        if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
+        float* o = row_sens + (size_t)row_loc[row] * row_stride;     // the row has one owner in this launch: a fire-and-forget "+="
+#pragma unroll
+        for (int c = 0; c < DR; ++c) unsafeAtomicAdd(o + c, t[c]);
+    }
+};
+
+template <int IT, int RS>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igraph_t G, PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DO = BackwardOp<IT, RS>::DO;
+    const int s = blockIdx.y;
+    const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
+    const PairLds L = pair_lds(lds, G, A.tab_floats);
+    unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
+    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
+    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
+    stage_table(L.tab, G.param, A.tab_floats);
+    // rows: [0,dim) coordinates, [6] per-element pair sensitivity (sides with dim <= 6), [7] element type
+    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, G.dim1 <= 6 ? S1 : nullptr, A.sens_stride);
+    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, G.dim2 <= 6 ? S2 : nullptr, A.sens_stride);
+    for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) oacc[t] = 0ull;
+    if (threadIdx.x == 0) *L.counter = 0;
+    stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
+    __syncthreads();
+    {
+        BackwardOp<IT, RS> op(G, L, oacc, A.sens_mode, s);
+        const int cap = RS == 1 ? G.cap1 : G.cap2;
+        group_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x);
+    }
+    __syncthreads();
+    const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;
+    const int* oloc = RS == 1 ? G.loc2 : G.loc1;
+    float* osens = C_SENS(onode, s);
+    unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
+    const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
+        const unsigned long long a = oacc[t];
+        if (!a) continue;
+        const int i = t / DO, c = t - i * DO;
+        if (alone) osens[(size_t)oloc[i] * onode.stride + c] += from_fixed32(a);
+        else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
+    }
+}
+// global accumulators (several workgroups per system) -> the other side's sens; cleared for the next evaluation
+__global__ void k_pair_backward_finish(upk_igraph_t G, int other_side) {
+    const int s = blockIdx.y;
+    const int n_other = other_side == 1 ? G.n1 : G.n2, dim = other_side == 1 ? G.dim1 : G.dim2;
+    const upk_coord_t& onode = other_side == 1 ? G.node1 : G.node2;
+    const int* oloc = other_side == 1 ? G.loc1 : G.loc2;
+    float* osens = C_SENS(onode, s);
+    unsigned long long* gacc = G.gacc + (size_t)s * n_other * 8;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_other * 8; t += gridDim.x * blockDim.x) {
+        const int i = t >> 3, c = t & 7;
+        if (c >= dim) continue;
+        const unsigned long long a = gacc[t];
+        if (a) { osens[(size_t)oloc[i] * onode.stride + c] += from_fixed32(a); gacc[t] = 0ull; }
+    }
+}
+
 // LDS bytes of a staged pair pass; false when the system does not fit (callers fall back to the list-walking kernels)
 static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes) {
     tab_floats = G->n_type1 * G->n_type2 * G->n_param;
@@ -202,6 +324,43 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
         case UPK_IT_PROTEIN_HBOND: rows_launch_sides<UPK_IT_PROTEIN_HBOND>(L, G, side, mode, grid, block, lds, A); break;
         default: return 9008;
     }
+    return launch_status();
+}
+
+extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
+                                   const float* sens2, long sens_sys_stride, int sens_stride) {
+    if (row_side != 1 && row_side != 2) return 9007;
+    PairArgs A; memset(&A, 0, sizeof(A));
+    A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
+    const int n_rows = row_side == 1 ? G->n1 : G->n2, n_other = row_side == 1 ? G->n2 : G->n1;
+    size_t lds;
+    const bool fits = pair_lds_bytes(G, A.tab_floats, lds);
+    lds += 8 + (size_t)n_other * 8 * sizeof(unsigned long long);          // the other side's accumulators (at most 7 per element)
+    if (!fits || lds > 158 * 1024) {      // list-walking kernels, one side at a time (they need no hit lists)
+        int r = upk_igraph_grad(L, G, 1, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
+        if (!r) r = upk_igraph_grad(L, G, 2, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
+        return r;
+    }
+    int bps, threads;
+    pair_geometry(L->n_system, n_rows, bps, threads);
+    if (!G->gacc) bps = 1;
+    const dim3 grid(bps, L->n_system), block(threads);
+    switch (G->itype) {
+        case UPK_IT_HBOND_COVERAGE:
+            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 1>), grid, block, lds, ST(L), *G, A);
+            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 2>), grid, block, lds, ST(L), *G, A);
+            break;
+        case UPK_IT_ENVIRONMENT:
+            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 1>), grid, block, lds, ST(L), *G, A);
+            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 2>), grid, block, lds, ST(L), *G, A);
+            break;
+        case UPK_IT_PROTEIN_HBOND:
+            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 1>), grid, block, lds, ST(L), *G, A);
+            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 2>), grid, block, lds, ST(L), *G, A);
+            break;
+        default: return 9008;
+    }
+    if (bps > 1) hipLaunchKernelGGL(k_pair_backward_finish, dim3((n_other * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, 3 - row_side);
     return launch_status();
 }
 

@@ -378,6 +378,7 @@ struct IGraphHost {
     DevBuf<float> d_param, cache_pos1, cache_pos2, cur_pos1, cur_pos2;
     DevBuf<int> hit1, hit2, hcnt1, hcnt2, hlo1;   // this step's in-range pairs per row (upk_pairlist_refine)
     DevBuf<unsigned short> ord1, ord2, ord1u;   // rows sorted by hit count (upk_pairlist_order)
+    DevBuf<unsigned long long> gacc;   // upk_igraph_backward's cross-workgroup accumulators (small batches only)
 
     float type_cutoff(const float* p) const {
         switch (G.itype) {
@@ -487,6 +488,7 @@ struct IGraphHost {
             if (G.symmetric) { /* (each pair once: the lists hold the partners above the row only) */ }
             else { hit2.alloc((size_t)S * G.n2 * G.cap2); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
         }
+        if (!G.symmetric && S < 256) { gacc.alloc((size_t)S * max(G.n1, G.n2) * 8); G.gacc = gacc.p; }   // (from 256 systems on a system has one workgroup)
         G.hit1 = hit1.p; G.hit2 = hit2.p; G.hcnt1 = hcnt1.p; G.hcnt2 = hcnt2.p; G.hlo1 = hlo1.p;
         G.ord1 = ord1.p; G.ord2 = ord2.p; G.ord1u = ord1u.p;
         G.cur_pos1 = cur_pos1.p; G.cur_pos2 = G.symmetric ? cur_pos1.p : cur_pos2.p;
@@ -608,10 +610,8 @@ RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
 // hbond_coverage: hbond.cpp:371-414
 struct HBondCoverage : public CoordNode {
     IGraphHost ig;
-    DevBuf<float> own_grad;   // [S][n_bead][8]: sum over sites of d(coverage)/d(bead), written by the forward pass
     HBondCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& infer_, CoordNode& sidechains_)
         : CoordNode(c, (int)dset_size(1, H(grp), "index2")[0], 1), ig(c, H(grp), UPK_IT_HBOND_COVERAGE, &infer_, &sidechains_) {
-        own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
         // protein_hbond copies the inferred H/O sites through unchanged (hbond.cpp:320-335) and only adds the bond
         // probability: the list upkeep needs positions only, so it can read them from infer_H_O and start before
         // protein_hbond's own pair kernels have run
@@ -624,7 +624,7 @@ struct HBondCoverage : public CoordNode {
     }
     const CoordNode* site_positions = nullptr;
     bool has_prepare() const override { return true; }
-    void prepare() override {   // lists + the hit lists of the bead rows (forward pass)
+    void prepare() override {   // lists + this step's hit lists of the bead rows (both passes gather over them)
         if (!site_positions) { ig.update_lists(2); return; }
         ig.begin_step();
         upk_igraph_t Gp = ig.G;
@@ -633,16 +633,13 @@ struct HBondCoverage : public CoordNode {
         upk_check(upk_pairlist_build(&ctx->L, &Gp), "pairlist_build");
         ig.refine(Gp, 2);
     }
-    bool has_prepare_backward() const override { return true; }
-    void prepare_backward() override { ig.refine(ig.G, 1); }   // the hit lists of the site rows (reads cur_pos only)
-    void compute_value(ComputeMode) override {   // rows = beads: coverage and its unweighted gradient w.r.t. the bead
+    void compute_value(ComputeMode) override {   // rows = beads
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 2, 1, output.p, sys_stride(), stride, 0, 0, 0, own_grad.p, 0, nullptr, nullptr, 0, 0), "hbond_coverage values");
+        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 2, 0, output.p, sys_stride(), stride, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0), "hbond_coverage values");
     }
-    void propagate_deriv() override {   // pair sensitivity = the bead's (hbond.cpp:395-397)
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);   // rows = sites
-          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 1, 2, nullptr, 0, 0, 0, 0, 0, nullptr, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage grad sites"); }
-        upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 2, own_grad.p, sens.p, sys_stride(), stride), "hbond_coverage grad beads");
+    void propagate_deriv() override {   // pair sensitivity = the bead's (hbond.cpp:395-397); beads and sites in one visit per pair
+        IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);
+        upk_check(upk_igraph_backward(&ctx->L, &ig.G, 2, 2, nullptr, sens.p, sys_stride(), stride), "hbond_coverage backward");
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
@@ -660,23 +657,17 @@ RegisterNodeType<HBondCoverage, 2> coverage_node("hbond_coverage");
 // environment_coverage: environment.cpp:71-109
 struct EnvironmentCoverage : public CoordNode {
     IGraphHost ig;
-    DevBuf<float> own_grad;   // [S][n_res][8]: sum over side chains of d(coverage)/d(CB frame)
     EnvironmentCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& cb_pos_, CoordNode& weighted_sidechains_)
-        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {
-        own_grad.alloc((size_t)ctx->n_system * n_elem * 8);
-    }
+        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {}
     bool has_prepare() const override { return true; }
-    void prepare() override { ig.update_lists(1); }
-    bool has_prepare_backward() const override { return true; }
-    void prepare_backward() override { ig.refine(ig.G, 2); }
+    void prepare() override { ig.update_lists(1); }   // rows = CB frames, for both passes
     void compute_value(ComputeMode) override {
         IGraphHost::Prof pr(ig, name, "igraph_fwd", 0);
-        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 1, 1, output.p, sys_stride(), stride, 0, 0, 0, own_grad.p, 0, nullptr, nullptr, 0, 0), "environment_coverage values");
+        upk_check(upk_igraph_rows(&ctx->L, &ig.G, 1, 0, output.p, sys_stride(), stride, 0, 0, 0, nullptr, 0, nullptr, nullptr, 0, 0), "environment_coverage values");
     }
     void propagate_deriv() override {   // pair sensitivity = the CB frame's (environment.cpp:93-101)
-        upk_check(upk_igraph_apply_own_grad(&ctx->L, &ig.G, 1, own_grad.p, sens.p, sys_stride(), stride), "environment_coverage grad cb");
-        { IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);   // rows = weighted side-chain beads
-          upk_check(upk_igraph_rows(&ctx->L, &ig.G, 2, 2, nullptr, 0, 0, 0, 0, 0, nullptr, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage grad sc"); }
+        IGraphHost::Prof pr(ig, name, "igraph_bwd", 1);
+        upk_check(upk_igraph_backward(&ctx->L, &ig.G, 1, 1, sens.p, nullptr, sys_stride(), stride), "environment_coverage backward");
     }
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
