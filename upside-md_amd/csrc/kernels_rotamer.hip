@@ -24,7 +24,12 @@ using namespace up;
 static inline int launch_status() { return (int)hipGetLastError(); }
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
-#define PIDX(R, sl, e) ((size_t)(e) * (R).slot_cap + (sl))
+// Slot matrices (pair energies / exp(-E), pair marginals): entry (i, j) of slot sl at [i][sl][j] -- the 6 entries of a matrix
+// row are contiguous (one 24-byte record), records of consecutive slots are adjacent.  The pair passes, whose neighbouring
+// lanes hold the rotamer states j = 0..5 of one partner residue, then touch one cache line where an entry-major layout
+// touched six; the solve, whose neighbouring lanes hold consecutive slots, still reads contiguous memory.
+#define PIDX6(cap, sl, i, j) ((((size_t)(i)) * (cap) + (sl)) * 6 + (j))
+#define PIDX(R, sl, e) PIDX6((R).slot_cap, sl, (e) / 6, (e) % 6)
 
 // slot classes in storage order
 enum { CL33 = 0, CL36 = 1, CL66 = 2, CL11 = 3, CL1X = 4, N_CLASS = 5 };
@@ -329,11 +334,11 @@ struct RotEnergyOp {
         const float E = quadspline_pair<0>(Q, p, xr, xo, nullptr, nullptr, nullptr, o1, o2);
         if (!live || sl == UPK_ROT_SLOT_NONE) return;         // (no slot: only after a capacity overflow, the error flag is set)
         const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
-        const int idx = a < b ? ra * 6 + rb : rb * 6 + ra;
+        float* pe = P + PIDX6(R.slot_cap, sl, a < b ? ra : rb, a < b ? rb : ra);
         // With one bead per rotamer state (every shipped side-chain library) an entry has a single writer and a plain
         // store does; device-scope float atomics on scattered lines cost 0.56 ms of this kernel's 1.37 at 1024 systems.
-        if (R.one_bead_per_state) P[PIDX(R, sl, idx)] = R.p_prob ? expf(-E) : E;
-        else atomicAdd(&P[PIDX(R, sl, idx)], E);
+        if (R.one_bead_per_state) *pe = R.p_prob ? expf(-E) : E;
+        else atomicAdd(pe, E);
         active[sl] = 1;
     }
     __device__ __forceinline__ void flush(int) {}
@@ -407,7 +412,7 @@ struct RotGradOp {
         // the pair sensitivity is a gather from global memory, issued before the functor: ONE unconditional load from a
         // selected address (node marginal of the multi-state side, or the pair marginal)
         const bool both1 = na == 1 && nb == 1, no_slot = na > 1 && nb > 1 && sl == UPK_ROT_SLOT_NONE;
-        const float* pp = na == 1 ? nbm + b * 6 + rb : (nb == 1 ? nbm + a * 6 + ra : marg + PIDX(R, no_slot ? 0 : sl, a < b ? ra * 6 + rb : rb * 6 + ra));
+        const float* pp = na == 1 ? nbm + b * 6 + rb : (nb == 1 ? nbm + a * 6 + ra : marg + PIDX6(R.slot_cap, no_slot ? 0 : sl, a < b ? ra : rb, a < b ? rb : ra));
         const float pv = *pp;
         const float ps = both1 ? 1.f : (no_slot ? 0.f : pv);
         int o1, o2;
@@ -521,7 +526,7 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
             if (na == 1 && nb == 1) ps = 1.f;
             else if (na == 1) ps = nbm[b * 6 + rb];
             else if (nb == 1) ps = nbm[a * 6 + ra];
-            else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX(R, sl, a < b ? ra * 6 + rb : rb * 6 + ra)];
+            else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX6(R.slot_cap, sl, a < b ? ra : rb, a < b ? rb : ra)];
             const size_t prow = (size_t)((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
             quadspline_param_accum(Q, G.param + prow, xr, xo, ps, table + prow);
         }
@@ -574,7 +579,7 @@ __device__ __forceinline__ void clear_class(float* P, int cap, int lo, int hi, i
     const int n = hi - lo;
     for (int i = tid; i < n * NA * NB; i += nt) {
         const int e = i / n, l = i - e * n;
-        P[(size_t)((e / NB) * 6 + e % NB) * cap + lo + l] = 0.f;
+        P[PIDX6(cap, lo + l, e / NB, e % NB)] = 0.f;
     }
 }
 // end of a solve: zero the accumulator entries of the slots that were written this step and hand their flags on
@@ -585,7 +590,7 @@ __device__ __forceinline__ void retire_class(float* P, int cap, int lo, int hi, 
         active_last[sl] = act; active_w[sl] = 0;
         if (act) {
 #pragma unroll
-            for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = rest;
+            for (int e = 0; e < NA * NB; ++e) P[PIDX6(cap, sl, e / NB, e % NB)] = rest;
         }
     }
 }
@@ -655,7 +660,12 @@ __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int
 template <int NA, int NB>
 __device__ __forceinline__ void bp_load_matrix(const BpCtx& C, int sl, float (&P)[NA * NB]) {
 #pragma unroll
-    for (int e = 0; e < NA * NB; ++e) P[e] = C.P[(size_t)((e / NB) * 6 + e % NB) * C.cap + sl];
+    for (int i = 0; i < NA; ++i) {      // one 24-byte record per matrix row: 8-byte loads
+        const float2* r = (const float2*)(C.P + PIDX6(C.cap, sl, i, 0));
+        const float2 a = r[0]; P[i * NB] = a.x; P[i * NB + 1] = a.y;
+        if (NB == 6) { const float2 b = r[1], c = r[2]; P[i * NB + 2] = b.x; P[i * NB + 3] = b.y; P[i * NB + 4] = c.x; P[i * NB + 5] = c.y; }
+        else P[i * NB + 2] = ((const float*)r)[2];
+    }
 }
 template <int NA, int NB, bool WT>
 __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
@@ -720,9 +730,9 @@ __device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int
         if (active && !active[sl]) continue;      // untouched accumulators stay 0: nobody reads the matrix of an inactive slot
         float v[NA * NB];
 #pragma unroll
-        for (int e = 0; e < NA * NB; ++e) v[e] = P[(size_t)((e / NB) * 6 + e % NB) * cap + sl];
+        for (int e = 0; e < NA * NB; ++e) v[e] = P[PIDX6(cap, sl, e / NB, e % NB)];
 #pragma unroll
-        for (int e = 0; e < NA * NB; ++e) P[(size_t)((e / NB) * 6 + e % NB) * cap + sl] = expf(-v[e]);
+        for (int e = 0; e < NA * NB; ++e) P[PIDX6(cap, sl, e / NB, e % NB)] = expf(-v[e]);
     }
 }
 
@@ -750,7 +760,7 @@ __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float pm = (P[i * NB + j] * bc1[i] * bc2[j]) * rs;
-            C.marg[(size_t)(i * 6 + j) * C.cap + sl] = pm;
+            C.marg[PIDX6(C.cap, sl, i, j)] = pm;
             if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i * NB + j] * nbm[a * 6 + i] * nbm[b * 6 + j]));
         }
     return en;
@@ -901,7 +911,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) row[u][r] = (r < 3 || n == 6) ? C.P[(size_t)r * C.cap + sl[u]] : 1.f;
+                for (int r = 0; r < 6; ++r) row[u][r] = (r < 3 || n == 6) ? C.P[PIDX6(C.cap, sl[u], 0, r)] : 1.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (act[u])
@@ -1057,7 +1067,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     if (want_energy) {
         for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
-            if (C.active[sl]) en += -logf(C.P[sl]);
+            if (C.active[sl]) en += -logf(C.P[PIDX6(C.cap, sl, 0, 0)]);
         for (int g = tid; g < NN; g += nt) {   // node_free_energy, rotamer.cpp:292-302
             const int n = nrot[g];
             float e = R.node_off[(size_t)s * NN + g];
@@ -1153,7 +1163,7 @@ __device__ __forceinline__ void bpc_stage(float* Pl, const upk_rotamer_t& R, int
     const float* P = R.P + (size_t)s * R.slot_cap * 36;
     for (int t = threadIdx.x; t < n_own * NA * NB; t += blockDim.x) {
         const int e = t / n_own, l = t - e * n_own, i = e / NB, j = e - i * NB;
-        Pl[t] = expf(-P[(size_t)(i * 6 + j) * R.slot_cap + lo + l]);
+        Pl[t] = expf(-P[PIDX6(R.slot_cap, lo + l, i, j)]);
     }
 }
 // update_beliefs for one slot (rotamer.cpp:468-499, 506-521); messages stay in registers, copies go to the inbox
@@ -1216,7 +1226,7 @@ __device__ __forceinline__ float bpc_marginal(const BpcSlot<NA, NB>& st, const f
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const float pm = (P[i][j] * bc1[i] * bc2[j]) * rs;      // recomputed: no second 36-register matrix
-            marg[(size_t)(i * 6 + j) * cap + st.sl] = pm;
+            marg[PIDX6(cap, st.sl, i, j)] = pm;
             if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i][j] * nbm[st.a * 6 + i] * nbm[st.b * 6 + j]));
         }
     return en;
@@ -1327,7 +1337,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
                 const int sl = adj_slot[g * R.adj_cap + k];
                 if (!active[sl]) continue;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) if (r < n) p[r] *= expf(-P[(size_t)r * R.slot_cap + sl]);
+                for (int r = 0; r < 6; ++r) if (r < n) p[r] *= expf(-P[PIDX6(R.slot_cap, sl, 0, r)]);
             }
 #pragma unroll
             for (int r = 0; r < 6; ++r) prob[g * 6 + r] = p[r];
@@ -1474,7 +1484,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     const int n11 = cls[CL11 + 1] - cls[CL11], lo11 = cls[CL11] + (int)((long)n11 * c / C), hi11 = cls[CL11] + (int)((long)n11 * (c + 1) / C);   // as clear_all_classes splits it
     if (want_energy) {
         for (int sl = lo11 + tid; sl < hi11; sl += nt)                     // 1-1 edges (rotamer.cpp:861): -log(exp(-E))
-            if (active_w[sl]) en += P[sl];
+            if (active_w[sl]) en += P[PIDX6(R.slot_cap, sl, 0, 0)];
         for (int g = g_lo + tid; g < g_hi; g += nt) {                      // node_free_energy, rotamer.cpp:292-302
             const int n = nrot[g];
             float e = R.node_off[(size_t)s * NN + g];

@@ -1276,7 +1276,7 @@ struct RotamerSidechain : public PotentialNode {
         auto nb = sys_slice(nb_cur, sys, (size_t)n_node * 6); auto mg = sys_slice(marg, sys, cap * 36);
         // classes in slot order: 3x3, 3x6, 6x6, 1x1, 1xN (kernels_rotamer.hip); a < b in node order, so a 1xN slot has a = the 1-state node
         for (int sl = cs[4]; sl < cs[5]; ++sl) if (act[sl])                                           // move_edge_prob_to_node2, rotamer.cpp:378-385
-            for (int r = 0; r < node_nrot[sb[sl]]; ++r) prob[sb[sl] * 6 + r] *= expf(-E[(size_t)r * cap + sl]);
+            for (int r = 0; r < node_nrot[sb[sl]]; ++r) prob[sb[sl] * 6 + r] *= expf(-E[((size_t)0 * cap + sl) * 6 + r]);
         if (want_node_energy) {
             vector<float> ne((size_t)n_node * 6);
             for (int g = 0; g < n_node; ++g) for (int r = 0; r < 6; ++r) ne[g * 6 + r] = r < node_nrot[g] ? -logf(prob[g * 6 + r]) : 1e5f;
@@ -1288,12 +1288,12 @@ struct RotamerSidechain : public PotentialNode {
             for (int r = 0; r < node_nrot[g]; ++r) { const float b = nb[g * 6 + r]; e += b * logf((1e-10f + b) / (1e-10f + prob[g * 6 + r])); }
             fe[g] += e;
         }
-        for (int sl = cs[3]; sl < cs[4]; ++sl) if (act[sl]) { const float en = E[sl]; fe[sa[sl]] += 0.5f * en; fe[sb[sl]] += 0.5f * en; }   // -log(prob) of a 1x1 edge
+        for (int sl = cs[3]; sl < cs[4]; ++sl) if (act[sl]) { const float en = E[(size_t)sl * 6]; fe[sa[sl]] += 0.5f * en; fe[sb[sl]] += 0.5f * en; }   // -log(prob) of a 1x1 edge
         for (int sl = cs[0]; sl < cs[3]; ++sl) if (act[sl]) {                                          // edge_free_energy, rotamer.cpp:431-451
             const int a = sa[sl], b = sb[sl];
             float en = 0.f;
             for (int i = 0; i < node_nrot[a]; ++i) for (int j = 0; j < node_nrot[b]; ++j) {
-                const float p = mg[(size_t)(i * 6 + j) * cap + sl], pr = expf(-E[(size_t)(i * 6 + j) * cap + sl]);
+                const float p = mg[((size_t)i * cap + sl) * 6 + j], pr = expf(-E[((size_t)i * cap + sl) * 6 + j]);   // slot matrices: [i][slot][j]
                 en += p * logf((1e-10f + p) / (1e-10f + pr * nb[a * 6 + i] * nb[b * 6 + j]));
             }
             fe[a] += 0.5f * en; fe[b] += 0.5f * en;
@@ -1353,7 +1353,7 @@ struct RotamerSidechain : public PotentialNode {
                 int a = sa[sl], b = sb[sl];
                 if (node_nrot[a] == 1 && node_nrot[b] != 1) continue;   // 1-3 / 1-6 edges are not listed (rotamer.cpp:745)
                 for (int r1 = 0; r1 < node_nrot[a]; ++r1) for (int r2 = 0; r2 < node_nrot[b]; ++r2) {
-                    float v = (do_marginal && node_nrot[b] == 1) ? 1.f : mg[(size_t)(r1 * 6 + r2) * R.slot_cap + sl];
+                    float v = (do_marginal && node_nrot[b] == 1) ? 1.f : mg[((size_t)r1 * R.slot_cap + sl) * 6 + r2];
                     ev[(((size_t)a * n_node + b) * 6 + r1) * 6 + r2] = v;
                     ev[(((size_t)b * n_node + a) * 6 + r2) * 6 + r1] = v;
                 }
