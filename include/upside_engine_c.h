@@ -130,6 +130,26 @@ int upside_hip_swap_systems(DerivEngine* engine, int system1, int system2);
 /* the same for n_pair disjoint pairs (pairs: host array (n_pair,2)) in one launch: the accepted on-GPU pairs of a swap set */
 int upside_hip_swap_system_pairs(DerivEngine* engine, int n_pair, const int* pairs);
 
+/* Replica exchange across GPUs over RCCL / xGMI, one process per GPU, no host staging (csrc/comm_rccl.cpp; reference
+ * semantics src/main.cpp:227-275 with the loop of :616-672).  Global system g = rank * n_system + local index, so a rank
+ * holds a contiguous block of the temperature ladder and only the pairs straddling a block boundary cross GPUs.
+ *   upside_hip_comm_get_unique_id: rank 0 makes the 128-byte ncclUniqueId; the launcher hands it to every rank (file, env,
+ *     torch.distributed, MPI ...).  Ranks must be started BEFORE any of them touches the GPU.
+ *   upside_hip_comm_init: ncclCommInitRank on the engine's device; temperature_global = the whole ladder (world * n_system).
+ *   upside_hip_comm_replica_swap: ONE swap set (pairs of GLOBAL system ids).  first_set != 0: the first set of an attempt
+ *     (force pass, device-side energy sum, ncclAllGather of one fp32 per replica); later sets of the attempt reuse the
+ *     gathered energies, accepted pairs having traded theirs.  Verdicts are computed on the device, identically on every rank
+ *     (Metropolis test and random stream of main.cpp:262-271); coordinates of straddling pairs move by grouped
+ *     ncclSend/ncclRecv on the engine's stream; momenta and temperatures stay with the slot.  accepted (n_pair) may be NULL:
+ *     then the call enqueues everything and returns without synchronising.
+ * With world = 1 the result is bit for bit that of upside_hip_replica_swap_from / _next. */
+#define UPSIDE_HIP_COMM_ID_BYTES 128
+int upside_hip_comm_get_unique_id(char* id_out /* [128] */);
+int upside_hip_comm_init(DerivEngine* engine, int rank, int world, const char* id /* [128] */, const float* temperature_global);
+int upside_hip_comm_replica_swap(DerivEngine* engine, int n_pair, const int* pairs_global, uint32_t base_seed, uint64_t round,
+                                 int first_set, int* accepted);
+int upside_hip_comm_free(DerivEngine* engine);
+
 /* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */
 int upside_hip_rebuild_flags(DerivEngine* engine, const char* node_name, int* flags);
 /* Parity/diagnostic access: the in-range pair list of an interaction-graph node of system `sys` after the

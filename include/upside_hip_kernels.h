@@ -348,6 +348,15 @@ int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_c
  * one receives the generator position after this set. */
 int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const float* energy, const float* beta, int n_pair,
                      const int* pairs, uint32_t seed, uint64_t round, int draw0, int* accepted);
+/* replica exchange across GPUs (src/main.cpp:227-275 over a ladder spread across ranks; host side: csrc/comm_rccl.cpp).
+ * Everything is device-resident and stream-ordered between the RCCL calls: total potentials (node order, fp32),
+ * Metropolis verdicts over the all-gathered energies (identical on every rank; accepted pairs trade their gathered
+ * energies; draw_io = generator position within the attempt), and the coordinate moves (plan[p] = {kind, a, b}: 1 = both
+ * local, swap; 2 = local system a takes staging row b, the partner's coordinates received from its rank). */
+int upk_sum_potentials(const upk_launch_t* L, const float* const* node_pot, int n_node, float* out);
+int upk_replica_decide(const upk_launch_t* L, float* energy_all, const float* beta_all, int n_pair, const int* pairs,
+                       uint32_t seed, uint64_t round, int* draw_io, int* accepted);
+int upk_replica_apply(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* plan, const int* accepted, const float* staging);
 /* swap the coordinates of n_pair disjoint (s1, s2) pairs of systems; pairs is a device array */
 int upk_swap_system_pairs(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* pairs);
 

@@ -454,6 +454,59 @@ def test_replica_swap_next_reuses_energies(hip):
     assert 0 < v[v < 2].sum() < len(v)            # both accepted and rejected swaps occurred (entries > 1 are draw counters)
 
 
+def test_rccl_exchange_loopback_matches_device_swap(hip):
+    """The C++ RCCL exchange (upside_hip_comm_*: device-side energy sum, ncclAllGather, device Metropolis, stream-ordered
+    coordinate moves) on a world of ONE rank must reproduce upside_hip_replica_swap_from / _next bit for bit: same verdicts
+    over several attempts of two alternating swap sets, same final coordinates.  (Cross-GPU pairs need a multi-GPU node; the
+    rank arithmetic they add is covered on CPU in tests/test_replicas_gloo.py.)"""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    for f in (c.upside_hip_replica_swap_from, c.upside_hip_replica_swap_next):
+        f.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
+    c.upside_hip_comm_get_unique_id.argtypes = [ct.c_char_p]
+    c.upside_hip_comm_init.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_char_p, ct.c_void_p]
+    c.upside_hip_comm_replica_swap.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
+    c.upside_hip_comm_free.argtypes = [ct.c_void_p]
+    c.upside_hip_run_steps.argtypes = [ct.c_void_p, ct.c_int]
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    rs = np.random.RandomState(4)
+    pos = np.stack([g['pos'] + np.float32(0.03 * k) * rs.normal(size=g['pos'].shape).astype('f4') for k in range(6)]).astype('f4')
+    temps = np.array([0.7, 0.74, 0.78, 0.82, 0.86, 0.9], 'f4')
+    sets = [np.array([[0, 1], [2, 3], [4, 5]], 'i4'), np.array([[1, 2], [3, 4]], 'i4')]
+    results = []
+    for use_comm in (False, True):
+        eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 6, True)
+        c.upside_hip_set_pos(eng, pos.ctypes.data)
+        c.upside_hip_init_md(eng, temps.ctypes.data, 5, 5.0, 0.009, 1)
+        if use_comm:
+            uid = ct.create_string_buffer(128)
+            assert c.upside_hip_comm_get_unique_id(uid) == 0, c.upside_hip_last_error()
+            assert c.upside_hip_comm_init(eng, 0, 1, uid, temps.ctypes.data) == 0, c.upside_hip_last_error()
+        verdicts = []
+        for rnd in range(1, 9):
+            draw = 0
+            for k, pairs in enumerate(sets):
+                if use_comm:
+                    acc = np.zeros(len(pairs), 'i4')
+                    assert c.upside_hip_comm_replica_swap(eng, len(pairs), pairs.ctypes.data, 11, rnd, int(k == 0), acc.ctypes.data) == 0, c.upside_hip_last_error()
+                    verdicts.append(acc.copy())
+                else:
+                    acc = np.zeros(len(pairs) + 1, 'i4')
+                    fn = c.upside_hip_replica_swap_from if k == 0 else c.upside_hip_replica_swap_next
+                    assert fn(eng, len(pairs), pairs.ctypes.data, 11, rnd, draw, acc.ctypes.data) == 0
+                    draw = int(acc[-1]); verdicts.append(acc[:-1].copy())
+            c.upside_hip_run_steps(eng, 3)      # a round of MD between attempts, as in a run
+        out = np.zeros_like(pos); c.upside_hip_get_pos(eng, out.ctypes.data)
+        results.append((np.concatenate(verdicts), out))
+        if use_comm:
+            c.upside_hip_comm_free(eng)
+        c.free_deriv_engine(ct.c_void_p(eng))
+    assert np.array_equal(results[0][0], results[1][0]), (results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])
+    v = results[0][0]
+    assert 0 < v.sum() < len(v)            # both accepted and rejected swaps occurred
+
+
 def test_ensemble_exchange_matches_device_swap(hip):
     """The cross-rank replica-exchange path (host verdicts from gathered energies + per-system coordinate moves,
     upside-md_amd/replicas.py) and the single-engine device kernel must agree: same accepted pairs, same final

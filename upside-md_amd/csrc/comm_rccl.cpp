@@ -1,0 +1,169 @@
+// Replica exchange across GPUs (the reference's ReplicaExchange::attempt_swaps, /root/reference/src/main.cpp:227-275, for a
+// temperature ladder spread over one process per GPU): RCCL over xGMI, no host staging.
+//
+// Global system g lives on rank g / n_system (contiguous temperature blocks, so only the pairs that straddle a block
+// boundary cross GPUs).  One swap set, all on the engine's stream:
+//   1. (first set of an attempt) force pass, total potentials summed on the device, ncclAllGather of ONE fp32 per replica;
+//   2. every rank runs the identical Metropolis kernel on the identical gathered arrays with the shared counter RNG
+//      (k_replica_decide) -- no verdict is communicated; accepted pairs trade their gathered energies, so the later sets of
+//      the attempt reuse them (a temperature exchange of one Hamiltonian permutes the energies);
+//   3. every pair that straddles two ranks sends its coordinates to the partner rank and receives the partner's into a
+//      staging row (one grouped ncclSend/ncclRecv of 3*n_atom floats per pair), whatever the verdict -- a couple of KB per
+//      rank and set buys a path with no host round trip; k_replica_apply then swaps accepted on-rank pairs in place and
+//      copies the staging row in for accepted cross-rank pairs.  Momenta and temperatures stay with the slot (main.cpp:244-247).
+// librccl is loaded on first use (dlopen), so processes that never exchange across GPUs do not pay for it.
+#include "../../include/upside_engine_c.h"
+#include "engine.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace std;
+
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.lib) return r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    if (!r.lib) throw string("cannot load librccl.so: ") + dlerror();
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) throw string("librccl.so lacks ") + n; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return r;
+}
+void nccl_check(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw string("RCCL error in ") + what + ": " + rccl().GetErrorString(r);
+}
+}  // namespace
+
+struct ReplicaComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf<float> energy_local, energy_all, beta_all, staging;
+    DevBuf<const float*> node_pot;
+    DevBuf<int> pairs_dev, plan_dev, accepted_dev, draw_dev;
+    int n_node_pot = 0, pair_cap = 0, staging_rows = 0;
+    uint64_t attempt_round = ~0ull; uint64_t attempt_compute = 0;   // the attempt the gathered energies belong to
+    ~ReplicaComm() { if (comm) (void)rccl().CommDestroy(comm); }
+};
+static void comm_deleter(void* p) { delete (ReplicaComm*)p; }
+
+#define API_TRY try {
+#define API_CATCH } catch (const string& s) { upside_hip_set_last_error(s.c_str()); return 1; } catch (const std::exception& e) { upside_hip_set_last_error(e.what()); return 1; } \
+    catch (...) { upside_hip_set_last_error("unknown error"); return 1; }
+extern "C" void upside_hip_set_last_error(const char* msg);
+
+extern "C" int upside_hip_comm_get_unique_id(char* id_out) {
+    API_TRY
+    static_assert(sizeof(ncclUniqueId) == UPSIDE_HIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+    API_CATCH
+}
+
+extern "C" int upside_hip_comm_init(DerivEngine* e, int rank, int world, const char* id_in, const float* temperature_global) {
+    API_TRY
+    if (!e || world < 1 || rank < 0 || rank >= world) throw string("invalid rank / world");
+    const int S = e->ctx.n_system;
+    unique_ptr<ReplicaComm> c(new ReplicaComm);
+    c->rank = rank; c->world = world;
+    ncclUniqueId id; memcpy(&id, id_in, sizeof(id));
+    nccl_check(rccl().CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+    c->energy_local.alloc(S); c->energy_all.alloc((size_t)world * S); c->draw_dev.alloc(1);
+    vector<float> beta((size_t)world * S);
+    for (size_t g = 0; g < beta.size(); ++g) beta[g] = 1.f / temperature_global[g];
+    c->beta_all.upload(beta);
+    vector<const float*> ptrs;
+    for (auto& n : e->nodes) if (n.computation->potential_term) ptrs.push_back(static_cast<PotentialNode*>(n.computation.get())->potential_dev.p);
+    c->n_node_pot = (int)ptrs.size(); c->node_pot.upload(ptrs);
+    if (e->comm) e->comm_free(e->comm);
+    e->comm = c.release(); e->comm_free = comm_deleter;
+    return 0;
+    API_CATCH
+}
+
+extern "C" int upside_hip_comm_free(DerivEngine* e) {
+    if (e && e->comm) { e->sync(); e->comm_free(e->comm); e->comm = nullptr; }
+    return 0;
+}
+
+extern "C" int upside_hip_comm_replica_swap(DerivEngine* e, int n_pair, const int* pairs_global, uint32_t base_seed, uint64_t round,
+                                            int first_set, int* accepted) {
+    API_TRY
+    if (!e || !e->comm) throw string("upside_hip_comm_init first");
+    ReplicaComm& c = *(ReplicaComm*)e->comm;
+    const int S = e->ctx.n_system, G = S * c.world, lo = c.rank * S;
+    hipStream_t st = e->ctx.stream;
+    const int n_row = e->pos->n_elem * e->pos->stride;
+    // plan of this set for this rank (host arithmetic on the pair list only)
+    vector<int> plan((size_t)n_pair * 3, 0);
+    struct Cross { int local, peer, slot; };
+    vector<Cross> cross;
+    vector<char> used((size_t)G, 0);
+    for (int p = 0; p < n_pair; ++p) {
+        const int g1 = pairs_global[2 * p], g2 = pairs_global[2 * p + 1];
+        if (g1 < 0 || g1 >= G || g2 < 0 || g2 >= G || g1 == g2) throw string("invalid system in swap set");
+        if (used[g1] || used[g2]) throw string("Overlapping indices in swap set.");
+        used[g1] = used[g2] = 1;
+        const int r1 = g1 / S, r2 = g2 / S;
+        if (r1 == c.rank && r2 == c.rank) { plan[3 * p] = 1; plan[3 * p + 1] = g1 - lo; plan[3 * p + 2] = g2 - lo; }
+        else if (r1 == c.rank || r2 == c.rank) {
+            const int mine = r1 == c.rank ? g1 : g2, peer = r1 == c.rank ? r2 : r1;
+            plan[3 * p] = 2; plan[3 * p + 1] = mine - lo; plan[3 * p + 2] = (int)cross.size();
+            cross.push_back(Cross{mine - lo, peer, (int)cross.size()});
+        }
+    }
+    if (n_pair > c.pair_cap) { c.pair_cap = n_pair; c.pairs_dev.alloc((size_t)n_pair * 2); c.plan_dev.alloc((size_t)n_pair * 3); c.accepted_dev.alloc(n_pair); }
+    if ((int)cross.size() > c.staging_rows) { c.staging_rows = (int)cross.size(); c.staging.alloc((size_t)c.staging_rows * n_row); }
+    if (n_pair) {
+        hip_check(hipMemcpyAsync(c.pairs_dev.p, pairs_global, (size_t)n_pair * 2 * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemcpyAsync(c.plan_dev.p, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
+    }
+    if (first_set) {   // main.cpp:251-256: energies of every system, once per attempt
+        e->compute(PotentialAndDerivMode);
+        upk_check(upk_sum_potentials(&e->ctx.L, c.node_pot.p, c.n_node_pot, c.energy_local.p), "sum_potentials");
+        nccl_check(rccl().AllGather(c.energy_local.p, c.energy_all.p, (size_t)S, ncclFloat, c.comm, st), "ncclAllGather");
+        hip_check(hipMemsetAsync(c.draw_dev.p, 0, sizeof(int), st), "memset");
+        c.attempt_round = round; c.attempt_compute = e->n_compute;
+    } else if (c.attempt_round != round || c.attempt_compute != e->n_compute)
+        throw string("a later swap set needs the first set of the same attempt (same round, no evaluation in between)");
+    if (n_pair) upk_check(upk_replica_decide(&e->ctx.L, c.energy_all.p, c.beta_all.p, n_pair, c.pairs_dev.p, base_seed, round, c.draw_dev.p, c.accepted_dev.p), "replica_decide");
+    if (!cross.empty()) {   // coordinates of the straddling pairs, both directions, one group
+        nccl_check(rccl().GroupStart(), "ncclGroupStart");
+        for (auto& x : cross) {
+            nccl_check(rccl().Send(e->pos->output.p + (size_t)x.local * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclSend");
+            nccl_check(rccl().Recv(c.staging.p + (size_t)x.slot * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclRecv");
+        }
+        nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    }
+    if (n_pair) upk_check(upk_replica_apply(&e->ctx.L, e->pos->coord(), n_pair, c.plan_dev.p, c.accepted_dev.p, c.staging.p), "replica_apply");
+    if (accepted && n_pair) {   // the caller wants the verdicts (logging): the only synchronisation of the call
+        hip_check(hipMemcpyAsync(accepted, c.accepted_dev.p, (size_t)n_pair * sizeof(int), hipMemcpyDeviceToHost, st), "D2H");
+        e->sync();
+    }
+    return 0;
+    API_CATCH
+}

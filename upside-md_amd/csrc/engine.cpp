@@ -131,6 +131,7 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
 }
 DerivEngine::~DerivEngine() {
     if (ctx.stream) { (void)hipStreamSynchronize(ctx.stream); }
+    if (comm && comm_free) { comm_free(comm); comm = nullptr; }
     invalidate_graph();
     for (auto& kv : side) {
         (void)hipStreamSynchronize(kv.second.stream);

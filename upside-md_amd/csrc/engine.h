@@ -225,6 +225,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     void load_jump_moves(hid_t_compat input_group);
     void mc_step(uint64_t round);                      // every loaded sampler in the reference's order (pivot, jump): two
                                                        // energy evaluations + proposal + Metropolis each, every system
+    void* comm = nullptr; void (*comm_free)(void*) = nullptr;   // replica exchange across GPUs (comm_rccl.cpp), owned by the engine
     void check_device_errors();                // throws if a capacity overflow was flagged
     void sync();
 };

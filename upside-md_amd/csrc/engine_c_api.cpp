@@ -29,6 +29,7 @@ static int fail(const string& s) { g_last_error = s; fprintf(stderr, "ERROR: %s\
     catch (const std::exception& e) { fail(e.what()); return ret; } catch (...) { fail("unknown error"); return ret; }
 
 extern "C" const char* upside_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" void upside_hip_set_last_error(const char* msg) { fail(msg); }   // (for the other translation units of the C-ABI)
 
 // ---- construction ----------------------------------------------------------------------------------
 extern "C" int upside_hip_set_device(int device) {

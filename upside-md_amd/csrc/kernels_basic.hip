@@ -1060,6 +1060,67 @@ extern "C" int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const fl
     return launch_status();
 }
 
+// ---- replica exchange across GPUs (comm_rccl.cpp): everything below runs on the engine's stream between RCCL calls --------
+// total potential of every system on the device: out[s] = sum over the potential nodes, in node order (the order and fp32
+// arithmetic of DerivEngine::fetch_potentials / deriv_engine.cpp:143-146, so the two give the same bits)
+__global__ void k_sum_potentials(const float* const* __restrict__ node_pot, int n_node, int S, float* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float t = 0.f;
+    for (int k = 0; k < n_node; ++k) t += node_pot[k][s];
+    out[s] = t;
+}
+extern "C" int upk_sum_potentials(const upk_launch_t* L, const float* const* node_pot, int n_node, float* out) {
+    hipLaunchKernelGGL(k_sum_potentials, grid1(L->n_system, 1), dim3(UPK_BLOCK), 0, ST(L), node_pot, n_node, L->n_system, out);
+    return launch_status();
+}
+// Metropolis verdicts of one swap set over the GLOBAL ladder (main.cpp:251-273), identical on every rank: same gathered
+// energies, same temperatures, same counter RNG.  draw_io: generator position within this attempt (in/out, device);
+// accepted pairs trade their entries of energy_all (temperature exchange of one Hamiltonian), so the later sets of the
+// attempt need no new evaluation.
+__global__ void k_replica_decide(float* __restrict__ energy_all, const float* __restrict__ beta_all, int n_pair, const int* __restrict__ pairs,
+                                 uint32_t seed, uint64_t round, int* __restrict__ draw_io, int* __restrict__ accepted) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int draw = *draw_io;
+    for (int p = 0; p < n_pair; ++p) {
+        const int s1 = pairs[p * 2], s2 = pairs[p * 2 + 1];
+        const float lb = (-beta_all[s1] * energy_all[s2] + -beta_all[s2] * energy_all[s1]) - (-beta_all[s1] * energy_all[s1] + -beta_all[s2] * energy_all[s2]);
+        int ok = 1;
+        if (lb < 0.f) {
+            const uint32_t key[4] = {seed, 1u /* REPLICA_EXCHANGE_RANDOM_STREAM */, 0u, 0u};
+            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, (uint32_t)draw};
+            threefry4x32_20(X, key);
+            ++draw;
+            if (expf(lb) < u01f(X[0])) ok = 0;
+        }
+        accepted[p] = ok;
+        if (ok) { const float t = energy_all[s1]; energy_all[s1] = energy_all[s2]; energy_all[s2] = t; }
+    }
+    *draw_io = draw;
+}
+extern "C" int upk_replica_decide(const upk_launch_t* L, float* energy_all, const float* beta_all, int n_pair, const int* pairs,
+                                  uint32_t seed, uint64_t round, int* draw_io, int* accepted) {
+    hipLaunchKernelGGL(k_replica_decide, dim3(1), dim3(64), 0, ST(L), energy_all, beta_all, n_pair, pairs, seed, round, draw_io, accepted);
+    return launch_status();
+}
+// apply the verdicts to this rank's coordinates.  plan[p] = {kind, a, b}: kind 1: both systems local (a, b = local ids:
+// swap in place); kind 2: system a is local, its partner lives on another rank and its coordinates arrived in staging row b
+__global__ void k_replica_apply(upk_coord_t pos, int n_pair, const int* __restrict__ plan, const int* __restrict__ accepted, const float* __restrict__ staging) {
+    const int p = blockIdx.y;
+    if (p >= n_pair || !accepted[p]) return;
+    const int kind = plan[p * 3], a = plan[p * 3 + 1], b = plan[p * 3 + 2];
+    const int n = pos.n_elem * pos.stride;
+    float* xa = C_OUT(pos, a);
+    if (kind == 1) { float* xb = C_OUT(pos, b); for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float t = xa[i]; xa[i] = xb[i]; xb[i] = t; } }
+    else if (kind == 2) { const float* in = staging + (size_t)b * n; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) xa[i] = in[i]; }
+}
+extern "C" int upk_replica_apply(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* plan, const int* accepted, const float* staging) {
+    if (n_pair <= 0) return 0;
+    const int n = pos.n_elem * pos.stride;
+    hipLaunchKernelGGL(k_replica_apply, dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)n_pair), dim3(UPK_BLOCK), 0, ST(L), pos, n_pair, plan, accepted, staging);
+    return launch_status();
+}
+
 // exchange the coordinates of disjoint pairs of systems in one launch (the accepted on-GPU pairs of a swap set)
 __global__ void k_swap_system_pairs(upk_coord_t pos, const int* __restrict__ pairs) {
     const int p = blockIdx.y;
