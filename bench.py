@@ -5,12 +5,20 @@
 
 A "step" is one force evaluation + one leapfrog stage of EVERY replica resident on the GPU (the reference's
 "MD step", /root/reference/src/main.cpp:677-682; one integration cycle = 3 steps,
-/root/reference/src/deriv_engine.cpp:172-192).  The workload is BASELINE.json configs[2]: the 300-residue
+/root/reference/src/deriv_engine.cpp:172-192).  The default workload is BASELINE.json configs[2]: the 300-residue
 synthetic protein with full side-chain belief propagation and the 10 A pair list (tests/golden/syn300_10A.up),
 held as R independent replicas per GPU (different thermostat seeds), everything resident in HBM.
 `value` = system-steps per second summed over all replicas and GPUs -- the reciprocal of the reference's own
-"us/systems/step" figure.  Multi-GPU runs are weak scaling: every rank owns R more replicas; there is no
+"us/systems/step" figure.  Multi-GPU runs of it are weak scaling: every rank owns R more replicas; there is no
 data-path collective (replicas are independent).
+
+Other workloads (--workload): any fixture name (tests/golden/<name>.up) held as R replicas, and BASELINE.json's two
+multi-GPU configurations, whose total work is fixed (strong scaling):
+  remd64_proteinG56  configs[3]: 64 temperatures of the 56-residue protein, a geometric ladder in contiguous blocks per GPU,
+                     replica exchange every 5 time units with two alternating neighbour swap sets through the C++ RCCL path
+                     (upside_hip_comm_*: one fp32 per replica all-gathered, verdicts on the device, straddling pairs moved
+                     by ncclSend/ncclRecv -- no host staging)
+  ens512_syn150      configs[4]: 512 independent 150-residue proteins, 512 / N per GPU, no communication
 
 Rank 0 prints ONE JSON line.
 """
@@ -29,6 +37,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL's version banner goes to stdout; rank 0 must print ONE JSON line there
+os.environ['NCCL_DEBUG'] = os.environ.get('UPSIDE_NCCL_DEBUG', 'WARN')
 from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -52,6 +62,11 @@ def bind(lib):
     c.upside_hip_igraph_bytes_per_system.restype = ct.c_double
     c.upside_hip_igraph_bytes_per_system.argtypes = [ct.c_void_p]
     c.upside_hip_last_error.restype = ct.c_char_p
+    c.upside_hip_calibrate_valu.argtypes = [ct.c_void_p]
+    c.upside_hip_comm_get_unique_id.argtypes = [ct.c_char_p]
+    c.upside_hip_comm_init.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_char_p, ct.c_void_p]
+    c.upside_hip_comm_replica_swap.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
+    c.upside_hip_comm_free.argtypes = [ct.c_void_p]
     return c
 
 
@@ -107,17 +122,29 @@ def cpu_baseline(fixture, variant, budget_s=float(os.environ.get('UPSIDE_BENCH_C
                 sample='%d steps of the C restatement (oracle/upside_oracle.c), 1 core' % (3 * n_round))
 
 
-def measured_traffic(kernel_label, workload, replicas):
-    """HBM bytes per launch of `kernel_label` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of this very command; tools/hbm_traffic.py applies the guide's gfx950
-    corrections).  None when no profile exists for this workload / replica count."""
-    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+PROFILE_TABLE = 'profiles/hbm_traffic.json'
+PROFILE_NOTE = ('from the rocprofv3 PMC passes of this command committed under profiles/ (FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in '
+                'separate passes, tools/refresh_profiles.sh); not collected in this run')
+
+
+def profiled(kernel_label, workload, replicas, field):
+    """per-launch counter value of `kernel_label` from the committed PMC passes (tools/hbm_traffic.py applies the guide's
+    gfx950 corrections to the byte counters); None when no profile exists for this workload / replica count."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, PROFILE_TABLE)) as f:
             tab = json.load(f)
-        return tab['%s/R%d' % (workload, replicas)][kernel_label]['bytes_per_launch']
+        return tab['%s/R%d' % (workload, replicas)][kernel_label][field]
     except (OSError, KeyError, ValueError):
         return None
+
+
+WORKLOADS = {   # name -> (fixture, description, total systems or None (= --replicas per GPU, weak scaling))
+    'remd64_proteinG56': ('proteinG56_7A', '64-temperature replica exchange of the 56-residue protein (BASELINE.json configs[3]): geometric '
+                          'ladder T=0.50..1.00 in contiguous blocks per GPU, exchange attempt every 5 time units (185 rounds) with two '
+                          'alternating neighbour swap sets over RCCL', 64),
+    'ens512_syn150': ('syn150_10A', '512 independent 150-residue proteins (BASELINE.json configs[4]), 512 / N per GPU, no communication', 512),
+}
+REPLICA_INTERVAL = 5.0     # time units between exchange attempts (README.md:189-193 pattern)
 
 
 def main():
@@ -149,23 +176,61 @@ def main():
     c = bind(lib)
     check(c, c.upside_hip_set_device(local_rank), 'set_device')
 
-    fixture = os.path.join(ROOT, 'tests', 'golden', args.workload + '.up')
-    variant = '10A' if args.workload.endswith('10A') else '7A'
+    total_systems = None
+    if args.workload in WORKLOADS:
+        fix_name, describe, total_systems = WORKLOADS[args.workload]
+        if total_systems % world:
+            raise SystemExit('%s needs a GPU count that divides %d' % (args.workload, total_systems))
+        R = total_systems // world
+    else:
+        fix_name, R = args.workload, args.replicas
+        describe = None
+    fixture = os.path.join(ROOT, 'tests', 'golden', fix_name + '.up')
+    variant = '10A' if fix_name.endswith('10A') else '7A'
     pos0 = pkg.config.read_pos(fixture)
     n_atom = pos0.shape[0]
-    R = args.replicas
     eng = c.upside_hip_construct(n_atom, fixture.encode(), R, True)
     if not eng:
         raise RuntimeError('engine construction failed: %s' % c.upside_hip_last_error().decode())
     pos = np.ascontiguousarray(np.tile(pos0[None], (R, 1, 1)).astype('f4'))
     check(c, c.upside_hip_set_pos(eng, pos.ctypes.data), 'set_pos')
-    temps = np.full(R, TEMPERATURE, dtype='f4')
-    # every replica of every rank gets its own thermostat stream: seed = base + GLOBAL replica index (main.cpp:459)
     first, _ = rep.weak_shard(R, world, rank)
+    remd = args.workload == 'remd64_proteinG56'
+    if remd:
+        ladder = rep.geometric_ladder(0.5, 1.0, total_systems)
+        temps = np.ascontiguousarray(ladder[first:first + R])
+    else:
+        ladder = None
+        temps = np.full(R, TEMPERATURE, dtype='f4')
+    # every replica of every rank gets its own thermostat stream: seed = base + GLOBAL replica index (main.cpp:459)
     check(c, c.upside_hip_init_md(eng, temps.ctypes.data, rep.system_seed(1000, first), 5.0, DT, 1), 'init_md')
+    swap_sets, exchange_steps = [], 0
+    if remd:
+        uid = ct.create_string_buffer(128)
+        if rank == 0:
+            check(c, c.upside_hip_comm_get_unique_id(uid), 'comm_get_unique_id')
+        if world > 1:       # the launcher's own rendezvous hands the id around
+            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).cuda()
+            dist.broadcast(t, 0)
+            uid = ct.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        check(c, c.upside_hip_comm_init(eng, rank, world, uid, np.ascontiguousarray(ladder).ctypes.data), 'comm_init')
+        swap_sets = [np.ascontiguousarray(np.array(x, 'i4')) for x in rep.neighbour_swap_sets(total_systems)]
+        exchange_steps = 3 * max(1, int(REPLICA_INTERVAL / (3 * DT)))      # main.cpp:445-447: the interval in rounds
+
+    state = dict(done=0, attempts=0)
 
     def run_steps(n):
-        check(c, c.upside_hip_run_steps(eng, n), 'run_steps')     # exactly n force evaluations; returns after the stream has drained
+        """exactly n force evaluations (+ the exchange attempts that fall due); returns after the stream has drained"""
+        left = n
+        while left > 0:
+            chunk = left if not exchange_steps else min(left, exchange_steps - state['done'] % exchange_steps)
+            check(c, c.upside_hip_run_steps(eng, chunk), 'run_steps')
+            state['done'] += chunk; left -= chunk
+            if exchange_steps and state['done'] % exchange_steps == 0:
+                rnd = state['done'] // 3
+                for k, pairs in enumerate(swap_sets):      # nothing comes back to the host: the sets are enqueued behind the MD steps
+                    check(c, c.upside_hip_comm_replica_swap(eng, len(pairs), pairs.ctypes.data, 1000, rnd, int(k == 0), None), 'comm_replica_swap')
+                state['attempts'] += 1
         return n
 
     def barrier():
@@ -173,11 +238,14 @@ def main():
 
     run_steps(args.warmup)
     barrier()
+    attempts0 = state['attempts']
     t0 = time.perf_counter()
     steps_done = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     value, elapsed = rep.job_throughput(dist, R * steps_done, elapsed, device='cuda')   # all ranks' units / slowest rank
+    timed_attempts = state['attempts'] - attempts0
+    exchange_steps_saved, exchange_steps = exchange_steps, 0      # the profiling legs below run plain MD
 
     # ---- roofline of the dominant kernel: HIP-event timing on the engine's stream, outside the timed region
     roofline = None
@@ -189,36 +257,87 @@ def main():
         check(c, c.upside_hip_profile_reset(eng, 0), 'profile_reset')
         rows = []
         for ln in buf.value.decode().strip().split('\n'):
-            nm, ms, n, by = ln.split()
-            rows.append((nm, float(ms), int(n), float(by)))
+            nm, ms, n, by, pr = ln.split()
+            rows.append((nm, float(ms), int(n), float(by), float(pr)))
         def entry(r):
             avg_ms = r[1] / r[2]
             bytes_per_launch = r[3] / r[2]
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            return dict(bound='hbm', kernel=r[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(r[0], args.workload, R), avg_launch_ms=avg_ms,
-                        algorithmic_bytes_per_launch=bytes_per_launch)
+            traffic = profiled(r[0], args.workload, R, 'bytes_per_launch')
+            d = dict(bound='hbm', kernel=r[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=avg_ms,
+                     algorithmic_bytes_per_launch=bytes_per_launch)
+            if traffic is not None:      # the rate the counters saw, beside the algorithmic one
+                d['traffic_source'] = PROFILE_NOTE
+                d['frac_counter'] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            return d
         # the dominant kernel of the step (most time): belief propagation, which streams the pair matrices and messages
-        # every sweep and IS bandwidth bound; the dominant interaction-graph pair kernel (VALU bound) is
-        # reported beside it because north_star's target names it
+        # every sweep
         dom = max(rows, key=lambda r: r[1])
         roofline = entry(dom)
-        roofline['igraph'] = entry(max([r for r in rows if r[0].startswith('igraph')], key=lambda r: r[1]))
+        # The interaction-graph kernel north_star names: the side-chain gradient pass.  It is bound by VALU issue, not by HBM
+        # (DESIGN.md section 3), so its roofline is instructions: achieved = wave-level VALU instructions per launch (PMC
+        # count of the committed profile) / the launch time measured here; peak = the issue rate a dependent scalar fp32 chain
+        # reaches on THIS device in the same launch shape (upside_hip_calibrate_valu, a known-instruction-count kernel run
+        # now).  The HBM view of the same kernel is kept under "hbm".
+        ig_rows = [r for r in rows if r[0].startswith('igraph')]
+        ig = next((r for r in ig_rows if r[0] == 'igraph_bwd:rotamer'), max(ig_rows, key=lambda r: r[1]))
+        rates = (ct.c_double * 2)()
+        check(c, c.upside_hip_calibrate_valu(rates), 'calibrate_valu')
+        # instructions of this launch = pair evaluations of this launch (counted by the engine) x the instructions one
+        # evaluation costs, the latter from the PMC pass of the default workload (SQ_INSTS_VALU / pair evaluations there)
+        per_pair = profiled(ig[0], 'syn300_10A', 4096, 'valu_insts_per_pair')
+        pairs = ig[4] / ig[2]
+        insts = per_pair * pairs if per_pair else None
+        ig_ms = ig[1] / ig[2]
+        achieved_valu = insts / (ig_ms * 1e-3) / 1e9 if insts else None
+        roofline['igraph'] = dict(bound='valu', kernel=ig[0], achieved=achieved_valu, peak=rates[0] / 1e9, unit='G wave-instr/s',
+                                  frac=(achieved_valu / (rates[0] / 1e9)) if achieved_valu else None, avg_launch_ms=ig_ms,
+                                  valu_insts_per_launch=insts, pair_evaluations_per_launch=pairs, valu_insts_per_pair=per_pair,
+                                  insts_source=('pair evaluations counted in this run x instructions per evaluation ' + PROFILE_NOTE) if insts else None,
+                                  peak_note='dependent scalar fp32 FMA chain, one 1024-lane workgroup per CU, measured in this run; '
+                                            'four independent chains per lane (packed issue) reach peak_ilp4',
+                                  peak_ilp4=rates[1] / 1e9, hbm=entry(ig))
         roofline['kernels'] = {r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
                                           GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows}
 
+    # single-system latency of the same workload (one replica on the GPU), outside the timed region
+    single = None
     if rank == 0:
-        res = dict(metric='MD steps/sec (force evals/sec) per 300-res protein', value=value, unit='system-steps/s',
+        eng1 = c.upside_hip_construct(n_atom, fixture.encode(), 1, True)
+        if eng1:
+            p1 = np.ascontiguousarray(pos0[None].astype('f4')); t1 = np.full(1, TEMPERATURE, dtype='f4')
+            check(c, c.upside_hip_set_pos(eng1, p1.ctypes.data), 'set_pos')
+            check(c, c.upside_hip_init_md(eng1, t1.ctypes.data, 7, 5.0, DT, 1), 'init_md')
+            check(c, c.upside_hip_run_steps(eng1, 150), 'run_steps')
+            ts = time.perf_counter()
+            check(c, c.upside_hip_run_steps(eng1, 600), 'run_steps')
+            single = 600 / (time.perf_counter() - ts)
+            lib.calc.free_deriv_engine(ct.c_void_p(eng1))
+
+    if rank == 0:
+        if describe is None:
+            describe = ('%s: 300-res synthetic protein, full side-chain BP, 10 A pair list (BASELINE.json configs[2]); %d independent '
+                        'replicas per GPU, T=%.1f, dt=%.3f, Langevin thermostat every round' % (args.workload, R, TEMPERATURE, DT)
+                        if args.workload == 'syn300_10A' else
+                        '%s: %d independent replicas per GPU, T=%.1f, dt=%.3f, Langevin thermostat every round' % (args.workload, R, TEMPERATURE, DT))
+        cfg = dict(workload=describe, replicas_per_gpu=R, n_atom=int(n_atom), per_system_steps_per_s=steps_done / elapsed,
+                   # the reference's own unit of simulated time (it defines no ns/day, README.md:173-177): steps/s x dt x 86400
+                   sim_time_units_per_day_per_system=steps_done / elapsed * DT * 86400.,
+                   single_system_steps_per_s=single)
+        if remd:
+            cfg.update(exchange_every_steps=exchange_steps_saved, exchange_attempts_timed=timed_attempts, swap_sets=len(swap_sets),
+                       exchange='RCCL: ncclAllGather of one fp32 per replica, device Metropolis, ncclSend/ncclRecv of straddling pairs')
+        res = dict(metric='MD steps/sec (force evals/sec) per 300-res protein' if fix_name.startswith('syn300') else
+                   'MD steps/sec (force evals/sec) per protein', value=value, unit='system-steps/s',
                    n_gpus=world, steps=steps_done, warmup=args.warmup, ms_per_step=elapsed / steps_done * 1e3,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='%s: 300-res synthetic protein, full side-chain BP, 10 A pair list '
-                                        '(BASELINE.json configs[2]); %d independent replicas per GPU, T=%.1f, dt=%.3f, '
-                                        'Langevin thermostat every round' % (args.workload, R, TEMPERATURE, DT),
-                               replicas_per_gpu=R, n_atom=int(n_atom), per_system_steps_per_s=steps_done / elapsed),
-                   roofline=roofline)
+                   higher_is_better=True, scaling='strong' if total_systems else 'weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=cfg, roofline=roofline)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (rank 0 has the host to itself)
             res['cpu_baseline'] = cpu_baseline(fixture, variant)
         print(json.dumps(res))
+    if remd:
+        c.upside_hip_comm_free(eng)
     lib.calc.free_deriv_engine(ct.c_void_p(eng))
     if dist is not None:
         dist.barrier()

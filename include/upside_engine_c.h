@@ -166,9 +166,14 @@ const char* upside_hip_last_error(void);
 
 /* Per-kernel timing hooks used by bench.py.  With profiling enabled every interaction-graph / BP kernel
  * launch is bracketed by HIP events on the engine's stream.  upside_hip_profile_dump writes one text line per
- * kernel: "<kind>:<node> <total ms> <launches> <total algorithmic bytes>" (bytes as defined in DESIGN.md). */
+ * kernel: "<kind>:<node> <total ms> <launches> <total algorithmic bytes> <total pair evaluations>" (bytes as defined in
+ * DESIGN.md; pair evaluations = in-range pairs of system 0 x systems, per launch of a pair pass). */
 int upside_hip_profile_reset(DerivEngine* engine, int enable);
 int upside_hip_profile_dump(DerivEngine* engine, char* buf, int buflen);
+/* VALU issue ceilings measured on this device with a known-instruction-count kernel of the pair kernels' launch shape
+ * (wave-level fp32 FMA instructions per second: rates[0] dependent scalar chain, rates[1] four independent chains per lane):
+ * the denominator of bench.py's roofline.igraph */
+int upside_hip_calibrate_valu(double* rates /* [2] */);
 /* algorithmic bytes of all interaction graphs for one force evaluation of one system */
 double upside_hip_igraph_bytes_per_system(DerivEngine* engine);
 

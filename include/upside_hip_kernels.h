@@ -228,6 +228,8 @@ typedef struct {
     const int* node_nrot;                /* [n_node] */
     const int *bead_node, *bead_rot;     /* [n_bead] */
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
+    const float* param_tri;              /* upper triangle of the (symmetric) pair table: row tri(lo, hi) = interaction_param[lo][hi], lo <= hi;
+                                            (hi, lo) reads the same row with its two angular blocks exchanged (is_compatible, bead_interaction.h:209-218) */
     float* bead_pack;                    /* [S][n_bead][8] packed bead rows for systems whose beads do not fit LDS (else NULL) */
     unsigned long long* grad_acc;        /* [S][n_bead][6] exact fixed-point (x 2^32) gradient accumulators of the gradient pass when a system is
                                             served by several workgroups or does not fit LDS; zero between evaluations */
@@ -297,6 +299,10 @@ int upk_nonlinear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t input,
                                        float inv_dx, int system, float* table);
 /* sum over the elements of output component `comp` (hbond.cpp:436-448: n_hbond) */
 int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, int system, float* out);
+
+/* measured VALU issue ceilings of the device for the pair kernels' launch shape (one 1024-lane workgroup per CU): wave-level
+ * fp32 FMA instructions per second, rates[0] for a dependent scalar chain, rates[1] with four independent chains per lane */
+int upk_calibrate_valu(double* rates);
 
 /* ---- optional restraint / external-field nodes (not emitted by the README configuration) ------------------------- */
 /* single-atom potentials on pos; par is [n][8]:

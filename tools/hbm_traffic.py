@@ -7,7 +7,13 @@ gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so a wide coalesced rea
 pair kernels here gather 16- and 32-byte rows, for which the factor is uncalibrated, so both the raw figure and
 the doubled upper bound are recorded and `bytes_per_launch` uses the raw read + write (a LOWER bound on traffic).
 
-usage: hbm_traffic.py fetch.db write.db workload replicas [out.json]"""
+A third database (the SQ pass) adds `valu_insts_per_launch` = SQ_INSTS_VALU per dispatch, the numerator of bench.py's
+VALU roofline for the interaction-graph kernel.
+
+`pairs` (optional, label=count,...: pair evaluations per launch as bench.py's profile dump reports them) adds
+`valu_insts_per_pair`.
+
+usage: hbm_traffic.py fetch.db write.db workload replicas [out.json] [sq.db] [pairs]"""
 import collections, json, os, sqlite3, sys
 
 LABEL = {  # rocprof kernel name prefix -> (bench.py profile label, index of the launch of that kernel within one force pass)
@@ -29,8 +35,11 @@ def per_kernel(dbfile, counter):
 
 def main():
     fetch_db, write_db, workload, replicas = sys.argv[1:5]
-    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'hbm_traffic.json')
+    sq_db = sys.argv[6] if len(sys.argv) > 6 else None
+    pairs = dict((kv.split('=')[0], float(kv.split('=')[1])) for kv in sys.argv[7].split(',')) if len(sys.argv) > 7 and sys.argv[7] else {}
+    out = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'hbm_traffic.json')
     f = per_kernel(fetch_db, 'FETCH_SIZE'); w = per_kernel(write_db, 'WRITE_SIZE')
+    q = per_kernel(sq_db, 'SQ_INSTS_VALU') if sq_db else {}
     try:
         tab = json.load(open(out))
     except (OSError, ValueError):
@@ -41,6 +50,10 @@ def main():
         label = next((v for key, v in LABEL.items() if key in k), k)   # template instances carry a 'void ...<true>' decoration
         entry[label] = dict(rocprof_kernel=k, launches_sampled=f.get(k, (0, 0))[1], fetch_bytes=fb, fetch_bytes_if_wide=2 * fb,
                             write_bytes=wb, bytes_per_launch=fb + wb)
+        if k in q:
+            entry[label]['valu_insts_per_launch'] = q[k][0]
+            if label in pairs and pairs[label] > 0:
+                entry[label]['valu_insts_per_pair'] = q[k][0] / pairs[label]
     tab['%s/R%s' % (workload, replicas)] = entry
     json.dump(tab, open(out, 'w'), indent=1, sort_keys=True)
     for k, v in sorted(entry.items(), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:

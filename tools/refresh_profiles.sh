@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-for R in 1 64 256 1024 4096; do
+for R in 1 8 64 256 1024 4096; do
   st=100; [ $R -le 64 ] && st=300
   python3 bench.py --replicas $R --steps $st --warmup 30 2>"$OUT/bench_R$R.err" | tail -1 > "$OUT/bench_R$R.json"
 done
@@ -20,7 +20,9 @@ for t in trace fetch write sq; do
   [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" "$OUT/${t}_summary.txt"
 done
 fdb=$(find "$OUT/fetch" -name "*.db" | head -1); wdb=$(find "$OUT/write" -name "*.db" | head -1)
-python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 4096 "$OUT/hbm_traffic.json" > "$OUT/hbm_traffic.txt" 2>&1
+sdb=$(find "$OUT/sq" -name "*.db" | head -1)
+PAIRS=$(python3 -c "import json; d=json.load(open('$OUT/bench_R4096.json')); p=d['roofline']['igraph']['pair_evaluations_per_launch']; print('igraph_bwd:rotamer=%r,igraph_fwd:rotamer=%r' % (p, p))")
+python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 4096 "$OUT/hbm_traffic.json" "$sdb" "$PAIRS" > "$OUT/hbm_traffic.txt" 2>&1
 # keep the merge small: drop the databases
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT"
@@ -30,3 +32,7 @@ for R in 1 8 64 512; do
   st=300; [ $R -ge 64 ] && st=150
   python3 bench.py --workload $w --replicas $R --steps $st --warmup 40 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', $R, round(d['value']))"
 done; done > "$OUT/other_configs.txt"
+# BASELINE configs[3] and [4] on one GPU (the multi-GPU lines need a node the builder cannot launch on)
+for w in remd64_proteinG56 ens512_syn150; do
+  python3 bench.py --workload $w --steps 1665 --warmup 111 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
+done

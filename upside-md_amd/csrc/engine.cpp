@@ -28,11 +28,11 @@ void DeviceCtx::begin(const std::string& fam) {
     hip_check(hipEventRecord(a, stream), "hipEventRecord");
     families[fam].pending.emplace_back(a, b);
 }
-void DeviceCtx::end(const std::string& fam, double algorithmic_bytes) {
+void DeviceCtx::end(const std::string& fam, double algorithmic_bytes, double pair_evaluations) {
     if (!profile) return;
     auto& f = families[fam];
     hip_check(hipEventRecord(f.pending.back().second, stream), "hipEventRecord");
-    f.launches += 1; f.bytes += algorithmic_bytes;
+    f.launches += 1; f.bytes += algorithmic_bytes; f.pairs += pair_evaluations;
 }
 void DeviceCtx::flush_profile() {
     for (auto& kv : families) {

@@ -63,10 +63,10 @@ struct DeviceCtx {
     DevBuf<int> error_flag;          // [1]: pair-list / slot capacity overflow
     // profiling (bench.py): HIP-event timing of kernel families on `stream`
     bool profile = false;
-    struct Family { double ms = 0; long launches = 0; double bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };   // one family = one kernel of one node
+    struct Family { double ms = 0; long launches = 0; double bytes = 0; double pairs = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };   // one family = one kernel of one node
     std::map<std::string, Family> families;
     void begin(const std::string& fam);
-    void end(const std::string& fam, double algorithmic_bytes);
+    void end(const std::string& fam, double algorithmic_bytes, double pair_evaluations = 0.);
     void flush_profile();
 };
 

@@ -29,6 +29,7 @@ static int fail(const string& s) { g_last_error = s; fprintf(stderr, "ERROR: %s\
     catch (const std::exception& e) { fail(e.what()); return ret; } catch (...) { fail("unknown error"); return ret; }
 
 extern "C" const char* upside_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int upside_hip_calibrate_valu(double* rates) { API_TRY upk_check(upk_calibrate_valu(rates), "calibrate_valu"); return 0; API_CATCH(1) }
 extern "C" void upside_hip_set_last_error(const char* msg) { fail(msg); }   // (for the other translation units of the C-ABI)
 
 // ---- construction ----------------------------------------------------------------------------------
@@ -499,7 +500,7 @@ extern "C" int upside_hip_profile_dump(DerivEngine* e, char* buf, int buflen) {
     const double bp_bytes = engine_bp_bytes(*e);   // of the last solve; the step-to-step variation is a few per cent
     for (auto& kv : e->ctx.families) {
         if (kv.first.compare(0, 3, "bp:") == 0 && kv.second.bytes == 0.) kv.second.bytes = bp_bytes * kv.second.launches;
-        snprintf(line, sizeof(line), "%s %.6f %ld %.1f\n", kv.first.c_str(), kv.second.ms, kv.second.launches, kv.second.bytes);
+        snprintf(line, sizeof(line), "%s %.6f %ld %.1f %.1f\n", kv.first.c_str(), kv.second.ms, kv.second.launches, kv.second.bytes, kv.second.pairs);
         out += line;
     }
     if ((int)out.size() + 1 > buflen) throw string("profile buffer too small");

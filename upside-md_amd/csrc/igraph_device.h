@@ -223,18 +223,9 @@ __device__ __forceinline__ void stage_table(float* lds, const float* __restrict_
     for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
 }
 // A symmetric pair table ([nt][nt][n_param] with row (t2, t1) = row (t1, t2) with the two angular blocks exchanged --
-// is_compatible, bead_interaction.h:209-218, checked when the node is built) staged as its upper triangle only: half the LDS
+// is_compatible, bead_interaction.h:209-218, checked when the node is built) is kept as its upper triangle only (the host
+// packs it, upk_rotamer_t::param_tri): half the LDS
 __device__ __forceinline__ int tri_row(int lo, int hi, int nt) { return lo * nt - ((lo * (lo - 1)) >> 1) + (hi - lo); }   // lo <= hi
-__device__ __forceinline__ void stage_table_sym(float* lds, const float* __restrict__ tab, int nt, int n_param) {
-    const int n = (nt * (nt + 1) / 2) * n_param;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const int r = t / n_param, c = t - r * n_param;
-        // row r of the triangle -> (lo, hi): walk the row starts (nt <= a few dozen)
-        int lo = 0, start = 0;
-        while (start + (nt - lo) <= r) { start += nt - lo; ++lo; }
-        lds[t] = tab[(size_t)(lo * nt + lo + (r - start)) * n_param + c];
-    }
-}
 // exact fixed-point image of a float (|v| < 2^31): v * 2^32 as a 64-bit two's-complement integer.  Integer adds commute, so
 // sums accumulated through LDS atomics in any order are the EXACT sum of the contributions (and bit-reproducible); LDS integer
 // atomics run at full rate on gfx950, float ones at 3 cycles per lane (tools/ubench/lds_atomics.hip)
@@ -352,11 +343,13 @@ static inline void pair_geometry(int n_system, int n_rows, int& wgs_per_system, 
     static int target = 0;
     if (!target) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
     int bps = (target + n_system - 1) / n_system;
-    const int max_bps = (n_rows + 31) / 32;                      // at least 32 rows (4 wavefronts' batches) each
+    // every workgroup stages the whole system (table, elements, row order): at least one batch of 8 rows per wavefront of a
+    // 1024-lane workgroup, i.e. 128 rows each -- a single system is served by ~10 fat workgroups, not by 40 thin ones
+    const int max_bps = (n_rows + 127) / 128;
     if (bps > max_bps) bps = max_bps;
     if (bps < 1) bps = 1;
     const int rows_per_wg = (n_rows + bps - 1) / bps;
-    int t = ((rows_per_wg * PG_LANES / 2 + 63) / 64) * 64;       // about two batches per wavefront
+    int t = ((rows_per_wg * PG_LANES + 63) / 64) * 64;           // one batch per wavefront
     threads = t < 256 ? 256 : (t > 1024 ? 1024 : t);
     wgs_per_system = bps;
 }

@@ -385,3 +385,46 @@ extern "C" int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph
                        sens, sens_sys_stride, sens_stride);
     return launch_status();
 }
+
+// ---- VALU issue ceiling of this device, measured (bench.py: roofline.igraph) ---------------------------------------------
+// The pair functors are long dependent chains of fp32 operations evaluated by one 1024-lane workgroup per CU (4 wavefronts
+// per SIMD).  k_valu_chain runs exactly that shape with a known instruction count: ILP independent fused multiply-adds per
+// lane, 16 * ILP per iteration.  ILP 1 = what scalar dependent code can issue (one VALU instruction per ~4.3 cycles per
+// SIMD on gfx950, whatever the occupancy); ILP 4 lets the compiler pack pairs (v_pk_fma_f32) and approaches the
+// 2-cycle-per-instruction peak the data sheet's 157 TFLOP/s assumes.
+template <int ILP>
+__global__ void __launch_bounds__(1024) k_valu_chain(float* out, int iters, float a, float b) {
+    float x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) x[i] = threadIdx.x * 1e-3f + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < ILP; ++i) x[i] = __builtin_fmaf(x[i], a, b);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) s += x[i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// rates in wave-level fp32 FMA instructions per second for the whole device: [0] dependent scalar chain, [1] four independent chains
+extern "C" int upk_calibrate_valu(double* rates) {
+    const int cu = upk_device_cu_count(), iters = 20000;
+    float* out = nullptr;
+    if (hipMalloc((void**)&out, (size_t)cu * 1024 * sizeof(float)) != hipSuccess) return 1;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int v = 0; v < 2; ++v) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {     // (the first launch warms the clocks)
+            (void)hipEventRecord(e0, nullptr);
+            if (v == 0) hipLaunchKernelGGL(k_valu_chain<1>, dim3(cu), dim3(1024), 0, nullptr, out, iters, 1.0001f, 0.5f);
+            else hipLaunchKernelGGL(k_valu_chain<4>, dim3(cu), dim3(1024), 0, nullptr, out, iters, 1.0001f, 0.5f);
+            (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+            (void)hipEventElapsedTime(&ms, e0, e1);
+        }
+        rates[v] = (double)cu * 16 /* wavefronts */ * iters * 16.0 * (v == 0 ? 1 : 4) / (ms * 1e-3);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+    return launch_status();
+}

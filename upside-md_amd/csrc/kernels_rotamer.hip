@@ -283,7 +283,7 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
     RotLds r;
     r.tab = lds;
     float* p = lds + ((tab_floats + 3) & ~3);
-    stage_table_sym(r.tab, G.param, G.n_type1, G.n_param);
+    stage_table(r.tab, R.param_tri, tab_floats);
     r.acc = nullptr;
     if (STAGED) {
         if (want_acc) { r.acc = (unsigned long long*)p; p += G.n1 * 12; for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) r.acc[t] = 0ull; }

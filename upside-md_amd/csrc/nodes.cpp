@@ -537,13 +537,14 @@ struct IGraphHost {
     double bytes_bwd(int n_launch) { return ctx->n_system * (coord_bytes() + 8. * edges()) / n_launch; }
     double algorithmic_bytes() { return bytes_fwd() + bytes_bwd(1); }
     struct Prof {   // brackets ONE kernel launch with HIP events when profiling is on
-        DeviceCtx* c; std::string nm; double bytes;
+        DeviceCtx* c; std::string nm; double bytes; double pairs = 0.;   // pairs: functor evaluations of the launch (in-range pairs of system 0 x systems; every pass visits a pair once)
         Prof(IGraphHost& ig, const std::string& owner, const char* kind, int bwd_launches) : c(ig.ctx) {
             if (!c->profile) return;
             nm = std::string(kind) + ":" + owner; bytes = bwd_launches ? ig.bytes_bwd(bwd_launches) : ig.bytes_fwd();
+            pairs = ig.edges() * c->n_system;
             c->begin(nm);
         }
-        ~Prof() { if (c->profile) c->end(nm, bytes); }
+        ~Prof() { if (c->profile) c->end(nm, bytes, pairs); }
     };
     // canonical in-range pair list of one system (parity/diagnostics)
     vector<pair<int, int>> pairlist(int sys) {
@@ -1041,7 +1042,7 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
-    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
@@ -1121,8 +1122,16 @@ struct RotamerSidechain : public PotentialNode {
         fill_struct();
     }
     bool one_bead_per_state = false;
+    void pack_param_tri() {   // upper triangle of the pair table, the form the bead-pair kernels stage in LDS
+        const int nt = ig.G.n_type1, np = ig.G.n_param;
+        vector<float> tri; tri.reserve((size_t)nt * (nt + 1) / 2 * np);
+        for (int lo = 0; lo < nt; ++lo) for (int hi = lo; hi < nt; ++hi)
+            tri.insert(tri.end(), ig.param.begin() + (size_t)(lo * nt + hi) * np, ig.param.begin() + (size_t)(lo * nt + hi + 1) * np);
+        param_tri.upload(tri); R.param_tri = param_tri.p;
+    }
     void fill_struct() {
         R.G = ig.G;
+        pack_param_tri();
         R.one_bead_per_state = one_bead_per_state ? 1 : 0;
         R.n_node = n_node; R.n_node1 = n1; R.n_node3 = n3;
         R.node_nrot = d_node_nrot.p; R.bead_node = d_bead_node.p; R.bead_rot = d_bead_rot.p;
@@ -1225,7 +1234,7 @@ struct RotamerSidechain : public PotentialNode {
             hip_check(hipMemcpyAsync(potential_dev.p, energy.p, ctx->n_system * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream), "D2D");
     }
     vector<float> get_param() const override { return ig.param; }
-    void set_param(const vector<float>& p) override { ig.set_param(p); R.G = ig.G; }
+    void set_param(const vector<float>& p) override { ig.set_param(p); R.G = ig.G; pack_param_tri(); }
     vector<float> get_param_deriv(int system) override {   // rotamer.cpp:1064-1066
         return param_deriv_table(ctx, ig.param.size(), [&](float* t) { upk_check(upk_rotamer_param_deriv(&ctx->L, &R, system, t), "rotamer param_deriv"); });
     }
