@@ -4,11 +4,18 @@
 // edge indices (engine_c_library.h:12-32), so this instantiates
 // InteractionGraph<preferred_bead_type> (interaction_graph.h:261, bead_interaction.h:221) on
 // /input/potential/rotamer/pair_interaction and dumps edge_indices1/2, edge_id1/2, edge_value.
+// The pair functors of the asymmetric graphs (hbond.cpp:152-286, environment.cpp:12-69) live in anonymous namespaces of
+// their translation units, so those two reference files are INCLUDED here from /root/reference/src (and their objects left
+// out of the link, oracle/Makefile): the node classes then are nameable, and the edge lists of the engine's own
+// protein_hbond / hbond_coverage* / environment_coverage nodes are dumped after the force pass, one section per node:
+//   graph <node name> n_edge <n>      followed by n lines  "i1 i2"
 //
 // usage: pairlist_dump config.up out.txt
 #include "deriv_engine.h"
 #include "interaction_graph.h"
 #include "bead_interaction.h"
+#include "hbond.cpp"
+#include "environment.cpp"
 #include <cstdio>
 using namespace h5;
 using namespace std;
@@ -36,6 +43,17 @@ int main(int argc, char** argv) try {
         for(int ne=0; ne<ig.n_edge; ++ne)
             fprintf(f, "%i %i %i %i %.9g\n", ig.edge_indices1[ne], ig.edge_indices2[ne],
                     ig.edge_id1[ne], ig.edge_id2[ne], ig.edge_value[ne]);
+    }
+    // the asymmetric graphs, straight from the engine's nodes (state of the force pass above)
+    for(auto& n : engine.nodes) {
+        auto* c = n.computation.get();
+        int n_edge = -1; const int *i1 = nullptr, *i2 = nullptr;
+        if(auto* p = dynamic_cast<ProteinHBond*>(c))             {n_edge = p->igraph.n_edge; i1 = p->igraph.edge_indices1; i2 = p->igraph.edge_indices2;}
+        else if(auto* p = dynamic_cast<HBondCoverage*>(c))       {n_edge = p->igraph.n_edge; i1 = p->igraph.edge_indices1; i2 = p->igraph.edge_indices2;}
+        else if(auto* p = dynamic_cast<EnvironmentCoverage*>(c)) {n_edge = p->igraph.n_edge; i1 = p->igraph.edge_indices1; i2 = p->igraph.edge_indices2;}
+        if(n_edge < 0) continue;
+        fprintf(f, "graph %s n_edge %i\n", n.name.c_str(), n_edge);
+        for(int ne=0; ne<n_edge; ++ne) fprintf(f, "%i %i\n", i1[ne], i2[ne]);
     }
     fclose(f);
     return 0;

@@ -84,18 +84,28 @@ def test_force_pass_matches_oracle(hip, name):
     up.close(); orc.close()
 
 
-@pytest.mark.parametrize('name', ['proteinG56_7A', 'syn300_10A'])
+@pytest.mark.parametrize('name', FIXTURES)
 def test_forces_match_reference_golden(hip, name):
-    """the committed golden vectors of the unmodified reference; tolerance = the reference's own build-to-build
-    spread (profiles/r01_reference_noise_floor.txt), see tests/test_oracle_pinning.py"""
+    """the committed golden vectors of the unmodified reference, all five fixtures, both structures (the second one through
+    the cached pair lists).  Forces and sensitivities within P.golden_tol = max(1e-5, 2 x the reference's own build-to-build
+    spread on that fixture and structure): 1e-5 on the benchmark fixture syn300_10A and on trpcage20_7A's first structure,
+    up to 9e-5 on the over-compact syn150_10A (tests/golden/reference_noise_floor.json); node outputs within 1e-5; the
+    reference's own canonical pair list of the side-chain graph bit for bit."""
     g = P.golden(name)
     up = P.pkg.Upside(P.fixture(name))
-    act = P.evaluate_all(up, g['pos'])
-    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4
-    for k in g:
-        if k.startswith('out/'):
-            assert P.rel_rms(g[k], act[k]) < 1e-5, k
-    assert np.array_equal(hip_pairlist(up, 'rotamer'), g['pairlist/edges'][:, :2])
+    for tag, dkey in (('pos', 'deriv'), ('pos2', 'deriv2')):
+        act = P.evaluate_all(up, g[tag])
+        err = P.rel_rms(g[dkey], act['deriv'])
+        assert err < P.golden_tol(name, tag, 'deriv'), (tag, err, P.golden_tol(name, tag, 'deriv'))
+        if tag == 'pos':
+            for k in g:
+                if k.startswith('out/'):
+                    assert P.rel_rms(g[k], act[k]) < 1e-5, k
+                elif k.startswith('sens/') and k in act:
+                    assert P.rel_rms(g[k], act[k]) < P.golden_tol(name, tag, 'sens'), (k, P.rel_rms(g[k], act[k]))
+            assert np.array_equal(hip_pairlist(up, 'rotamer'), g['pairlist/edges'][:, :2])
+            for node in IGRAPH_NODES[1:]:      # the four asymmetric graphs against the reference's own edge lists
+                assert np.array_equal(hip_pairlist(up, node), g['pairlist/' + node]), node
     up.close()
 
 
@@ -137,7 +147,7 @@ def test_optional_restraint_nodes_match_oracle_and_reference(hip):
     assert_close(ref, act, keys=keys)
     scale = sum(abs(float(ref['pot/' + k])) for k in P.POTENTIAL_NODES + P.RESTRAINT_POTENTIALS)
     assert abs(float(ref['energy']) - float(act['energy'])) < RTOL * scale
-    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4                       # the reference's own spread, as above
+    assert P.rel_rms(g['deriv'], act['deriv']) < P.golden_tol(name, 'pos', 'deriv')      # 2 x the reference's own spread, as above
     for k in g:
         if k.startswith('pot/') and k[4:] in P.RESTRAINT_POTENTIALS:
             assert abs(float(g[k]) - float(act[k])) < RTOL * max(1., abs(float(g[k]))), k
@@ -164,7 +174,7 @@ def test_degenerate_sequences(hip, name):
     assert_close(ref, act, keys=[k for k in ref if k != 'energy' and np.asarray(ref[k]).size])
     scale = sum(abs(float(ref['pot/' + k])) for k in P.POTENTIAL_NODES)
     assert abs(float(ref['energy']) - float(act['energy'])) <= RTOL * scale
-    assert P.rel_rms(g['deriv'], act['deriv']) < 3e-4
+    assert P.rel_rms(g['deriv'], act['deriv']) < P.golden_tol(name, 'pos', 'deriv')
     assert abs(float(g['energy']) - float(act['energy'])) < 1e-4 * max(1., scale)
     for node in IGRAPH_NODES:
         assert np.array_equal(hip_pairlist(up, node), P.oracle_pairlist(orc, node)), node
@@ -579,7 +589,7 @@ def test_alternate_code_paths_agree(tmp_path):
 
     base = run({}, 'default')
     for tag in ('pos', 'pos2'):
-        assert P.rel_rms(g['deriv' if tag == 'pos' else 'deriv2'], base['force_' + tag]) < 3e-4
+        assert P.rel_rms(g['deriv' if tag == 'pos' else 'deriv2'], base['force_' + tag]) < P.golden_tol(name, tag, 'deriv')
     assert P.rel_rms(base['force_pos'], base['ens_force'][0]) < 1e-6
     for i, env_extra in enumerate(ALT_PATHS):
         alt = run(env_extra, 'alt%d' % i)
@@ -898,6 +908,49 @@ def test_long_md_is_thermalised_and_stable(hip):
     assert len({round(float(x), 3) for x in e1}) == 8          # independent thermostat streams -> distinct trajectories
     e0b, e1b, ratios_b, pos_b = run()
     assert np.array_equal(pos, pos_b) and np.array_equal(e1, e1b)   # bit-reproducible run to run
+
+
+def test_protein_g_10k_steps_match_reference_statistics(hip, tmp_path):
+    """BASELINE.json configs[1] at full length: Protein G (56 residues), constant-T Langevin MD, 10 k force evaluations
+    (--duration 90 = 3334 rounds), through `upside_main` on the GPU and through the unmodified reference executable on the
+    host, 8 independent copies each (different seeds, one config file per copy as in the reference).  fp32 MD is chaotic, so
+    the two programs are compared as samplers of the same ensemble (what the reference itself prints at the end of a run,
+    main.cpp:684-697): the mean potential over the second half of the run agrees within 4 combined standard errors (block
+    averages over the copies), the kinetic energy equilibrates to 1.5 kT per atom in both, and every copy stays finite."""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name = 'proteinG56_7A'
+    n_copy, T = 8, 0.8
+    args = ['--duration', '90', '--frame-interval', '0.9', '--temperature', str(T), '--seed', '31']     # a frame every 33 rounds: 101 frames
+    files = {}
+    for who in ('ref', 'hip'):
+        files[who] = [str(tmp_path / ('%s%d.up' % (who, i))) for i in range(n_copy)]
+        for f in files[who]:
+            shutil.copyfile(P.fixture(name), f)
+    subprocess.run([ref_exe] + args + files['ref'], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900,
+                   env=dict(os.environ, OMP_NUM_THREADS=str(n_copy)))
+    hip.in_process_upside(args + files['hip'], verbose=False)
+    n_atom = P.golden(name)['pos'].shape[0]
+    stats = {}
+    for who in ('ref', 'hip'):
+        pot, kin = [], []
+        for f in files[who]:
+            out, _ = _read_output(f)
+            assert out['potential'].shape[0] >= 100 and np.all(np.isfinite(out['pos'])), (who, out['potential'].shape)
+            half = out['potential'].shape[0] // 2
+            pot.append(np.asarray(out['potential'][half:, 0], 'f8')); kin.append(np.asarray(out['kinetic'][half:, 0], 'f8'))
+        pot, kin = np.array(pot), np.array(kin)                 # (copy, frame)
+        per_copy = pot.mean(axis=1)
+        stats[who] = dict(mean=per_copy.mean(), se=per_copy.std(ddof=1) / np.sqrt(n_copy), kin=kin.mean() / (1.5 * T))
+    # kinetic is logged per atom: <p^2>/2 per atom = 1.5 kT in equilibrium (main.cpp:686-697)
+    for who in ('ref', 'hip'):
+        assert abs(stats[who]['kin'] - 1.0) < 0.03, (who, stats[who])
+    d = abs(stats['ref']['mean'] - stats['hip']['mean'])
+    se = np.hypot(stats['ref']['se'], stats['hip']['se'])
+    assert d < 4. * se + 1e-3 * abs(stats['ref']['mean']), (stats, d, se)
 
 
 def test_upside_main_jump_moves_match_reference(hip, tmp_path):

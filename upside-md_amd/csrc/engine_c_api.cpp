@@ -204,8 +204,9 @@ void clamped_de_boor(float& val, float& der, const float* c, float x, int n, boo
 }
 }  // namespace
 extern "C" int clamped_spline_solve(int N, float* bspline_coeff, const float* values) {
-    vector<double> temp(3 * N), c(N), v(values, values + (N - 2));
-    splinefit::solve_clamped_1d_spline_for_bsplines(N, c.data(), v.data(), temp.data());
+    if (N < 3) return 1;
+    const vector<double> v(values, values + (N - 2));
+    const vector<double> c = tablefit::clamped_control_values_with_ghosts(v.data(), N - 2);
     for (int i = 0; i < N; ++i) bspline_coeff[i] = (float)c[i];
     return 0;
 }

@@ -1,123 +1,148 @@
-// Host-side, construction-time spline fitting (double precision), as in the reference where tables are
-// fitted once while the engine is built: /root/reference/src/spline.cpp:7-156, 158-189, 262-292 and
-// spline.h:396-431 (LayeredPeriodicSpline2D::fit_spline).  Also the four scalar spline helpers the C-ABI
-// exports (engine_c_library.cpp:196-276), which never touch an engine.
+// Host-side, construction-time fitting of interpolating cubic splines (double precision) for the device tables: the
+// Ramachandran maps and the rotamer placement maps (periodic, bicubic patches) and the membrane profiles (clamped ends).
+// What has to come out is fixed by the reference -- the same interpolant in the same storage layout
+// (/root/reference/src/spline.h:396-431, 456-493 read the tables as per-cell monomial coefficients; the maths is the
+// uniform cubic B-spline through the samples, spline.cpp) -- how it is computed is not: here one generic routine solves the
+// constant-coefficient interpolation system  (c[i-1] + 4 c[i] + c[i+1]) / 6 = y[i]  for the B-spline control values with
+// either boundary rule (wrap-around or mirrored ghosts = zero end slope) by plain elimination that carries the wrap-around
+// column along, and one 4x4 matrix turns four consecutive control values into the monomial coefficients of a cell.
 #pragma once
-#include <cstring>
+#include <cstddef>
 #include <vector>
+using std::size_t;
 
-namespace splinefit {
+namespace tablefit {
 
-inline void solve_tridiagonal_system(int n, double* d, double* a, double* b, double* c) {   // Thomas algorithm
-    for (int k = 1; k < n; ++k) { const double m = a[k - 1] / b[k - 1]; b[k] -= m * c[k - 1]; d[k] -= m * d[k - 1]; }
-    d[n - 1] = d[n - 1] / b[n - 1];
-    for (int k = n - 2; k >= 0; --k) d[k] = (d[k] - c[k] * d[k + 1]) / b[k];
-}
+enum class Ends { Periodic, ZeroSlope };
 
-// periodic tridiagonal system through the Sherman-Morrison formula
-inline void solve_periodic_tridiagonal_system(int n, double* solution, double* d, double* a, double* b, double* c, double* tmp) {
-    const double b1 = b[0], cn = c[n - 1], ratio = a[0] / b1;
-    b[0] += b1; b[n - 1] += ratio * cn;
-    std::memcpy(tmp, a, n * sizeof(double)); std::memcpy(tmp + n, b, n * sizeof(double)); std::memcpy(tmp + 2 * n, c, n * sizeof(double));
-    solution[0] = -b1;
-    for (int i = 1; i < n - 1; ++i) solution[i] = 0.;
-    solution[n - 1] = cn;
-    double* q = solution;
-    solve_tridiagonal_system(n, q, a + 1, b, c);
-    std::memcpy(a, tmp, n * sizeof(double)); std::memcpy(b, tmp + n, n * sizeof(double)); std::memcpy(c, tmp + 2 * n, n * sizeof(double));
-    double* y = d;
-    solve_tridiagonal_system(n, d, a + 1, b, c);
-    const double q_prefactor = (y[0] - y[n - 1] * ratio) / (1. + q[0] - q[n - 1] * ratio);
-    for (int i = 0; i < n; ++i) solution[i] = y[i] - q_prefactor * q[i];
-}
-
-// cubic B-spline pieces in the monomial basis on [0,1)
-static const double kBsplineMonomial[4][4] = {
-    {0. / 6., 0. / 6., 0. / 6., 1. / 6.}, {1. / 6., 3. / 6., 3. / 6., -3. / 6.},
-    {4. / 6., 0. / 6., -6. / 6., 3. / 6.}, {1. / 6., -3. / 6., 3. / 6., -1. / 6.}};
-
-inline void solve_periodic_1d_spline(int n, double* coefficients, const double* data, double* ts) {
-    double *a = ts, *b = ts + n, *c = ts + 2 * n, *d = ts + 3 * n, *solution = ts + 4 * n, *later = ts + 5 * n;
-    for (int i = 0; i < n; ++i) { a[i] = 1. / 6.; b[i] = 2. / 3.; c[i] = 1. / 6.; d[i] = data[i]; }
-    solve_periodic_tridiagonal_system(n, solution, d, a, b, c, later);
-    for (int i = 0; i < 4 * n; ++i) coefficients[i] = 0.;
-    for (int i = 0; i < n; ++i)
-        for (int inc = 0; inc < 4; ++inc) {
-            int idx = i + inc - 2;
-            if (idx < 0) idx += n;
-            if (idx >= n) idx -= n;
-            for (int k = 0; k < 4; ++k) coefficients[idx * 4 + k] += solution[i] * kBsplineMonomial[inc][k];
+// control values c[0..n) of the uniform cubic B-spline that interpolates y[0..n) on the integer grid.
+// Periodic: c[-1] = c[n-1], c[n] = c[0].  ZeroSlope: mirrored ghosts c[-1] = c[1], c[n] = c[n-2] (first derivative 0 at both ends).
+inline std::vector<double> control_values(const double* y, int n, Ends ends) {
+    std::vector<double> c(y, y + n);
+    if (n == 1) { c[0] = y[0]; return c; }            // a constant
+    // rows: lower[i] c[i-1] + diag[i] c[i] + upper[i] c[i+1] (+ wrap[i] c[n-1] for the periodic corner) = rhs[i]
+    std::vector<double> diag(n, 4. / 6.), upper(n, 1. / 6.), lower(n, 1. / 6.), wrap(n, 0.);
+    double last_row_first = 0.;                        // coefficient of c[0] in the last row (periodic corner)
+    if (ends == Ends::ZeroSlope) { upper[0] = 2. / 6.; lower[n - 1] = 2. / 6.; }
+    else if (n == 2) { upper[0] = 2. / 6.; lower[1] = 2. / 6.; }      // both neighbours of a point are the other point
+    else { wrap[0] = 1. / 6.; last_row_first = 1. / 6.; }
+    // forward elimination of the sub-diagonal; the last row is kept apart and reduced against every pivot row as well, so
+    // its c[0] entry (the second corner) travels right until it lands on the last two columns
+    double lr_coef = last_row_first;                   // entry of the last row in the current pivot column
+    double lr_diag = diag[n - 1], lr_rhs = c[n - 1];   // its c[n-1] entry and right-hand side
+    double lr_prev = lower[n - 1];                     // its genuine c[n-2] entry
+    for (int i = 0; i + 1 < n; ++i) {
+        const bool last_pivot = i == n - 2;
+        if (last_pivot) lr_coef += lr_prev;            // the wandering entry has reached column n-2
+        // reduce the last row against pivot row i (entries of row i: diag[i] at i, upper[i] at i+1, wrap[i] at n-1)
+        const double f = lr_coef / diag[i];
+        lr_rhs -= f * c[i];
+        lr_diag -= f * (last_pivot ? upper[i] + wrap[i] : wrap[i]);
+        lr_coef = last_pivot ? 0. : -f * upper[i];     // becomes the entry in column i+1
+        if (!last_pivot) {                             // reduce row i+1 (its sub-diagonal) against row i
+            const double g = lower[i + 1] / diag[i];
+            diag[i + 1] -= g * upper[i];
+            wrap[i + 1] -= g * wrap[i];
+            c[i + 1] -= g * c[i];
         }
-}
-
-inline void solve_periodic_2d_spline(int nx, int ny, double* coefficients, const double* data, double* ts) {
-    const int sum_dim = nx + ny;
-    double* splines_1d = ts;
-    double* scratch = splines_1d + (size_t)nx * ny * 4;
-    double* values_temp = scratch + sum_dim * 8;
-    double* coeffs_temp = values_temp + sum_dim * 4;
-    for (int ix = 0; ix < nx; ++ix) solve_periodic_1d_spline(ny, splines_1d + (size_t)ix * ny * 4, data + (size_t)ix * ny, scratch);
-    for (int iy = 0; iy < ny; ++iy)
-        for (int py = 0; py < 4; ++py) {
-            for (int ix = 0; ix < nx; ++ix) values_temp[ix] = splines_1d[(size_t)ix * ny * 4 + iy * 4 + py];
-            solve_periodic_1d_spline(nx, coeffs_temp, values_temp, scratch);
-            for (int ix = 0; ix < nx; ++ix)
-                for (int px = 0; px < 4; ++px) coefficients[(size_t)ix * ny * 16 + iy * 16 + px * 4 + py] = coeffs_temp[ix * 4 + px];
-        }
-}
-
-inline void solve_clamped_1d_spline_for_bsplines(int n_coeff, double* coefficients, const double* data, double* ts) {
-    const int n = n_coeff - 2;
-    double *a = ts, *b = ts + n_coeff, *c = ts + 2 * n_coeff;
-    for (int i = 0; i < n; ++i) { a[i] = 1. / 6.; b[i] = 2. / 3.; c[i] = 1. / 6.; coefficients[i + 1] = data[i]; }
-    a[n - 1] *= 2.; c[0] *= 2.;
-    solve_tridiagonal_system(n_coeff - 2, coefficients + 1, a + 1, b, c);
-    coefficients[0] = coefficients[2];
-    coefficients[n_coeff - 1] = coefficients[n_coeff - 3];
-}
-
-// spline.cpp:192-259: clamped (zero end-slope) interpolating cubic through n points on the integer grid, as monomial
-// coefficients of its n-1 intervals
-inline void solve_clamped_1d_spline(int n, double* coefficients, const double* data, double* ts) {
-    double *a = ts, *b = ts + n, *c = ts + 2 * n, *solution = ts + 3 * n;
-    for (int i = 0; i < n; ++i) { a[i] = 1. / 6.; b[i] = 2. / 3.; c[i] = 1. / 6.; solution[i] = data[i]; }
-    a[n - 1] *= 2.; c[0] *= 2.;
-    solve_tridiagonal_system(n, solution, a + 1, b, c);
-    for (int i = 0; i < 4 * (n - 1); ++i) coefficients[i] = 0.;
-    for (int i = 0; i < n; ++i)
-        for (int inc = 0; inc < 4; ++inc) {
-            const int idx = i + inc - 2;
-            if (idx < 0 || idx >= n - 1) continue;
-            for (int k = 0; k < 4; ++k) coefficients[idx * 4 + k] += solution[i] * kBsplineMonomial[inc][k];
-        }
-    for (int k = 0; k < 4; ++k) coefficients[k] += solution[1] * kBsplineMonomial[3][k];                      // left wing
-    for (int k = 0; k < 4; ++k) coefficients[(n - 2) * 4 + k] += solution[n - 2] * kBsplineMonomial[0][k];    // right wing
-}
-
-}  // namespace splinefit
-
-// spline.h:456-493 LayeredClampedSpline1D<1>::fit_spline: data (n_layer,nx) -> fp32 (n_layer,nx-1,4)
-inline std::vector<float> fit_layered_clamped_spline1d(const std::vector<double>& data, int n_layer, int nx) {
-    std::vector<float> out((size_t)n_layer * (nx - 1) * 4);
-    std::vector<double> coeff((size_t)(nx - 1) * 4), ts((size_t)4 * nx);
-    for (int il = 0; il < n_layer; ++il) {
-        splinefit::solve_clamped_1d_spline(nx, coeff.data(), data.data() + (size_t)il * nx, ts.data());
-        for (size_t i = 0; i < coeff.size(); ++i) out[(size_t)il * (nx - 1) * 4 + i] = (float)coeff[i];
     }
+    // back substitution (row n-2's "upper" and "wrap" are the same column)
+    c[n - 1] = lr_rhs / lr_diag;
+    for (int i = n - 2; i >= 0; --i) {
+        const double tail = i == n - 2 ? (upper[i] + wrap[i]) * c[n - 1] : upper[i] * c[i + 1] + wrap[i] * c[n - 1];
+        c[i] = (c[i] - tail) / diag[i];
+    }
+    return c;
+}
+
+// monomial coefficients (powers 0..3 of the offset t in [0,1) from the cell's left sample) of the cell whose four
+// relevant control values are c[-1], c[0], c[1], c[2]
+static const double kCellFromControl[4][4] = {
+    { 1. / 6.,  4. / 6.,  1. / 6., 0.      },
+    {-3. / 6.,  0.,       3. / 6., 0.      },
+    { 3. / 6., -6. / 6.,  3. / 6., 0.      },
+    {-1. / 6.,  3. / 6., -3. / 6., 1. / 6. }};
+
+inline int wrap_index(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+inline int mirror_index(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// (n-1 cells) x 4 monomial coefficients of the zero-end-slope interpolant through y[0..n)
+inline std::vector<double> clamped_cells(const double* y, int n) {
+    const std::vector<double> c = control_values(y, n, Ends::ZeroSlope);
+    std::vector<double> cell((size_t)(n - 1) * 4);
+    for (int i = 0; i + 1 < n; ++i)
+        for (int p = 0; p < 4; ++p) {
+            double v = 0.;
+            for (int k = 0; k < 4; ++k) v += kCellFromControl[p][k] * c[mirror_index(i - 1 + k, n)];
+            cell[(size_t)i * 4 + p] = v;
+        }
+    return cell;
+}
+
+// nx x ny cells x 16 (power of x major, power of y minor) of the doubly periodic interpolant through y[ix*ny + iy]
+inline std::vector<double> periodic_patches(const double* y, int nx, int ny) {
+    // control values of the tensor-product spline: the 1-d solve along y for every x, then along x for every y
+    std::vector<double> ctl((size_t)nx * ny), line(nx > ny ? nx : ny);
+    for (int ix = 0; ix < nx; ++ix) {
+        const std::vector<double> c = control_values(y + (size_t)ix * ny, ny, Ends::Periodic);
+        for (int iy = 0; iy < ny; ++iy) ctl[(size_t)ix * ny + iy] = c[iy];
+    }
+    for (int iy = 0; iy < ny; ++iy) {
+        for (int ix = 0; ix < nx; ++ix) line[ix] = ctl[(size_t)ix * ny + iy];
+        const std::vector<double> c = control_values(line.data(), nx, Ends::Periodic);
+        for (int ix = 0; ix < nx; ++ix) ctl[(size_t)ix * ny + iy] = c[ix];
+    }
+    std::vector<double> patch((size_t)nx * ny * 16);
+    for (int ix = 0; ix < nx; ++ix)
+        for (int iy = 0; iy < ny; ++iy) {
+            double nb[4][4], half[4][4];       // the cell's 4x4 control values; after the x transform
+            for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) nb[a][b] = ctl[(size_t)wrap_index(ix - 1 + a, nx) * ny + wrap_index(iy - 1 + b, ny)];
+            for (int px = 0; px < 4; ++px) for (int b = 0; b < 4; ++b) {
+                double v = 0.;
+                for (int a = 0; a < 4; ++a) v += kCellFromControl[px][a] * nb[a][b];
+                half[px][b] = v;
+            }
+            double* out = &patch[((size_t)ix * ny + iy) * 16];
+            for (int px = 0; px < 4; ++px) for (int py = 0; py < 4; ++py) {
+                double v = 0.;
+                for (int b = 0; b < 4; ++b) v += kCellFromControl[py][b] * half[px][b];
+                out[px * 4 + py] = v;
+            }
+        }
+    return patch;
+}
+
+// the N + 2 control values (ghosts included) of the zero-end-slope interpolant through N samples: what the C-ABI's
+// clamped_spline_solve returns (engine_c_library.cpp:196-212)
+inline std::vector<double> clamped_control_values_with_ghosts(const double* y, int n) {
+    const std::vector<double> c = control_values(y, n, Ends::ZeroSlope);
+    std::vector<double> out((size_t)n + 2);
+    for (int i = 0; i < n; ++i) out[i + 1] = c[i];
+    out[0] = c[mirror_index(-1, n)]; out[n + 1] = c[mirror_index(n, n)];
     return out;
 }
 
-// data (n_layer,nx,ny,ndim) -> fp32 bicubic patch coefficients (n_layer,nx,ny,ndim,16)
+}  // namespace tablefit
+
+// data (n_layer,nx) -> fp32 (n_layer,nx-1,4): the membrane profiles (reference storage: spline.h:456-493)
+inline std::vector<float> fit_layered_clamped_spline1d(const std::vector<double>& data, int n_layer, int nx) {
+    std::vector<float> out;
+    out.reserve((size_t)n_layer * (nx - 1) * 4);
+    for (int il = 0; il < n_layer; ++il)
+        for (double v : tablefit::clamped_cells(data.data() + (size_t)il * nx, nx)) out.push_back((float)v);
+    return out;
+}
+
+// data (n_layer,nx,ny,ndim) -> fp32 bicubic patch coefficients (n_layer,nx,ny,ndim,16) (reference storage: spline.h:396-431)
 inline std::vector<float> fit_layered_periodic_spline2d(const std::vector<double>& data, int n_layer, int nx, int ny, int ndim) {
     std::vector<float> out((size_t)n_layer * nx * ny * ndim * 16);
-    std::vector<double> coeff_tmp((size_t)nx * ny * 16), data_tmp((size_t)nx * ny), ts((size_t)(nx + 8) * (ny + 8) * 4 + 64 * (size_t)(nx + ny));
+    std::vector<double> plane((size_t)nx * ny);
     for (int il = 0; il < n_layer; ++il)
         for (int id = 0; id < ndim; ++id) {
-            for (int ix = 0; ix < nx; ++ix) for (int iy = 0; iy < ny; ++iy)
-                data_tmp[(size_t)ix * ny + iy] = data[(((size_t)il * nx + ix) * ny + iy) * ndim + id];
-            splinefit::solve_periodic_2d_spline(nx, ny, coeff_tmp.data(), data_tmp.data(), ts.data());
-            for (int ix = 0; ix < nx; ++ix) for (int iy = 0; iy < ny; ++iy) for (int ic = 0; ic < 16; ++ic)
-                out[((((size_t)il * nx + ix) * ny + iy) * ndim + id) * 16 + ic] = (float)coeff_tmp[((size_t)ix * ny + iy) * 16 + ic];
+            for (size_t cell = 0; cell < plane.size(); ++cell) plane[cell] = data[((size_t)il * nx * ny + cell) * ndim + id];
+            const std::vector<double> patch = tablefit::periodic_patches(plane.data(), nx, ny);
+            for (size_t cell = 0; cell < plane.size(); ++cell)
+                for (int k = 0; k < 16; ++k) out[(((size_t)il * nx * ny + cell) * ndim + id) * 16 + k] = (float)patch[cell * 16 + k];
         }
     return out;
 }
