@@ -156,6 +156,8 @@ def main():
                     help='independent replicas resident per GPU')
     ap.add_argument('--workload', default='syn300_10A')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-single-system', action='store_true',
+                    help='skip the one-replica latency leg (PMC passes: keeps its small launches out of the per-kernel averages)')
     args = ap.parse_args()
 
     pkg = load_package()
@@ -299,11 +301,12 @@ def main():
                                             'four independent chains per lane (packed issue) reach peak_ilp4',
                                   peak_ilp4=rates[1] / 1e9, hbm=entry(ig))
         roofline['kernels'] = {r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
-                                          GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None) for r in rows}
+                                          GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None,
+                                          pair_evaluations=(r[4] / r[2]) if r[4] else None) for r in rows}
 
     # single-system latency of the same workload (one replica on the GPU), outside the timed region
     single = None
-    if rank == 0:
+    if rank == 0 and not args.no_single_system:
         eng1 = c.upside_hip_construct(n_atom, fixture.encode(), 1, True)
         if eng1:
             p1 = np.ascontiguousarray(pos0[None].astype('f4')); t1 = np.full(1, TEMPERATURE, dtype='f4')

@@ -177,6 +177,15 @@ int upside_hip_calibrate_valu(double* rates /* [2] */);
 /* algorithmic bytes of all interaction graphs for one force evaluation of one system */
 double upside_hip_igraph_bytes_per_system(DerivEngine* engine);
 
+/* Node types defined outside this library (include/upside_hip_plugin.h): load a shared library whose static initialisers
+ * register them (the equivalent of linking another node's .cpp into the reference's libupside.so,
+ * /root/reference/src/deriv_engine.h:297-335).  Must be called before the configuration that names the node is opened.
+ * The libraries listed in the environment variable UPSIDE_HIP_PLUGINS (':'-separated) are loaded by the first engine
+ * construction.  Returns 0 on success, 1 on failure (upside_hip_last_error has the dlopen / registry message). */
+int upside_hip_load_plugin(const char* shared_library_path);
+/* 1 if a node type is registered under exactly this name prefix (built in or from a plug-in), else 0 */
+int upside_hip_node_type_registered(const char* name_prefix);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,11 @@ typedef struct {
     unsigned long long* gacc;            /* [S][n_other][8] exact fixed-point (x 2^32) gradient accumulators of upk_igraph_backward when several
                                             workgroups serve one system (small batches); NULL: one workgroup per system; zero between evaluations */
     int nbr_j_bits;                      /* 0: a list word is the element index; else the index is its low nbr_j_bits bits */
+    /* quadspline graphs (hbond_coverage): the same table as `param`, every knot interval of every spline expanded on the host
+       into its cubic's 4 monomial coefficients: [n_type1][n_type2][n_poly], n_poly = 8 (n_knot_angular - 3) + 8 (n_knot - 1),
+       rows 16-byte aligned (layout: igraph_device.h, quadspline_pair<.., POLY>).  The LDS-staged pair passes read this one;
+       NULL: they read `param`. */
+    const float* param_poly; int n_poly;
 } upk_igraph_t;
 #define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8192 beads, < 2^19 - 1 slots */
 #define UPK_ROT_SLOT_NONE 0x7FFFF        /* slot field of a cached bead pair whose residue pair got no slot (capacity overflow) */
@@ -230,6 +235,8 @@ typedef struct {
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     const float* param_tri;              /* upper triangle of the (symmetric) pair table: row tri(lo, hi) = interaction_param[lo][hi], lo <= hi;
                                             (hi, lo) reads the same row with its two angular blocks exchanged (is_compatible, bead_interaction.h:209-218) */
+    const float* param_tri_poly; int n_poly;   /* the same triangle as per-interval polynomials (upk_igraph_t::param_poly layout, n_poly floats per row); the
+                                            energy pass stages it when it fits LDS next to the beads (NULL / does not fit: param_tri) */
     float* bead_pack;                    /* [S][n_bead][8] packed bead rows for systems whose beads do not fit LDS (else NULL) */
     unsigned long long* grad_acc;        /* [S][n_bead][6] exact fixed-point (x 2^32) gradient accumulators of the gradient pass when a system is
                                             served by several workgroups or does not fit LDS; zero between evaluations */

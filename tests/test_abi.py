@@ -69,3 +69,22 @@ def test_no_cpu_fallback(lib):
     assert b'no HIP device' in lib.upside_hip_last_error()
     with pytest.raises(RuntimeError):
         P.pkg.Upside(P.fixture('trpcage20_7A'))
+
+
+def test_plugin_library_registers_external_node_types(lib):
+    """the plug-in side of the boundary (include/upside_hip_plugin.h; the reference's registry, deriv_engine.h:239-335):
+    a shared library built against include/ only registers its node types through its static initialisers when loaded"""
+    plug = os.path.join(P.ROOT, 'tests', 'plugin', 'libhost_pull.so')
+    if not os.path.exists(plug):
+        pytest.skip('tests/plugin/libhost_pull.so not built (run __graft_entry__.build())')
+    lib.upside_hip_load_plugin.argtypes = [ct.c_char_p]
+    lib.upside_hip_node_type_registered.argtypes = [ct.c_char_p]
+    lib.upside_hip_last_error.restype = ct.c_char_p
+    for builtin in (b'rotamer', b'environment_coverage', b'atom_pos_spring', b'pos'):
+        assert lib.upside_hip_node_type_registered(builtin) == 1
+    assert lib.upside_hip_load_plugin(b'/nonexistent/libnothing.so') == 1
+    assert b'libnothing' in lib.upside_hip_last_error()
+    assert lib.upside_hip_load_plugin(plug.encode()) == 0, lib.upside_hip_last_error()
+    assert lib.upside_hip_node_type_registered(b'host_pull') == 1 and lib.upside_hip_node_type_registered(b'host_scale') == 1
+    assert lib.upside_hip_node_type_registered(b'host_nothing') == 0
+    assert lib.upside_hip_load_plugin(plug.encode()) == 0      # twice: no-op, no duplicate-prefix error

@@ -910,6 +910,45 @@ def test_long_md_is_thermalised_and_stable(hip):
     assert np.array_equal(pos, pos_b) and np.array_equal(e1, e1b)   # bit-reproducible run to run
 
 
+def test_upside_main_refuses_mixed_potentials(hip, tmp_path):
+    """one engine serves all systems of an `upside_main` run, so config files with different /input/potential (here: the
+    same protein with and without restraint nodes -- same atom count) must be refused, not simulated under the first file's
+    force field (the reference builds one engine per file, main.cpp:450-571)"""
+    import shutil
+    a = str(tmp_path / 'a.up'); b = str(tmp_path / 'b.up'); c = str(tmp_path / 'c.up')
+    shutil.copyfile(P.fixture('proteinG56_7A'), a); shutil.copyfile(P.fixture('proteinG56_restraints'), b); shutil.copyfile(P.fixture('proteinG56_7A'), c)
+    args = ['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '3']
+    with pytest.raises(RuntimeError):
+        hip.in_process_upside(args + [a, b], verbose=False)
+    hip.in_process_upside(args + [a, c], verbose=False)        # identical potentials, different files: fine
+
+
+def test_replica_swap_next_rejects_stale_energies(hip):
+    """a later swap set may only reuse the energies of its own attempt: after MD steps, new coordinates or another round the
+    call must fail instead of testing Metropolis on stale numbers"""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    for f in (c.upside_hip_replica_swap_from, c.upside_hip_replica_swap_next):
+        f.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
+    c.upside_hip_run_steps.argtypes = [ct.c_void_p, ct.c_int]
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    pos = np.stack([g['pos']] * 4).astype('f4'); temps = np.array([0.7, 0.8, 0.9, 1.0], 'f4')
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 4, True)
+    c.upside_hip_set_pos(eng, pos.ctypes.data); c.upside_hip_init_md(eng, temps.ctypes.data, 5, 5.0, 0.009, 1)
+    p0 = np.array([[0, 1], [2, 3]], 'i4'); p1 = np.array([[1, 2]], 'i4')
+    acc = np.zeros(3, 'i4'); acc1 = np.zeros(2, 'i4')
+    assert c.upside_hip_replica_swap_from(eng, 2, p0.ctypes.data, 11, 1, 0, acc.ctypes.data) == 0
+    assert c.upside_hip_replica_swap_next(eng, 1, p1.ctypes.data, 11, 1, int(acc[-1]), acc1.ctypes.data) == 0      # same attempt: fine
+    assert c.upside_hip_replica_swap_next(eng, 1, p1.ctypes.data, 11, 2, 0, acc1.ctypes.data) != 0                  # another round
+    assert c.upside_hip_replica_swap_from(eng, 2, p0.ctypes.data, 11, 2, 0, acc.ctypes.data) == 0
+    assert c.upside_hip_run_steps(eng, 3) == 0
+    assert c.upside_hip_replica_swap_next(eng, 1, p1.ctypes.data, 11, 2, int(acc[-1]), acc1.ctypes.data) != 0      # MD in between
+    assert c.upside_hip_replica_swap_from(eng, 2, p0.ctypes.data, 11, 3, 0, acc.ctypes.data) == 0
+    c.upside_hip_set_pos(eng, pos.ctypes.data)
+    assert c.upside_hip_replica_swap_next(eng, 1, p1.ctypes.data, 11, 3, int(acc[-1]), acc1.ctypes.data) != 0      # new coordinates
+    c.free_deriv_engine(ct.c_void_p(eng))
+
+
 def test_protein_g_10k_steps_match_reference_statistics(hip, tmp_path):
     """BASELINE.json configs[1] at full length: Protein G (56 residues), constant-T Langevin MD, 10 k force evaluations
     (--duration 90 = 3334 rounds), through `upside_main` on the GPU and through the unmodified reference executable on the
@@ -986,3 +1025,90 @@ def test_upside_main_jump_moves_match_reference(hip, tmp_path):
         assert n_try == 15 and 0 < n_ok < n_try, ref['jump_stats']
         for f in range(1, 4):
             assert P.rel_rms(ref['pos'][f], got['pos'][f]) < 2e-3, (with_pivot, f)
+
+
+def test_external_plugin_node(hip, tmp_path):
+    """node types defined OUTSIDE the library (tests/plugin/host_pull.cpp: compiled against include/upside_hip_plugin.h only,
+    linked against libupside_hip.so, registered by its static initialisers -- the contract of deriv_engine.h:239-335):
+    unknown before upside_hip_load_plugin, constructed from the configuration after it; the host-fallback potential node
+    reproduces the built-in device node of the same maths (atom_pos_spring, bonds.cpp:9-50), the host-fallback coordinate
+    node feeds a built-in node and back-propagates through it, and MD runs with both in a batch"""
+    import shutil
+    plug = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'plugin', 'libhost_pull.so')
+    assert os.path.exists(plug), 'tests/plugin/libhost_pull.so is missing: run __graft_entry__.build()'
+    name = 'proteinG56_7A'
+    g = P.golden(name); pos = g['pos']; n_atom = pos.shape[0]
+    rs = np.random.RandomState(11)
+    atoms = rs.choice(n_atom, 25, replace=False).astype('i4')
+    x0 = (pos[atoms] + rs.normal(size=(25, 3))).astype('f4'); k = rs.uniform(0.5, 3., 25).astype('f4')
+    scale = np.float32(0.5)
+
+    def config(path, nodes):
+        shutil.copyfile(P.fixture(name), path)
+        with P.pkg.h5lite.open_file(path, 'r+') as f:
+            pot = f.group('input').group('potential')
+            for node, arg, idname in nodes:
+                grp = pot.create_group(node); grp.set_attr('arguments', [arg])
+                if node.startswith('host_scale'):
+                    grp.set_attr('scale', np.float32(scale))
+                else:
+                    grp.write(idname, atoms); grp.write('x0', x0); grp.write('spring_const', k)
+        return path
+    builtin = config(str(tmp_path / 'builtin.up'), [('atom_pos_spring', 'pos', 'id')])
+    plugged = config(str(tmp_path / 'plugged.up'), [('host_pull', 'pos', 'atom')])
+    chained = config(str(tmp_path / 'chained.up'), [('host_scale', 'pos', None), ('atom_pos_spring', 'host_scale', 'id')])
+
+    c = hip.calc
+    c.upside_hip_load_plugin.argtypes = [ct.c_char_p]
+    c.upside_hip_node_type_registered.argtypes = [ct.c_char_p]
+    if not c.upside_hip_node_type_registered(b'host_pull'):
+        with pytest.raises(RuntimeError):                       # no such node type yet
+            P.pkg.Upside(plugged)
+        assert c.upside_hip_load_plugin(b'/nonexistent/libnothing.so') == 1 and b'libnothing' in c.upside_hip_last_error()
+        assert c.upside_hip_load_plugin(plug.encode()) == 0, c.upside_hip_last_error()
+    assert c.upside_hip_load_plugin(plug.encode()) == 0          # loading twice is a no-op
+
+    base = P.pkg.Upside(P.fixture(name)); e_base = base.energy(pos); d_base = base.deriv(pos); base.close()
+    ref = P.pkg.Upside(builtin); act = P.pkg.Upside(plugged)
+    for x in (pos, g['pos2']):
+        e_ref, e_act = ref.energy(x), act.energy(x)
+        d_ref, d_act = ref.deriv(x), act.deriv(x)
+        assert abs(float(ref.get_output('atom_pos_spring')[0, 0]) - float(act.get_output('host_pull')[0, 0])) < 1e-5 * max(1., abs(e_ref))
+        assert abs(e_ref - e_act) < 1e-5 * max(1., abs(e_ref), abs(float(ref.get_output('atom_pos_spring')[0, 0])))
+        assert P.rel_rms(d_ref, d_act) < 1e-6
+    ref.close(); act.close()
+    # and against the closed form, so the pair above is not a shared mistake
+    dx = pos[atoms] - x0
+    e_pull = float((0.5 * k[:, None] * dx * dx).sum())
+    up = P.pkg.Upside(plugged)
+    assert abs(up.energy(pos) - (e_base + e_pull)) < 1e-5 * max(1., abs(e_base) + e_pull)
+    want = d_base.copy(); want[atoms] += k[:, None] * dx
+    assert P.rel_rms(want, up.deriv(pos)) < 1e-5
+    up.close()
+
+    # host coordinate node -> built-in potential node: value, chain rule back to pos
+    up = P.pkg.Upside(chained)
+    e = up.energy(pos); d = up.deriv(pos)
+    assert np.abs(up.get_output('host_scale') - scale * pos).max() < 1e-6
+    dxs = scale * pos[atoms] - x0
+    e_scaled = float((0.5 * k[:, None] * dxs * dxs).sum())
+    assert abs(e - (e_base + e_scaled)) < 1e-5 * max(1., abs(e_base) + e_scaled)
+    want = d_base.copy(); want[atoms] += scale * k[:, None] * dxs
+    assert P.rel_rms(want, d) < 1e-5
+    assert np.abs(up.get_sens('host_scale')[atoms] - k[:, None] * dxs).max() < 1e-4
+    up.close()
+
+    # a batch under MD: the host nodes synchronise every force pass (no hipGraph replay) and stay in step with the
+    # device-only configuration of the same physics
+    def run(path):
+        eng = c.upside_hip_construct(n_atom, path.encode(), 3, True)
+        assert eng, c.upside_hip_last_error()
+        x = np.tile(pos[None], (3, 1, 1)).astype('f4'); temps = np.array([0.7, 0.8, 0.9], 'f4')
+        assert c.upside_hip_set_pos(eng, x.ctypes.data) == 0
+        assert c.upside_hip_init_md(eng, temps.ctypes.data, 7, 5.0, 0.009, 1) == 0
+        assert c.upside_hip_run_md(eng, 30) == 0, c.upside_hip_last_error()
+        assert c.upside_hip_get_pos(eng, x.ctypes.data) == 0
+        c.free_deriv_engine(ct.c_void_p(eng))
+        return x
+    xa, xb = run(builtin), run(plugged)
+    assert np.isfinite(xb).all() and np.abs(xa - xb).max() < 1e-3

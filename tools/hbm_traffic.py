@@ -45,7 +45,9 @@ def main():
     except (OSError, ValueError):
         tab = {}
     entry = {}
-    for k in sorted(set(f) | set(w)):
+    total = lambda k: (f.get(k, (0, 0))[0] * f.get(k, (0, 0))[1] + w.get(k, (0, 0))[0] * w.get(k, (0, 0))[1])
+    # (template instances of one labelled kernel: lightest first, so the one that moves the most bytes ends up in the table)
+    for k in sorted(set(f) | set(w), key=lambda k: (next((v for key, v in LABEL.items() if key in k), k), total(k))):
         fb = f.get(k, (0, 0))[0] * 1024.0; wb = w.get(k, (0, 0))[0] * 1024.0
         label = next((v for key, v in LABEL.items() if key in k), k)   # template instances carry a 'void ...<true>' decoration
         entry[label] = dict(rocprof_kernel=k, launches_sampled=f.get(k, (0, 0))[1], fetch_bytes=fb, fetch_bytes_if_wide=2 * fb,

@@ -3,7 +3,10 @@
 // only enqueues work on the engine's HIP stream; data stays in HBM.
 #include "engine.h"
 #include "h5util.h"
+#include <dlfcn.h>
 #include <algorithm>
+#include <cstdlib>
+#include <set>
 #include <functional>
 #include <cmath>
 #include <cstdio>
@@ -84,6 +87,88 @@ void CoordNode::gather_contributions() {
     if (scatter.sources.empty()) return;
     upk_check(upk_gather_contrib(&ctx->L, scatter.arena.p, scatter.arena_size, scatter.csr_start.p, scatter.csr_entry.p, coord(),
                                  scatter.width, 0), "gather_contrib");
+}
+
+// ---- host-fallback nodes (include/upside_hip_plugin.h) ------------------------------------------------------
+namespace {
+vector<int> identity_targets(int n) { vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = i; return v; }
+
+// all systems of a CoordNode's output (or sens), padding dropped: dst[system][elem][width]
+void fetch_dense(DeviceCtx* ctx, const CoordNode& n, const float* dev, vector<float>& stage, vector<float>& dst) {
+    const size_t total = (size_t)ctx->n_system * n.n_elem * n.stride;
+    stage.resize(total); dst.resize((size_t)ctx->n_system * n.n_elem * n.elem_width);
+    if (!total) return;
+    hip_check(hipMemcpyAsync(stage.data(), dev, total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream), "D2H");
+    hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    for (size_t e = 0; e < (size_t)ctx->n_system * n.n_elem; ++e)
+        for (int d = 0; d < n.elem_width; ++d) dst[e * n.elem_width + d] = stage[e * n.stride + d];
+}
+
+// din[a][system][elem][width] -> the scatter source `src[a]` of argument a (gathered into its sens in the backward sweep)
+void push_arg_derivs(DeviceCtx* ctx, const vector<CoordNode*>& args, const vector<int>& src, const vector<vector<float>>& din) {
+    for (size_t a = 0; a < args.size(); ++a) {
+        CoordNode& n = *args[a];
+        const size_t per_sys = (size_t)n.n_elem * n.elem_width;
+        for (int s = 0; s < ctx->n_system && per_sys; ++s)
+            hip_check(hipMemcpyAsync(n.scatter.source_ptr(src[a]) + (size_t)s * n.scatter.arena_size, din[a].data() + s * per_sys,
+                                     per_sys * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "H2D");
+    }
+    hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");   // the host vectors may be reused right away
+}
+}  // namespace
+
+HostPotentialNode::HostPotentialNode(DeviceCtx* c, const vector<CoordNode*>& args_) : PotentialNode(c), args(args_) {
+    for (CoordNode* a : args) src_.push_back(a->scatter.add_source(a->n_elem, 1, a->elem_width, identity_targets(a->n_elem)));
+    in_.resize(args.size()); din_.resize(args.size()); stage_.resize(args.size());
+}
+void HostPotentialNode::compute_value(ComputeMode) {
+    for (size_t a = 0; a < args.size(); ++a) {
+        fetch_dense(ctx, *args[a], args[a]->output.p, stage_[a], in_[a]);
+        din_[a].assign(in_[a].size(), 0.f);
+    }
+    vector<const float*> in(args.size()); vector<float*> din(args.size());
+    for (int s = 0; s < ctx->n_system; ++s) {
+        for (size_t a = 0; a < args.size(); ++a) {
+            const size_t off = (size_t)s * args[a]->n_elem * args[a]->elem_width;
+            in[a] = in_[a].data() + off; din[a] = din_[a].data() + off;
+        }
+        potential[s] = host_potential(s, in, din);
+    }
+    hip_check(hipMemcpyAsync(potential_dev.p, potential.data(), ctx->n_system * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "H2D");
+    push_arg_derivs(ctx, args, src_, din_);
+}
+
+HostCoordNode::HostCoordNode(DeviceCtx* c, int n_elem_, int elem_width_, const vector<CoordNode*>& args_)
+    : CoordNode(c, n_elem_, elem_width_), args(args_) {
+    for (CoordNode* a : args) src_.push_back(a->scatter.add_source(a->n_elem, 1, a->elem_width, identity_targets(a->n_elem)));
+    in_.resize(args.size()); din_.resize(args.size()); stage_.resize(args.size());
+}
+void HostCoordNode::compute_value(ComputeMode) {
+    for (size_t a = 0; a < args.size(); ++a) fetch_dense(ctx, *args[a], args[a]->output.p, stage_[a], in_[a]);
+    out_.assign((size_t)ctx->n_system * n_elem * stride, 0.f);
+    vector<const float*> in(args.size()); vector<float> dense((size_t)n_elem * elem_width);
+    for (int s = 0; s < ctx->n_system; ++s) {
+        for (size_t a = 0; a < args.size(); ++a) in[a] = in_[a].data() + (size_t)s * args[a]->n_elem * args[a]->elem_width;
+        host_value(s, in, dense.data());
+        for (int e = 0; e < n_elem; ++e) for (int d = 0; d < elem_width; ++d) out_[((size_t)s * n_elem + e) * stride + d] = dense[(size_t)e * elem_width + d];
+    }
+    if (!out_.empty()) hip_check(hipMemcpyAsync(output.p, out_.data(), out_.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "H2D");
+    // the arguments' derivative slots must not keep the previous evaluation's values if the backward sweep is skipped
+    hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+void HostCoordNode::propagate_deriv() {
+    vector<float> stage;
+    fetch_dense(ctx, *this, sens.p, stage, dout_);
+    vector<const float*> in(args.size()); vector<float*> din(args.size());
+    for (size_t a = 0; a < args.size(); ++a) din_[a].assign(in_[a].size(), 0.f);
+    for (int s = 0; s < ctx->n_system; ++s) {
+        for (size_t a = 0; a < args.size(); ++a) {
+            const size_t off = (size_t)s * args[a]->n_elem * args[a]->elem_width;
+            in[a] = in_[a].data() + off; din[a] = din_[a].data() + off;
+        }
+        host_deriv(s, in, dout_.data() + (size_t)s * n_elem * elem_width, din);
+    }
+    push_arg_derivs(ctx, args, src_, din_);
 }
 
 // ---- registry (deriv_engine.cpp:50-92, 272-281) ------------------------------------------------------
@@ -458,15 +543,22 @@ void DerivEngine::load_jump_moves(hid_t_compat input_group_) {
 }
 void DerivEngine::mc_step(uint64_t round) {   // MultipleMonteCarloSampler::execute, monte_carlo_sampler.cpp:255-288
     if (!pivot.loaded && !jump.loaded) throw string("no Monte-Carlo moves loaded");
-    pivot.temperature.upload(temperature);
+    const size_t S = (size_t)ctx.n_system;
+    if (pivot.temperature.n != S) pivot.temperature.alloc(S);          // (allocated once: no free / malloc / device-wide sync per move)
+    auto refresh = [&](DevBuf<float>& b, const vector<float>& v) {
+        if (b.n != S) b.alloc(S);
+        hip_check(hipMemcpyAsync(b.p, v.data(), S * sizeof(float), hipMemcpyHostToDevice, ctx.stream), "H2D");
+    };
+    refresh(pivot.temperature, temperature);
+    swap_energy.clear();                                                // coordinates may move: no swap set can reuse older energies
     for (int sampler = 0; sampler < 2; ++sampler) {
         if (sampler == 0 ? !pivot.loaded : !jump.loaded) continue;
         compute(PotentialAndDerivMode); fetch_potentials();
-        pivot.e_old.upload(potential);
+        refresh(pivot.e_old, potential);
         if (sampler == 0) upk_check(upk_pivot_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &pivot.P, seed.p, round, pivot.delta_lprob.p), "pivot_propose");
         else upk_check(upk_jump_propose(&ctx.L, pos->coord(), pivot.pos_copy.p, &jump.J, seed.p, round, pivot.delta_lprob.p), "jump_propose");
         compute(PotentialAndDerivMode); fetch_potentials();
-        pivot.e_new.upload(potential);
+        refresh(pivot.e_new, potential);
         // the acceptance uniform is the generator's next draw: the pivot proposal used one, the jump proposal two
         upk_check(upk_mc_accept(&ctx.L, pos->coord(), pivot.pos_copy.p, pivot.e_old.p, pivot.e_new.p, pivot.delta_lprob.p, pivot.temperature.p,
                                 seed.p, round, sampler == 0 ? 2 : 3, sampler == 0 ? 1 : 2, (sampler == 0 ? pivot.stats : jump.stats).p), "mc_accept");
@@ -480,14 +572,40 @@ void DerivEngine::check_device_errors() {
     auto f = ctx.error_flag.download();
     if (f[0]) {
         ctx.error_flag.fill_bytes(0);
+        if (f[0] == 7)   // kernels_rotamer.hip: cluster_barrier gave up waiting -- the cluster's workgroups were not all resident
+            throw string("belief propagation: a workgroup of a solve cluster never arrived (the cluster solve needs all its workgroups "
+                         "co-resident; something else occupied the device): the forces of this step are not valid.  Set UPSIDE_HIP_BP_CLUSTER=1 "
+                         "to use the one-workgroup solve");
         throw string("device capacity overflow (code ") + to_string(f[0]) +
             "): raise UPSIDE_HIP_NBR_CAP / UPSIDE_HIP_SLOT_FACTOR (1 = neighbour list, 2 = residue-pair slots, 3 = node adjacency)";
     }
 }
 
 // ---- graph construction (deriv_engine.cpp:195-270) ---------------------------------------------------
+// external node types (include/upside_hip_plugin.h): their static initialisers call add_node_creation_function
+void load_plugin_library(const string& path) {
+    static set<string> loaded;
+    if (loaded.count(path)) return;
+    if (!dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL)) throw string("cannot load plug-in ") + path + ": " + dlerror();
+    loaded.insert(path);
+}
+static void load_plugins_from_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("UPSIDE_HIP_PLUGINS");
+    if (!e) return;
+    string all(e);
+    for (size_t b = 0; b <= all.size();) {
+        size_t c = all.find(':', b); if (c == string::npos) c = all.size();
+        if (c > b) load_plugin_library(all.substr(b, c - b));
+        b = c + 1;
+    }
+}
+
 DerivEngine* initialize_engine_from_hdf5(int n_atom, int n_system, hid_t_compat potential_group_, bool quiet) {
     (void)quiet;
+    load_plugins_from_env();
     hid_t potential_group = (hid_t)potential_group_;
     unique_ptr<DerivEngine> engine(new DerivEngine(n_atom, n_system));
     auto& m = node_creation_map();

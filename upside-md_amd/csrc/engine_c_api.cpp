@@ -30,6 +30,9 @@ static int fail(const string& s) { g_last_error = s; fprintf(stderr, "ERROR: %s\
 
 extern "C" const char* upside_hip_last_error(void) { return g_last_error.c_str(); }
 extern "C" int upside_hip_calibrate_valu(double* rates) { API_TRY upk_check(upk_calibrate_valu(rates), "calibrate_valu"); return 0; API_CATCH(1) }
+void load_plugin_library(const string& path);   // engine.cpp
+extern "C" int upside_hip_load_plugin(const char* path) { API_TRY load_plugin_library(path); return 0; API_CATCH(1) }
+extern "C" int upside_hip_node_type_registered(const char* prefix) { API_TRY return node_creation_map().count(prefix) ? 1 : 0; API_CATCH(0) }
 extern "C" void upside_hip_set_last_error(const char* msg) { fail(msg); }   // (for the other translation units of the C-ABI)
 
 // ---- construction ----------------------------------------------------------------------------------
@@ -72,7 +75,7 @@ static void download_rows(DerivEngine* e, const float* dev, int n_elem, int stri
         out[((size_t)s * n_elem + i) * width + d] = buf[((size_t)s * n_elem + i) * stride + d];
 }
 
-extern "C" int upside_hip_set_pos(DerivEngine* e, const float* pos) { API_TRY upload_pos(e, pos, e->ctx.n_system); return 0; API_CATCH(1) }
+extern "C" int upside_hip_set_pos(DerivEngine* e, const float* pos) { API_TRY upload_pos(e, pos, e->ctx.n_system); e->swap_energy.clear(); return 0; API_CATCH(1) }
 extern "C" int upside_hip_get_pos(DerivEngine* e, float* pos) {
     API_TRY download_rows(e, e->pos->output.p, e->pos->n_atom, e->pos->stride, 3, pos, e->ctx.n_system); return 0; API_CATCH(1) }
 extern "C" int upside_hip_set_mom(DerivEngine* e, const float* mom) {
@@ -332,11 +335,15 @@ static int replica_swap_impl(DerivEngine* e, int n_pair, const int* pairs, uint3
     const int S = e->ctx.n_system;
     for (int i = 0; i < 2 * n_pair; ++i) if (pairs[i] < 0 || pairs[i] >= S) throw string("invalid system");
     if (reuse_energy) {
-        if ((int)e->swap_energy.size() != S) throw string("upside_hip_replica_swap_next needs a preceding upside_hip_replica_swap(_from) of the same attempt");
+        // the energies must be those of THIS attempt: captured in the same round with no force pass (MD, Monte Carlo, another
+        // evaluation) and no new coordinates since
+        if ((int)e->swap_energy.size() != S || e->swap_energy_round != round || e->swap_energy_compute != e->n_compute)
+            throw string("upside_hip_replica_swap_next needs a preceding upside_hip_replica_swap(_from) of the same attempt (same round, nothing evaluated or moved in between)");
     } else {
         e->compute(PotentialAndDerivMode);
         e->fetch_potentials();
         e->swap_energy = e->potential;
+        e->swap_energy_round = round; e->swap_energy_compute = e->n_compute;
     }
     vector<float> beta(S);
     for (int s = 0; s < S; ++s) beta[s] = 1.f / e->temperature[s];

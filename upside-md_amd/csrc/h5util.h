@@ -123,4 +123,51 @@ inline std::vector<std::string> node_names_in_group(hid_t loc) {   // h5_support
     return names;
 }
 
+// 64-bit FNV-1a digest of everything below a group: object paths, attribute names and raw bytes, dataset shapes and raw
+// bytes (in the file's own types).  Two configuration files hold the same potential iff their /input/potential digests agree.
+struct DigestCtx {
+    unsigned long long h = 1469598103934665603ull; hid_t root = -1; std::string error;
+    void bytes(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } }
+    void text(const std::string& s) { bytes(s.data(), s.size()); const unsigned char z = 0; bytes(&z, 1); }
+};
+inline herr_t digest_attribute(hid_t obj, const char* name, const H5A_info_t*, void* data) {
+    DigestCtx& c = *static_cast<DigestCtx*>(data);
+    c.text(std::string("@") + name);
+    Handle a(H5Aopen(obj, name, H5P_DEFAULT), H5Aclose);
+    Handle ty(H5Aget_type(a), H5Tclose);
+    Handle sp(H5Aget_space(a), H5Sclose);
+    if (H5Tis_variable_str(ty) > 0) { c.error = "variable-length strings not supported"; return -1; }
+    const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    std::vector<unsigned char> buf((size_t)(n > 0 ? n : 0) * H5Tget_size(ty));
+    if (!buf.empty() && H5Aread(a, ty, buf.data()) < 0) { c.error = std::string("unable to read attribute ") + name; return -1; }
+    c.bytes(buf.data(), buf.size());
+    return 0;
+}
+inline herr_t digest_object(hid_t, const char* name, const H5O_info_t* info, void* data) {
+    DigestCtx& c = *static_cast<DigestCtx*>(data);
+    c.text(name);
+    Handle obj(H5Oopen(c.root, name, H5P_DEFAULT), H5Oclose);
+    if (obj < 0) { c.error = std::string("unable to open ") + name; return -1; }
+    hsize_t idx = 0;
+    if (H5Aiterate2(obj, H5_INDEX_NAME, H5_ITER_INC, &idx, digest_attribute, data) < 0) return -1;
+    if (info->type == H5O_TYPE_DATASET) {
+        Handle sp(H5Dget_space(obj), H5Sclose);
+        Handle ty(H5Dget_type(obj), H5Tclose);
+        const int nd = H5Sget_simple_extent_ndims(sp);
+        std::vector<hsize_t> dims(nd > 0 ? nd : 1, 0);
+        if (nd > 0) H5Sget_simple_extent_dims(sp, dims.data(), NULL);
+        c.bytes(dims.data(), sizeof(hsize_t) * (size_t)(nd > 0 ? nd : 0));
+        const hssize_t n = H5Sget_simple_extent_npoints(sp);
+        std::vector<unsigned char> buf((size_t)(n > 0 ? n : 0) * H5Tget_size(ty));
+        if (!buf.empty() && H5Dread(obj, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data()) < 0) { c.error = std::string("unable to read ") + name; return -1; }
+        c.bytes(buf.data(), buf.size());
+    }
+    return 0;
+}
+inline unsigned long long group_digest(hid_t group) {
+    DigestCtx c; c.root = group;
+    if (H5Ovisit(group, H5_INDEX_NAME, H5_ITER_INC, digest_object, &c) < 0) throw std::string("while hashing a group: ") + c.error;
+    return c.h;
+}
+
 }  // namespace h5u

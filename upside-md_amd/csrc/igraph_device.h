@@ -56,19 +56,48 @@ __device__ __forceinline__ QuadShape quad_shape(const upk_igraph_t& G) { QuadSha
 //   d(value)/d(x1) = (-dd, g1),  d(value)/d(x2) = (dd, g2)      (positions, then direction vectors)
 // off1 / off2: where the angular coefficients of x1 / x2 start in the parameter row (0 / ka as stored; ka / 0 when a row of
 // the type pair (t2, t1) is used for (t1, t2), see stage_table_sym)
-template <int WANT_D, typename P>
+//
+// POLY: p is a row of the per-interval polynomial table (quadspline_poly_row, packed on the host from the same spline
+// coefficients): every knot interval of every spline holds its cubic as 4 monomial coefficients of the offset y from the
+// interval's left knot, 16-byte aligned -- one ds_read_b128 and 3 + 3 FMAs per spline for value and slope instead of four
+// scattered coefficient reads, the 18-operation basis evaluation and 8 multiply-adds.  Row layout:
+//   [angular of x1: (ka-3) x 4] [angular of x2: (ka-3) x 4] [radial: (k-1) x (wide 4, narrow 4)]
+// The radial part carries one extra constant interval at each end (the clamped values of spline.h:275-310), so clamping is
+// an index clamp: no selects, no second set of reads.  off1 / off2 are then offsets in this layout (0 / 4 (ka-3) as stored).
+template <int WANT_D, bool POLY = false, typename P>
 __device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const float* x1, const float* x2, float* dd, float* g1, float* g2,
                                                  int off1 = 0, int off2 = -1) {
-    if (off2 < 0) off2 = Q.ka;
+    if (off2 < 0) off2 = POLY ? 4 * (Q.ka - 3) : Q.ka;
     const f3 displace = mk3(x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]);
     const f3 rvec1 = mk3(x1[3], x1[4], x1[5]), rvec2 = mk3(x2[3], x2[4], x2[5]);
     const float dist2 = mag2(displace), inv_dist = rsqrtf(dist2);
     const float dist_coord = dist2 * (inv_dist * Q.inv_dx);
     const f3 u = inv_dist * displace;
     const float cos1 = dot(rvec1, u), cos2 = -dot(rvec2, u);
+    float a1, da1, a2, da2, wide, dwide, narrow, dnarrow;
+    if constexpr (POLY) {
+        auto cubic = [](const float* c4, float y, float& v, float& d) {
+            const float4 c = *(const float4*)c4;
+            v = fmaf(fmaf(fmaf(c.w, y, c.z), y, c.y), y, c.x);
+            d = fmaf(fmaf(3.f * c.w, y, c.z + c.z), y, c.y);
+        };
+        {   // angular splines (unclamped, spline.h:228-242): |cos| can pass 1 by an ulp, the end intervals extrapolate
+            const float x = (cos1 + 1.f) * Q.inv_dtheta; const int i = min(max((int)x, 0), Q.ka - 4);
+            cubic(p + off1 + 4 * i, x - (float)i, a1, da1);
+        }
+        {
+            const float x = (cos2 + 1.f) * Q.inv_dtheta; const int i = min(max((int)x, 0), Q.ka - 4);
+            cubic(p + off2 + 4 * i, x - (float)i, a2, da2);
+        }
+        {   // radial splines: interval 0 (dist_coord < 1) and interval k-2 (beyond the last knot) are the clamped constants
+            const int i = min((int)dist_coord, Q.k - 2);
+            const float y = dist_coord - (float)i;
+            const float* r = p + 8 * (Q.ka - 3) + 8 * i;
+            cubic(r, y, wide, dwide); cubic(r + 4, y, narrow, dnarrow);
+        }
+    } else {
     float b[4], db[4];
     // angular splines (unclamped, spline.h:228-242)
-    float a1, da1, a2, da2;
     {
         const float x = (cos1 + 1.f) * Q.inv_dtheta + 1.f; const int bin = (int)x;
         bspline_basis(x - (float)bin, b, db); bspline_vd(a1, da1, p + off1, bin, b, db);
@@ -78,7 +107,6 @@ __device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const 
         bspline_basis(x - (float)bin, b, db); bspline_vd(a2, da2, p + off2, bin, b, db);
     }
     // radial splines share one coordinate; clamped ends (spline.h:275-310)
-    float wide, dwide, narrow, dnarrow;
     {
         const bool too_small = dist_coord < 1.f, too_big = (float)(Q.k - 2) <= dist_coord;
         const float xc = (too_small || too_big) ? 1.f : dist_coord;
@@ -93,6 +121,7 @@ __device__ __forceinline__ float quadspline_pair(const QuadShape& Q, P p, const 
             wide = (1.f / 6.f) * pw[o] + (2.f / 3.f) * pw[o + 1] + (1.f / 6.f) * pw[o + 2];
             narrow = (1.f / 6.f) * pn[o] + (2.f / 3.f) * pn[o + 1] + (1.f / 6.f) * pn[o + 2];
         }
+    }
     }
     const float angular_weight = a1 * a2;
     if (WANT_D) {
@@ -220,20 +249,21 @@ __device__ __forceinline__ void stage_rows(float* lds, const upk_coord_t& node, 
     }
 }
 __device__ __forceinline__ void stage_table(float* lds, const float* __restrict__ tab, int n) {
-    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
+    const int n4 = (((size_t)tab & 15) == 0) ? n >> 2 : 0;      // (hipMalloc'ed tables are aligned; the LDS side always is)
+    for (int t = threadIdx.x; t < n4; t += blockDim.x) ((float4*)lds)[t] = ((const float4*)tab)[t];
+    for (int t = 4 * n4 + threadIdx.x; t < n; t += blockDim.x) lds[t] = tab[t];
 }
 // A symmetric pair table ([nt][nt][n_param] with row (t2, t1) = row (t1, t2) with the two angular blocks exchanged --
 // is_compatible, bead_interaction.h:209-218, checked when the node is built) is kept as its upper triangle only (the host
 // packs it, upk_rotamer_t::param_tri): half the LDS
 __device__ __forceinline__ int tri_row(int lo, int hi, int nt) { return lo * nt - ((lo * (lo - 1)) >> 1) + (hi - lo); }   // lo <= hi
-// exact fixed-point image of a float (|v| < 2^31): v * 2^32 as a 64-bit two's-complement integer.  Integer adds commute, so
+// fixed-point image of a float (|v| < 2^31): v * 2^32 as a 64-bit two's-complement integer, exact down to 2^-31.  Integer adds commute, so
 // sums accumulated through LDS atomics in any order are the EXACT sum of the contributions (and bit-reproducible); LDS integer
 // atomics run at full rate on gfx950, float ones at 3 cycles per lane (tools/ubench/lds_atomics.hip)
 __device__ __forceinline__ unsigned long long to_fixed32(float v) {
-    const float h = truncf(v);                                    // integer part; v - h keeps v's sign and is exact (Sterbenz)
-    const float f = (v - h) * 4294967296.f;                       // |f| < 2^32, exact
-    const unsigned long long hi = (unsigned long long)(unsigned)(int)h << 32, lo = (unsigned)fabsf(f);
-    return f < 0.f ? hi - lo : hi + lo;
+    const float h = rintf(v);                                     // nearest integer; v - h is exact (|v| < 0.5: h = 0; else h within a factor 2 of v)
+    const int hi = (int)h, half = (int)((v - h) * 2147483648.f);  // |v - h| <= 0.5: the product is exact, |half| <= 2^30 (resolution 2^-31)
+    return ((unsigned long long)(unsigned)(hi + (half >> 31)) << 32) | (unsigned)(half << 1);   // hi * 2^32 + sign-extended 2 * half: 8 instructions
 }
 __device__ __forceinline__ float from_fixed32(unsigned long long a) { return (float)((double)(long long)a * 2.3283064365386963e-10); }
 __device__ __forceinline__ void lds_add_fixed(unsigned long long* p, float v) {

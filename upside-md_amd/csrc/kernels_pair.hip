@@ -25,10 +25,10 @@ struct PairArgs {
 template <int IT, int ROW_SIDE, bool GRAD>
 __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
                                               const float* x1, const float* x2, float* d) {
-    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
+    const float* p = tab + (t1 * G.n_type2 + t2) * (IT == UPK_IT_HBOND_COVERAGE ? G.n_poly : G.n_param);   // (hbond_coverage: the polynomial table)
     if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
         float dd[3], g1[3], g2[3];
-        const float coverage = quadspline_pair<GRAD ? 3 : 0>(Q, p, x1, x2, dd, g1, g2);
+        const float coverage = quadspline_pair<GRAD ? 3 : 0, true>(Q, p, x1, x2, dd, g1, g2);
         const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
         if (GRAD) {
 #pragma unroll
@@ -55,10 +55,10 @@ __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadS
 template <int IT>
 __device__ __forceinline__ float pair_functor_both(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
                                                    const float* x1, const float* x2, float* d1, float* d2) {
-    const float* p = tab + (t1 * G.n_type2 + t2) * G.n_param;
+    const float* p = tab + (t1 * G.n_type2 + t2) * (IT == UPK_IT_HBOND_COVERAGE ? G.n_poly : G.n_param);
     if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
         float dd[3], g1[3], g2[3];
-        const float coverage = quadspline_pair<3>(Q, p, x1, x2, dd, g1, g2);
+        const float coverage = quadspline_pair<3, true>(Q, p, x1, x2, dd, g1, g2);
         const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d1[c] = -prefactor * dd[c]; d1[3 + c] = prefactor * g1[c]; d2[c] = prefactor * dd[c]; d2[3 + c] = prefactor * g2[c]; }
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
     const PairLds L = pair_lds(lds, G, A.tab_floats);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
-    stage_table(L.tab, G.param, A.tab_floats);
+    stage_table(L.tab, IT == UPK_IT_HBOND_COVERAGE ? G.param_poly : G.param, A.tab_floats);
     // rows: [0,dim) coordinates, [6] per-element pair sensitivity (mode 2, sides with dim <= 6), [7] element type
     stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (MODE == 2 && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (MODE == 2 && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
     unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
-    stage_table(L.tab, G.param, A.tab_floats);
+    stage_table(L.tab, IT == UPK_IT_HBOND_COVERAGE ? G.param_poly : G.param, A.tab_floats);
     // rows: [0,dim) coordinates, [6] per-element pair sensitivity (sides with dim <= 6), [7] element type
     stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, G.dim1 <= 6 ? S1 : nullptr, A.sens_stride);
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, G.dim2 <= 6 ? S2 : nullptr, A.sens_stride);
@@ -273,7 +273,8 @@ __global__ void k_pair_backward_finish(upk_igraph_t G, int other_side) {
 
 // LDS bytes of a staged pair pass; false when the system does not fit (callers fall back to the list-walking kernels)
 static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes) {
-    tab_floats = G->n_type1 * G->n_type2 * G->n_param;
+    tab_floats = G->n_type1 * G->n_type2 * (G->itype == UPK_IT_HBOND_COVERAGE ? G->n_poly : G->n_param);
+    if (G->itype == UPK_IT_HBOND_COVERAGE && !G->param_poly) return false;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + PG_WALK_LDS_WORDS(n_max) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
@@ -335,7 +336,10 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     const int n_rows = row_side == 1 ? G->n1 : G->n2, n_other = row_side == 1 ? G->n2 : G->n1;
     size_t lds;
     const bool fits = pair_lds_bytes(G, A.tab_floats, lds);
-    lds += 8 + (size_t)n_other * 8 * sizeof(unsigned long long);          // the other side's accumulators (at most 7 per element)
+    const int d_other = G->itype == UPK_IT_HBOND_COVERAGE ? (row_side == 1 ? PairDims<UPK_IT_HBOND_COVERAGE>::d2 : PairDims<UPK_IT_HBOND_COVERAGE>::d1)
+                      : G->itype == UPK_IT_ENVIRONMENT    ? (row_side == 1 ? PairDims<UPK_IT_ENVIRONMENT>::d2 : PairDims<UPK_IT_ENVIRONMENT>::d1)
+                                                          : (row_side == 1 ? PairDims<UPK_IT_PROTEIN_HBOND>::d2 : PairDims<UPK_IT_PROTEIN_HBOND>::d1);
+    lds += 8 + (size_t)n_other * d_other * sizeof(unsigned long long);    // the other side's accumulators (BackwardOp::DO per element)
     if (!fits || lds > 158 * 1024) {      // list-walking kernels, one side at a time (they need no hit lists)
         int r = upk_igraph_grad(L, G, 1, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
         if (!r) r = upk_igraph_grad(L, G, 2, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);

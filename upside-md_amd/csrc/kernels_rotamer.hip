@@ -277,13 +277,13 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
 // written by k_rotamer_pack_beads and the gradient accumulates in global memory.
 struct RotLds { float* tab; const float* rows; unsigned long long* acc; int* range; unsigned short* ord; int* counter; };
-template <bool STAGED>
+template <bool STAGED, bool POLY = false>
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats, bool want_acc) {
     const upk_igraph_t& G = R.G;
     RotLds r;
     r.tab = lds;
     float* p = lds + ((tab_floats + 3) & ~3);
-    stage_table(r.tab, R.param_tri, tab_floats);
+    stage_table(r.tab, POLY ? R.param_tri_poly : R.param_tri, tab_floats);
     r.acc = nullptr;
     if (STAGED) {
         if (want_acc) { r.acc = (unsigned long long*)p; p += G.n1 * 12; for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) r.acc[t] = 0ull; }
@@ -298,11 +298,12 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
 }
 // parameter row of the bead pair (row type tr, partner type to) in the triangle table, and where the two beads' angular
 // coefficients start in it
+template <bool POLY = false>
 __device__ __forceinline__ const float* rot_param_row(const upk_rotamer_t& R, const float* tab, int tr, int to, int& off_row, int& off_oth) {
     const bool sw = tr > to;
-    const int ka = R.G.n_knot_angular;
+    const int ka = POLY ? 4 * (R.G.n_knot_angular - 3) : R.G.n_knot_angular;     // length of one angular block in the row
     off_row = sw ? ka : 0; off_oth = sw ? 0 : ka;
-    return tab + tri_row(sw ? to : tr, sw ? tr : to, R.G.n_type1) * R.G.n_param;
+    return tab + tri_row(sw ? to : tr, sw ? tr : to, R.G.n_type1) * (POLY ? R.n_poly : R.G.n_param);
 }
 __global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
     const int s = blockIdx.y, n = R.G.n1;
@@ -316,6 +317,7 @@ __global__ void k_rotamer_pack_beads(upk_rotamer_t R) {
 }
 
 // bead-pair energies into the slot matrices (interaction_graph.h:470-503 + rotamer.cpp:832-846)
+template <bool POLY>
 struct RotEnergyOp {
     const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
     float* P; int* active;
@@ -330,8 +332,8 @@ struct RotEnergyOp {
         const int mr = __float_as_int(xr[6]), a = __float_as_int(xr[7]);
         const int mo = __float_as_int(xo[6]), b = __float_as_int(xo[7]);
         int o1, o2;
-        const float* p = rot_param_row(R, L.tab, mr & 0xFF, mo & 0xFF, o1, o2);   // row < partner: types [type(i1)][type(i2)], i1 < i2
-        const float E = quadspline_pair<0>(Q, p, xr, xo, nullptr, nullptr, nullptr, o1, o2);
+        const float* p = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mo & 0xFF, o1, o2);   // row < partner: types [type(i1)][type(i2)], i1 < i2
+        const float E = quadspline_pair<0, POLY>(Q, p, xr, xo, nullptr, nullptr, nullptr, o1, o2);
         if (!live || sl == UPK_ROT_SLOT_NONE) return;         // (no slot: only after a capacity overflow, the error flag is set)
         const int ra = (mr >> 8) & 0xF, rb = (mo >> 8) & 0xF;
         float* pe = P + PIDX6(R.slot_cap, sl, a < b ? ra : rb, a < b ? rb : ra);
@@ -343,20 +345,21 @@ struct RotEnergyOp {
     }
     __device__ __forceinline__ void flush(int) {}
 };
-template <bool STAGED>
+template <bool STAGED, bool POLY>
 __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy(upk_rotamer_t R, int tab_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<STAGED>(R, lds, s, tab_floats, false);
-    RotEnergyOp op(R, L, s);
+    const RotLds L = rot_stage<STAGED, POLY>(R, lds, s, tab_floats, false);
+    RotEnergyOp<POLY> op(R, L, s);
     group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
 }
 
 // 1 = table + beads (+ accumulators) staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
-static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want_acc, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block) {
+static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want_acc, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block,
+                        bool poly = false) {
     const int nt = R->G.n_type1;
-    tab_floats = (nt * (nt + 1) / 2) * R->G.n_param;
+    tab_floats = (nt * (nt + 1) / 2) * (poly ? R->n_poly : R->G.n_param);
     const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + PG_WALK_LDS_WORDS(R->G.n1) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
@@ -371,12 +374,18 @@ static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
+    static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
+    if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_ROT_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
+    if (R->param_tri_poly && !no_poly && rot_geometry(L, R, false, tab_floats, lds, grid, block, true) == 1) {   // polynomial table + beads fit LDS
+        hipLaunchKernelGGL((k_rotamer_pair_energy<true, true>), grid, block, lds, ST(L), *R, tab_floats);
+        return launch_status();
+    }
     const int staged = rot_geometry(L, R, false, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;   // interaction table larger than LDS
-    if (staged) hipLaunchKernelGGL(k_rotamer_pair_energy<true>, grid, block, lds, ST(L), *R, tab_floats);
+    if (staged) hipLaunchKernelGGL((k_rotamer_pair_energy<true, false>), grid, block, lds, ST(L), *R, tab_floats);
     else {
         hipLaunchKernelGGL(k_rotamer_pack_beads, dim3((R->G.n1 * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);   // also serves upk_rotamer_grad
-        hipLaunchKernelGGL(k_rotamer_pair_energy<false>, grid, block, lds, ST(L), *R, tab_floats);
+        hipLaunchKernelGGL((k_rotamer_pair_energy<false, false>), grid, block, lds, ST(L), *R, tab_floats);
     }
     return launch_status();
 }

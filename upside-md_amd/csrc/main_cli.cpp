@@ -221,9 +221,13 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
 
     if (anneal_duration == -1.) anneal_duration = duration;      // main.cpp:434
     const vector<float> initial_temps = temps;
-    // all systems must share the topology of the first file; only /input/pos differs
+    // One engine serves every system, so all files must hold the SAME potential (the reference builds one engine per file,
+    // main.cpp:450-571, and so also runs mixtures -- e.g. Hamiltonian replica exchange; here such a run is refused rather
+    // than silently simulated under the first file's force field): /input/potential is compared by digest, node names,
+    // arguments, attributes and dataset bytes alike.  Only /input/pos (and the output) differ between the files.
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
     int n_atom = 0;
+    unsigned long long potential_digest = 0;
     vector<float> all_pos;
     for (int ns = 0; ns < n_system; ++ns) {
         hid_t f = H5Fopen(files[ns].c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
@@ -232,8 +236,11 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         vector<hsize_t> dims;
         auto p = h5u::read<float>(f, "/input/pos", 3, &dims);
         if (dims[1] != 3 || dims[2] != 1) throw string("invalid dimensions for initial position");
-        if (ns == 0) n_atom = (int)dims[0];
-        else if ((int)dims[0] != n_atom) throw string("all systems of one run must share a topology");
+        const unsigned long long dg = h5u::group_digest(h5u::open_group(f, "/input/potential"));
+        if (ns == 0) { n_atom = (int)dims[0]; potential_digest = dg; }
+        else if ((int)dims[0] != n_atom || dg != potential_digest)
+            throw string("systems must share one potential: /input/potential of ") + files[ns] + " differs from that of " + files[0] +
+                " (one engine holds all systems of a run; run different potentials as separate runs)";
         all_pos.insert(all_pos.end(), p.begin(), p.end());
     }
     DerivEngine* e = upside_hip_construct(n_atom, files[0].c_str(), n_system, !verbose);

@@ -368,6 +368,31 @@ RegisterNodeType<BackbonePairs, 1> backbone_pairs_node("backbone_pairs");
 
 // ---------------------------------------------------------------------------------------------------
 // interaction graph host side: interaction_graph.h:261-398
+// One row of the per-interval polynomial table of a quadspline pair potential (igraph_device.h, quadspline_pair<.., POLY>)
+// from its spline coefficients p = [angular 1: ka][angular 2: ka][radial wide: k][radial narrow: k] (bead_interaction.h:30-84).
+// The cubic B-spline over the window c0..c3 is  a + b y + c y^2 + d y^3  with the coefficients below; computed in double.
+// Radial intervals 0 and k-2 are the clamped constants of spline.h:275-310.
+static int quadspline_poly_width(int ka, int k) { return 8 * (ka - 3) + 8 * (k - 1); }
+static void quadspline_poly_row(const float* p, int ka, int k, float* out) {
+    auto cubic = [](const float* c, float* o) {
+        const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        o[0] = (float)((c0 + 4. * c1 + c2) / 6.); o[1] = (float)((c2 - c0) / 2.);
+        o[2] = (float)((c0 - 2. * c1 + c2) / 2.); o[3] = (float)((-c0 + 3. * c1 - 3. * c2 + c3) / 6.);
+    };
+    auto constant = [](const float* c, float* o) {
+        o[0] = (float)((1. / 6.) * c[0] + (2. / 3.) * c[1] + (1. / 6.) * c[2]); o[1] = o[2] = o[3] = 0.f;
+    };
+    for (int a = 0; a < 2; ++a)
+        for (int i = 0; i + 3 < ka; ++i) cubic(p + a * ka + i, out + (a * (ka - 3) + i) * 4);
+    float* r = out + 8 * (ka - 3);
+    for (int w = 0; w < 2; ++w) {
+        const float* c = p + 2 * ka + w * k;
+        constant(c, r + w * 4);
+        for (int i = 1; i <= k - 3; ++i) cubic(c + i - 1, r + i * 8 + w * 4);
+        constant(c + k - 3, r + (k - 2) * 8 + w * 4);
+    }
+}
+
 struct IGraphHost {
     DeviceCtx* ctx;
     upk_igraph_t G;
@@ -375,7 +400,7 @@ struct IGraphHost {
     vector<int> loc1, loc2, type1, type2, id1, id2;
     vector<float> param;
     DevBuf<int> d_loc1, d_loc2, d_type1, d_type2, d_id1, d_id2, nbr1, cnt1, nbr2, cnt2, rebuild_flag, flagged;
-    DevBuf<float> d_param, cache_pos1, cache_pos2, cur_pos1, cur_pos2;
+    DevBuf<float> d_param, d_param_poly, cache_pos1, cache_pos2, cur_pos1, cur_pos2;
     DevBuf<int> hit1, hit2, hcnt1, hcnt2, hlo1;   // this step's in-range pairs per row (upk_pairlist_refine)
     DevBuf<unsigned short> ord1, ord2, ord1u;   // rows sorted by hit count (upk_pairlist_order)
     DevBuf<unsigned long long> gacc;   // upk_igraph_backward's cross-workgroup accumulators (small batches only)
@@ -495,11 +520,22 @@ struct IGraphHost {
         G.loc1 = d_loc1.p; G.type1 = d_type1.p; G.id1 = d_id1.p;
         G.loc2 = G.symmetric ? d_loc1.p : d_loc2.p; G.type2 = G.symmetric ? d_type1.p : d_type2.p; G.id2 = G.symmetric ? d_id1.p : d_id2.p;
         G.param = d_param.p;
+        pack_param_poly();
         G.nbr1 = nbr1.p; G.cnt1 = cnt1.p; G.nbr2 = nbr2.p; G.cnt2 = cnt2.p;
         G.cache_pos1 = cache_pos1.p; G.cache_pos2 = G.symmetric ? cache_pos1.p : cache_pos2.p;
         G.rebuild_flag = rebuild_flag.p; G.error_flag = c->error_flag.p;
         flagged.alloc(2 * (size_t)(S + 1)); G.flagged = flagged.p; G.flag_stride = S + 1; G.parity = 0;
         G.node1 = node1->coord(); G.node2 = node2->coord();
+    }
+    // the polynomial image of the table for the LDS-staged pair passes (hbond_coverage); follows every set_param
+    void pack_param_poly() {
+        if (G.itype != UPK_IT_HBOND_COVERAGE) return;
+        G.n_poly = quadspline_poly_width(G.n_knot_angular, G.n_knot);
+        vector<float> poly((size_t)G.n_type1 * G.n_type2 * G.n_poly);
+        for (int t = 0; t < G.n_type1 * G.n_type2; ++t)
+            quadspline_poly_row(&param[(size_t)t * G.n_param], G.n_knot_angular, G.n_knot, &poly[(size_t)t * G.n_poly]);
+        if (d_param_poly.n != poly.size()) { d_param_poly.upload(poly); G.param_poly = d_param_poly.p; }
+        else hip_check(hipMemcpy(d_param_poly.p, poly.data(), poly.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
     }
     void begin_step() { G.parity ^= 1; }
     // K1 + K2 + K2b/c for the rows of `sides` (bit 1: side 1, bit 2: side 2); the other side's hit lists follow in refine()
@@ -522,8 +558,11 @@ struct IGraphHost {
         if (p.size() != param.size()) throw string("Bad param size, got ") + to_string(p.size()) + " params, but expected " + to_string(param.size());
         param = p; update_cutoffs();
         hip_check(hipMemcpy(d_param.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
-        cache_pos1.upload(vector<float>(cache_pos1.n, 1e10f)); G.cache_pos1 = cache_pos1.p;
-        if (G.symmetric) G.cache_pos2 = cache_pos1.p;
+        pack_param_poly();
+        // force a rebuild with the new cutoffs: refill the existing reference positions of BOTH sides in place (the buffers
+        // keep their addresses: other structs hold copies of them)
+        for (DevBuf<float>* b : {&cache_pos1, &cache_pos2})
+            if (b->n) hip_check(hipMemsetD32Async((hipDeviceptr_t)b->p, 0x501502f9 /* 1e10f */, b->n, ctx->stream), "fill");
     }
     // Algorithmic bytes: one force evaluation of one graph moves
     //   8*(n1*d1 + n2*d2) + 16*E + 4*n_type1*n_type2*n_param   bytes
@@ -1042,7 +1081,7 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
-    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri, param_tri_poly;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
@@ -1128,6 +1167,11 @@ struct RotamerSidechain : public PotentialNode {
         for (int lo = 0; lo < nt; ++lo) for (int hi = lo; hi < nt; ++hi)
             tri.insert(tri.end(), ig.param.begin() + (size_t)(lo * nt + hi) * np, ig.param.begin() + (size_t)(lo * nt + hi + 1) * np);
         param_tri.upload(tri); R.param_tri = param_tri.p;
+        // ... and as per-interval polynomials for the energy pass (quadspline_poly_row)
+        const int npoly = quadspline_poly_width(ig.G.n_knot_angular, ig.G.n_knot);
+        vector<float> poly((size_t)nt * (nt + 1) / 2 * npoly);
+        for (size_t r = 0; r < (size_t)nt * (nt + 1) / 2; ++r) quadspline_poly_row(&tri[r * np], ig.G.n_knot_angular, ig.G.n_knot, &poly[r * npoly]);
+        param_tri_poly.upload(poly); R.param_tri_poly = param_tri_poly.p; R.n_poly = npoly;
     }
     void fill_struct() {
         R.G = ig.G;
