@@ -563,6 +563,8 @@ ALT_PATHS = [
     {'UPSIDE_HIP_ROTAMER_ATOMIC': '1'},      # pair matrices accumulated with atomics (libraries with several beads per state)
     {'UPSIDE_HIP_PLB_UNSTAGED': '1'},        # list build reading the other side from global memory (very large systems)
     {'UPSIDE_HIP_SKIN_SCALE': '1.0'},        # the reference's cached-list margin
+    {'UPSIDE_HIP_ROT_POLY': '0'},            # side-chain energy pass on the spline-coefficient table (tables too large for the polynomial form)
+    {'UPSIDE_HIP_UPKEEP_STREAMS': '1'},      # one shared upkeep stream (the large-batch choice) for a small batch
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '0'},      # one-workgroup BP of 1024 lanes streaming every pair matrix
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '1'},      # 512 lanes, two 6x6 trips of pair matrices pinned in registers (large batches)
@@ -610,6 +612,25 @@ def test_large_batch_solver_on_every_fixture():
                           '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200).stdout.decode()
     assert ' passed' in out and 'failed' not in out and 'error' not in out.lower(), out[-3000:]
+
+
+def test_side_chain_node_limit_is_refused_with_a_message():
+    """the device solve serves one system per workgroup and keeps the residue-pair bookkeeping in LDS: more than 1024
+    side-chain nodes are refused at construction with a message naming the limit (never a silent wrong answer).  The limit
+    is lowered through the environment so that a shipped fixture exceeds it."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import parity_util as P, ctypes as ct\n"
+            "lib = P.pkg.default_library(); c = lib.calc\n"
+            "c.construct_deriv_engine.restype = ct.c_void_p; c.upside_hip_last_error.restype = ct.c_char_p\n"
+            "e = c.construct_deriv_engine(900, P.fixture('syn300_10A').encode(), True)\n"
+            "print('ENGINE', bool(e)); print('MSG', c.upside_hip_last_error().decode())\n") % (P.ROOT, os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UPSIDE_HIP_MAX_ROTAMER_NODES='299')
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    assert 'ENGINE False' in out and '300 side-chain nodes' in out and 'at most 299' in out, out[-2000:]
+    env = dict(os.environ, UPSIDE_HIP_MAX_ROTAMER_NODES='300')
+    out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    assert 'ENGINE True' in out, out[-2000:]
 
 
 def test_capacity_overflow_fails_loudly():

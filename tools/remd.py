@@ -4,9 +4,14 @@ ReplicaExchange::attempt_swaps every --replica-interval).  One process per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
         tools/remd.py --fixture proteinG56_7A --temperatures 64 --t-low 0.7 --t-high 1.0 --rounds 600
 
-Rank r owns a contiguous block of the temperature ladder (most neighbour swaps stay on one GPU).  Per swap set the
-ranks all-gather one energy per replica over RCCL, reach identical Metropolis verdicts on the host, and move the
-coordinates of accepted cross-GPU pairs point to point; nothing else crosses xGMI.  Also runs as a single process."""
+Rank r owns a contiguous block of the temperature ladder (most neighbour swaps stay on one GPU).  Per attempt the
+ranks all-gather one energy per replica over RCCL, every rank reaches the identical Metropolis verdicts and the coordinates
+of accepted cross-GPU pairs move point to point; nothing else crosses xGMI.  Also runs as a single process.
+
+--exchange rccl (default): the exchange runs inside the library (upside_hip_comm_*, comm_rccl.cpp: ncclAllGather, verdicts on
+the device, ncclSend/ncclRecv), enqueued behind the MD steps with no host staging; the verdicts are read back only for the
+statistics printed here.  --exchange host: the same protocol driven from Python over torch.distributed
+(replicas.exchange_swap_set; gloo-testable, tests/test_replicas_gloo.py)."""
 import argparse
 import json
 import os
@@ -29,6 +34,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=300, help='integration cycles (3 MD steps each)')
     ap.add_argument('--replica-interval', type=int, default=5, help='rounds between exchange attempts (README.md:189-193)')
     ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--exchange', choices=['rccl', 'host'], default='rccl')
     args = ap.parse_args()
 
     pkg = load_package()
@@ -53,6 +59,11 @@ def main():
     ens.set_pos(pkg.config.read_pos(fixture))
     ens.init_md(ladder[lo:hi], rep.system_seed(args.seed, lo))
     swap_sets = rep.neighbour_swap_sets(args.temperatures)
+    if args.exchange == 'rccl':
+        uid = [ens.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        ens.comm_init(rank, world, uid[0], ladder)
     n_attempt = np.zeros(len(swap_sets), 'i8'); n_success = np.zeros(len(swap_sets), 'i8')
     replica_index = np.arange(args.temperatures)            # which starting replica sits in each temperature slot
     rep.barrier(dist, torch.cuda.synchronize)
@@ -63,10 +74,14 @@ def main():
         ens.run_rounds(n)
         done += n
         draw = 0
-        energy = rep.all_gather_f32(dist, ens.energies(), device)      # one force evaluation per attempt ...
+        if args.exchange == 'host':
+            energy = rep.all_gather_f32(dist, ens.energies(), device)      # one force evaluation per attempt ...
         for k, pairs in enumerate(swap_sets):
-            acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, args.seed, done, draw, device, energy_global=energy)
-            energy = rep.swap_energies(energy, pairs, acc)               # ... the later sets see the traded energies
+            if args.exchange == 'rccl':
+                acc = ens.comm_replica_swap(pairs, args.seed, done, k == 0, want_accepted=True)
+            else:
+                acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, args.seed, done, draw, device, energy_global=energy)
+                energy = rep.swap_energies(energy, pairs, acc)               # ... the later sets see the traded energies
             n_attempt[k] += len(pairs); n_success[k] += int(acc.sum())
             for (s1, s2), ok in zip(pairs, acc):
                 if ok:

@@ -346,22 +346,42 @@ __global__ void k_affine_bwd(upk_coord_t aff, const float* __restrict__ ref_geom
         2.f * (tq[1] * EV(0, 0) + tq[2] * EV(0, 1) - tq[0] * EV(0, 3)),
         2.f * (tq[2] * EV(0, 0) + tq[0] * EV(0, 2) - tq[1] * EV(0, 1))};
     float qsdb[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int dd = 0; dd < 4; ++dd) for (int i = 0; i < 4; ++i) qsdb[dd] += quat_sens[i] * EV(dd, i);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qsdb[dd] += quat_sens[i] * EV(dd, i);
+    }
+    // symmetrised products of eigenvector k with eigenvector 0, m = r_idx(i, j), i <= j: they depend on neither the atom
+    // nor the component, so they are formed once (the loops below are fully unrolled: every index is a constant and the
+    // tables live in registers -- left to the compiler's partial unrolling they were indexed dynamically and spilled to
+    // 280 bytes of scratch per lane)
+    float t[3][10];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = i; j < 4; ++j)
+                t[k - 1][r_idx(i, j)] = (i == j) ? EV(k, i) * EV(0, j) : EV(k, i) * EV(0, j) + EV(k, j) * EV(0, i);
+        }
+    }
     float* out = contrib + (size_t)s * contrib_stride + (size_t)nr * 9;
+#pragma unroll
     for (int na = 0; na < 3; ++na) {
         const float* g = ref_geom + nr * 9 + na * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
         const float f[3][10] = {
-            {g[0], 0.f, g[2], -g[1], g[0], g[1], g[2], -g[0], 0.f, -g[0]},
-            {g[1], -g[2], 0.f, g[0], -g[1], g[0], 0.f, g[1], g[2], -g[1]},
-            {g[2], g[1], -g[0], 0.f, -g[2], 0.f, g[0], -g[2], g[1], g[2]}};
+            {g0, 0.f, g2, -g1, g0, g1, g2, -g0, 0.f, -g0},
+            {g1, -g2, 0.f, g0, -g1, g0, 0.f, g1, g2, -g1},
+            {g2, g1, -g0, 0.f, -g2, 0.f, g0, -g2, g1, g2}};
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             float deriv = (1.f / 3.f) * sens3[c];
+#pragma unroll
             for (int k = 1; k < 4; ++k) {
                 float acc = 0.f;
-                for (int i = 0; i < 4; ++i) for (int j = i; j < 4; ++j) {
-                    const float t = (i == j) ? EV(k, i) * EV(0, j) : EV(k, i) * EV(0, j) + EV(k, j) * EV(0, i);
-                    acc += f[c][r_idx(i, j)] * t;
-                }
+#pragma unroll
+                for (int m = 0; m < 10; ++m) acc += f[c][m] * t[k - 1][m];     // (m ascends in the order of the i <= j double loop)
                 deriv += (inv_evals[k] * acc) * qsdb[k];
             }
             out[na * 3 + c] = deriv;

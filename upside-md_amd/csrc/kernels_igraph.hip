@@ -205,10 +205,13 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
             for (int j = threadIdx.x; j < n_pad; j += blockDim.x) oth[j] = j < n_other ? src[j] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
             __syncthreads();
         }
+        float4 x_next = make_float4(0.f, 0.f, 0.f, 0.f);       // the next row's element is fetched while this row is tested
+        { const int i0 = rb * rows_per_wg + wave; if (wave < rows_per_wg && i0 < n_my) x_next = mine[i0]; }
         for (int r = wave; r < rows_per_wg; r += n_wave) {
             const int i = rb * rows_per_wg + r;
             if (i >= n_my) break;
-            const float4 x = mine[i];
+            const float4 x = x_next;
+            { const int in = i + n_wave; if (r + n_wave < rows_per_wg && in < n_my) x_next = mine[in]; }
             const int my_id = __float_as_int(x.w);
             int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
             int count = 0;

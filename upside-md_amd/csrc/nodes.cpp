@@ -1109,8 +1109,12 @@ struct RotamerSidechain : public PotentialNode {
             n_elem_rot[n_rot] = max(n_elem_rot[n_rot], (int)id + 1);
         }
         n1 = n_elem_rot[1]; n3 = n_elem_rot[3]; n6 = n_elem_rot[6]; n_node = n1 + n3 + n6;
-        if (n_node > 1024)   // one lane per node in the slot numbering and the one-workgroup solve (kernels_rotamer.hip)
-            throw string("rotamer: ") + to_string(n_node) + " side-chain nodes, but the device belief-propagation solve handles at most 1024";
+        // one lane per node in the slot numbering and the LDS bit matrix of residue pairs (kernels_rotamer.hip: 1024 x 1024 bits = 128 KB);
+        // UPSIDE_HIP_MAX_ROTAMER_NODES lowers the limit so that the refusal can be tested with the shipped fixtures
+        const int max_node = min(1024, env_int("UPSIDE_HIP_MAX_ROTAMER_NODES", 1024));
+        if (n_node > max_node)
+            throw string("rotamer: ") + to_string(n_node) + " side-chain nodes, but the device belief-propagation solve handles at most " + to_string(max_node) +
+                  " (one system per workgroup: slot numbering and pair-matrix bookkeeping live in the 160 KB LDS of a CU)";
         const int start[7] = {0, 0, 0, n1, 0, 0, n1 + n3};
         node_nrot.assign(n_node, 0);
         for (int g = 0; g < n_node; ++g) node_nrot[g] = g < n1 ? 1 : (g < n1 + n3 ? 3 : 6);

@@ -244,6 +244,10 @@ class Ensemble(object):
         c.upside_hip_set_system_pos.argtypes = [vp, i32, vp]
         c.upside_hip_swap_systems.argtypes = [vp, i32, i32]
         c.upside_hip_swap_system_pairs.argtypes = [vp, i32, vp]
+        c.upside_hip_comm_get_unique_id.argtypes = [ct.c_char_p]
+        c.upside_hip_comm_init.argtypes = [vp, i32, i32, ct.c_char_p, vp]
+        c.upside_hip_comm_replica_swap.argtypes = [vp, i32, vp, u32, u64, i32, vp]
+        c.upside_hip_comm_free.argtypes = [vp]
         c.upside_hip_last_error.restype = ct.c_char_p
         c._ensemble_bound = True
 
@@ -309,6 +313,34 @@ class Ensemble(object):
 
     def run_rounds(self, n_round):
         self._check(self.calc.upside_hip_run_md(self.engine, int(n_round)), 'run_md')
+
+    # -- replica exchange across the engines of a job, inside the library (comm_rccl.cpp) -------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """rank 0: the rendezvous token every rank passes to comm_init (hand it around with any host channel)"""
+        uid = ct.create_string_buffer(self.COMM_ID_BYTES)
+        self._check(self.calc.upside_hip_comm_get_unique_id(uid), 'comm_get_unique_id')
+        return uid.raw
+
+    def comm_init(self, rank, world, unique_id, temperature_global):
+        """joins this engine (rank `rank` of `world`, equal system counts) to the exchange group; temperature_global:
+        the whole ladder, rank r owns entries [r*n_system, (r+1)*n_system)"""
+        t = np.ascontiguousarray(np.asarray(temperature_global, 'f4'))
+        assert t.shape == (int(world) * self.n_system,)
+        uid = ct.create_string_buffer(bytes(unique_id), self.COMM_ID_BYTES)
+        self._check(self.calc.upside_hip_comm_init(self.engine, int(rank), int(world), uid, t.ctypes.data), 'comm_init')
+
+    def comm_replica_swap(self, pairs_global, base_seed, round_num, first_set, want_accepted=False):
+        """one swap set over GLOBAL replica indices: energies all-gathered over RCCL (first set of an attempt only),
+        Metropolis verdicts on the device, coordinates of accepted pairs traded (ncclSend/ncclRecv when they straddle
+        ranks).  Everything is enqueued behind the MD steps; want_accepted reads the verdicts back (synchronises)."""
+        p = np.ascontiguousarray(np.asarray(pairs_global, 'i4').reshape(-1, 2))
+        acc = np.zeros(len(p), 'i4') if want_accepted else None
+        self._check(self.calc.upside_hip_comm_replica_swap(self.engine, int(len(p)), p.ctypes.data, int(base_seed) & 0xFFFFFFFF,
+                                                           int(round_num), int(bool(first_set)),
+                                                           acc.ctypes.data if want_accepted else None), 'comm_replica_swap')
+        return acc.astype(bool) if want_accepted else None
 
     def close(self):
         if getattr(self, 'engine', None):
