@@ -338,7 +338,9 @@ def main():
                    config=cfg, roofline=roofline)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (rank 0 has the host to itself)
             res['cpu_baseline'] = cpu_baseline(fixture, variant)
-        print(json.dumps(res))
+        # (flushed at once: tearing down the RCCL communicator below has been seen to end the process without running Python's
+        #  exit-time flush of a buffered stdout)
+        print(json.dumps(res), flush=True)
     if remd:
         c.upside_hip_comm_free(eng)
     lib.calc.free_deriv_engine(ct.c_void_p(eng))

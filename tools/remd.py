@@ -94,7 +94,7 @@ def main():
                               md_steps_per_replica=3 * args.rounds, seconds=elapsed,
                               system_steps_per_s=3 * args.rounds * args.temperatures / elapsed,
                               swap_acceptance=[float(s) / max(a, 1) for s, a in zip(n_success, n_attempt)],
-                              replica_index=replica_index.tolist(), final_energy=[float(e) for e in energy])))
+                              replica_index=replica_index.tolist(), final_energy=[float(e) for e in energy])), flush=True)
     ens.close()
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

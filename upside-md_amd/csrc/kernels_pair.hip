@@ -22,13 +22,14 @@ struct PairArgs {
 };
 
 // value of one pair and, if GRAD, its derivative w.r.t. the ROW element in d[0..8); x1 is always the side-1 element
-template <int IT, int ROW_SIDE, bool GRAD>
+// POLY (hbond_coverage only): `tab` is the per-interval polynomial table (upk_igraph_t::param_poly), else the spline coefficients
+template <int IT, int ROW_SIDE, bool GRAD, bool POLY>
 __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
                                               const float* x1, const float* x2, float* d) {
-    const float* p = tab + (t1 * G.n_type2 + t2) * (IT == UPK_IT_HBOND_COVERAGE ? G.n_poly : G.n_param);   // (hbond_coverage: the polynomial table)
+    const float* p = tab + (t1 * G.n_type2 + t2) * (POLY ? G.n_poly : G.n_param);
     if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
         float dd[3], g1[3], g2[3];
-        const float coverage = quadspline_pair<GRAD ? 3 : 0, true>(Q, p, x1, x2, dd, g1, g2);
+        const float coverage = quadspline_pair<GRAD ? 3 : 0, POLY>(Q, p, x1, x2, dd, g1, g2);
         const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
         if (GRAD) {
 #pragma unroll
@@ -52,13 +53,13 @@ __device__ __forceinline__ float pair_functor(const upk_igraph_t& G, const QuadS
 }
 
 // value of one pair with BOTH elements' derivatives: d1[0..7) w.r.t. the side-1 element, d2[0..6) w.r.t. the side-2 element
-template <int IT>
+template <int IT, bool POLY>
 __device__ __forceinline__ float pair_functor_both(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1, int t2,
                                                    const float* x1, const float* x2, float* d1, float* d2) {
-    const float* p = tab + (t1 * G.n_type2 + t2) * (IT == UPK_IT_HBOND_COVERAGE ? G.n_poly : G.n_param);
+    const float* p = tab + (t1 * G.n_type2 + t2) * (POLY ? G.n_poly : G.n_param);
     if (IT == UPK_IT_HBOND_COVERAGE) {                               // hbond.cpp:261-276
         float dd[3], g1[3], g2[3];
-        const float coverage = quadspline_pair<3, true>(Q, p, x1, x2, dd, g1, g2);
+        const float coverage = quadspline_pair<3, POLY>(Q, p, x1, x2, dd, g1, g2);
         const float one_m = 1.f - x1[6], prefactor = one_m * one_m;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d1[c] = -prefactor * dd[c]; d1[3 + c] = prefactor * g1[c]; d2[c] = prefactor * dd[c]; d2[3 + c] = prefactor * g2[c]; }
@@ -86,7 +87,7 @@ __device__ __forceinline__ PairLds pair_lds(float* lds, const upk_igraph_t& G, i
 }
 
 // MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element); 2: sum of sens(pair) * d(value)/d(row element)
-template <int IT, int ROW_SIDE, int MODE>
+template <int IT, int ROW_SIDE, int MODE, bool POLY>
 struct RowOp {
     static constexpr int NV = MODE == 0 ? 1 : 8;
     const upk_igraph_t& G; const QuadShape Q; const PairLds& L; const PairArgs& A;
@@ -104,8 +105,8 @@ struct RowOp {
         float xo[8], d[8];
         load_row8(xo, (ROW_SIDE == 1 ? L.c2 : L.c1) + j * 8);
         const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
-        const float v = ROW_SIDE == 1 ? pair_functor<IT, 1, MODE != 0>(G, Q, L.tab, tr, to, xr, xo, d)
-                                      : pair_functor<IT, 2, MODE != 0>(G, Q, L.tab, to, tr, xo, xr, d);
+        const float v = ROW_SIDE == 1 ? pair_functor<IT, 1, MODE != 0, POLY>(G, Q, L.tab, tr, to, xr, xo, d)
+                                      : pair_functor<IT, 2, MODE != 0, POLY>(G, Q, L.tab, to, tr, xo, xr, d);
         if (MODE == 0) acc[0] += live ? v : 0.f;
         if (MODE == 1) {
 #pragma unroll
@@ -142,14 +143,14 @@ struct RowOp {
 };
 
 // SIDES: 1 or 2 = the rows of that side; 3 = side 1, then side 2 (protein_hbond: both row sets in one launch)
-template <int IT, int SIDES, int MODE>
+template <int IT, int SIDES, int MODE, bool POLY>
 __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t G, PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y;
     const PairLds L = pair_lds(lds, G, A.tab_floats);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
-    stage_table(L.tab, IT == UPK_IT_HBOND_COVERAGE ? G.param_poly : G.param, A.tab_floats);
+    stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
     // rows: [0,dim) coordinates, [6] per-element pair sensitivity (mode 2, sides with dim <= 6), [7] element type
     stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (MODE == 2 && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (MODE == 2 && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
         if (threadIdx.x == 0) *L.counter = 0;
         stage_ranges(L.range, L.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
         __syncthreads();
-        RowOp<IT, 1, MODE> op(G, L, A, s);
+        RowOp<IT, 1, MODE, POLY> op(G, L, A, s);
         group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
     }
     if (SIDES & 2) {
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
         if (threadIdx.x == 0) *L.counter = 0;
         stage_ranges(L.range, L.ord, G.hcnt2 + (size_t)s * G.n2, nullptr, G.ord2 + (size_t)s * G.n2, G.n2);
         __syncthreads();
-        RowOp<IT, 2, MODE> op(G, L, A, s);
+        RowOp<IT, 2, MODE, POLY> op(G, L, A, s);
         group_batch_loop(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, blockIdx.x, gridDim.x);
     }
 }
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
 // ---- backward, ONE visit per pair over the rows of side RS (the side the forward pass ran over): the row element's gradient
 // accumulates in registers; the other element's goes through 64-bit integer LDS atomics as exact fixed point (igraph_device.h:
 // to_fixed32), so its total does not depend on the order in which the pairs arrive -- results stay bit-reproducible
-template <int IT, int RS>
+template <int IT, int RS, bool POLY>
 struct BackwardOp {
     static constexpr int DR = RS == 1 ? PairDims<IT>::d1 : PairDims<IT>::d2;     // components of the row / the other element
     static constexpr int DO = RS == 1 ? PairDims<IT>::d2 : PairDims<IT>::d1;
@@ -195,8 +196,8 @@ struct BackwardOp {
         float xo[8], d1[8], d2[8];
         load_row8(xo, (RS == 1 ? L.c2 : L.c1) + j * 8);
         const int tr = __float_as_int(xr[7]), to = __float_as_int(xo[7]);
-        if (RS == 1) pair_functor_both<IT>(G, Q, L.tab, tr, to, xr, xo, d1, d2);
-        else pair_functor_both<IT>(G, Q, L.tab, to, tr, xo, xr, d1, d2);
+        if (RS == 1) pair_functor_both<IT, POLY>(G, Q, L.tab, tr, to, xr, xo, d1, d2);
+        else pair_functor_both<IT, POLY>(G, Q, L.tab, to, tr, xo, xr, d1, d2);
         // pair sensitivity = (row part) + (other part); the parts ride in slot 6 of the staged rows
         const float ps = (row_has ? xr[6] : 0.f) + (oth_has ? xo[6] : 0.f);
         const float* dr = RS == 1 ? d1 : d2; const float* dv = RS == 1 ? d2 : d1;
@@ -218,17 +219,17 @@ struct BackwardOp {
     }
 };
 
-template <int IT, int RS>
+template <int IT, int RS, bool POLY>
 __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igraph_t G, PairArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int DO = BackwardOp<IT, RS>::DO;
+    constexpr int DO = BackwardOp<IT, RS, POLY>::DO;
     const int s = blockIdx.y;
     const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
     const PairLds L = pair_lds(lds, G, A.tab_floats);
     unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
-    stage_table(L.tab, IT == UPK_IT_HBOND_COVERAGE ? G.param_poly : G.param, A.tab_floats);
+    stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
     // rows: [0,dim) coordinates, [6] per-element pair sensitivity (sides with dim <= 6), [7] element type
     stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, G.dim1 <= 6 ? S1 : nullptr, A.sens_stride);
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, G.dim2 <= 6 ? S2 : nullptr, A.sens_stride);
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
     stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
     __syncthreads();
     {
-        BackwardOp<IT, RS> op(G, L, oacc, A.sens_mode, s);
+        BackwardOp<IT, RS, POLY> op(G, L, oacc, A.sens_mode, s);
         const int cap = RS == 1 ? G.cap1 : G.cap2;
         group_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x);
     }
@@ -272,9 +273,9 @@ __global__ void k_pair_backward_finish(upk_igraph_t G, int other_side) {
 }
 
 // LDS bytes of a staged pair pass; false when the system does not fit (callers fall back to the list-walking kernels)
-static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes) {
-    tab_floats = G->n_type1 * G->n_type2 * (G->itype == UPK_IT_HBOND_COVERAGE ? G->n_poly : G->n_param);
-    if (G->itype == UPK_IT_HBOND_COVERAGE && !G->param_poly) return false;
+static bool pair_lds_bytes(const upk_igraph_t* G, bool poly, int& tab_floats, size_t& bytes) {
+    tab_floats = G->n_type1 * G->n_type2 * (poly ? G->n_poly : G->n_param);
+    if (poly && !(G->itype == UPK_IT_HBOND_COVERAGE && G->param_poly)) return false;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     bytes = ((size_t)((tab_floats + 3) & ~3) + (size_t)(G->n1 + G->n2) * 8 + PG_WALK_LDS_WORDS(n_max) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_IG_UNSTAGED=1 exercises the path taken by systems too large for LDS staging
@@ -282,17 +283,25 @@ static bool pair_lds_bytes(const upk_igraph_t* G, int& tab_floats, size_t& bytes
     return bytes <= 158 * 1024 && !force_unstaged && n_max < 65536 && G->cap1 < 65536 && G->cap2 < 65536;
 }
 
-template <int IT, int SIDES>
+template <int IT, int SIDES, bool POLY>
 static void rows_launch(const upk_launch_t* L, const upk_igraph_t* G, int mode, dim3 grid, dim3 block, size_t lds, const PairArgs& A) {
-    if (mode == 0) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 0>), grid, block, lds, ST(L), *G, A);
-    else if (mode == 1) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 1>), grid, block, lds, ST(L), *G, A);
-    else hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 2>), grid, block, lds, ST(L), *G, A);
+    if (mode == 0) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 0, POLY>), grid, block, lds, ST(L), *G, A);
+    else if (mode == 1) hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 1, POLY>), grid, block, lds, ST(L), *G, A);
+    else hipLaunchKernelGGL((k_pair_rows<IT, SIDES, 2, POLY>), grid, block, lds, ST(L), *G, A);
 }
-template <int IT>
+template <int IT, bool POLY = false>
 static void rows_launch_sides(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, dim3 grid, dim3 block, size_t lds, const PairArgs& A) {
-    if (side == 1) rows_launch<IT, 1>(L, G, mode, grid, block, lds, A);
-    else if (side == 2) rows_launch<IT, 2>(L, G, mode, grid, block, lds, A);
-    else rows_launch<IT, 3>(L, G, mode, grid, block, lds, A);
+    if (side == 1) rows_launch<IT, 1, POLY>(L, G, mode, grid, block, lds, A);
+    else if (side == 2) rows_launch<IT, 2, POLY>(L, G, mode, grid, block, lds, A);
+    else rows_launch<IT, 3, POLY>(L, G, mode, grid, block, lds, A);
+}
+// the polynomial table when it fits LDS next to the elements (and extra bytes), else the spline coefficients, else nothing fits
+static int pair_table_choice(const upk_igraph_t* G, size_t extra, int& tab_floats, size_t& lds) {
+    static int no_poly = -1;      // UPSIDE_HIP_IG_POLY=0: always the spline-coefficient table (A/B and the large-table path)
+    if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_IG_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
+    if (!no_poly && pair_lds_bytes(G, true, tab_floats, lds) && lds + extra <= 158 * 1024) return 2;
+    if (pair_lds_bytes(G, false, tab_floats, lds) && lds + extra <= 158 * 1024) return 1;
+    return 0;
 }
 
 extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride,
@@ -305,7 +314,8 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     A.own_grad = own_grad;
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
     size_t lds;
-    if (!pair_lds_bytes(G, A.tab_floats, lds)) {      // list-walking kernels, one side at a time
+    const int table = pair_table_choice(G, 0, A.tab_floats, lds);
+    if (!table) {                                      // list-walking kernels, one side at a time
         int r = 0;
         for (int sd = 1; sd <= 2 && !r; ++sd) {
             if (!(side & sd)) continue;
@@ -320,7 +330,10 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     pair_geometry(L->n_system, n_rows, bps, threads);
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
-        case UPK_IT_HBOND_COVERAGE: rows_launch_sides<UPK_IT_HBOND_COVERAGE>(L, G, side, mode, grid, block, lds, A); break;
+        case UPK_IT_HBOND_COVERAGE:
+            if (table == 2) rows_launch_sides<UPK_IT_HBOND_COVERAGE, true>(L, G, side, mode, grid, block, lds, A);
+            else rows_launch_sides<UPK_IT_HBOND_COVERAGE, false>(L, G, side, mode, grid, block, lds, A);
+            break;
         case UPK_IT_ENVIRONMENT: rows_launch_sides<UPK_IT_ENVIRONMENT>(L, G, side, mode, grid, block, lds, A); break;
         case UPK_IT_PROTEIN_HBOND: rows_launch_sides<UPK_IT_PROTEIN_HBOND>(L, G, side, mode, grid, block, lds, A); break;
         default: return 9008;
@@ -334,13 +347,14 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     PairArgs A; memset(&A, 0, sizeof(A));
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
     const int n_rows = row_side == 1 ? G->n1 : G->n2, n_other = row_side == 1 ? G->n2 : G->n1;
-    size_t lds;
-    const bool fits = pair_lds_bytes(G, A.tab_floats, lds);
     const int d_other = G->itype == UPK_IT_HBOND_COVERAGE ? (row_side == 1 ? PairDims<UPK_IT_HBOND_COVERAGE>::d2 : PairDims<UPK_IT_HBOND_COVERAGE>::d1)
                       : G->itype == UPK_IT_ENVIRONMENT    ? (row_side == 1 ? PairDims<UPK_IT_ENVIRONMENT>::d2 : PairDims<UPK_IT_ENVIRONMENT>::d1)
                                                           : (row_side == 1 ? PairDims<UPK_IT_PROTEIN_HBOND>::d2 : PairDims<UPK_IT_PROTEIN_HBOND>::d1);
-    lds += 8 + (size_t)n_other * d_other * sizeof(unsigned long long);    // the other side's accumulators (BackwardOp::DO per element)
-    if (!fits || lds > 158 * 1024) {      // list-walking kernels, one side at a time (they need no hit lists)
+    const size_t acc_bytes = 8 + (size_t)n_other * d_other * sizeof(unsigned long long);    // the other side's accumulators (BackwardOp::DO per element)
+    size_t lds;
+    const int table = pair_table_choice(G, acc_bytes, A.tab_floats, lds);
+    lds += acc_bytes;
+    if (!table) {      // list-walking kernels, one side at a time (they need no hit lists)
         int r = upk_igraph_grad(L, G, 1, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
         if (!r) r = upk_igraph_grad(L, G, 2, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
         return r;
@@ -351,16 +365,21 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
         case UPK_IT_HBOND_COVERAGE:
-            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 1>), grid, block, lds, ST(L), *G, A);
-            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 2>), grid, block, lds, ST(L), *G, A);
+            if (table == 2) {
+                if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 1, true>), grid, block, lds, ST(L), *G, A);
+                else hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 2, true>), grid, block, lds, ST(L), *G, A);
+            } else {
+                if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 1, false>), grid, block, lds, ST(L), *G, A);
+                else hipLaunchKernelGGL((k_pair_backward<UPK_IT_HBOND_COVERAGE, 2, false>), grid, block, lds, ST(L), *G, A);
+            }
             break;
         case UPK_IT_ENVIRONMENT:
-            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 1>), grid, block, lds, ST(L), *G, A);
-            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 2>), grid, block, lds, ST(L), *G, A);
+            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 1, false>), grid, block, lds, ST(L), *G, A);
+            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_ENVIRONMENT, 2, false>), grid, block, lds, ST(L), *G, A);
             break;
         case UPK_IT_PROTEIN_HBOND:
-            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 1>), grid, block, lds, ST(L), *G, A);
-            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 2>), grid, block, lds, ST(L), *G, A);
+            if (row_side == 1) hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 1, false>), grid, block, lds, ST(L), *G, A);
+            else hipLaunchKernelGGL((k_pair_backward<UPK_IT_PROTEIN_HBOND, 2, false>), grid, block, lds, ST(L), *G, A);
             break;
         default: return 9008;
     }
