@@ -171,6 +171,7 @@ typedef struct {
        rows 16-byte aligned (layout: igraph_device.h, quadspline_pair<.., POLY>).  The LDS-staged pair passes read this one;
        NULL: they read `param`. */
     const float* param_poly; int n_poly;
+    int sens_overlap;                    /* node1 and node2 are one node AND some element is listed on both sides (set by the host) */
 } upk_igraph_t;
 #define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8192 beads, < 2^19 - 1 slots */
 #define UPK_ROT_SLOT_NONE 0x7FFFF        /* slot field of a cached bead pair whose residue pair got no slot (capacity overflow) */
@@ -181,6 +182,12 @@ int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G);
 /* K2: where flag[s] is set rebuild the row lists with d < cache_cutoff and acceptable_id_pair
  * (interaction_graph.h:116-158); clears the flag */
 int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G);
+/* ... of the sides in `sides` only (bit 1: side-1 rows, bit 2: side-2 rows): a graph whose pair passes all gather over the rows of
+ * one side never reads the other side's lists on the MD path (they can be built later from the same cache_pos) */
+int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_t* G, int sides);
+/* 1 if upk_igraph_rows and upk_igraph_backward over the rows of `row_side` take the LDS-staged (hit-list) path for this graph,
+ * 0 if they fall back to the list-walking kernels, which read the cached lists of BOTH sides */
+int upk_igraph_passes_staged(const upk_launch_t* L, const upk_igraph_t* G, int row_side);
 /* K2b: this step's in-range pairs of every system for the rows of `side` (hit lists above), from the cached lists and
  * cur_pos; then the rows of that side sorted by descending hit count (ord1 / ord2, and ord1u for symmetric graphs) */
 int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side);

@@ -254,10 +254,12 @@ static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, 
     if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1, rows);
     else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1, rows);
 }
-extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
+extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) { return upk_pairlist_build_sides(L, G, 3); }
+extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_t* G, int sides) {
     const int rows = plb_rows(L->n_system);
-    const int blocks1 = (G->n1 + rows - 1) / rows;
-    const int blocks2 = G->symmetric ? 0 : (G->n2 + rows - 1) / rows;
+    const int blocks1 = (sides & 1) ? (G->n1 + rows - 1) / rows : 0;
+    const int blocks2 = (G->symmetric || !(sides & 2)) ? 0 : (G->n2 + rows - 1) / rows;
+    if (blocks1 + blocks2 == 0) return 0;
     const int n_max = G->n1 > G->n2 ? G->n1 : G->n2;
     const size_t lds = (size_t)((n_max + 63) & ~63) * 16;
     const dim3 grid(blocks1 + blocks2, UPK_FLAG_GRID(L->n_system));

@@ -19,6 +19,7 @@ struct PairArgs {
     float* own_grad;                                                                         // mode 1
     int sens_mode; const float* sens1; const float* sens2; long sens_sys_stride; int sens_stride;   // mode 2
     int tab_floats;
+    int atomic_sens;      // mode 2, both row sets in one launch, the sides share elements of one node: the row "+=" must be atomic
 };
 
 // value of one pair and, if GRAD, its derivative w.r.t. the ROW element in d[0..8); x1 is always the side-1 element
@@ -132,12 +133,20 @@ struct RowOp {
             float4* o = (float4*)(A.own_grad + ((size_t)s * n_rows + row) * 8);
             o[0] = make_float4(t[0], t[1], t[2], t[3]); o[1] = make_float4(t[4], t[5], t[6], 0.f);
         }
-        if (MODE == 2) {   // one writer per element in this launch: the no-return atomic is a fire-and-forget "+=" (nothing waits for the old value)
+        if (MODE == 2) {
             const upk_coord_t& node = ROW_SIDE == 1 ? G.node1 : G.node2;
             const int dim = ROW_SIDE == 1 ? G.dim1 : G.dim2;
             float* o = C_SENS(node, s) + (size_t)(ROW_SIDE == 1 ? G.loc1 : G.loc2)[row] * node.stride;
+            // a row has one owner in this launch, so the "+=" is a plain read-modify-write (16.6 M device-scope float atomics per
+            // launch of the backbone-hbond pass cost 0.23 of its 0.64 ms); the one exception is a graph whose two sides share
+            // elements of one node while both row sets run in one launch (sens_overlap, set by the host): atomics there
+            if (A.atomic_sens) {
 #pragma unroll
-            for (int c = 0; c < 7; ++c) if (c < dim) unsafeAtomicAdd(o + c, t[c]);
+                for (int c = 0; c < 7; ++c) if (c < dim) unsafeAtomicAdd(o + c, t[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 7; ++c) if (c < dim) o[c] += t[c];
+            }
         }
     }
 };
@@ -213,9 +222,9 @@ struct BackwardOp {
 #pragma unroll
         for (int c = 0; c < DR; ++c) t[c] = group_sum(acc[c]);
         if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
-        float* o = row_sens + (size_t)row_loc[row] * row_stride;     // the row has one owner in this launch: a fire-and-forget "+="
+        float* o = row_sens + (size_t)row_loc[row] * row_stride;     // the row has one owner in this launch: a plain "+="
 #pragma unroll
-        for (int c = 0; c < DR; ++c) unsafeAtomicAdd(o + c, t[c]);
+        for (int c = 0; c < DR; ++c) o[c] += t[c];      // (the element's other writer, the epilogue below / the finish kernel, runs after a barrier)
     }
 };
 
@@ -304,6 +313,15 @@ static int pair_table_choice(const upk_igraph_t* G, size_t extra, int& tab_float
     return 0;
 }
 
+extern "C" int upk_igraph_passes_staged(const upk_launch_t* L, const upk_igraph_t* G, int row_side) {
+    (void)L;
+    if (row_side != 1 && row_side != 2) return 0;
+    const int n_other = row_side == 1 ? G->n2 : G->n1;
+    int tab_floats; size_t lds;
+    if (!pair_table_choice(G, 0, tab_floats, lds)) return 0;
+    return pair_table_choice(G, 8 + (size_t)n_other * 8 * sizeof(unsigned long long), tab_floats, lds) ? 1 : 0;   // (an upper bound of the accumulators)
+}
+
 extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride,
                                int out_stride, int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode,
                                const float* sens1, const float* sens2, long sens_sys_stride, int sens_stride) {
@@ -313,6 +331,7 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     A.out_row0 = side == 2 ? 0 : out_row0; A.out_row0_2 = side == 2 ? out_row0 : out_row0_2;
     A.own_grad = own_grad;
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
+    A.atomic_sens = side == 3 && G->sens_overlap;
     size_t lds;
     const int table = pair_table_choice(G, 0, A.tab_floats, lds);
     if (!table) {                                      // list-walking kernels, one side at a time

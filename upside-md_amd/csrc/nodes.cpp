@@ -404,6 +404,27 @@ struct IGraphHost {
     DevBuf<int> hit1, hit2, hcnt1, hcnt2, hlo1;   // this step's in-range pairs per row (upk_pairlist_refine)
     DevBuf<unsigned short> ord1, ord2, ord1u;   // rows sorted by hit count (upk_pairlist_order)
     DevBuf<unsigned long long> gacc;   // upk_igraph_backward's cross-workgroup accumulators (small batches only)
+    // Sides whose cached lists the MD path reads (bit 1 / bit 2).  A graph whose pair passes all gather over the rows of one side
+    // (coverage graphs) rebuilds that side only; the other side's lists are brought up to date on demand, from the same
+    // reference positions, by the few off-path readers (canonical pair list, parameter derivatives): ensure_all_sides().
+    int md_sides = 3; bool other_side_stale = false;
+    DevBuf<int> all_systems;           // flag list naming every system (ensure_all_sides)
+    void use_sides(int sides) {        // called by the owning node once the graph is complete
+        const int row_side = sides == 1 ? 1 : 2;
+        md_sides = (!G.symmetric && (sides == 1 || sides == 2) && upk_igraph_passes_staged(&ctx->L, &G, row_side)) ? sides : 3;
+        // the hit lists of a side that no pass walks are never written: give the memory back (1.2-1.8 MB per system and graph)
+        if (!(md_sides & 1)) { hit1.alloc(0); hcnt1.alloc(0); ord1.alloc(0); G.hit1 = nullptr; G.hcnt1 = nullptr; G.ord1 = nullptr; }
+        if (!(md_sides & 2)) { hit2.alloc(0); hcnt2.alloc(0); ord2.alloc(0); G.hit2 = nullptr; G.hcnt2 = nullptr; G.ord2 = nullptr; }
+    }
+    void ensure_all_sides() {
+        if (!other_side_stale) return;
+        const int S = ctx->n_system;
+        if (!all_systems.n) { vector<int> v(S + 1); v[0] = S; for (int i = 0; i < S; ++i) v[1 + i] = i; all_systems.upload(v); }
+        upk_igraph_t Gall = G;
+        Gall.flagged = all_systems.p; Gall.parity = 0; Gall.flag_stride = S + 1;
+        upk_check(upk_pairlist_build_sides(&ctx->L, &Gall, 3 & ~md_sides), "pairlist_build (other side)");
+        other_side_stale = false;
+    }
 
     float type_cutoff(const float* p) const {
         switch (G.itype) {
@@ -526,6 +547,10 @@ struct IGraphHost {
         G.rebuild_flag = rebuild_flag.p; G.error_flag = c->error_flag.p;
         flagged.alloc(2 * (size_t)(S + 1)); G.flagged = flagged.p; G.flag_stride = S + 1; G.parity = 0;
         G.node1 = node1->coord(); G.node2 = node2->coord();
+        if (!G.symmetric && node1 == node2) {    // the two sides of one node may name the same element (pair kernels: atomic row updates then)
+            set<int> side1(loc1.begin(), loc1.end());
+            for (int x : loc2) if (side1.count(x)) G.sens_overlap = 1;
+        }
     }
     // the polynomial image of the table for the LDS-staged pair passes (hbond_coverage); follows every set_param
     void pack_param_poly() {
@@ -542,12 +567,13 @@ struct IGraphHost {
     void update_lists(int sides = 3) {
         begin_step();
         upk_check(upk_pairlist_check(&ctx->L, &G), "pairlist_check");
-        upk_check(upk_pairlist_build(&ctx->L, &G), "pairlist_build");
+        upk_check(upk_pairlist_build_sides(&ctx->L, &G, md_sides), "pairlist_build");
+        other_side_stale = md_sides != 3;
         refine(G, sides);
     }
     // this step's in-range pairs + the row order of the pair passes (G_: the graph, possibly with a substituted source node)
     void refine(const upk_igraph_t& G_, int sides = 3) {
-        if (!G_.hit1) return;
+        if (!G_.hit1 && !G_.hit2) return;
         for (int side = 1; side <= (G_.symmetric ? 1 : 2); ++side) {
             if (!(sides & side)) continue;
             upk_check(upk_pairlist_refine(&ctx->L, &G_, side), "pairlist_refine");
@@ -587,6 +613,7 @@ struct IGraphHost {
     };
     // canonical in-range pair list of one system (parity/diagnostics)
     vector<pair<int, int>> pairlist(int sys) {
+        ensure_all_sides();
         DevBuf<unsigned char> flags((size_t)ctx->n_system * G.n1 * G.cap1);
         upk_check(upk_igraph_inrange(&ctx->L, &G, flags.p), "igraph_inrange");
         hip_check(hipStreamSynchronize(ctx->stream), "sync");
@@ -661,6 +688,7 @@ struct HBondCoverage : public CoordNode {
                 prepare_deps.push_back(site_positions); prepare_deps.push_back(&sidechains_);
             }
         }
+        ig.use_sides(2);        // both pair passes gather over the bead rows
     }
     const CoordNode* site_positions = nullptr;
     bool has_prepare() const override { return true; }
@@ -670,7 +698,8 @@ struct HBondCoverage : public CoordNode {
         upk_igraph_t Gp = ig.G;
         Gp.node1 = site_positions->coord();
         upk_check(upk_pairlist_check(&ctx->L, &Gp), "pairlist_check");
-        upk_check(upk_pairlist_build(&ctx->L, &Gp), "pairlist_build");
+        upk_check(upk_pairlist_build_sides(&ctx->L, &Gp, ig.md_sides), "pairlist_build");
+        ig.other_side_stale = ig.md_sides != 3;
         ig.refine(Gp, 2);
     }
     void compute_value(ComputeMode) override {   // rows = beads
@@ -684,6 +713,7 @@ struct HBondCoverage : public CoordNode {
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
     vector<float> get_param_deriv(int system) override {   // hbond.cpp:401-402 (this class); pair sensitivity of :395-397
+        ig.ensure_all_sides();
         return param_deriv_table(ctx, ig.param.size(), [&](float* t) {
             upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 2, nullptr, sens.p, sys_stride(), stride, t), "hbond_coverage param_deriv"); });
     }
@@ -698,7 +728,9 @@ RegisterNodeType<HBondCoverage, 2> coverage_node("hbond_coverage");
 struct EnvironmentCoverage : public CoordNode {
     IGraphHost ig;
     EnvironmentCoverage(DeviceCtx* c, hid_t_compat grp, CoordNode& cb_pos_, CoordNode& weighted_sidechains_)
-        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {}
+        : CoordNode(c, (int)dset_size(1, H(grp), "index1")[0], 1), ig(c, H(grp), UPK_IT_ENVIRONMENT, &cb_pos_, &weighted_sidechains_) {
+        ig.use_sides(1);        // both pair passes gather over the CB rows
+    }
     bool has_prepare() const override { return true; }
     void prepare() override { ig.update_lists(1); }   // rows = CB frames, for both passes
     void compute_value(ComputeMode) override {
@@ -712,6 +744,7 @@ struct EnvironmentCoverage : public CoordNode {
     vector<float> get_param() const override { return ig.param; }
     void set_param(const vector<float>& p) override { ig.set_param(p); }
     vector<float> get_param_deriv(int system) override {   // environment.cpp:104-105; the functor's derivative is all zeros (:62-65)
+        ig.ensure_all_sides();
         return param_deriv_table(ctx, ig.param.size(), [&](float* t) {
             upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 1, sens.p, nullptr, sys_stride(), stride, t), "environment_coverage param_deriv"); });
     }
