@@ -586,7 +586,10 @@ void DerivEngine::check_device_errors() {
 void load_plugin_library(const string& path) {
     static set<string> loaded;
     if (loaded.count(path)) return;
-    if (!dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL)) throw string("cannot load plug-in ") + path + ": " + dlerror();
+    // RTLD_LOCAL: the plug-in finds this library through its own DT_NEEDED entry (it must be linked against libupside_hip.so);
+    // a global load would also promote this library's C++ symbols -- add_node_creation_function, node_creation_map: the
+    // reference's own names -- to the global scope, where a later-loaded libupside.so would bind to them
+    if (!dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) throw string("cannot load plug-in ") + path + ": " + dlerror();
     loaded.insert(path);
 }
 static void load_plugins_from_env() {
