@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # RCCL's version banner goes to stdout; rank 0 must print ONE JSON line there
 os.environ['NCCL_DEBUG'] = os.environ.get('UPSIDE_NCCL_DEBUG', 'WARN')
+os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')      # ... and its warnings do not belong there either
 from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -68,6 +69,11 @@ def bind(lib):
     c.upside_hip_comm_replica_swap.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_uint32, ct.c_uint64, ct.c_int, ct.c_void_p]
     c.upside_hip_comm_free.argtypes = [ct.c_void_p]
     return c
+
+
+def _trace(msg):
+    if os.environ.get('UPSIDE_BENCH_TRACE'):
+        print('[bench] ' + msg, file=sys.stderr, flush=True)
 
 
 def check(c, rc, what):
@@ -238,8 +244,10 @@ def main():
     def barrier():
         rep.barrier(dist, torch.cuda.synchronize)
 
+    _trace('engine ready, warm-up')
     run_steps(args.warmup)
     barrier()
+    _trace('timed region')
     attempts0 = state['attempts']
     t0 = time.perf_counter()
     steps_done = run_steps(args.steps)
@@ -249,6 +257,7 @@ def main():
     timed_attempts = state['attempts'] - attempts0
     exchange_steps_saved, exchange_steps = exchange_steps, 0      # the profiling legs below run plain MD
 
+    _trace('timed region done: %d steps' % steps_done)
     # ---- roofline of the dominant kernel: HIP-event timing on the engine's stream, outside the timed region
     roofline = None
     if rank == 0:
@@ -304,6 +313,7 @@ def main():
                                           GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None,
                                           pair_evaluations=(r[4] / r[2]) if r[4] else None) for r in rows}
 
+    _trace('roofline leg done')
     # single-system latency of the same workload (one replica on the GPU), outside the timed region
     single = None
     if rank == 0 and not args.no_single_system:
@@ -318,6 +328,7 @@ def main():
             single = 600 / (time.perf_counter() - ts)
             lib.calc.free_deriv_engine(ct.c_void_p(eng1))
 
+    _trace('single-system leg done')
     if rank == 0:
         if describe is None:
             describe = ('%s: 300-res synthetic protein, full side-chain BP, 10 A pair list (BASELINE.json configs[2]); %d independent '
@@ -340,7 +351,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline(fixture, variant)
         # (flushed at once: tearing down the RCCL communicator below has been seen to end the process without running Python's
         #  exit-time flush of a buffered stdout)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        print('\n' + json.dumps(res), flush=True)      # (own line even if a C library left an unterminated line on fd 1)
     if remd:
         c.upside_hip_comm_free(eng)
     lib.calc.free_deriv_engine(ct.c_void_p(eng))

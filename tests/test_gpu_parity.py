@@ -1134,3 +1134,48 @@ def test_external_plugin_node(hip, tmp_path):
         return x
     xa, xb = run(builtin), run(plugged)
     assert np.isfinite(xb).all() and np.abs(xa - xb).max() < 1e-3
+
+
+def test_upside_main_exchange_through_rccl_equals_in_engine_exchange(hip, tmp_path):
+    """`upside_main` one-process-per-GPU mode (RANK / WORLD_SIZE from the launcher; here a world of one, forced with
+    UPSIDE_HIP_COMM=1): the replica exchange goes through upside_hip_comm_* (energies all-gathered over RCCL, verdicts on
+    the device) instead of the in-engine swap calls.  Same ladder, seeds and swap sets must give the same verdicts and the
+    same trajectories as the in-engine path, frame for frame (main.cpp:227-275, 616-672)."""
+    import shutil
+    name = 'trpcage20_7A'
+    runs = {}
+    rargs = ['--duration', '2.7', '--frame-interval', '0.27', '--temperature', '0.70,0.74,0.78,0.82', '--seed', '5',
+             '--replica-interval', '0.135', '--swap-set', '0-1,2-3', '--swap-set', '1-2']
+    for tag, env in (('engine', {}), ('rccl', {'UPSIDE_HIP_COMM': '1'})):
+        fs = [str(tmp_path / ('%s_%d.up' % (tag, i))) for i in range(4)]
+        for f in fs:
+            shutil.copyfile(P.fixture(name), f)
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hip.in_process_upside(rargs + fs, verbose=False)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        runs[tag] = [_read_output(f)[0] for f in fs]
+    # the same through the stand-alone executable, launched the way a rank is (RANK / WORLD_SIZE / LOCAL_RANK in the environment)
+    exe = os.path.join(P.ROOT, 'upside-md_amd', 'csrc', 'upside_hip')
+    assert os.path.exists(exe), 'upside_hip is missing: run __graft_entry__.build()'
+    import subprocess
+    fs = [str(tmp_path / ('exe_%d.up' % i)) for i in range(4)]
+    for f in fs:
+        shutil.copyfile(P.fixture(name), f)
+    subprocess.run([exe] + rargs + fs, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                   env=dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', UPSIDE_HIP_COMM='1'))
+    for a, b in zip(runs['rccl'], [_read_output(f)[0] for f in fs]):
+        assert np.array_equal(a['replica_index'], b['replica_index']) and np.array_equal(a['pos'], b['pos'])
+    swapped = False
+    for a, b in zip(runs['engine'], runs['rccl']):
+        assert a['replica_index'].shape == b['replica_index'].shape and a['replica_index'].shape[0] >= 10
+        assert np.array_equal(a['replica_index'], b['replica_index'])
+        assert np.array_equal(a['pos'], b['pos']) and np.array_equal(a['potential'], b['potential'])
+        swapped = swapped or len(np.unique(a['replica_index'])) > 1
+    assert swapped, 'no exchange was accepted: the comparison would be vacuous'

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 using namespace std;
@@ -204,7 +206,23 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     if (duration < 0.) throw string("--duration is required");
     if (frame_interval < 0.) throw string("--frame-interval is required");
     if (files.empty()) throw string("no configuration given");
-    const int n_system = (int)files.size();
+    // One process per GPU (started by any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK, e.g. torch.distributed.run, or
+    // UPSIDE_HIP_RANK / _WORLD / _LOCAL_RANK): every rank receives the SAME command line; rank r simulates a contiguous
+    // block of the configuration files on device LOCAL_RANK and replica exchange runs over RCCL inside the library
+    // (upside_hip_comm_*, comm_rccl.cpp).  UPSIDE_HIP_COMM=1 takes the same path with a single process (tests).
+    auto env_int_of = [](const char* a, const char* b, int dflt) {
+        const char* v = getenv(a); if (!v) v = getenv(b);
+        return v ? atoi(v) : dflt; };
+    const int world = max(1, env_int_of("UPSIDE_HIP_WORLD", "WORLD_SIZE", 1));
+    const int rank = env_int_of("UPSIDE_HIP_RANK", "RANK", 0), local_rank = env_int_of("UPSIDE_HIP_LOCAL_RANK", "LOCAL_RANK", 0);
+    const bool use_comm = world > 1 || (getenv("UPSIDE_HIP_COMM") && atoi(getenv("UPSIDE_HIP_COMM")));
+    if (rank < 0 || rank >= world) throw string("invalid rank");
+    const int n_total = (int)files.size();
+    if (n_total % world) throw to_string(n_total) + " systems do not divide over " + to_string(world) + " processes";
+    const int n_system = n_total / world, sys_lo = rank * n_system;
+    const vector<string> all_files = files;
+    files.assign(all_files.begin() + sys_lo, all_files.begin() + sys_lo + n_system);
+    if (world > 1 && upside_hip_set_device(local_rank)) throw string(upside_hip_last_error());
     const float dt = (float)time_step;
     // intervals in rounds of 3 steps (main.cpp:399-411,445-447)
     const uint64_t n_round = (uint64_t)round(duration / (3 * dt));
@@ -214,10 +232,12 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     const int mc_rounds = mc_interval > 0. ? max(1, (int)(mc_interval / (3 * dt))) : 0;   // main.cpp:411
     const uint32_t base_seed = (uint32_t)(seed % 4294967291ul);   // main.cpp:403-404
 
-    vector<float> temps;
-    for (auto& t : split_string(temperature_str, ",")) temps.push_back((float)stod(t));
-    if (temps.size() != 1u && (int)temps.size() != n_system) throw string("Received ") + to_string(temps.size()) + " temperatures but have " + to_string(n_system) + " systems";
-    if (temps.size() == 1u) temps.assign(n_system, temps[0]);
+    vector<float> temps_global;
+    for (auto& t : split_string(temperature_str, ",")) temps_global.push_back((float)stod(t));
+    if (temps_global.size() != 1u && (int)temps_global.size() != n_total) throw string("Received ") + to_string(temps_global.size()) + " temperatures but have " + to_string(n_total) + " systems";
+    if (temps_global.size() == 1u) temps_global.assign(n_total, temps_global[0]);
+    vector<float> temps(temps_global.begin() + sys_lo, temps_global.begin() + sys_lo + n_system);
+    if (use_comm && anneal_factor != 1.) throw string("--anneal-factor is not available together with replica exchange across processes");
 
     if (anneal_duration == -1.) anneal_duration = duration;      // main.cpp:434
     const vector<float> initial_temps = temps;
@@ -265,7 +285,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             throw string("You have re-centering and a radial potential turned on.  This is not what you want.  Consider --disable-recentering.");
     }
     if (upside_hip_set_pos(e, all_pos.data())) throw string(upside_hip_last_error());
-    if (upside_hip_init_md(e, temps.data(), base_seed, (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
+    // (thermostat streams are keyed by the GLOBAL system index, main.cpp:459)
+    if (upside_hip_init_md(e, temps.data(), base_seed + (uint32_t)sys_lo, (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
 
     // swap sets (main.cpp:146-219)
     vector<vector<int>> sets;
@@ -275,11 +296,38 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             auto p = split_string(ps, "-");
             if (p.size() != 2u) throw string("invalid swap pair");
             int a = stoi(p[0]), b = stoi(p[1]);
-            if (a >= n_system || b >= n_system || a < 0 || b < 0) throw string("invalid system");
+            if (a >= n_total || b >= n_total || a < 0 || b < 0) throw string("invalid system");
             if (used.count(a) || used.count(b) || a == b) throw string("Overlapping indices in swap set.");
             used.insert(a); used.insert(b); prs.push_back(a); prs.push_back(b);
         }
         sets.push_back(prs);
+    }
+
+    if (!use_comm)      // (inside one engine the swap sets address its own systems)
+        for (auto& st : sets) for (int x : st) if (x >= n_system) throw string("invalid system");
+    if (use_comm && !sets.empty()) {
+        // rendezvous: rank 0 creates the communicator id and leaves it in a file every rank of the job can see
+        string path = getenv("UPSIDE_HIP_COMM_FILE") ? getenv("UPSIDE_HIP_COMM_FILE")
+                    : string("/tmp/upside_hip_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + to_string((long)getppid());
+        char id[UPSIDE_HIP_COMM_ID_BYTES];
+        if (rank == 0) {
+            if (upside_hip_comm_get_unique_id(id)) throw string(upside_hip_last_error());
+            const string tmp = path + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw string("cannot write ") + tmp;
+            fclose(f);
+            if (rename(tmp.c_str(), path.c_str())) throw string("cannot publish ") + path;
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 1200 && !got; ++tries) {      // up to two minutes
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+                if (!got) this_thread::sleep_for(chrono::milliseconds(100));
+            }
+            if (!got) throw string("no communicator id at ") + path + " (is rank 0 running?)";
+        }
+        if (upside_hip_comm_init(e, rank, world, id, temps_global.data())) throw string(upside_hip_last_error());
+        if (rank == 0 && world == 1) remove(path.c_str());
     }
 
     vector<float> energy(n_system);
@@ -307,8 +355,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
         for (int ns = 0; ns < n_system; ++ns) loggers[ns].add_node_loggers(node_loggers);
     }
-    vector<int> replica_index(n_system);
-    for (int ns = 0; ns < n_system; ++ns) replica_index[ns] = ns;
+    vector<int> replica_index(n_total);     // by GLOBAL slot; every rank keeps the whole table (the verdicts are identical everywhere)
+    for (int ns = 0; ns < n_total; ++ns) replica_index[ns] = ns;
     vector<float> frame_pos((size_t)n_system * n_atom * 3), frame_mom((size_t)n_system * n_atom * 3);
 
     auto tstart = chrono::high_resolution_clock::now();
@@ -335,7 +383,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                 const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
                 double sum_kin = 0.;
                 for (int i = 0; i < n_atom * 3; ++i) sum_kin += (double)(m[i] * m[i]);
-                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[ns], &mc_stats[(size_t)ns * 2], &mcj_stats[(size_t)ns * 2]);
+                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[sys_lo + ns], &mc_stats[(size_t)ns * 2], &mcj_stats[(size_t)ns * 2]);
                 double com[3] = {0, 0, 0}, rg = 0.;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
                 for (int d = 0; d < 3; ++d) com[d] /= n_atom;
@@ -347,7 +395,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                         if (!v.empty()) n_hbond += v[0];
                     }
                     printf("%*.0f / %*.0f elapsed %2i system %.2f temp %5.1f hbonds, Rg %5.1f A, potential % 8.2f\n", 8, rnd * 3 * double(dt), 8,
-                           duration, ns, temps[ns], n_hbond, sqrt(rg / n_atom), energy[ns]);
+                           duration, sys_lo + ns, temps[ns], n_hbond, sqrt(rg / n_atom), energy[ns]);
                 }
             }
             fflush(stdout);
@@ -375,9 +423,14 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             for (size_t k = 0; k < sets.size(); ++k) {
                 vector<int> acc(sets[k].size() / 2 + 1);
                 // one force evaluation per attempt: the later sets see the energies the accepted pairs traded
-                if ((k == 0 ? upside_hip_replica_swap_from : upside_hip_replica_swap_next)(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, draw, acc.data()))
-                    throw string(upside_hip_last_error());
-                draw = acc.back();
+                if (use_comm) {     // global indices; energies all-gathered, verdicts on the device, straddling pairs over RCCL
+                    if (upside_hip_comm_replica_swap(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, k == 0, acc.data()))
+                        throw string(upside_hip_last_error());
+                } else {
+                    if ((k == 0 ? upside_hip_replica_swap_from : upside_hip_replica_swap_next)(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, draw, acc.data()))
+                        throw string(upside_hip_last_error());
+                    draw = acc.back();
+                }
                 for (size_t i = 0; i < sets[k].size() / 2; ++i) {
                     n_attempt[k]++; n_success[k] += acc[i];
                     if (acc[i]) swap(replica_index[sets[k][2 * i]], replica_index[sets[k][2 * i + 1]]);
@@ -386,6 +439,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
     }
     e->sync();
+    if (use_comm) upside_hip_comm_free(e);
     for (auto& lg : loggers) lg.close();          // buffered frames reach the files also after an early stop
     stop_signal = g_received_signal;
     }   // the caller's signal handlers are back
