@@ -13,9 +13,11 @@
 //     row sums in registers (3 DPP steps per component at the end of the batch instead of a segmented 64-lane reduction per
 //     64 pairs).  Rows of a batch have (nearly) the same length, so the groups run in lock step and the batch bookkeeping is
 //     uniform code, amortised over the batch's trips;
-//   * every pass is a gather with a fixed summation order: no floating-point atomics (LDS float atomics run at 3 cycles per
-//     LANE on gfx950 -- tools/ubench/lds_atomics.hip: 192 cycles per wave instruction against <= 20 for integer ones --
-//     which is what sank the one-visit backward pass that was tried first), so results are reproducible bit for bit.
+//   * forward passes are gathers with a fixed summation order; backward passes visit a pair ONCE and hand the partner
+//     element's share to 64-bit fixed-point integer LDS atomics (to_fixed32 below), whose sums do not depend on the order of
+//     arrival -- no floating-point atomic decides a result, so trajectories are reproducible bit for bit.  (LDS float
+//     atomics run at 3 cycles per LANE on gfx950 -- tools/ubench/lds_atomics.hip: 192 cycles per wave instruction against
+//     <= 20 for integer ones -- which is what sank the float version of the one-visit pass that was tried first.)
 #pragma once
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"

@@ -2,7 +2,8 @@
 // step's hit lists: replaces the compute_edges / propagate_derivatives loops of /root/reference/src/interaction_graph.h:443-556
 // together with the node-side accumulation loops of hbond.cpp:387-397, environment.cpp:85-101 and hbond.cpp:316-365.
 //
-// See igraph_device.h for the decomposition.  Every pass is a per-row gather over the row's in-range partners; pair
+// See igraph_device.h for the decomposition.  Forward passes are per-row gathers over the row's in-range partners, the
+// backward pass visits each pair once (row share in registers, partner share through fixed-point LDS atomics); pair
 // gradients are re-evaluated in the backward pass instead of being stored (the reference keeps 12-13 floats of edge_deriv per
 // edge, interaction_graph.h:294-296: ~150 flop against 100+ bytes of HBM traffic per edge).
 #include "igraph_device.h"
