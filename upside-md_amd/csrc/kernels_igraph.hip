@@ -284,7 +284,12 @@ extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_
 // popcount prefix).  Latency bound by design -- it runs on the upkeep streams next to the VALU-bound pair passes -- so a
 // wavefront fetches the positions and list lengths of ALL its rows with one load each and keeps the first list words of
 // PLR_AHEAD rows in flight.
+#ifndef PLR_BLOCK
 #define PLR_BLOCK 256
+#endif
+#ifndef PLR_ROWS
+#define PLR_ROWS 256
+#endif
 #ifndef PLR_AHEAD
 #define PLR_AHEAD 4
 #endif
@@ -367,7 +372,7 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
     const size_t lds = (size_t)(n_other > 0 ? n_other : 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
-    const int rows_per_wg = L->n_system >= upk_device_cu_count() ? 256 : (L->n_system >= 16 ? 64 : 16);
+    const int rows_per_wg = L->n_system >= upk_device_cu_count() ? PLR_ROWS : (L->n_system >= 16 ? 64 : 16);
     const dim3 grid((n_rows + rows_per_wg - 1) / rows_per_wg, L->n_system);
     if (G->symmetric) hipLaunchKernelGGL(k_pairlist_refine<true>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
     else hipLaunchKernelGGL(k_pairlist_refine<false>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
