@@ -239,6 +239,8 @@ typedef struct {
     int n_node, n_node1, n_node3;        /* global node ids: class 1, then 3, then 6 */
     const int* node_nrot;                /* [n_node] */
     const int *bead_node, *bead_rot;     /* [n_bead] */
+    const int *bead_orig;                /* [n_bead] the bead's index in the configuration's own order (NULL: unchanged); the parameter
+                                            derivative orients a pair (i1 < i2) by it, as the reference's edge list does */
     const int *bead_meta;                /* [n_bead] type | rot<<8 | n_rot<<12 (staged into the LDS bead rows) */
     const float* param_tri;              /* upper triangle of the (symmetric) pair table: row tri(lo, hi) = interaction_param[lo][hi], lo <= hi;
                                             (hi, lo) reads the same row with its two angular blocks exchanged (is_compatible, bead_interaction.h:209-218) */

@@ -564,6 +564,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_PLB_UNSTAGED': '1'},        # list build reading the other side from global memory (very large systems)
     {'UPSIDE_HIP_SKIN_SCALE': '1.0'},        # the reference's cached-list margin
     {'UPSIDE_HIP_IG_POLY': '0'},             # coverage pair passes on the spline-coefficient table (tables too large for the polynomial form)
+    {'UPSIDE_HIP_ROT_SORT_BEADS': '0'},      # side-chain beads in the configuration's own order (no renumbering by pair-matrix node)
     {'UPSIDE_HIP_ROT_POLY': '0'},            # side-chain energy pass on the spline-coefficient table (tables too large for the polynomial form)
     {'UPSIDE_HIP_UPKEEP_STREAMS': '1'},      # one shared upkeep stream (the large-batch choice) for a small batch
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself

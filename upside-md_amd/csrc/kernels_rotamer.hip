@@ -536,8 +536,11 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
             else if (na == 1) ps = nbm[b * 6 + rb];
             else if (nb == 1) ps = nbm[a * 6 + ra];
             else ps = sl == UPK_ROT_SLOT_NONE ? 0.f : marg[PIDX6(R.slot_cap, sl, a < b ? ra : rb, a < b ? rb : ra)];
-            const size_t prow = (size_t)((mr & 0xFF) * G.n_type2 + (mo & 0xFF)) * G.n_param;
-            quadspline_param_accum(Q, G.param + prow, xr, xo, ps, table + prow);
+            // the reference's edge is (i1 < i2) in the configuration's own bead order: types [type(i1)][type(i2)], x1 = bead i1
+            const bool row_first = !R.bead_orig || R.bead_orig[row] < R.bead_orig[j];
+            const size_t prow = (size_t)(row_first ? (mr & 0xFF) * G.n_type2 + (mo & 0xFF) : (mo & 0xFF) * G.n_type2 + (mr & 0xFF)) * G.n_param;
+            if (row_first) quadspline_param_accum(Q, G.param + prow, xr, xo, ps, table + prow);
+            else quadspline_param_accum(Q, G.param + prow, xo, xr, ps, table + prow);
         }
     }
 }

@@ -562,6 +562,25 @@ struct IGraphHost {
         if (d_param_poly.n != poly.size()) { d_param_poly.upload(poly); G.param_poly = d_param_poly.p; }
         else hip_check(hipMemcpy(d_param_poly.p, poly.data(), poly.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
     }
+    // Renumber the elements of a symmetric graph (new element k = old element perm[k]); everything derived from the element
+    // arrays afterwards sees the new order only.  The canonical pair list and the edge counts keep reporting the ORIGINAL
+    // numbering (orig_of).  Used by the side-chain node, which sorts its beads by (residue-pair-matrix node, rotamer state):
+    // with i < j implying node(i) <= node(j) the row bead always owns the FIRST index of the pair matrix, so the 8 lanes of a
+    // row group (consecutive partners = the rotamer states of one partner residue) store one contiguous 24-byte record of
+    // the matrix instead of six scattered words whenever the partner residue has the lower node id.
+    vector<int> orig_of, new_of, type_by_orig;     // new -> original element, original -> new, type by original element
+    void permute_elements(const vector<int>& perm) {
+        if (!G.symmetric) throw string("element renumbering is for symmetric graphs");
+        if ((int)perm.size() != G.n1) throw string("bad permutation");
+        type_by_orig = type1; orig_of = perm;
+        new_of.assign(perm.size(), 0); for (size_t k = 0; k < perm.size(); ++k) new_of[perm[k]] = (int)k;
+        auto apply = [&](vector<int>& v) { vector<int> t(v.size()); for (size_t k = 0; k < v.size(); ++k) t[k] = v[perm[k]]; v.swap(t); };
+        apply(loc1); apply(type1); apply(id1);
+        loc2 = loc1; type2 = type1; id2 = id1;
+        hip_check(hipMemcpy(d_loc1.p, loc1.data(), loc1.size() * sizeof(int), hipMemcpyHostToDevice), "H2D");
+        hip_check(hipMemcpy(d_type1.p, type1.data(), type1.size() * sizeof(int), hipMemcpyHostToDevice), "H2D");
+        hip_check(hipMemcpy(d_id1.p, id1.data(), id1.size() * sizeof(int), hipMemcpyHostToDevice), "H2D");
+    }
     void begin_step() { G.parity ^= 1; }
     // K1 + K2 + K2b/c for the rows of `sides` (bit 1: side 1, bit 2: side 2); the other side's hit lists follow in refine()
     void update_lists(int sides = 3) {
@@ -625,7 +644,8 @@ struct IGraphHost {
                 int j = G.nbr_j_bits ? (nb[idx] & ((1 << G.nbr_j_bits) - 1)) : nb[idx];
                 if (!f[idx]) continue;
                 if (G.symmetric && j <= i) continue;
-                out.emplace_back(i, j);
+                if (orig_of.empty()) out.emplace_back(i, j);
+                else out.emplace_back(min(orig_of[i], orig_of[j]), max(orig_of[i], orig_of[j]));     // the caller's numbering
             }
         sort(out.begin(), out.end(), [](const pair<int, int>& a, const pair<int, int>& b) {   // (i1>>2, i2, i1&3)
             if ((a.first >> 2) != (b.first >> 2)) return (a.first >> 2) < (b.first >> 2);
@@ -635,7 +655,9 @@ struct IGraphHost {
     }
     vector<float> count_edges_by_type(int sys) {   // interaction_graph.h:427-441
         vector<float> r((size_t)G.n_type1 * G.n_type2, 0.f);
-        for (auto& e : pairlist(sys)) r[(size_t)type1[e.first] * G.n_type2 + type2[e.second]] += 1.f;
+        const vector<int>& t1 = type_by_orig.empty() ? type1 : type_by_orig;     // (pairlist() reports original element numbers)
+        const vector<int>& t2 = type_by_orig.empty() ? type2 : type_by_orig;
+        for (auto& e : pairlist(sys)) r[(size_t)t1[e.first] * G.n_type2 + t2[e.second]] += 1.f;
         return r;
     }
 };
@@ -1114,7 +1136,7 @@ struct RotamerSidechain : public PotentialNode {
     vector<int> node_nrot, bead_node, bead_rot;
     DevBuf<long long> bp_trace;
     DevBuf<unsigned char> mark;
-    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri, param_tri_poly;
+    DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri, param_tri_poly; DevBuf<int> d_bead_orig;
     bool bp_C_chosen = false;
     DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
@@ -1149,6 +1171,16 @@ struct RotamerSidechain : public PotentialNode {
             throw string("rotamer: ") + to_string(n_node) + " side-chain nodes, but the device belief-propagation solve handles at most " + to_string(max_node) +
                   " (one system per workgroup: slot numbering and pair-matrix bookkeeping live in the 160 KB LDS of a CU)";
         const int start[7] = {0, 0, 0, n1, 0, 0, n1 + n3};
+        if (env_int("UPSIDE_HIP_ROT_SORT_BEADS", 1)) {      // beads in (node, rotamer state) order: see IGraphHost::permute_elements
+            vector<int> perm(ig.G.n1);
+            for (int i = 0; i < ig.G.n1; ++i) perm[i] = i;
+            auto key = [&](int i) {
+                unsigned id = (unsigned)ig.id1[i]; const unsigned rot = id & selector; id >>= 4; const unsigned n_rot = id & selector; id >>= 4;
+                return (long)(start[n_rot] + (int)id) * 16 + (long)rot; };
+            stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key(a) < key(b); });
+            ig.permute_elements(perm);
+            d_bead_orig.upload(ig.orig_of);
+        }
         node_nrot.assign(n_node, 0);
         for (int g = 0; g < n_node; ++g) node_nrot[g] = g < n1 ? 1 : (g < n1 + n3 ? 3 : 6);
         int n_bead = ig.G.n1;
@@ -1215,7 +1247,7 @@ struct RotamerSidechain : public PotentialNode {
         pack_param_tri();
         R.one_bead_per_state = one_bead_per_state ? 1 : 0;
         R.n_node = n_node; R.n_node1 = n1; R.n_node3 = n3;
-        R.node_nrot = d_node_nrot.p; R.bead_node = d_bead_node.p; R.bead_rot = d_bead_rot.p;
+        R.node_nrot = d_node_nrot.p; R.bead_node = d_bead_node.p; R.bead_rot = d_bead_rot.p; R.bead_orig = d_bead_orig.p;
         R.node_bead_start = d_nb_start.p; R.node_bead_list = d_nb_list.p;
         R.n_prob = (int)prob_nodes.size(); R.prob_out = d_prob_out.p; R.prob_sens = d_prob_sens.p; R.prob_stride = d_prob_stride.p;
         R.prob_sys_stride = d_prob_sys_stride.p;
@@ -1410,7 +1442,8 @@ struct RotamerSidechain : public PotentialNode {
     vector<float> arrange_by_residue(const vector<float>& per_node, int width) const {
         vector<float> out; out.reserve(per_node.size());
         vector<char> seen(n_node, 0);
-        for (int i = 0; i < ig.G.n1; ++i) {
+        for (int o = 0; o < ig.G.n1; ++o) {          // residues in the order of the configuration's bead list
+            const int i = ig.new_of.empty() ? o : ig.new_of[o];
             const int g = bead_node[i];
             if (bead_rot[i] != 0 || seen[g]) continue;
             seen[g] = 1;
