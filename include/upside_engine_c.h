@@ -177,6 +177,12 @@ int upside_hip_calibrate_valu(double* rates /* [2] */);
 /* algorithmic bytes of all interaction graphs for one force evaluation of one system */
 double upside_hip_igraph_bytes_per_system(DerivEngine* engine);
 
+/* The per-interval polynomial image of one quadspline parameter row ([angular 1: ka][angular 2: ka][radial wide: k][radial narrow: k],
+ * /root/reference/src/bead_interaction.h:30-84) that the LDS-staged pair passes read (layout: upside_hip_kernels.h, param_poly);
+ * host arithmetic, exported so that it can be checked without a GPU.  poly_out: upside_hip_quadspline_poly_width floats. */
+int upside_hip_quadspline_poly_width(int n_knot_angular, int n_knot);
+int upside_hip_quadspline_poly_row(const float* spline_coeff, int n_knot_angular, int n_knot, float* poly_out);
+
 /* Node types defined outside this library (include/upside_hip_plugin.h): load a shared library whose static initialisers
  * register them (the equivalent of linking another node's .cpp into the reference's libupside.so,
  * /root/reference/src/deriv_engine.h:297-335).  Must be called before the configuration that names the node is opened.

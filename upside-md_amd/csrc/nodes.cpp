@@ -393,6 +393,14 @@ static void quadspline_poly_row(const float* p, int ka, int k, float* out) {
     }
 }
 
+// (exported for tests/test_abi.py: the table is host arithmetic and can be checked without a GPU)
+extern "C" int upside_hip_quadspline_poly_row(const float* spline_coeff, int n_knot_angular, int n_knot, float* poly_out) {
+    if (n_knot_angular < 4 || n_knot < 4) return 1;
+    quadspline_poly_row(spline_coeff, n_knot_angular, n_knot, poly_out);
+    return 0;
+}
+extern "C" int upside_hip_quadspline_poly_width(int n_knot_angular, int n_knot) { return quadspline_poly_width(n_knot_angular, n_knot); }
+
 struct IGraphHost {
     DeviceCtx* ctx;
     upk_igraph_t G;
