@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
                 if (UPPER) hit = hit & (j > i);
                 else if (SYM) hit = hit & (j != i);
                 const unsigned long long b = __ballot(hit);
+                if (!b) continue;                                  // (wave-uniform: most trips of a row find nobody within reach)
                 const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
                 if (hit & (pos < cap)) nbr[pos] = j;
                 count += __popcll(b);
