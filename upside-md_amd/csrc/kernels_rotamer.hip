@@ -722,11 +722,44 @@ __device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict_
 template <int NA, int NB>
 __device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int end, const float* __restrict__ nb_old, int tid, int nt,
                                                __amdgpu_buffer_rsrc_t rs) {
-    for (int idx = first + tid; idx < end; idx += nt) {
-        const int4 r = C.rec[idx];
+#ifndef BP_REC_AHEAD
+#define BP_REC_AHEAD 1
+#endif
+#ifndef BP_MATRIX_AHEAD
+#define BP_MATRIX_AHEAD 1
+#endif
+    // A trip is a chain of dependent round trips: record -> matrix + messages -> stores.  At two wavefronts per SIMD nothing
+    // else hides them, so the NEXT trip's record (16 bytes) is fetched while this one is processed (solve 8.3 -> 7.9 ms at 4096
+    // systems), and in the 3x3 / 3x6 instances, whose registers are not the kernel's peak, the next trip's matrix as well
+    // (which needs the record after that one step earlier still).
+    if (BP_MATRIX_AHEAD && NA * NB <= 18) {
+        int idx = first + tid;
+        if (idx >= end) return;
+        int4 r0 = C.rec[idx], r1 = r0;
+        if (idx + nt < end) r1 = C.rec[idx + nt];
+        float P0[NA * NB];
+        bp_load_matrix<NA, NB>(C, r0.w, P0);
+        for (; idx < end; idx += nt) {
+            int4 r2 = r1;
+            if (idx + 2 * nt < end) r2 = C.rec[idx + 2 * nt];
+            float P1[NA * NB];
+            bp_load_matrix<NA, NB>(C, r1.w, P1);                  // (the last trip re-reads its own matrix: harmless)
+            bp_edge_slot<NA, NB, false>(C, r0.x, r0.y, r0.z & 0xffff, r0.z >> 16, P0, nb_old, rs);
+            r0 = r1; r1 = r2;
+#pragma unroll
+            for (int e = 0; e < NA * NB; ++e) P0[e] = P1[e];
+        }
+        return;
+    }
+    int idx = first + tid;
+    int4 r = idx < end ? C.rec[idx] : make_int4(0, 0, 0, 0);
+    for (; idx < end; idx += nt) {
+        int4 rn = r;
+        if (BP_REC_AHEAD && idx + nt < end) rn = C.rec[idx + nt];
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, r.w, P);
         bp_edge_slot<NA, NB, false>(C, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nb_old, rs);
+        if (BP_REC_AHEAD) r = rn; else if (idx + nt < end) r = C.rec[idx + nt];
     }
 }
 template <int NA, int NB>
@@ -793,13 +826,30 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
 template <int NA, int NB>
 __device__ __forceinline__ float bp_marginal_packed(const BpCtx& C, int first, int end, const float* __restrict__ nbm, int tid, int nt, bool want_energy) {
     float en = 0.f;
-    for (int idx = first + tid; idx < end; idx += nt) {
-        const int4 r = C.rec[idx];
+    int idx = first + tid;                                         // (the next trip's record is fetched one trip ahead, as in bp_edge_packed)
+    int4 r = idx < end ? C.rec[idx] : make_int4(0, 0, 0, 0);
+    for (; idx < end; idx += nt) {
+        int4 rn = r;
+        if (idx + nt < end) rn = C.rec[idx + nt];
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, r.w, P);
         en += bp_marginal_slot<NA, NB>(C, r.w, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nbm, want_energy);
+        r = rn;
     }
     return en;
+}
+// end of a solve, packed classes: the matrices of the ACTIVE slots back to their resting value, straight from the records (no
+// flag loads in front of the stores); the flags themselves are handed on by retire_flags
+template <int NA, int NB>
+__device__ __forceinline__ void retire_packed(const BpCtx& C, int first, int end, int tid, int nt, float rest) {
+    for (int idx = first + tid; idx < end; idx += nt) {
+        const int sl = C.rec[idx].w;
+#pragma unroll
+        for (int e = 0; e < NA * NB; ++e) C.P[PIDX6(C.cap, sl, e / NB, e % NB)] = rest;
+    }
+}
+__device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ active_w, int* __restrict__ active_last, int tid, int nt) {
+    for (int sl = lo + tid; sl < hi; sl += nt) { active_last[sl] = active_w[sl]; active_w[sl] = 0; }
 }
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
@@ -1096,9 +1146,16 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
     const float rest = R.p_prob ? 1.f : 0.f;
-    retire_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], active_w, active_last, tid, nt, rest);
-    retire_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], active_w, active_last, tid, nt, rest);
-    retire_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], active_w, active_last, tid, nt, rest);
+    if (PACK) {     // the records name the active slots of the multi-state classes: no flag round trip in front of the stores
+        retire_packed<3, 3>(C, cls[CL33], e33, tid, nt, rest);
+        retire_packed<3, 6>(C, cls[CL36], e36, tid, nt, rest);
+        retire_packed<6, 6>(C, cls[CL66], e66, tid, nt, rest);
+        retire_flags(cls[CL33], cls[CL66 + 1], active_w, active_last, tid, nt);      // (the three classes are adjacent: CL33 < CL36 < CL66)
+    } else {
+        retire_class<3, 3>(C.P, C.cap, cls[CL33], cls[CL33 + 1], active_w, active_last, tid, nt, rest);
+        retire_class<3, 6>(C.P, C.cap, cls[CL36], cls[CL36 + 1], active_w, active_last, tid, nt, rest);
+        retire_class<6, 6>(C.P, C.cap, cls[CL66], cls[CL66 + 1], active_w, active_last, tid, nt, rest);
+    }
     retire_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], active_w, active_last, tid, nt, rest);
     retire_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], active_w, active_last, tid, nt, rest);
     for (int i = cls[N_CLASS] + tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }   // (no slot lies outside the classes)
