@@ -1598,7 +1598,9 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     // win from there on (128: 73.3 vs 72.7 k, 192: 77.6 vs 75.9 k, 256: 96 vs 93 k, 1024: 108 vs 103 k)
     static int resident_env = -2;
     if (resident_env == -2) { const char* e = getenv("UPSIDE_HIP_BP_RESIDENT"); resident_env = e ? atoi(e) : -1; }
-    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() * 3 / 8 ? 1 : 0);
+    // (re-measured after the look-ahead loads of bp_edge_packed: 32 systems 0.381 vs 0.379 ms, 64: 0.411 vs 0.466, 96: 0.470 vs 0.510,
+    //  128: 0.489 vs 0.527 -- the register layout from 1/8 system per CU on)
+    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 0);
     const dim3 grid(1, L->n_system);
     if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);

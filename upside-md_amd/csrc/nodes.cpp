@@ -1324,7 +1324,9 @@ struct RotamerSidechain : public PotentialNode {
         const int n_cu = upk_device_cu_count();
         int per_launch = C > 1 ? n_cu / C : 0;
         if (per_launch >= 8) per_launch &= ~7;
-        const int resident_limit = C >= env_int("UPSIDE_HIP_BP_CLUSTER_MIN_C", 6) ? per_launch + per_launch / 4 : 0;
+        // (round 2, after the one-workgroup solve got its look-ahead loads: 32 systems 0.37 vs 0.38 ms, 40: 0.41 vs 0.39, 48 (two launches):
+        //  0.61 vs 0.39 -- the cluster up to 4/5 of one launch)
+        const int resident_limit = C >= env_int("UPSIDE_HIP_BP_CLUSTER_MIN_C", 6) ? per_launch * 4 / 5 : 0;
         if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", resident_limit)) C = 1;
         if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
