@@ -1018,9 +1018,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
         float dev = 0.f;
-        for (int g0 = 0; g0 < NN; g0 += n_grp) {
+        // Rounds of n_grp nodes; a round waits for its slowest load.  The inbox rows of the 6-state nodes are the ones that
+        // spill to global memory, those of the 3-state nodes all sit in LDS: the 6-state nodes go first, in rounds of their own
+        // (one round for the 128 of the benchmark protein), instead of being spread over every round; 1-state nodes have no
+        // inbox and take no slot.  (Node order in the arrays: 1-state, 3-state, 6-state.)
+        const int e1n = R.n_node1, e3n = R.n_node1 + R.n_node3;
+        for (int part = 0; part < 2; ++part)
+        for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += n_grp) {
             const int g = g0 + tid / BP_GROUP;
-            const bool live = g < NN && nrot[g] > 1;
+            const bool live = g < g_hi;
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
