@@ -7,6 +7,7 @@
 // gradients are re-evaluated in the backward pass instead of being stored (the reference keeps 12-13 floats of edge_deriv per
 // edge, interaction_graph.h:294-296: ~150 flop against 100+ bytes of HBM traffic per edge).
 #include "igraph_device.h"
+#include "pair2_device.h"
 #include <cstring>
 
 using namespace up;
@@ -266,8 +267,197 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
         else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
     }
 }
+// ---- packed passes of the hbond_coverage graphs (pair2_device.h): two partners per lane, 4-lane row groups ----------------
+// x1 is always the side-1 element (H-bond site, 7 components: [6] = its bond probability), x2 the side-2 element (bead).
+// Staged rows carry a sentinel element behind each side (lanes past the end of their row evaluate it with weight zero).
+__device__ __forceinline__ PairLds pair2_lds(float* lds, const upk_igraph_t& G, int tab_floats) {
+    PairLds L;
+    L.tab = lds;
+    L.c1 = lds + ((tab_floats + 3) & ~3);
+    L.c2 = L.c1 + (G.n1 + 1) * 8;
+    const int n_max = G.n1 > G.n2 ? G.n1 : G.n2;
+    L.range = (int*)(L.c2 + (G.n2 + 1) * 8);
+    L.ord = (unsigned short*)(L.range + n_max);
+    L.counter = L.range + PG_WALK_LDS_WORDS(n_max);
+    return L;
+}
+// value of two hbond_coverage pairs (hbond.cpp:261-276) and, if WANT_D, the derivatives: d1[0..7) w.r.t. the sites, d2[0..6) w.r.t. the beads
+template <bool WANT_D, bool POLY>
+__device__ __forceinline__ v2 coverage_pair2(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1A, int t1B, int t2A, int t2B,
+                                             const v2* x1, v2 hb1, const v2* x2, v2* d1, v2* d2) {
+    const int n = POLY ? G.n_poly : G.n_param;
+    const float* pA = tab + (t1A * G.n_type2 + t2A) * n; const float* pB = tab + (t1B * G.n_type2 + t2B) * n;
+    const int o2 = POLY ? 4 * (Q.ka - 3) : Q.ka;
+    v2 dd[3], g1[3], g2[3];
+    const v2 coverage = quadspline_pair2<WANT_D, POLY>(Q, pA, pB, x1, x2, dd, g1, g2, 0, o2, 0, o2);
+    const v2 one_m = bc2(1.f) - hb1, prefactor = one_m * one_m;
+    if (WANT_D) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d2[c] = prefactor * dd[c]; d1[c] = -d2[c]; d1[3 + c] = prefactor * g1[c]; d2[3 + c] = prefactor * g2[c]; }
+        d1[6] = coverage * (one_m * bc2(-2.f));
+    }
+    return prefactor * coverage;
+}
+
+// forward: row sums of the pair value over the rows of side RS
+template <int RS, bool POLY>
+struct CovRowOp2 {
+    const upk_igraph_t& G; const QuadShape Q; const PairLds& L; const PairArgs& A; const int s;
+    v2 xr[6], hbr, acc; int tr;
+    __device__ __forceinline__ CovRowOp2(const upk_igraph_t& G_, const PairLds& L_, const PairArgs& A_, int s_) : G(G_), Q(quad_shape(G_)), L(L_), A(A_), s(s_) {}
+    __device__ __forceinline__ void begin(int row) {
+        float x[8]; load_row8(x, (RS == 1 ? L.c1 : L.c2) + row * 8);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xr[c] = bc2(x[c]);
+        hbr = bc2(x[6]); tr = __float_as_int(x[7]); acc = bc2(0.f);
+    }
+    __device__ __forceinline__ void body(int, int jA, int jB, bool liveA, bool liveB) {
+        float xa[8], xb[8];
+        load_row8(xa, (RS == 1 ? L.c2 : L.c1) + jA * 8); load_row8(xb, (RS == 1 ? L.c2 : L.c1) + jB * 8);
+        v2 xo[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xo[c] = mk2(xa[c], xb[c]);
+        const int toA = __float_as_int(xa[7]), toB = __float_as_int(xb[7]);
+        const v2 v = RS == 1 ? coverage_pair2<false, POLY>(G, Q, L.tab, tr, tr, toA, toB, xr, hbr, xo, nullptr, nullptr)
+                             : coverage_pair2<false, POLY>(G, Q, L.tab, toA, toB, tr, tr, xo, mk2(xa[6], xb[6]), xr, nullptr, nullptr);
+        acc += mk2(liveA ? v.x : 0.f, liveB ? v.y : 0.f);
+    }
+    __device__ __forceinline__ void flush(int row) {
+        const float t = group_sum4(acc.x + acc.y);
+        if ((threadIdx.x & (P2_LANES - 1)) != 0) return;
+        A.out[(size_t)s * A.out_sys_stride + (size_t)((RS == 1 ? A.out_row0 : A.out_row0_2) + row) * A.out_stride + A.out_comp] = t;
+    }
+};
+template <int RS, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t G, PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const PairLds L = pair2_lds(lds, G, A.tab_floats);
+    stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
+    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0);
+    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, nullptr, 0);
+    stage_sentinel(L.c1, G.n1, 0.f, __int_as_float(0)); stage_sentinel(L.c2, G.n2, 0.f, __int_as_float(0));
+    if (threadIdx.x == 0) *L.counter = 0;
+    const int n_rows = RS == 1 ? G.n1 : G.n2, cap = RS == 1 ? G.cap1 : G.cap2;
+    stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
+    __syncthreads();
+    CovRowOp2<RS, POLY> op(G, L, A, s);
+    group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x, RS == 1 ? G.n2 : G.n1);
+}
+
+// backward over the rows of side RS, ONE visit per pair: the row element's gradient in registers, the partner's through the
+// fixed-point LDS accumulators (k_pair_backward above, two partners per lane)
+template <int RS, bool POLY>
+struct CovBackwardOp2 {
+    static constexpr int DR = RS == 1 ? 7 : 6, DO = RS == 1 ? 6 : 7;
+    const upk_igraph_t& G; const QuadShape Q; const PairLds& L; unsigned long long* oacc;
+    const bool row_has, oth_has;
+    v2 xr[6], hbr, acc[DR]; float sr; int tr;
+    float* row_sens; const int* row_loc; int row_stride;
+    __device__ __forceinline__ CovBackwardOp2(const upk_igraph_t& G_, const PairLds& L_, unsigned long long* oacc_, int sens_mode, int s)
+        : G(G_), Q(quad_shape(G_)), L(L_), oacc(oacc_), row_has(sens_mode == 3 || sens_mode == RS), oth_has(sens_mode == 3 || sens_mode == 3 - RS) {
+        const upk_coord_t& node = RS == 1 ? G.node1 : G.node2;
+        row_sens = node.sens + (size_t)s * node.n_elem * node.stride; row_loc = RS == 1 ? G.loc1 : G.loc2; row_stride = node.stride;
+    }
+    // staged rows: sites [0,7) coordinates, beads [0,6) coordinates + [6] the bead's pair sensitivity; [7] the type.  The sites' pair
+    // sensitivity (sens_mode 1 / 3) rides in a separate LDS array in front of the accumulators: L-side detail of the kernel below.
+    const float* site_sens = nullptr;
+    __device__ __forceinline__ void begin(int row) {
+        float x[8]; load_row8(x, (RS == 1 ? L.c1 : L.c2) + row * 8);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xr[c] = bc2(x[c]);
+        hbr = bc2(x[6]); tr = __float_as_int(x[7]);
+        sr = !row_has ? 0.f : (RS == 1 ? site_sens[row] : x[6]);
+#pragma unroll
+        for (int c = 0; c < DR; ++c) acc[c] = bc2(0.f);
+    }
+    __device__ __forceinline__ void body(int, int jA, int jB, bool liveA, bool liveB) {
+        float xa[8], xb[8];
+        load_row8(xa, (RS == 1 ? L.c2 : L.c1) + jA * 8); load_row8(xb, (RS == 1 ? L.c2 : L.c1) + jB * 8);
+        v2 xo[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xo[c] = mk2(xa[c], xb[c]);
+        const int toA = __float_as_int(xa[7]), toB = __float_as_int(xb[7]);
+        v2 d1[7], d2[6];
+        if (RS == 1) coverage_pair2<true, POLY>(G, Q, L.tab, tr, tr, toA, toB, xr, hbr, xo, d1, d2);
+        else coverage_pair2<true, POLY>(G, Q, L.tab, toA, toB, tr, tr, xo, mk2(xa[6], xb[6]), xr, d1, d2);
+        // pair sensitivity = (row part) + (other part), zero for the dead halves
+        float soA = 0.f, soB = 0.f;
+        if (oth_has) { soA = RS == 1 ? xa[6] : site_sens[jA]; soB = RS == 1 ? xb[6] : site_sens[jB]; }
+        const v2 ps = mk2(liveA ? sr + soA : 0.f, liveB ? sr + soB : 0.f);
+        const v2* dr = RS == 1 ? d1 : d2; const v2* dv = RS == 1 ? d2 : d1;
+#pragma unroll
+        for (int c = 0; c < DR; ++c) acc[c] = fma2(ps, dr[c], acc[c]);
+        v2 od[DO];
+#pragma unroll
+        for (int c = 0; c < DO; ++c) od[c] = ps * dv[c];
+        if (liveA) {
+#pragma unroll
+            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + jA * DO + c, od[c].x);
+        }
+        if (liveB) {
+#pragma unroll
+            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + jB * DO + c, od[c].y);
+        }
+    }
+    __device__ __forceinline__ void flush(int row) {
+        float t[DR];
+#pragma unroll
+        for (int c = 0; c < DR; ++c) t[c] = group_sum4(acc[c].x + acc[c].y);
+        if ((threadIdx.x & (P2_LANES - 1)) != 0) return;
+        float* o = row_sens + (size_t)row_loc[row] * row_stride;     // the row has one owner in this launch: a plain "+="
+#pragma unroll
+        for (int c = 0; c < DR; ++c) o[c] += t[c];
+    }
+};
+template <int RS, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igraph_t G, PairArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DO = CovBackwardOp2<RS, POLY>::DO;
+    const int s = blockIdx.y;
+    const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
+    const PairLds L = pair2_lds(lds, G, A.tab_floats);
+    unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
+    float* site_sens = (float*)(oacc + (size_t)n_other * DO);            // [n1] (only when the sites carry a pair sensitivity)
+    const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
+    const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
+    stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
+    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0);
+    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, S2, A.sens_stride);
+    stage_sentinel(L.c1, G.n1, 0.f, __int_as_float(0)); stage_sentinel(L.c2, G.n2, 0.f, __int_as_float(0));
+    if (S1) for (int t = threadIdx.x; t < G.n1; t += blockDim.x) site_sens[t] = S1[(size_t)t * A.sens_stride];
+    for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) oacc[t] = 0ull;
+    if (threadIdx.x == 0) *L.counter = 0;
+    stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
+    __syncthreads();
+    {
+        CovBackwardOp2<RS, POLY> op(G, L, oacc, A.sens_mode, s);
+        op.site_sens = site_sens;
+        const int cap = RS == 1 ? G.cap1 : G.cap2;
+        group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x, n_other);
+    }
+    __syncthreads();
+    const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;
+    const int* oloc = RS == 1 ? G.loc2 : G.loc1;
+    float* osens = C_SENS(onode, s);
+    unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
+    const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
+        const unsigned long long a = oacc[t];
+        if (!a) continue;
+        const int i = t / DO, c = t - i * DO;
+        if (alone) osens[(size_t)oloc[i] * onode.stride + c] += from_fixed22(a);
+        else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
+    }
+}
+static bool pair2_enabled() {          // UPSIDE_HIP_PAIR2=0: the scalar passes (one partner per lane) -- A/B and tests
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UPSIDE_HIP_PAIR2"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v != 0;
+}
+
 // global accumulators (several workgroups per system) -> the other side's sens; cleared for the next evaluation
-__global__ void k_pair_backward_finish(upk_igraph_t G, int other_side) {
+__global__ void k_pair_backward_finish(upk_igraph_t G, int other_side, double unit) {   // unit: value of one accumulator count
     const int s = blockIdx.y;
     const int n_other = other_side == 1 ? G.n1 : G.n2, dim = other_side == 1 ? G.dim1 : G.dim2;
     const upk_coord_t& onode = other_side == 1 ? G.node1 : G.node2;
@@ -278,7 +468,7 @@ __global__ void k_pair_backward_finish(upk_igraph_t G, int other_side) {
         const int i = t >> 3, c = t & 7;
         if (c >= dim) continue;
         const unsigned long long a = gacc[t];
-        if (a) { osens[(size_t)oloc[i] * onode.stride + c] += from_fixed32(a); gacc[t] = 0ull; }
+        if (a) { osens[(size_t)oloc[i] * onode.stride + c] += (float)((double)(long long)a * unit); gacc[t] = 0ull; }
     }
 }
 
@@ -347,6 +537,13 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     }
     const int n_rows = side == 1 ? G->n1 : (side == 2 ? G->n2 : (G->n1 > G->n2 ? G->n1 : G->n2));
     int bps, threads;
+    if (G->itype == UPK_IT_HBOND_COVERAGE && mode == 0 && side != 3 && pair2_enabled() && lds + 64 <= 158 * 1024) {   // packed pass
+        pair2_geometry(L->n_system, n_rows, bps, threads);
+        const dim3 grid2(bps, L->n_system), block2(threads);
+        if (side == 1) { if (table == 2) hipLaunchKernelGGL((k_cov_rows2<1, true>), grid2, block2, lds + 64, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_rows2<1, false>), grid2, block2, lds + 64, ST(L), *G, A); }
+        else { if (table == 2) hipLaunchKernelGGL((k_cov_rows2<2, true>), grid2, block2, lds + 64, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_rows2<2, false>), grid2, block2, lds + 64, ST(L), *G, A); }
+        return launch_status();
+    }
     pair_geometry(L->n_system, n_rows, bps, threads);
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
@@ -380,6 +577,21 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
         return r;
     }
     int bps, threads;
+    if (G->itype == UPK_IT_HBOND_COVERAGE && pair2_enabled()) {            // packed pass: + sentinel rows and the sites' sensitivities
+        const size_t extra = 64 + (size_t)G->n1 * sizeof(float);
+        size_t lds2; int tf;
+        const int table2 = pair_table_choice(G, acc_bytes + extra, tf, lds2);
+        if (table2) {
+            A.tab_floats = tf; lds2 += acc_bytes + extra;
+            pair2_geometry(L->n_system, n_rows, bps, threads);
+            if (!G->gacc) bps = 1;
+            const dim3 grid2(bps, L->n_system), block2(threads);
+            if (row_side == 1) { if (table2 == 2) hipLaunchKernelGGL((k_cov_backward2<1, true>), grid2, block2, lds2, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_backward2<1, false>), grid2, block2, lds2, ST(L), *G, A); }
+            else { if (table2 == 2) hipLaunchKernelGGL((k_cov_backward2<2, true>), grid2, block2, lds2, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_backward2<2, false>), grid2, block2, lds2, ST(L), *G, A); }
+            if (bps > 1) hipLaunchKernelGGL(k_pair_backward_finish, dim3((n_other * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, 3 - row_side, 1.0 / (double)(1 << P2_FIX_BITS));
+            return launch_status();
+        }
+    }
     pair_geometry(L->n_system, n_rows, bps, threads);
     if (!G->gacc) bps = 1;
     const dim3 grid(bps, L->n_system), block(threads);
@@ -403,7 +615,7 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
             break;
         default: return 9008;
     }
-    if (bps > 1) hipLaunchKernelGGL(k_pair_backward_finish, dim3((n_other * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, 3 - row_side);
+    if (bps > 1) hipLaunchKernelGGL(k_pair_backward_finish, dim3((n_other * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, 3 - row_side, 1.0 / 4294967296.0);
     return launch_status();
 }
 

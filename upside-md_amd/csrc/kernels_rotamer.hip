@@ -16,6 +16,7 @@
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
 #include "igraph_device.h"
+#include "pair2_device.h"
 
 using namespace up;
 
@@ -277,7 +278,7 @@ extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t*
 // STAGED = false (systems whose beads do not fit LDS next to the table): the rows are read from a packed global copy
 // written by k_rotamer_pack_beads and the gradient accumulates in global memory.
 struct RotLds { float* tab; const float* rows; unsigned long long* acc; int* range; unsigned short* ord; int* counter; };
-template <bool STAGED, bool POLY = false>
+template <bool STAGED, bool POLY = false, bool SENTINEL = false>
 __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, int s, int tab_floats, bool want_acc) {
     const upk_igraph_t& G = R.G;
     RotLds r;
@@ -287,8 +288,9 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
     r.acc = nullptr;
     if (STAGED) {
         if (want_acc) { r.acc = (unsigned long long*)p; p += G.n1 * 12; for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) r.acc[t] = 0ull; }
-        r.rows = p; p += G.n1 * 8;
+        r.rows = p; p += (G.n1 + (SENTINEL ? 1 : 0)) * 8;
         stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
+        if (SENTINEL) stage_sentinel((float*)r.rows, G.n1, __int_as_float(1 << 12) /* type 0, state 0 of 1 */, __int_as_float(0) /* node 0 */);
     } else r.rows = R.bead_pack + (size_t)s * G.n1 * 8;
     r.range = (int*)p; r.ord = (unsigned short*)(r.range + G.n1); r.counter = r.range + PG_WALK_LDS_WORDS(G.n1);
     stage_ranges(r.range, r.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
@@ -356,19 +358,176 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy(upk
 }
 
 // 1 = table + beads (+ accumulators) staged in LDS, 0 = beads read from the packed global copy, -1 = not even the table fits
+// ---- packed passes (pair2_device.h): two partners per lane, 4-lane row groups ------------------------------------------
+// hit-list word -> partner bead, slot; the bead rows carry type | rot << 8 | nrot << 12 in [6] and the node id in [7]
+struct RotPairMeta { int j, sl, mo, b; };
+__device__ __forceinline__ RotPairMeta rot_pair_meta(int w, const float* xo) {
+    RotPairMeta m;
+    m.j = w & ((1 << UPK_ROT_J_BITS) - 1); m.sl = (int)((unsigned)w >> UPK_ROT_J_BITS);
+    m.mo = __float_as_int(xo[6]); m.b = __float_as_int(xo[7]);
+    return m;
+}
+template <bool POLY>
+struct RotEnergyOp2 {
+    const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
+    float* P; int* active;
+    v2 x1[6]; int mr, a;
+    __device__ __forceinline__ RotEnergyOp2(const upk_rotamer_t& R_, const RotLds& L_, int s)
+        : R(R_), Q(quad_shape(R_.G)), L(L_), P(R_.P + (size_t)s * R_.slot_cap * 36), active(R_.slot_active + (size_t)s * R_.slot_cap) {}
+    __device__ __forceinline__ void begin(int row) {
+        float xr[8]; load_row8(xr, L.rows + row * 8);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x1[c] = bc2(xr[c]);
+        mr = __float_as_int(xr[6]); a = __float_as_int(xr[7]);
+    }
+    __device__ __forceinline__ void store(const RotPairMeta& m, float E) const {
+        if (m.sl == UPK_ROT_SLOT_NONE) return;              // (no slot: only after a capacity overflow, the error flag is set)
+        const int ra = (mr >> 8) & 0xF, rb = (m.mo >> 8) & 0xF;
+        float* pe = P + PIDX6(R.slot_cap, m.sl, a < m.b ? ra : rb, a < m.b ? rb : ra);
+        if (R.one_bead_per_state) *pe = R.p_prob ? expf(-E) : E;      // single writer per entry: plain store
+        else atomicAdd(pe, E);
+        active[m.sl] = 1;
+    }
+    __device__ __forceinline__ void body(int, int wA, int wB, bool liveA, bool liveB) {
+        float xa[8], xb[8];
+        load_row8(xa, L.rows + (wA & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        load_row8(xb, L.rows + (wB & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        const RotPairMeta mA = rot_pair_meta(wA, xa), mB = rot_pair_meta(wB, xb);
+        v2 x2[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x2[c] = mk2(xa[c], xb[c]);
+        int o1A, o2A, o1B, o2B;
+        const float* pA = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mA.mo & 0xFF, o1A, o2A);   // row < partner: types [type(i1)][type(i2)], i1 < i2
+        const float* pB = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mB.mo & 0xFF, o1B, o2B);
+        const v2 E = quadspline_pair2<false, POLY>(Q, pA, pB, x1, x2, nullptr, nullptr, nullptr, o1A, o2A, o1B, o2B);
+        if (liveA) store(mA, E.x);
+        if (liveB) store(mB, E.y);
+    }
+    __device__ __forceinline__ void flush(int) {}
+};
+template <bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy2(upk_rotamer_t R, int tab_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const upk_igraph_t& G = R.G;
+    const RotLds L = rot_stage<true, POLY, true>(R, lds, s, tab_floats, false);
+    RotEnergyOp2<POLY> op(R, L, s);
+    group2_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x, G.n1);
+}
+
+template <bool POLY>
+struct RotGradOp2 {
+    const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
+    const float* marg; const float* nbm;
+    v2 x1[6], acc[6]; int mr, a;
+    __device__ __forceinline__ RotGradOp2(const upk_rotamer_t& R_, const RotLds& L_, int s)
+        : R(R_), Q(quad_shape(R_.G)), L(L_), marg(R_.marg + (size_t)s * R_.slot_cap * 36), nbm(R_.nb_cur + (size_t)s * R_.n_node * 6) {}
+    __device__ __forceinline__ void begin(int row) {
+        float xr[8]; load_row8(xr, L.rows + row * 8);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { x1[c] = bc2(xr[c]); acc[c] = bc2(0.f); }
+        mr = __float_as_int(xr[6]); a = __float_as_int(xr[7]);
+    }
+    // pair sensitivity = pair marginal of the two rotamer states (the node marginal when one side has a single state,
+    // rotamer.cpp:956-966): ONE unconditional load from a selected address, issued before the functor
+    __device__ __forceinline__ float sens_of(const RotPairMeta& m, bool live) const {
+        const int ra = (mr >> 8) & 0xF, na = (mr >> 12) & 0xF, rb = (m.mo >> 8) & 0xF, nb = (m.mo >> 12) & 0xF;
+        const bool both1 = na == 1 && nb == 1, multi = na > 1 && nb > 1, no_slot = multi && m.sl == UPK_ROT_SLOT_NONE;
+        // (selects on integers, no divergent address code: the two tables differ in base and offset only)
+        const bool lo = a < m.b;
+        const int off_m = ((lo ? ra : rb) * R.slot_cap + (no_slot ? 0 : m.sl)) * 6 + (lo ? rb : ra);       // PIDX6
+        const int off_n = na == 1 ? m.b * 6 + rb : a * 6 + ra;
+        const uintptr_t base = multi ? (uintptr_t)marg : (uintptr_t)nbm;
+        const float pv = ((const float*)base)[multi ? off_m : off_n];
+        return !live ? 0.f : (both1 ? 1.f : (no_slot ? 0.f : pv));
+    }
+    __device__ __forceinline__ void body(int, int wA, int wB, bool liveA, bool liveB) {
+        float xa[8], xb[8];
+        load_row8(xa, L.rows + (wA & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        load_row8(xb, L.rows + (wB & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        const RotPairMeta mA = rot_pair_meta(wA, xa), mB = rot_pair_meta(wB, xb);
+        const v2 ps = mk2(sens_of(mA, liveA), sens_of(mB, liveB));
+        v2 x2[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x2[c] = mk2(xa[c], xb[c]);
+        int o1A, o2A, o1B, o2B;
+        const float* pA = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mA.mo & 0xFF, o1A, o2A);
+        const float* pB = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mB.mo & 0xFF, o1B, o2B);
+        v2 dd[3], g1[3], g2[3];
+        quadspline_pair2<true, POLY>(Q, pA, pB, x1, x2, dd, g1, g2, o1A, o2A, o1B, o2B);
+        v2 od[6];                                           // the partners' shares
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            od[c] = ps * dd[c]; od[3 + c] = ps * g2[c];
+            acc[c] -= od[c]; acc[3 + c] = fma2(ps, g1[c], acc[3 + c]);
+        }
+        if (liveA) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + mA.j * 6 + c, od[c].x);
+        }
+        if (liveB) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + mB.j * 6 + c, od[c].y);
+        }
+    }
+    __device__ __forceinline__ void flush(int row) {
+        float t[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t[c] = group_sum4(acc[c].x + acc[c].y);
+        if ((threadIdx.x & (P2_LANES - 1)) != 0) return;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + row * 6 + c, t[c]);
+    }
+};
+template <bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad2(upk_rotamer_t R, int tab_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const upk_igraph_t& G = R.G;
+    const RotLds L = rot_stage<true, POLY, true>(R, lds, s, tab_floats, true);
+    {
+        RotGradOp2<POLY> op(R, L, s);
+        group2_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x, G.n1);
+    }
+    __syncthreads();
+    float* sens = C_SENS(G.node1, s);
+    unsigned long long* gacc = R.grad_acc + (size_t)s * G.n1 * 6;
+    const bool alone = gridDim.x == 1;     // the system's only workgroup: its accumulators are the totals
+    for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) {
+        const unsigned long long a = L.acc[t];
+        if (!a) continue;
+        if (alone) { const int i = t / 6, c = t - i * 6; sens[(size_t)G.loc1[i] * G.node1.stride + c] += from_fixed22(a); }
+        else atomicAdd(gacc + t, a);       // several workgroups share the system: exact partial sums, k_rotamer_grad_finish converts
+    }
+    if (alone) {   // the node marginal of the bead's rotamer state goes to the 1-body parents (rotamer.cpp:968-984)
+        const float* nbm = R.nb_cur + (size_t)s * R.n_node * 6;
+        for (int i = threadIdx.x; i < G.n1; i += blockDim.x) {
+            const float mg = nbm[R.bead_node[i] * 6 + ((R.bead_meta[i] >> 8) & 0xF)];
+            const int loc = G.loc1[i];
+            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+        }
+    }
+}
+
+static bool rot_pair2_enabled() {          // UPSIDE_HIP_PAIR2=0: the scalar passes (one partner per lane) -- A/B and tests
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UPSIDE_HIP_PAIR2"); v = (e && !atoi(e)) ? 0 : 1; }
+    return v != 0;
+}
 static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want_acc, int& tab_floats, size_t& lds_bytes, dim3& grid, dim3& block,
-                        bool poly = false) {
+                        bool poly = false, bool pair2 = false) {
     const int nt = R->G.n_type1;
     tab_floats = (nt * (nt + 1) / 2) * (poly ? R->n_poly : R->G.n_param);
     const size_t fixed = ((size_t)((tab_floats + 3) & ~3) + PG_WALK_LDS_WORDS(R->G.n1) + 4) * sizeof(float);
     static int force_unstaged = -1;   // UPSIDE_HIP_ROT_UNSTAGED=1 exercises the large-system path
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_ROT_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     int staged = 1;
-    lds_bytes = fixed + (size_t)R->G.n1 * (want_acc ? 20 : 8) * sizeof(float);
+    lds_bytes = fixed + (size_t)R->G.n1 * (want_acc ? 20 : 8) * sizeof(float) + (pair2 ? 32 : 0);
     if (lds_bytes > 158 * 1024 || force_unstaged || R->bead_pack) { staged = 0; lds_bytes = fixed; }   // (a system whose gradient pass needs the packed copy uses it in both passes)
     if (lds_bytes > 158 * 1024 || (!staged && !R->bead_pack)) return -1;
     int bps, threads;
-    pair_geometry(L->n_system, R->G.n1, bps, threads);
+    if (pair2) pair2_geometry(L->n_system, R->G.n1, bps, threads);
+    else pair_geometry(L->n_system, R->G.n1, bps, threads);
     grid = dim3(bps, L->n_system); block = dim3(threads);
     return staged;
 }
@@ -376,6 +535,15 @@ extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_
     int tab_floats; size_t lds; dim3 grid, block;
     static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
     if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_ROT_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
+    if (rot_pair2_enabled()) {                     // packed passes (two partners per lane)
+        for (int poly = no_poly ? 0 : 1; poly >= 0; --poly) {
+            if (poly && !R->param_tri_poly) continue;
+            if (rot_geometry(L, R, false, tab_floats, lds, grid, block, poly != 0, true) != 1) continue;
+            if (poly) hipLaunchKernelGGL(k_rotamer_pair_energy2<true>, grid, block, lds, ST(L), *R, tab_floats);
+            else hipLaunchKernelGGL(k_rotamer_pair_energy2<false>, grid, block, lds, ST(L), *R, tab_floats);
+            return launch_status();
+        }
+    }
     if (R->param_tri_poly && !no_poly && rot_geometry(L, R, false, tab_floats, lds, grid, block, true) == 1) {   // polynomial table + beads fit LDS
         hipLaunchKernelGGL((k_rotamer_pair_energy<true, true>), grid, block, lds, ST(L), *R, tab_floats);
         return launch_status();
@@ -475,7 +643,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad(upk_rotame
     }
 }
 // global accumulators -> sens (and cleared for the next evaluation); the 1-body marginal push of the systems that took this path
-__global__ void k_rotamer_grad_finish(upk_rotamer_t R) {
+__global__ void k_rotamer_grad_finish(upk_rotamer_t R, double unit) {   // unit: value of one accumulator count (2^-32 or 2^-22)
     const int s = blockIdx.y;
     const upk_igraph_t& G = R.G;
     float* sens = C_SENS(G.node1, s);
@@ -485,21 +653,33 @@ __global__ void k_rotamer_grad_finish(upk_rotamer_t R) {
         const int i = t / 6, c = t - i * 6;
         const unsigned long long a = gacc[t];
         const int loc = G.loc1[i];
-        if (a) { sens[(size_t)loc * G.node1.stride + c] += from_fixed32(a); gacc[t] = 0ull; }
+        if (a) { sens[(size_t)loc * G.node1.stride + c] += (float)((double)(long long)a * unit); gacc[t] = 0ull; }
         if (c == 0) {
             const float mg = nbm[R.bead_node[i] * 6 + ((R.bead_meta[i] >> 8) & 0xF)];
             for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
         }
     }
 }
+
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
     int tab_floats; size_t lds; dim3 grid, block;
+    const double unit32 = 1.0 / 4294967296.0, unit22 = 1.0 / (double)(1 << P2_FIX_BITS);
+    if (rot_pair2_enabled()) {                     // packed passes: polynomial table if it fits beside the accumulators, else spline coefficients
+        for (int poly = 1; poly >= 0; --poly) {
+            if (poly && !R->param_tri_poly) continue;
+            if (rot_geometry(L, R, true, tab_floats, lds, grid, block, poly != 0, true) != 1) continue;
+            if (poly) hipLaunchKernelGGL(k_rotamer_grad2<true>, grid, block, lds, ST(L), *R, tab_floats);
+            else hipLaunchKernelGGL(k_rotamer_grad2<false>, grid, block, lds, ST(L), *R, tab_floats);
+            if (grid.x > 1) hipLaunchKernelGGL(k_rotamer_grad_finish, dim3((R->G.n1 * 6 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R, unit22);
+            return launch_status();
+        }
+    }
     const int staged = rot_geometry(L, R, true, tab_floats, lds, grid, block);
     if (staged < 0) return 9005;
     if (staged) hipLaunchKernelGGL(k_rotamer_grad<true>, grid, block, lds, ST(L), *R, tab_floats);
     else hipLaunchKernelGGL(k_rotamer_grad<false>, grid, block, lds, ST(L), *R, tab_floats);   // beads packed by upk_rotamer_pair_energy this step
     if (!staged || grid.x > 1)
-        hipLaunchKernelGGL(k_rotamer_grad_finish, dim3((R->G.n1 * 6 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
+        hipLaunchKernelGGL(k_rotamer_grad_finish, dim3((R->G.n1 * 6 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R, unit32);
     return launch_status();
 }
 

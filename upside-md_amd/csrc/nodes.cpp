@@ -538,9 +538,10 @@ struct IGraphHost {
         cur_pos1.alloc((size_t)S * G.n1 * 4);
         if (!G.symmetric) cur_pos2.alloc((size_t)S * G.n2 * 4);
         if (itype != UPK_IT_RADIAL && itype != UPK_IT_HBOND_SC_RADIAL) {   // (the radial potentials walk the cached lists themselves)
-            hit1.alloc((size_t)S * G.n1 * G.cap1); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
+            // (+4 words: the packed pair passes fetch a lane's two list words together, the second may lie one past the last row's end)
+            hit1.alloc((size_t)S * G.n1 * G.cap1 + 4); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
             if (G.symmetric) { /* (each pair once: the lists hold the partners above the row only) */ }
-            else { hit2.alloc((size_t)S * G.n2 * G.cap2); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
+            else { hit2.alloc((size_t)S * G.n2 * G.cap2 + 4); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
         }
         if (!G.symmetric && S < 256) { gacc.alloc((size_t)S * max(G.n1, G.n2) * 8); G.gacc = gacc.p; }   // (from 256 systems on a system has one workgroup)
         G.hit1 = hit1.p; G.hit2 = hit2.p; G.hcnt1 = hcnt1.p; G.hcnt2 = hcnt2.p; G.hlo1 = hlo1.p;

@@ -1,0 +1,242 @@
+// Packed-fp32 pair passes (round 3): every lane evaluates TWO partners of its row at once, as the two halves of 64-bit
+// register pairs, so that the geometry, the spline polynomials, the derivative assembly and the sensitivity products of
+// /root/reference/src/bead_interaction.h:30-84 issue as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- one wave64 VALU
+// instruction per TWO pair evaluations.  The scalar formulation of igraph_device.h sits at the issue ceiling of a dependent
+// fp32 chain (one instruction per 4 cycles and SIMD), which is half of what the vector unit can do.
+//
+// What stays per pair (not packable on gfx950): v_rsq_f32, the float -> interval-index conversions, the LDS reads of the
+// partner row and of the four cubic pieces, the gather of the pair sensitivity, the fixed-point conversion and the LDS atomics.
+//
+// Work decomposition: a wavefront serves a batch of 16 rows of the sorted row order; each 4-lane group owns one row and takes
+// 8 consecutive words of its hit list per trip (lane l: words l and l+4, so that each half-evaluation covers 4 consecutive
+// partners: contiguous pair-matrix stores, distinct accumulator banks), i.e. the same 8 pairs per row and trip as the
+// 8-lane groups of the scalar passes, so the tail waste per row is unchanged.  A lane past the end of its row evaluates the
+// SENTINEL element (a far-away, finite dummy row staged behind the real ones) with sensitivity zero: every body is
+// branch-free and the discarded halves contribute an exact +0.
+//
+// Gradient accumulators: 64-bit integer LDS atomics as before (order-independent, bit-reproducible), but a contribution is
+// converted as round(v * 2^22) -- 4 instructions instead of the 8 of the 2^32 split (igraph_device.h: to_fixed32): resolution
+// 2.4e-7, below the rounding of the fp32 sums it replaces; |v| >= 512 saturates (v_cvt_i32_f32), sums cannot overflow.
+#pragma once
+#include "igraph_device.h"
+
+namespace up {
+
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 mk2(float a, float b) { v2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2 bc2(float a) { v2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+#define P2_FIX_BITS 22
+__device__ __forceinline__ unsigned long long to_fixed22(float v) {
+    const int q = (int)rintf(v * (float)(1 << P2_FIX_BITS));         // v_mul, v_rndne, v_cvt_i32 (saturating)
+    return (unsigned long long)(long long)q;                           // v_ashrrev 31
+}
+__device__ __forceinline__ float from_fixed22(unsigned long long a) { return (float)((double)(long long)a * (1.0 / (double)(1 << P2_FIX_BITS))); }
+__device__ __forceinline__ void lds_add_fixed22(unsigned long long* p, float v) {
+    __hip_atomic_fetch_add(p, to_fixed22(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// the far-away dummy element behind the real rows of a staged side: finite everywhere in the functors, beyond every cutoff
+__device__ __forceinline__ void stage_sentinel(float* lds_rows, int n, float aux6, float aux7) {
+    if (threadIdx.x < 8) {
+        const int c = threadIdx.x;
+        lds_rows[n * 8 + c] = c < 3 ? 1.0e4f : (c == 3 ? 1.f : (c == 6 ? aux6 : (c == 7 ? aux7 : 0.f)));
+    }
+}
+
+// one cubic piece for two pairs: value and slope of  c0 + c1 y + c2 y^2 + c3 y^3  with 5 packed FMAs
+// (s = c1 + t y, t = c2 + c3 y are the Horner intermediates; slope = s + y (t + c3 y))
+__device__ __forceinline__ void cubic2(const float* cA, const float* cB, v2 y, v2& v, v2& d) {
+    const float4 a = *(const float4*)cA, b = *(const float4*)cB;
+    const v2 c0 = mk2(a.x, b.x), c1 = mk2(a.y, b.y), c2 = mk2(a.z, b.z), c3 = mk2(a.w, b.w);
+    const v2 t = fma2(c3, y, c2), s = fma2(t, y, c1);
+    v = fma2(s, y, c0);
+    d = fma2(fma2(c3, y, t), y, s);
+}
+__device__ __forceinline__ v2 cubic2_value(const float* cA, const float* cB, v2 y) {
+    const float4 a = *(const float4*)cA, b = *(const float4*)cB;
+    return fma2(fma2(fma2(mk2(a.w, b.w), y, mk2(a.z, b.z)), y, mk2(a.y, b.y)), y, mk2(a.x, b.x));
+}
+// the four basis polynomials of a uniform cubic B-spline and their slopes, for two pairs (igraph_device.h: bspline_basis)
+__device__ __forceinline__ void bspline_basis2(v2 y, v2 b[4], v2 d[4]) {
+    const v2 y2 = y * y, omy = bc2(1.f) - y, omy2 = omy * omy;
+    const float s = 1.f / 6.f;
+    b[0] = omy2 * (omy * bc2(s));
+    b[1] = fma2(fma2(bc2(0.5f), y, bc2(-1.f)), y2, bc2(2.f / 3.f));
+    b[2] = fma2(fma2(fma2(bc2(-0.5f), y, bc2(0.5f)), y, bc2(0.5f)), y, bc2(s));
+    b[3] = y2 * (y * bc2(s));
+    d[0] = bc2(-0.5f) * omy2;
+    d[1] = y * fma2(bc2(1.5f), y, bc2(-2.f));
+    d[2] = fma2(fma2(bc2(-1.5f), y, bc2(1.f)), y, bc2(0.5f));
+    d[3] = bc2(0.5f) * y2;
+}
+// value and slope from the 4-coefficient windows starting at cA[0] / cB[0]
+template <bool WANT_D>
+__device__ __forceinline__ void window2(const float* cA, const float* cB, const v2 b[4], const v2 d[4], v2& val, v2& der) {
+    const v2 c0 = mk2(cA[0], cB[0]), c1 = mk2(cA[1], cB[1]), c2 = mk2(cA[2], cB[2]), c3 = mk2(cA[3], cB[3]);
+    val = fma2(c3, b[3], fma2(c2, b[2], fma2(c1, b[1], c0 * b[0])));
+    if (WANT_D) der = fma2(c3, d[3], fma2(c2, d[2], fma2(c1, d[1], c0 * d[0])));
+}
+
+// bead_interaction.h:30-84 for two pairs.  x1 / x2: components 0..5 of the two elements as packed values (the row element is
+// a broadcast, the partners are packed by the caller); pA / pB: parameter rows of the two type pairs; off1 / off2: where the
+// angular pieces of x1 / x2 start in each row (quadspline_pair).  WANT_D: derivatives in the compact form
+//   d(value)/d(x1) = (-dd, g1),  d(value)/d(x2) = (dd, g2).
+// POLY: rows of the per-interval polynomial table, else spline coefficients [ang1: ka][ang2: ka][wide: k][narrow: k].
+template <bool WANT_D, bool POLY>
+__device__ __forceinline__ v2 quadspline_pair2(const QuadShape& Q, const float* pA, const float* pB, const v2* x1, const v2* x2,
+                                               v2* dd, v2* g1, v2* g2, int off1A, int off2A, int off1B, int off2B) {
+    const v2 dx = x2[0] - x1[0], dy = x2[1] - x1[1], dz = x2[2] - x1[2];
+    const v2 dist2 = fma2(dz, dz, fma2(dy, dy, dx * dx));
+    const v2 inv_dist = mk2(__builtin_amdgcn_rsqf(dist2.x), __builtin_amdgcn_rsqf(dist2.y));   // v_rsq_f32, 1 ulp (no denormal rescaling: dist2 is O(1..100))
+    const v2 dist_coord = dist2 * (inv_dist * bc2(Q.inv_dx));
+    const v2 ux = inv_dist * dx, uy = inv_dist * dy, uz = inv_dist * dz;
+    const v2 cos1 = fma2(x1[5], uz, fma2(x1[4], uy, x1[3] * ux));
+    const v2 ncos2 = fma2(x2[5], uz, fma2(x2[4], uy, x2[3] * ux));       // = -cos2
+    v2 a1, da1, a2, da2, wide, dwide, narrow, dnarrow;
+    if constexpr (POLY) {
+        const v2 xa = fma2(cos1, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta));    // (cos1 + 1) inv_dtheta
+        const v2 xb = fma2(-ncos2, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta));
+        const int iaA = min(max((int)xa.x, 0), Q.ka - 4), iaB = min(max((int)xa.y, 0), Q.ka - 4);
+        const int ibA = min(max((int)xb.x, 0), Q.ka - 4), ibB = min(max((int)xb.y, 0), Q.ka - 4);
+        const int irA = min((int)dist_coord.x, Q.k - 2), irB = min((int)dist_coord.y, Q.k - 2);
+        const v2 ya = xa - mk2((float)iaA, (float)iaB), yb = xb - mk2((float)ibA, (float)ibB);
+        const v2 yr = dist_coord - mk2((float)irA, (float)irB);
+        const float* rA = pA + 8 * (Q.ka - 3) + 8 * irA; const float* rB = pB + 8 * (Q.ka - 3) + 8 * irB;
+        if (WANT_D) {
+            cubic2(pA + off1A + 4 * iaA, pB + off1B + 4 * iaB, ya, a1, da1);
+            cubic2(pA + off2A + 4 * ibA, pB + off2B + 4 * ibB, yb, a2, da2);
+            cubic2(rA, rB, yr, wide, dwide);
+            cubic2(rA + 4, rB + 4, yr, narrow, dnarrow);
+        } else {
+            a1 = cubic2_value(pA + off1A + 4 * iaA, pB + off1B + 4 * iaB, ya);
+            a2 = cubic2_value(pA + off2A + 4 * ibA, pB + off2B + 4 * ibB, yb);
+            wide = cubic2_value(rA, rB, yr);
+            narrow = cubic2_value(rA + 4, rB + 4, yr);
+        }
+    } else {
+        v2 b[4], db[4];
+        {
+            const v2 x = fma2(cos1, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta + 1.f));
+            const int binA = (int)x.x, binB = (int)x.y;
+            bspline_basis2(x - mk2((float)binA, (float)binB), b, db);
+            window2<WANT_D>(pA + off1A + binA - 1, pB + off1B + binB - 1, b, db, a1, da1);
+        }
+        {
+            const v2 x = fma2(-ncos2, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta + 1.f));
+            const int binA = (int)x.x, binB = (int)x.y;
+            bspline_basis2(x - mk2((float)binA, (float)binB), b, db);
+            window2<WANT_D>(pA + off2A + binA - 1, pB + off2B + binB - 1, b, db, a2, da2);
+        }
+        {   // radial splines share one coordinate.  Clamped ends (spline.h:275-310): the window at the first / last interval
+            // evaluated AT the knot gives exactly (c0 + 4 c1 + c2) / 6, and the slope is masked to zero there
+            const float kmax = (float)(Q.k - 2);
+            const v2 xc = mk2(fminf(fmaxf(dist_coord.x, 1.f), kmax), fminf(fmaxf(dist_coord.y, 1.f), kmax));
+            const int binA = min((int)xc.x, Q.k - 3), binB = min((int)xc.y, Q.k - 3);
+            bspline_basis2(xc - mk2((float)binA, (float)binB), b, db);
+            const float* wA = pA + 2 * Q.ka + binA - 1; const float* wB = pB + 2 * Q.ka + binB - 1;
+            window2<WANT_D>(wA, wB, b, db, wide, dwide);
+            window2<WANT_D>(wA + Q.k, wB + Q.k, b, db, narrow, dnarrow);
+            if (WANT_D) {
+                const v2 inside = mk2((dist_coord.x >= 1.f && dist_coord.x < kmax) ? 1.f : 0.f, (dist_coord.y >= 1.f && dist_coord.y < kmax) ? 1.f : 0.f);
+                dwide *= inside; dnarrow *= inside;
+            }
+        }
+    }
+    const v2 angular_weight = a1 * a2;
+    if (WANT_D) {
+        const v2 radial_deriv = bc2(Q.inv_dx) * fma2(angular_weight, dnarrow, dwide);
+        const v2 ad1 = (bc2(Q.inv_dtheta) * da1) * (a2 * narrow);
+        const v2 ad2 = (bc2(Q.inv_dtheta) * a1) * (da2 * narrow);
+        // rXX = ad1 rvec1 - ad2 rvec2; deriv_dir = inv_dist (rXX - (u . rXX) u); dd = radial_deriv u + deriv_dir
+        const v2 rx = fma2(ad1, x1[3], -(ad2 * x2[3])), ry = fma2(ad1, x1[4], -(ad2 * x2[4])), rz = fma2(ad1, x1[5], -(ad2 * x2[5]));
+        const v2 ur = fma2(uz, rz, fma2(uy, ry, ux * rx));
+        const v2 k = fma2(-ur, inv_dist, radial_deriv);                    // coefficient of u:  radial_deriv - inv_dist (u . rXX)
+        dd[0] = fma2(k, ux, inv_dist * rx); dd[1] = fma2(k, uy, inv_dist * ry); dd[2] = fma2(k, uz, inv_dist * rz);
+        g1[0] = ad1 * ux; g1[1] = ad1 * uy; g1[2] = ad1 * uz;
+        g2[0] = -(ad2 * ux); g2[1] = -(ad2 * uy); g2[2] = -(ad2 * uz);
+    }
+    return fma2(angular_weight, narrow, wide);
+}
+
+// ---- 4-lane groups, two hit-list words per lane and trip ---------------------------------------------------------------
+#define P2_LANES 4
+#define P2_ROWS (UP_WAVE / P2_LANES)
+#ifndef P2_CHUNK
+#define P2_CHUNK 2      // trips whose list words are loaded together, one chunk ahead (a trip = 8 words of a row)
+#endif
+__device__ __forceinline__ float group_sum4(float v) {
+    v += dpp_mov<UP_DPP_XOR2>(v);
+    v += dpp_mov<UP_DPP_XOR1>(v);
+    return v;
+}
+// As group_batch_loop (igraph_device.h), for batches of 16 rows.  Op provides
+//   begin(row)                       -- load the row element, reset the row accumulators
+//   body(row, wA, wB, liveA, liveB)  -- two hit-list words per lane; a dead half carries `dead_word` (the sentinel element)
+//   flush(row)                       -- reduce over the group and write the row's results (also for rows without hits)
+template <typename Op>
+__device__ __forceinline__ void group2_batch_loop(Op& op, int n_rows, const unsigned short* ord, const int* range,
+                                                  const int* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step, int dead_word) {
+    const int lane = threadIdx.x & 63, gl = lane & (P2_LANES - 1), g = lane / P2_LANES;
+    const int n_batch = (n_rows + P2_ROWS - 1) / P2_ROWS;
+    auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
+    struct Batch { int row, n_mine; const int* hrow; int wa[P2_CHUNK], wb[P2_CHUNK]; bool valid; };
+    auto load2 = [&](const Batch& B, int t, int& a, int& b) {        // this lane's two words of trip t: positions l and l + 4 of the trip's 8
+        const int k = t * 2 * P2_LANES;
+        a = k < B.n_mine ? B.hrow[k] : dead_word;
+        b = k + P2_LANES < B.n_mine ? B.hrow[k + P2_LANES] : dead_word;
+    };
+    auto fetch = [&](int i, Batch& B) -> bool {
+        const int b = batch_first + i * batch_step;
+        if (b >= n_batch) return false;
+        const int ri = b * P2_ROWS + g;
+        B.valid = ri < n_rows;
+        B.row = B.valid ? (int)ord[ri] : 0;
+        const int rg = B.valid ? range[B.row] : 0;
+        const int first = rg & 0xffff, end = (int)((unsigned)rg >> 16);
+        B.hrow = hit + (size_t)B.row * cap + first + gl;
+        B.n_mine = end - first - gl;                             // word k of this lane (k = 8 t, 8 t + 4) is live iff k < n_mine
+#pragma unroll
+        for (int u = 0; u < P2_CHUNK; ++u) load2(B, u, B.wa[u], B.wb[u]);
+        return true;
+    };
+    Batch cur, nxt;
+    bool have = fetch(claim(), cur);
+    while (have) {
+        const bool have_next = fetch(claim(), nxt);
+        const int n_trip = __builtin_amdgcn_readfirstlane((cur.n_mine + 2 * P2_LANES - 1) / (2 * P2_LANES));   // lane 0: group 0 holds the batch's longest row
+        op.begin(cur.row);
+        for (int t0 = 0; t0 < n_trip; t0 += P2_CHUNK) {
+            int na[P2_CHUNK], nb[P2_CHUNK];
+#pragma unroll
+            for (int u = 0; u < P2_CHUNK; ++u) load2(cur, t0 + P2_CHUNK + u, na[u], nb[u]);
+#pragma unroll
+            for (int u = 0; u < P2_CHUNK; ++u) {
+                if (t0 + u >= n_trip) break;        // (wave-uniform)
+                const int k = (t0 + u) * 2 * P2_LANES;
+                op.body(cur.row, cur.wa[u], cur.wb[u], k < cur.n_mine, k + P2_LANES < cur.n_mine);
+            }
+#pragma unroll
+            for (int u = 0; u < P2_CHUNK; ++u) { cur.wa[u] = na[u]; cur.wb[u] = nb[u]; }
+        }
+        if (cur.valid) op.flush(cur.row);
+        cur = nxt; have = have_next;
+    }
+}
+
+// launch geometry as pair_geometry, for 16-row batches
+static inline void pair2_geometry(int n_system, int n_rows, int& wgs_per_system, int& threads) {
+    static int target = 0;
+    if (!target) { const char* e = getenv("UPSIDE_HIP_IG_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+    int bps = (target + n_system - 1) / n_system;
+    const int max_bps = (n_rows + 255) / 256;                    // one 16-row batch per wavefront of a 1024-lane workgroup = 256 rows
+    if (bps > max_bps) bps = max_bps;
+    if (bps < 1) bps = 1;
+    const int rows_per_wg = (n_rows + bps - 1) / bps;
+    int t = ((rows_per_wg * P2_LANES + 63) / 64) * 64;
+    threads = t < 256 ? 256 : (t > 1024 ? 1024 : t);
+    wgs_per_system = bps;
+}
+
+}  // namespace up
