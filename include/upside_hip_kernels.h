@@ -262,6 +262,10 @@ typedef struct {
     unsigned char* mark;                 /* [S][n_node^2] residue pairs owning a cached bead pair (= G.mark_table) */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
+    int *row_start, *slot_row;           /* the same inbox counted in ROWS (one per message): [S][n_node+2] first row of a node (entry n_node: end;
+                                            entry n_node+1: R6, the first row of the 6-state block = rows of the 3-state nodes rounded up to 32),
+                                            [S][cap][2] rows of a slot's two messages.  The large-batch solve lays the messages of the slots ACTIVE
+                                            in this evaluation out densely (3 / 6 floats per row) so that they fit the LDS; NULL: not kept */
     int *class_start;                    /* [S][6] slot ranges by class: 3x3, 3x6, 6x6, 1x1, 1xN */
     int *slot_active_last;               /* [S][cap] activity flags of the last solve (diagnostics) */
     float *P, *msg_cur, *marg;           /* P, marg: SoA [S][36][cap]; msg_cur: inbox [S][cap][16] floats at most: message rows grouped by

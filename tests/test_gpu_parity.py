@@ -1180,3 +1180,180 @@ def test_upside_main_exchange_through_rccl_equals_in_engine_exchange(hip, tmp_pa
         assert np.array_equal(a['pos'], b['pos']) and np.array_equal(a['potential'], b['potential'])
         swapped = swapped or len(np.unique(a['replica_index'])) > 1
     assert swapped, 'no exchange was accepted: the comparison would be vacuous'
+
+
+def _env_patch(env):
+    class _Ctx:
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+        def __exit__(self, *a):
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _Ctx()
+
+
+def test_remd64_proteinG56(hip, tmp_path):
+    """BASELINE.json configs[3] at its full width on one GPU: 64 temperatures of the 56-residue protein (geometric ladder
+    0.5..1.0), two alternating neighbour swap sets, an exchange attempt every second round for ten rounds -- (i) through
+    `upside_main` with the in-engine device swap, (ii) through `upside_main` with upside_hip_comm_* (world of one) and (iii)
+    through the unmodified reference executable on the same 64 files.  replica_index of every file and frame must be
+    IDENTICAL in all three (same Metropolis verdicts from the same counter-based random stream, main.cpp:227-275); the two
+    device paths must also agree on every coordinate bit.  (The attempts come early so that the fp32 trajectories of the
+    two programs have not separated yet: a verdict only flips if a Boltzmann factor lands within ~1e-5 of its uniform.)"""
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    name, n = 'proteinG56_7A', 64
+    ladder = P.pkg.replicas.geometric_ladder(0.5, 1.0, n)
+    sets = P.pkg.replicas.neighbour_swap_sets(n)
+    rargs = ['--duration', '0.27', '--frame-interval', '0.054', '--temperature', ','.join('%.6f' % t for t in ladder), '--seed', '11',
+             '--replica-interval', '0.055']
+    for st in sets:
+        rargs += ['--swap-set', ','.join('%d-%d' % (a, b) for a, b in np.asarray(st).reshape(-1, 2))]
+    out = {}
+    for tag in ('ref', 'engine', 'comm'):
+        fs = [str(tmp_path / ('%s_%02d.up' % (tag, i))) for i in range(n)]
+        for f in fs:
+            shutil.copyfile(P.fixture(name), f)
+        if tag == 'ref':
+            subprocess.run([ref_exe] + rargs + fs, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1))))
+        else:
+            with _env_patch({'UPSIDE_HIP_COMM': '1'} if tag == 'comm' else {}):
+                hip.in_process_upside(rargs + fs, verbose=False)
+        out[tag] = [_read_output(f)[0] for f in fs]
+    n_frame = out['ref'][0]['replica_index'].shape[0]
+    assert n_frame >= 5
+    ri = {tag: np.stack([o['replica_index'].reshape(n_frame) for o in out[tag]]) for tag in out}     # [slot][frame]
+    assert np.array_equal(ri['engine'], ri['ref']), np.argwhere(ri['engine'] != ri['ref'])[:10]
+    assert np.array_equal(ri['comm'], ri['ref'])
+    for a, b in zip(out['engine'], out['comm']):
+        assert np.array_equal(a['pos'], b['pos']) and np.array_equal(a['potential'], b['potential'])
+    # both swap sets accepted something, and every frame is a permutation of the replicas
+    assert all(sorted(ri['ref'][:, f]) == list(range(n)) for f in range(n_frame))
+    moved = (ri['ref'][:, -1] != np.arange(n)).sum()
+    assert moved >= 8, moved
+    assert len({abs(int(ri['ref'][s, -1]) - s) for s in range(n)}) >= 2            # some replica travelled through both sets
+    for tag in ('engine', 'comm'):
+        for s in (0, 31, 63):
+            assert P.rel_rms(out['ref'][s]['pos'][-1], out[tag][s]['pos'][-1]) < 1e-3
+            assert np.allclose(out[tag][s]['temperature'], ladder[s])
+
+
+def test_ens512_syn150(hip):
+    """BASELINE.json configs[4] on one GPU: 512 independent 150-residue proteins in one engine, every one started from its own
+    structure.  Eight of them, drawn at random, must (i) equal a fresh single-system engine on the same structure bit for bit,
+    (ii) agree with the CPU oracle within 1e-5 (forces: relative RMS; energy: relative to the sum of |node potentials| as
+    everywhere in this file); then 300 MD steps of all 512: everything finite, kinetic energy at 1.5 kT per atom."""
+    name, S, T = 'syn150_10A', 512, 0.8
+    c = hip.calc
+    g = P.golden(name)
+    n_atom = g['pos'].shape[0]
+    rng = np.random.RandomState(512)
+    # independent starting structures: points on the segment pos..pos2 (two structures of the fixture) plus 0.02 A of noise
+    w = rng.uniform(0., 0.15, size=S).astype('f4')
+    pos = (g['pos'][None] * (1 - w[:, None, None]) + g['pos2'][None] * w[:, None, None] + rng.normal(0., 0.02, (S, n_atom, 3))).astype('f4')
+    pos = np.ascontiguousarray(pos)
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), S, True)
+    assert eng
+    assert c.upside_hip_set_pos(eng, pos.ctypes.data) == 0
+    en = np.zeros(S, 'f4'); der = np.zeros((S, n_atom, 3), 'f4')
+    assert c.upside_hip_compute(eng, en.ctypes.data, der.ctypes.data) == 0, c.upside_hip_last_error()
+    assert np.isfinite(en).all() and np.isfinite(der).all()
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    for s in rng.choice(S, 8, replace=False):
+        single = P.pkg.Upside(P.fixture(name), library=hip)
+        d1 = single.deriv(pos[s]); e1 = single.energy(pos[s])
+        assert np.array_equal(d1, der[s]) and e1 == en[s], s
+        single.close()
+        ref_e = orc.energy(pos[s]); ref_d = orc.deriv(pos[s])
+        assert P.rel_rms(ref_d, der[s]) < RTOL, (s, P.rel_rms(ref_d, der[s]))
+        scale = sum(abs(orc.get_output(nm)[0, 0]) for nm in P.POTENTIAL_NODES + ['rotamer'])
+        assert abs(ref_e - en[s]) < RTOL * scale, (s, ref_e, en[s], scale)
+    orc.close()
+    temps = np.full(S, T, 'f4')
+    assert c.upside_hip_init_md(eng, temps.ctypes.data, 4242, 5.0, 0.009, 1) == 0
+    assert c.upside_hip_run_md(eng, 100) == 0, c.upside_hip_last_error()          # 100 rounds = 300 force evaluations
+    mom = np.zeros((S, n_atom, 3), 'f4'); p2 = np.zeros((S, n_atom, 3), 'f4')
+    assert c.upside_hip_get_mom(eng, mom.ctypes.data) == 0 and c.upside_hip_get_pos(eng, p2.ctypes.data) == 0
+    assert c.upside_hip_compute(eng, en.ctypes.data, None) == 0
+    assert np.isfinite(mom).all() and np.isfinite(p2).all() and np.isfinite(en).all()
+    ratio = 0.5 * (mom.astype('f8') ** 2).sum(axis=(1, 2)) / n_atom / (1.5 * T)
+    assert abs(ratio.mean() - 1.0) < 0.03, ratio.mean()
+    assert len({round(float(x), 2) for x in en}) > S // 2                          # distinct trajectories
+    c.free_deriv_engine(ct.c_void_p(eng))
+
+
+def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
+    """The cross-rank half of csrc/comm_rccl.cpp and the multi-rank branch of `upside_main` (main.cpp:227-275, 616-672 for a
+    ladder spread over processes), executed for real: TWO processes on this one GPU, each with RANK / WORLD_SIZE in its
+    environment before its first GPU call, 2 x 4 replicas, swap sets whose pair 3-4 straddles the rank boundary.  The
+    collective library is tests/plugin/libshmccl.so (UPSIDE_HIP_COMM_LIB): the nine RCCL entry points over POSIX shared
+    memory, because RCCL itself cannot put two ranks on one device.  Everything else is the product path: plan of local /
+    straddling pairs, all-gather of the energies, device Metropolis on every rank, unconditional grouped send / receive of the
+    straddling coordinates into the staging rows, k_replica_apply kind 2.  Frame for frame, coordinates, potentials and
+    replica_index of the eight files must equal the single-engine run of the same eight replicas BIT FOR BIT."""
+    import shutil
+    import subprocess
+    exe = os.path.join(P.ROOT, 'upside-md_amd', 'csrc', 'upside_hip')
+    shm = os.path.join(P.ROOT, 'tests', 'plugin', 'libshmccl.so')
+    assert os.path.exists(exe) and os.path.exists(shm), 'run __graft_entry__.build()'
+    name, n = 'trpcage20_7A', 8
+    temps = ','.join('%.3f' % (0.70 + 0.02 * i) for i in range(n))
+    rargs = ['--duration', '2.7', '--frame-interval', '0.27', '--temperature', temps, '--seed', '9',
+             '--replica-interval', '0.135', '--swap-set', '0-1,2-3,4-5,6-7', '--swap-set', '1-2,3-4,5-6']
+    one = [str(tmp_path / ('one_%d.up' % i)) for i in range(n)]
+    two = [str(tmp_path / ('two_%d.up' % i)) for i in range(n)]
+    for f in one + two:
+        shutil.copyfile(P.fixture(name), f)
+    hip.in_process_upside(rargs + one, verbose=False)
+    rendezvous = str(tmp_path / 'comm_id')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_COMM_FILE=rendezvous)
+        env.pop('UPSIDE_HIP_COMM', None)
+        procs.append(subprocess.Popen([exe] + rargs + two, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
+    logs = []
+    try:
+        for p in procs:
+            logs.append(p.communicate(timeout=600)[0].decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    assert not os.path.exists(rendezvous), 'rank 0 leaves no rendezvous file behind'
+    a = [_read_output(f)[0] for f in one]; b = [_read_output(f)[0] for f in two]
+    for s in range(n):
+        assert a[s]['replica_index'].shape[0] >= 10
+        assert np.array_equal(a[s]['replica_index'], b[s]['replica_index']), s
+        assert np.array_equal(a[s]['pos'], b[s]['pos']), s
+        assert np.array_equal(a[s]['potential'], b[s]['potential']) and np.array_equal(a[s]['kinetic'], b[s]['kinetic']), s
+    ri = np.stack([x['replica_index'].reshape(-1) for x in b])                       # [slot][frame]
+    crossed = set(ri[:4].ravel()) & set(range(4, 8))
+    assert crossed, 'no replica crossed the rank boundary: the comparison would not exercise the transfer'
+    # a rank whose files hold another potential than rank 0's is refused (the device Metropolis assumes one Hamiltonian):
+    # same protein with and without restraint nodes -- same atom count, different /input/potential
+    other = [str(tmp_path / ('mix_%d.up' % i)) for i in range(4)]
+    for i, f in enumerate(other):
+        shutil.copyfile(P.fixture('proteinG56_7A' if i < 2 else 'proteinG56_restraints'), f)
+    margs = ['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8,0.82,0.84,0.86', '--seed', '3',
+             '--replica-interval', '0.135', '--swap-set', '0-1,2-3', '--swap-set', '1-2']
+    procs = [subprocess.Popen([exe] + margs + other, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
+                                       UPSIDE_HIP_COMM_FILE=rendezvous + '2')) for r in range(2)]
+    try:
+        out1 = procs[1].communicate(timeout=300)[0].decode()
+        assert procs[1].returncode != 0 and 'different /input/potential' in out1, out1
+    finally:
+        for p in procs:                     # (rank 0 is left waiting for a peer that has refused to join)
+            if p.poll() is None:
+                p.kill()
+        if os.path.exists(rendezvous + '2'):
+            os.remove(rendezvous + '2')

@@ -34,11 +34,18 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 Rccl& rccl() {
     static Rccl r;
     if (r.lib) return r;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    // UPSIDE_HIP_COMM_LIB names another library with the same nine entry points (tests: tests/plugin/libshmccl.so runs
+    // two ranks on one GPU, which RCCL cannot)
+    if (const char* over = getenv("UPSIDE_HIP_COMM_LIB")) {
+        r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) throw string("cannot load UPSIDE_HIP_COMM_LIB=") + over + ": " + dlerror();
+    } else
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
     if (!r.lib) throw string("cannot load librccl.so: ") + dlerror();
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) throw string("librccl.so lacks ") + n; return p; };
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
@@ -50,6 +57,7 @@ Rccl& rccl() {
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");        // optional
     return r;
 }
 void nccl_check(ncclResult_t r, const char* what) {
@@ -57,15 +65,33 @@ void nccl_check(ncclResult_t r, const char* what) {
 }
 }  // namespace
 
+// host staging of one swap set's pair list and plan: pinned, owned by the communicator and recycled only after the copy that
+// reads it has completed (an asynchronous copy from a pageable or stack buffer would either block the call or outlive its source)
+struct PinnedSet {
+    int* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false;
+    int* reserve(size_t n) {
+        if (pending) { hip_check(hipEventSynchronize(done), "hipEventSynchronize"); pending = false; }
+        if (n > cap) {
+            if (host) (void)hipHostFree(host);
+            hip_check(hipHostMalloc((void**)&host, n * sizeof(int), hipHostMallocDefault), "hipHostMalloc"); cap = n;
+        }
+        if (!done) hip_check(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
+        return host;
+    }
+    void sent(hipStream_t st) { hip_check(hipEventRecord(done, st), "hipEventRecord"); pending = true; }
+    ~PinnedSet() { if (done) { if (pending) (void)hipEventSynchronize(done); (void)hipEventDestroy(done); } if (host) (void)hipHostFree(host); }
+};
 struct ReplicaComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     DevBuf<float> energy_local, energy_all, beta_all, staging;
     DevBuf<const float*> node_pot;
     DevBuf<int> pairs_dev, plan_dev, accepted_dev, draw_dev;
+    PinnedSet stage[2];              // [0] pair list, [1] plan; double use per call is serialised by the events
     int n_node_pot = 0, pair_cap = 0, staging_rows = 0;
+    bool broken = false;             // a collective failed part-way: the communicator is aborted, later calls are refused
     uint64_t attempt_round = ~0ull; uint64_t attempt_compute = 0;   // the attempt the gathered energies belong to
-    ~ReplicaComm() { if (comm) (void)rccl().CommDestroy(comm); }
+    ~ReplicaComm() { if (comm) (void)((broken && rccl().CommAbort) ? rccl().CommAbort(comm) : rccl().CommDestroy(comm)); }
 };
 static void comm_deleter(void* p) { delete (ReplicaComm*)p; }
 
@@ -115,6 +141,7 @@ extern "C" int upside_hip_comm_replica_swap(DerivEngine* e, int n_pair, const in
     API_TRY
     if (!e || !e->comm) throw string("upside_hip_comm_init first");
     ReplicaComm& c = *(ReplicaComm*)e->comm;
+    if (c.broken) throw string("the communicator was aborted after a failed collective");
     const int S = e->ctx.n_system, G = S * c.world, lo = c.rank * S;
     hipStream_t st = e->ctx.stream;
     const int n_row = e->pos->n_elem * e->pos->stride;
@@ -138,14 +165,19 @@ extern "C" int upside_hip_comm_replica_swap(DerivEngine* e, int n_pair, const in
     }
     if (n_pair > c.pair_cap) { c.pair_cap = n_pair; c.pairs_dev.alloc((size_t)n_pair * 2); c.plan_dev.alloc((size_t)n_pair * 3); c.accepted_dev.alloc(n_pair); }
     if ((int)cross.size() > c.staging_rows) { c.staging_rows = (int)cross.size(); c.staging.alloc((size_t)c.staging_rows * n_row); }
-    if (n_pair) {
-        hip_check(hipMemcpyAsync(c.pairs_dev.p, pairs_global, (size_t)n_pair * 2 * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
-        hip_check(hipMemcpyAsync(c.plan_dev.p, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
+    if (n_pair) {      // through the communicator's pinned buffers: truly asynchronous, and the sources outlive the copies
+        int* hp = c.stage[0].reserve((size_t)n_pair * 2); memcpy(hp, pairs_global, (size_t)n_pair * 2 * sizeof(int));
+        hip_check(hipMemcpyAsync(c.pairs_dev.p, hp, (size_t)n_pair * 2 * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
+        c.stage[0].sent(st);
+        int* hq = c.stage[1].reserve(plan.size()); memcpy(hq, plan.data(), plan.size() * sizeof(int));
+        hip_check(hipMemcpyAsync(c.plan_dev.p, hq, plan.size() * sizeof(int), hipMemcpyHostToDevice, st), "H2D");
+        c.stage[1].sent(st);
     }
     if (first_set) {   // main.cpp:251-256: energies of every system, once per attempt
         e->compute(PotentialAndDerivMode);
         upk_check(upk_sum_potentials(&e->ctx.L, c.node_pot.p, c.n_node_pot, c.energy_local.p), "sum_potentials");
-        nccl_check(rccl().AllGather(c.energy_local.p, c.energy_all.p, (size_t)S, ncclFloat, c.comm, st), "ncclAllGather");
+        { const ncclResult_t ag = rccl().AllGather(c.energy_local.p, c.energy_all.p, (size_t)S, ncclFloat, c.comm, st);
+          if (ag != ncclSuccess) { c.broken = true; nccl_check(ag, "ncclAllGather"); } }
         hip_check(hipMemsetAsync(c.draw_dev.p, 0, sizeof(int), st), "memset");
         c.attempt_round = round; c.attempt_compute = e->n_compute;
     } else if (c.attempt_round != round || c.attempt_compute != e->n_compute)
@@ -153,11 +185,18 @@ extern "C" int upside_hip_comm_replica_swap(DerivEngine* e, int n_pair, const in
     if (n_pair) upk_check(upk_replica_decide(&e->ctx.L, c.energy_all.p, c.beta_all.p, n_pair, c.pairs_dev.p, base_seed, round, c.draw_dev.p, c.accepted_dev.p), "replica_decide");
     if (!cross.empty()) {   // coordinates of the straddling pairs, both directions, one group
         nccl_check(rccl().GroupStart(), "ncclGroupStart");
-        for (auto& x : cross) {
-            nccl_check(rccl().Send(e->pos->output.p + (size_t)x.local * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclSend");
-            nccl_check(rccl().Recv(c.staging.p + (size_t)x.slot * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclRecv");
+        try {
+            for (auto& x : cross) {
+                nccl_check(rccl().Send(e->pos->output.p + (size_t)x.local * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclSend");
+                nccl_check(rccl().Recv(c.staging.p + (size_t)x.slot * n_row, (size_t)n_row, ncclFloat, x.peer, c.comm, st), "ncclRecv");
+            }
+        } catch (...) {      // a group left open would leave this rank's peers waiting: close it, give the communicator up
+            (void)rccl().GroupEnd();
+            c.broken = true;
+            throw;
         }
-        nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+        const ncclResult_t ge = rccl().GroupEnd();
+        if (ge != ncclSuccess) { c.broken = true; nccl_check(ge, "ncclGroupEnd"); }
     }
     if (n_pair) upk_check(upk_replica_apply(&e->ctx.L, e->pos->coord(), n_pair, c.plan_dev.p, c.accepted_dev.p, c.staging.p), "replica_apply");
     if (accepted && n_pair) {   // the caller wants the verdicts (logging): the only synchronisation of the call

@@ -160,6 +160,16 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
         __syncthreads();
         int* bp_start = R.bp_start + (size_t)s * (NN + 1);
         for (int g = tid; g <= NN; g += blockDim.x) bp_start[g] = bp_s[g];
+        // the same inbox as ROWS (one per message; a 6-state row is two quads): rows of the 3-state nodes in [0, rows3), rows of
+        // the 6-state nodes from R6 = rows3 rounded up to 32 on -- so that every 32-row word of a per-solve activity mask holds
+        // rows of ONE width (k_rotamer_bp<.., COMPACT>)
+        const int rows3 = bp_s[e3 < NN ? e3 : NN], R6 = (rows3 + 31) & ~31;
+        auto row_of = [&](int g) { return g < e3 ? bp_s[g] : R6 + ((bp_s[g] - rows3) >> 1); };   // first row of node g (g = NN: end)
+        if (R.row_start) {
+            int* row_start = R.row_start + (size_t)s * (NN + 2);
+            for (int g = tid; g <= NN; g += blockDim.x) row_start[g] = g < e1 ? 0 : row_of(g);
+            if (tid == 0) row_start[NN + 1] = R6;
+        }
         if (a < NN) {
             const int d = na > 1 ? deg1[a] : 0;
             R.adj_cnt[(size_t)s * NN + a] = d < R.adj_cap ? d : R.adj_cap;
@@ -192,8 +202,10 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                             const int pos = rank_below(b, a);              // 1-state partners of b below a
                             if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
                         } else if (na > 1) {
+                            const int kb = rank_below(b, a) - deg1[b];
                             slot_off[sl * 2] = (bp_s[a] + k_multi * (na == 6 ? 2 : 1)) * 4;
-                            slot_off[sl * 2 + 1] = (bp_s[b] + (rank_below(b, a) - deg1[b]) * (nb == 6 ? 2 : 1)) * 4;
+                            slot_off[sl * 2 + 1] = (bp_s[b] + kb * (nb == 6 ? 2 : 1)) * 4;
+                            if (R.slot_row) { int* sr = R.slot_row + (size_t)s * R.slot_cap * 2; sr[sl * 2] = row_of(a) + k_multi; sr[sl * 2 + 1] = row_of(b) + kb; }
                         }
                     } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
                     if (na > 1) ++k_multi;
@@ -798,6 +810,7 @@ __device__ __forceinline__ void clear_all_classes(float* P, int cap, const int* 
 
 struct BpCtx {
     const int *slot_a, *slot_b, *active, *slot_off;
+    const int* slot_row = nullptr;
     float *P, *inbox, *marg;
     int cap;
     const int4* rec = nullptr;     // one-workgroup solve: the active slots of each class, packed (see bp_pack_active)
@@ -878,7 +891,8 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
 // pair in range on a given step), and trips and pinned registers are spent on active slots only.  Order-preserving (the
 // free-energy sum keeps its summation order from run to run): 64-slot chunks are counted by ballot, one barrier, then
 // every chunk finds its base as the sum of the counts before it in its class.  chunk_cnt: LDS scratch, one int per chunk.
-__device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict__ rec, const int* cls, int* n_act, int* chunk_cnt, int tid, int nt) {
+template <typename OffFn>      // off(sl, side): float offset of the slot's message row to node a (side 0) / node b (side 1)
+__device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict__ rec, const int* cls, int* n_act, int* chunk_cnt, int tid, int nt, OffFn off) {
     const int lane = tid & 63, wave = tid >> 6, n_wave = nt >> 6;
     const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
     for (int pass = 0; pass < 2; ++pass) {
@@ -893,7 +907,7 @@ __device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict_
             for (int k = first + lane; k < ch; k += 64) before += chunk_cnt[k];
             before = __builtin_amdgcn_readfirstlane((int)wave_sum((float)before));      // counts are < 2^24: exact in fp32
             if (act) rec[cls[c] + before + __popcll(b & ((1ull << lane) - 1ull))] =
-                make_int4(C.slot_off[sl * 2], C.slot_off[sl * 2 + 1], C.slot_a[sl] | (C.slot_b[sl] << 16), sl);
+                make_int4(off(sl, 0), off(sl, 1), C.slot_a[sl] | (C.slot_b[sl] << 16), sl);
             if (lane == 0 && ch == first + (c == CL33 ? nc0 : (c == CL36 ? nc1 : nc2)) - 1) n_act[c] = before + __popcll(b);
         }
         __syncthreads();
@@ -1070,7 +1084,10 @@ struct BpResident {
     }
 };
 
-template <int BLOCK, int K66, int K36, int K33>
+// COMPACT: the message inbox is laid out per solve for the slots ACTIVE in this evaluation only, 3 / 6 floats per row instead of
+// the cached layout's 4 / 8 for every cached residue pair (a quarter of which has no bead pair in range on a given step): 137 KB
+// instead of 244 KB for the 300-residue benchmark protein, so that all but a sliver of it stays in the LDS for all sweeps.
+template <int BLOCK, int K66, int K36, int K33, bool COMPACT = false>
 __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -1101,7 +1118,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
-    for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
+    if (COMPACT) { C.slot_row = R.slot_row + (size_t)s * R.slot_cap * 2; for (int i = tid; i <= NN; i += nt) bp_start[i] = R.row_start[(size_t)s * (NN + 2) + i]; }   // (rows for now)
+    else for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
     if (tid < 3) n_act[tid] = 0;
     for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
@@ -1118,22 +1136,64 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
     constexpr bool PACK = K66 + K36 + K33 > 0;
-    if (PACK) {
+    static_assert(!COMPACT || PACK, "the compact inbox is laid out by the packing pass");
+    int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
+    if (COMPACT) {
+        // Which rows carry a message in this solve: an activity bit per cached row (LDS, in the region the messages will take),
+        // a prefix sum over its 32-row words (every word holds rows of one width: build_slots pads the 3-state block to 32), and
+        // the dense position of row r is  wbase[r / 32] + width * popcount(bits of the word below r).
+        const int R6 = R.row_start[(size_t)s * (NN + 2) + NN + 1], n_rows = bp_start[NN], n_words = (n_rows + 31) >> 5;
+        unsigned* rmask = (unsigned*)C.inbox_lds;      // [n_words]
+        int* wbase = (int*)(rmask + n_words);          // [n_words + 1]
+        for (int i = tid; i < n_words; i += nt) rmask[i] = 0u;
+        __syncthreads();
+        for (int sl = cls[CL33] + tid; sl < cls[CL66 + 1]; sl += nt)
+            if (C.active[sl]) {
+                const int ra = C.slot_row[sl * 2], rb = C.slot_row[sl * 2 + 1];
+                atomicOr(&rmask[ra >> 5], 1u << (ra & 31)); atomicOr(&rmask[rb >> 5], 1u << (rb & 31));
+            }
+        __syncthreads();
+        {
+            const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
+            int sum = 0;
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) sum += __popc(rmask[w]) * (w * 32 < R6 ? 3 : 6); }
+            int total;
+            int run = block_excl_scan(sum, (int*)scratch, &total);
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { wbase[w] = run; run += __popc(rmask[w]) * (w * 32 < R6 ? 3 : 6); } }
+            if (tid == 0) wbase[n_words] = total;
+            inbox_floats = total;
+        }
+        __syncthreads();
+        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? 3 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
+        int my_start[(1024 + BLOCK - 1) / BLOCK + 1];          // first message float of the nodes this lane copies (NN <= 1024)
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; my_start[k] = g <= NN ? dense(bp_start[g]) : 0; }
+        inbox_floats3 = dense(R6);
         int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
         C.rec = rec;
-        bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt);     // (nb0 / nb1 are filled after the fold below)
+        bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return dense(C.slot_row[sl * 2 + side]); });   // (ends with a barrier)
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; if (g <= NN) bp_start[g] = my_start[k]; }   // rows -> floats
+    } else {
+        if (PACK) {
+            int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
+            C.rec = rec;
+            bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return C.slot_off[sl * 2 + side]; });     // (nb0 / nb1 are filled after the fold below)
+        }
+        inbox_floats3 = bp_start[R.n_node1 + R.n_node3] * 4; inbox_floats = bp_start[NN] * 4;
     }
     // old edge beliefs = 1 (rotamer.cpp:1015-1032); also for slots without an in-range bead pair this step,
     // whose unit message then multiplies as an exact 1
-    // the head of the inbox stays in LDS as far as it reaches: the 4-float rows to the 3-state nodes come first, then
-    // the 8-float rows to the 6-state nodes (the boundary never cuts a row)
+    // the head of the inbox stays in LDS as far as it reaches: the rows to the 3-state nodes come first, then the rows to the
+    // 6-state nodes (the boundary never cuts a row)
     {
-        const int q3 = bp_start[R.n_node1 + R.n_node3] * 4, q_all = bp_start[NN] * 4;
-        int n = lds_msg_floats < q_all ? lds_msg_floats : q_all;
-        if (n > q3) n = q3 + ((n - q3) / 8) * 8;
+        constexpr int W3 = COMPACT ? 3 : 4, W6 = COMPACT ? 6 : 8;
+        int n = lds_msg_floats < inbox_floats ? lds_msg_floats : inbox_floats;
+        if (n > inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / W3) * W3;
         C.lds_floats = n;
     }
-    for (int i = tid; i < bp_start[NN] * 4; i += nt) *C.msg(i) = 1.f;
+    __syncthreads();       // (bp_start holds float offsets now; the scratch of the compact layout is dead)
+    for (int i = tid; i < inbox_floats; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     // (four partners per trip: slot ids, then flags, then the rows, each as one batch of loads; same product order)
@@ -1210,7 +1270,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int q = n == 6 ? 2 : 1, base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
+                const int q = COMPACT ? (n == 6 ? 6 : 3) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
                 constexpr int ROWS = BLOCK == BP_BLOCK ? 4 : 8;
@@ -1221,9 +1281,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                         const int k = k0 + u * BP_GROUP;
                         m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
-                            const float* m = C.msg((base + k * q) * 4);
-                            m0[u] = *(const float4*)m;
-                            if (n == 6) m1[u] = *(const float2*)(m + 4);
+                            if (COMPACT) {       // dense rows of 3 / 6 floats, 4-byte aligned
+                                const float* m = C.msg(base + k * q);
+                                m0[u].x = m[0]; m0[u].y = m[1]; m0[u].z = m[2];
+                                if (n == 6) { m0[u].w = m[3]; m1[u].x = m[4]; m1[u].y = m[5]; }
+                            } else {
+                                const float* m = C.msg((base + k * q) * 4);
+                                m0[u] = *(const float4*)m;
+                                if (n == 6) m1[u] = *(const float2*)(m + 4);
+                            }
                         }
                     }
 #pragma unroll
@@ -1348,7 +1414,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     if (trace) {
         long long* T = R.bp_trace + (size_t)s * 16;
         T[0] = tr_pro - tr_t0; T[1] = tr_loop - tr_pro; T[2] = wall_clock64() - tr_loop; T[3] = tr_edge; T[4] = tr_node;
-        T[5] = iter; T[6] = n_slot; T[7] = bp_start[NN];
+        T[5] = iter; T[6] = n_slot; T[7] = COMPACT ? C.lds_floats : bp_start[NN];
         for (int c = 0; c <= N_CLASS; ++c) T[8 + c] = cls[c];
     }
 }
@@ -1792,8 +1858,13 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else                      // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else {                    // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
+        static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
+        if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
+        if (compact && R->slot_row && R->row_start)
+            hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+        else hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    }
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
     const size_t lds_base = ((size_t)R->n_node * 20 + 64 + 8) * sizeof(float);

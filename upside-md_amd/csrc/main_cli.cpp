@@ -13,6 +13,8 @@
 #include "h5util.h"
 #include <chrono>
 #include <csignal>
+#include <ctime>
+#include <fcntl.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -256,7 +258,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         vector<hsize_t> dims;
         auto p = h5u::read<float>(f, "/input/pos", 3, &dims);
         if (dims[1] != 3 || dims[2] != 1) throw string("invalid dimensions for initial position");
-        const unsigned long long dg = h5u::group_digest(h5u::open_group(f, "/input/potential"));
+        // (hashed only when there is something to compare with: a single-file run loads whatever the node loader accepts)
+        const unsigned long long dg = (n_total > 1) ? h5u::group_digest(h5u::open_group(f, "/input/potential")) : 0ull;
         if (ns == 0) { n_atom = (int)dims[0]; potential_digest = dg; }
         else if ((int)dims[0] != n_atom || dg != potential_digest)
             throw string("systems must share one potential: /input/potential of ") + files[ns] + " differs from that of " + files[0] +
@@ -306,28 +309,44 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     if (!use_comm)      // (inside one engine the swap sets address its own systems)
         for (auto& st : sets) for (int x : st) if (x >= n_system) throw string("invalid system");
     if (use_comm && !sets.empty()) {
-        // rendezvous: rank 0 creates the communicator id and leaves it in a file every rank of the job can see
-        string path = getenv("UPSIDE_HIP_COMM_FILE") ? getenv("UPSIDE_HIP_COMM_FILE")
-                    : string("/tmp/upside_hip_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + to_string((long)getppid());
-        char id[UPSIDE_HIP_COMM_ID_BYTES];
+        // Rendezvous: rank 0 creates the communicator id and leaves it, with the digest of its potential, in a file every rank
+        // of the job can see.  The default name carries what tells one launch from another (the launcher's port, its process
+        // id, and torchrun's run id and restart count when present); rank 0 publishes with an exclusive create + rename after
+        // removing whatever an earlier crashed attempt left behind, and removes the file once every rank has joined.
+        string path;
+        if (const char* f = getenv("UPSIDE_HIP_COMM_FILE")) path = f;
+        else {
+            path = string("/tmp/upside_hip_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + to_string((long)getppid());
+            for (const char* v : {"TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) if (const char* x = getenv(v)) path += string("_") + x;
+        }
+        struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long digest; long long stamp; } rec;
+        memset(&rec, 0, sizeof(rec));
+        const long long started = (long long)time(nullptr);
         if (rank == 0) {
-            if (upside_hip_comm_get_unique_id(id)) throw string(upside_hip_last_error());
-            const string tmp = path + ".tmp";
-            FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw string("cannot write ") + tmp;
-            fclose(f);
-            if (rename(tmp.c_str(), path.c_str())) throw string("cannot publish ") + path;
+            if (upside_hip_comm_get_unique_id(rec.id)) throw string(upside_hip_last_error());
+            rec.digest = potential_digest; rec.stamp = started;
+            remove(path.c_str());                                   // a stale record of an earlier attempt under this name
+            const string tmp = path + ".tmp." + to_string((long)getpid());
+            const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
+            if (fd < 0 || write(fd, &rec, sizeof(rec)) != (ssize_t)sizeof(rec)) { if (fd >= 0) close(fd); throw string("cannot write ") + tmp; }
+            close(fd);
+            if (rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw string("cannot publish ") + path; }
         } else {
             bool got = false;
             for (int tries = 0; tries < 1200 && !got; ++tries) {      // up to two minutes
                 FILE* f = fopen(path.c_str(), "rb");
-                if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); }
+                if (f) { got = fread(&rec, 1, sizeof(rec), f) == sizeof(rec); fclose(f); }
+                if (got && rec.stamp + 600 < started) got = false;    // written long before this process started: not this launch's
                 if (!got) this_thread::sleep_for(chrono::milliseconds(100));
             }
             if (!got) throw string("no communicator id at ") + path + " (is rank 0 running?)";
+            // every rank keeps its own files under ONE engine and the Metropolis kernel assumes one Hamiltonian for the whole
+            // ladder: the ranks' potentials must agree as the files of one rank must
+            if (rec.digest != potential_digest)
+                throw string("the configuration files of rank ") + to_string(rank) + " hold a different /input/potential than those of rank 0";
         }
-        if (upside_hip_comm_init(e, rank, world, id, temps_global.data())) throw string(upside_hip_last_error());
-        if (rank == 0 && world == 1) remove(path.c_str());
+        if (upside_hip_comm_init(e, rank, world, rec.id, temps_global.data())) throw string(upside_hip_last_error());
+        if (rank == 0) remove(path.c_str());                         // (ncclCommInitRank returns when every rank has joined)
     }
 
     vector<float> energy(n_system);
@@ -365,6 +384,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     int stop_signal = -1;
     {
     SignalGuard on_int(SIGINT), on_term(SIGTERM);
+    uint64_t sync_start = 0;      // round at which the reference's outer loop (main.cpp:616) last started an iteration
     for (uint64_t rnd = 0; rnd < n_round && g_received_signal == -1;) {
         // pivots before the frame of the same round, never at t = 0 (main.cpp:626-630)
         if (have_mc && rnd && !(rnd % mc_rounds)) if (upside_hip_mc_step(e, rnd)) throw string(upside_hip_last_error());
@@ -414,11 +434,15 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             }
             next = min<uint64_t>(next, (rnd / thermo_rounds + 1) * (uint64_t)thermo_rounds);
         }
-        if (replica_rounds) next = min<uint64_t>(next, (rnd / replica_rounds + 1) * (uint64_t)replica_rounds);
+        // the reference leaves its inner loop for an exchange attempt only at a round AFTER the one the loop started with
+        // (main.cpp:665: nr > last_start), so with an interval of one round it attempts every second round
+        if (replica_rounds) next = min<uint64_t>(next, ((sync_start + 2 + replica_rounds - 1) / replica_rounds) * (uint64_t)replica_rounds);
         if (have_mc) next = min<uint64_t>(next, (rnd / mc_rounds + 1) * (uint64_t)mc_rounds);
         if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error());
         rnd = next;
-        if (replica_rounds && !(rnd % replica_rounds)) {   // main.cpp:667-668; one generator per attempt (main.cpp:249)
+        const bool at_sync = replica_rounds && (rnd == n_round || rnd == ((sync_start + 2 + replica_rounds - 1) / replica_rounds) * (uint64_t)replica_rounds);
+        if (at_sync) sync_start = rnd;
+        if (at_sync && !(rnd % replica_rounds)) {   // main.cpp:667-668; one generator per attempt (main.cpp:249)
             int draw = 0;
             for (size_t k = 0; k < sets.size(); ++k) {
                 vector<int> acc(sets[k].size() / 2 + 1);
@@ -439,8 +463,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         }
     }
     e->sync();
+    for (auto& lg : loggers) lg.close();          // buffered frames reach the files also after an early stop (and before the communicator goes)
     if (use_comm) upside_hip_comm_free(e);
-    for (auto& lg : loggers) lg.close();          // buffered frames reach the files also after an early stop
     stop_signal = g_received_signal;
     }   // the caller's signal handlers are back
     if (stop_signal != -1) fprintf(stderr, "Received early termination signal\n");

@@ -1147,7 +1147,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<unsigned char> mark;
     DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri, param_tri_poly; DevBuf<int> d_bead_orig;
     bool bp_C_chosen = false;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec, row_start, slot_row;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     DevBuf<int> n_bad;
@@ -1223,6 +1223,7 @@ struct RotamerSidechain : public PotentialNode {
         bp_rec.alloc((size_t)S * R.slot_cap * 4);
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
+        row_start.alloc((size_t)S * (n_node + 2)); slot_row.alloc((size_t)S * R.slot_cap * 2);
         ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
         mark.alloc((size_t)S * ig.G.mark_stride);
         ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
@@ -1264,6 +1265,7 @@ struct RotamerSidechain : public PotentialNode {
         R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p; R.mark = mark.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
+        R.row_start = row_start.p; R.slot_row = slot_row.p;
         R.P = P.p; R.msg_cur = msg_cur.p; R.marg = marg.p;
         R.iters = iters.p; R.n_bad = n_bad.p; R.bp_rec = bp_rec.p; R.energy = energy.p;
         { const size_t nS = ctx->n_system; bp_bar.alloc(nS); bp_fallback.alloc(nS); bp_nbx.alloc(nS * 2 * n_node * 8); bp_dev.alloc(nS * 32); bp_en_part.alloc(nS * 16); }
