@@ -133,13 +133,24 @@ PROFILE_NOTE = ('from the rocprofv3 PMC passes of this command committed under p
                 'separate passes, tools/refresh_profiles.sh); not collected in this run')
 
 
+_TABLE_STATE = {}
+
+
 def profiled(kernel_label, workload, replicas, field):
     """per-launch counter value of `kernel_label` from the committed PMC passes (tools/hbm_traffic.py applies the guide's
-    gfx950 corrections to the byte counters); None when no profile exists for this workload / replica count."""
+    gfx950 corrections to the byte counters); None when no profile exists for this workload / replica count, or when the
+    kernel sources have changed since the counters were collected (the table records their sha256)."""
     try:
         with open(os.path.join(ROOT, PROFILE_TABLE)) as f:
             tab = json.load(f)
-        return tab['%s/R%d' % (workload, replicas)][kernel_label][field]
+        entry = tab['%s/R%d' % (workload, replicas)]
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import hbm_traffic
+        stamp = entry.get('_kernel_sources_sha256')
+        _TABLE_STATE['stale'] = stamp != hbm_traffic.kernel_source_stamp()
+        if _TABLE_STATE['stale']:
+            return None
+        return entry[kernel_label][field]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -200,7 +211,13 @@ def main():
     eng = c.upside_hip_construct(n_atom, fixture.encode(), R, True)
     if not eng:
         raise RuntimeError('engine construction failed: %s' % c.upside_hip_last_error().decode())
-    pos = np.ascontiguousarray(np.tile(pos0[None], (R, 1, 1)).astype('f4'))
+    pos = np.tile(pos0[None], (R, 1, 1)).astype('f4')
+    first_global, _ = rep.weak_shard(R, world, rank)
+    if R > 1:      # every replica starts from its own structure (0.05 A of noise keyed by the GLOBAL replica index), so that the
+                   # pair-list rebuilds of the replicas are out of phase from the first timed step on
+        for r in range(R):
+            pos[r] += np.random.RandomState(977 + first_global + r).normal(0., 0.05, pos0.shape).astype('f4')
+    pos = np.ascontiguousarray(pos)
     check(c, c.upside_hip_set_pos(eng, pos.ctypes.data), 'set_pos')
     first, _ = rep.weak_shard(R, world, rank)
     remd = args.workload == 'remd64_proteinG56'
@@ -281,6 +298,8 @@ def main():
             if traffic is not None:      # the rate the counters saw, beside the algorithmic one
                 d['traffic_source'] = PROFILE_NOTE
                 d['frac_counter'] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            elif _TABLE_STATE.get('stale'):
+                d['traffic_source'] = 'profiles/hbm_traffic.json is STALE: the kernel sources changed after its PMC passes (rerun tools/refresh_profiles.sh pmc)'
             return d
         # the dominant kernel of the step (most time): belief propagation, which streams the pair matrices and messages
         # every sweep

@@ -74,6 +74,9 @@ int upside_hip_compute(DerivEngine* engine, float* energy, float* deriv);
  * (seed_s = base_seed + s, main.cpp:459), momenta fully resampled, n_invocations reset. */
 int upside_hip_init_md(DerivEngine* engine, const float* temperature, uint32_t base_seed,
                        float thermostat_timescale, float dt, int thermostat_interval_rounds);
+/* ... with one seed per system (a run whose systems are spread over several engines keeps seed = base + GLOBAL index) */
+int upside_hip_init_md_seeds(DerivEngine* engine, const float* temperature, const uint32_t* seeds,
+                             float thermostat_timescale, float dt, int thermostat_interval_rounds);
 
 /* n_round integration cycles (3 leapfrog stages each, deriv_engine.cpp:172-192) with the
  * Ornstein-Uhlenbeck thermostat (thermostat.cpp:9-18) every thermostat_interval rounds; everything
@@ -124,6 +127,12 @@ int upside_hip_replica_swap_next(DerivEngine* engine, int n_pair, const int* pai
  * engine with upside_hip_swap_systems, otherwise get/set_system_pos around a point-to-point transfer. */
 int upside_replica_decide(int n_pair, const int* pairs, const float* beta, const float* energy, uint32_t base_seed,
                           uint64_t round, int draw0, int* accepted);
+/* Mixed Hamiltonians (one engine per distinct potential, main.cpp:450-571): the reference's own procedure, main.cpp:251-273 --
+ * log-Boltzmann factors of every system before and after trading the coordinates of a set's pairs,
+ * lboltz_diff[p] = (new[s1]+new[s2]) - (old[s1]+old[s2]), this Metropolis test on them (same generator, a uniform drawn
+ * only for a rejectable pair), rejected pairs traded back.  upside_hip_swap_between moves coordinates device to device. */
+int upside_replica_decide_lboltz(int n_pair, const float* lboltz_diff, uint32_t base_seed, uint64_t round, int draw0, int* accepted);
+int upside_hip_swap_between(DerivEngine* engine1, int system1, DerivEngine* engine2, int system2);
 int upside_hip_get_system_pos(DerivEngine* engine, int system, float* pos);        /* host (n_atom,3) */
 int upside_hip_set_system_pos(DerivEngine* engine, int system, const float* pos);
 int upside_hip_swap_systems(DerivEngine* engine, int system1, int system2);

@@ -933,17 +933,80 @@ def test_long_md_is_thermalised_and_stable(hip):
     assert np.array_equal(pos, pos_b) and np.array_equal(e1, e1b)   # bit-reproducible run to run
 
 
-def test_upside_main_refuses_mixed_potentials(hip, tmp_path):
-    """one engine serves all systems of an `upside_main` run, so config files with different /input/potential (here: the
-    same protein with and without restraint nodes -- same atom count) must be refused, not simulated under the first file's
-    force field (the reference builds one engine per file, main.cpp:450-571)"""
+def test_upside_main_mixed_potentials_match_reference(hip, tmp_path):
+    """Configuration files with DIFFERENT /input/potential in one `upside_main` run (the reference builds one engine per file,
+    main.cpp:450-571: Hamiltonian replica exchange, mixed runs): here one batched engine per distinct potential.  Two copies
+    of the 56-residue protein with and two without the restraint / external-field nodes (same atoms, different Hamiltonians),
+    four temperatures, two alternating swap sets whose pairs cross the two potentials, so every verdict needs the second
+    energy pass of main.cpp:251-259.  Against the unmodified reference executable on the same four files: replica_index of
+    every frame identical, the potentials of frame 0 equal (each file under ITS OWN force field), trajectories still the same
+    trajectory after the first exchanges."""
     import shutil
-    a = str(tmp_path / 'a.up'); b = str(tmp_path / 'b.up'); c = str(tmp_path / 'c.up')
-    shutil.copyfile(P.fixture('proteinG56_7A'), a); shutil.copyfile(P.fixture('proteinG56_restraints'), b); shutil.copyfile(P.fixture('proteinG56_7A'), c)
-    args = ['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '3']
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    if not os.path.exists(ref_exe):
+        pytest.skip('reference executable not built (oracle/_ref)')
+    names = ['proteinG56_7A', 'proteinG56_restraints', 'proteinG56_7A', 'proteinG56_restraints']
+    rargs = ['--duration', '0.27', '--frame-interval', '0.054', '--temperature', '0.80,0.82,0.84,0.86', '--seed', '3',
+             '--replica-interval', '0.055', '--swap-set', '0-1,2-3', '--swap-set', '1-2', '--disable-recentering']
+    out = {}
+    for tag in ('ref', 'hip'):
+        fs = [str(tmp_path / ('%s_%d.up' % (tag, i))) for i in range(4)]
+        for f, nm in zip(fs, names):
+            shutil.copyfile(P.fixture(nm), f)
+        if tag == 'ref':
+            subprocess.run([ref_exe] + rargs + fs, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                           env=dict(os.environ, OMP_NUM_THREADS='4'))
+        else:
+            hip.in_process_upside(rargs + fs, verbose=False)
+        out[tag] = [_read_output(f)[0] for f in fs]
+    n_frame = out['ref'][0]['replica_index'].shape[0]
+    assert n_frame >= 5
+    for s_ in range(4):
+        r, g_ = out['ref'][s_], out['hip'][s_]
+        assert np.array_equal(g_['replica_index'], r['replica_index']), (s_, g_['replica_index'].ravel(), r['replica_index'].ravel())
+        assert abs(g_['potential'][0, 0] - r['potential'][0, 0]) < 1e-4 * max(1., abs(r['potential'][0, 0])), s_
+        assert abs(g_['kinetic'][0, 0] - r['kinetic'][0, 0]) < 1e-5 * r['kinetic'][0, 0]       # seeds follow the system index of the RUN
+        assert P.rel_rms(r['pos'][1], g_['pos'][1]) < 1e-3
+        assert set(r.keys()) <= set(g_.keys())                                               # every file logs its own nodes' values
+        # the exchange bookkeeping of main.cpp:203-217: partners of this system's swap pairs, running (success, attempt) counts
+        assert np.array_equal(g_['replica_swap_partner'], r['replica_swap_partner'])
+        assert np.array_equal(g_['replica_cumulative_swaps'], r['replica_cumulative_swaps'])
+    # the two force fields really differ on the same structure
+    assert abs(out['hip'][0]['potential'][0, 0] - out['hip'][1]['potential'][0, 0]) > 1e-2
+    # Hamiltonian replica exchange proper: the same protein under two strengths of the backbone hydrogen-bond energy (the
+    # attribute of /input/potential/hbond_energy scaled by 0.9 in two of the four files) -- close enough for accepted swaps
+    fs_by_tag = {}
+    for tag in ('ref', 'hip'):
+        fs = [str(tmp_path / ('h%s_%d.up' % (tag, i))) for i in range(4)]
+        for i, f in enumerate(fs):
+            shutil.copyfile(P.fixture('proteinG56_7A'), f)
+            if i % 2:
+                with P.pkg.h5lite.open_file(f, 'r+') as t:
+                    g = t.group('input/potential/hbond_energy')
+                    g.set_attr('protein_hbond_energy', np.float64(0.9 * float(np.asarray(g.get_attr('protein_hbond_energy')).ravel()[0])))
+        fs_by_tag[tag] = fs
+    hargs = [a for a in rargs if a != '--disable-recentering']
+    subprocess.run([ref_exe] + hargs + fs_by_tag['ref'], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                   env=dict(os.environ, OMP_NUM_THREADS='4'))
+    hip.in_process_upside(hargs + fs_by_tag['hip'], verbose=False)
+    ref = [_read_output(f)[0] for f in fs_by_tag['ref']]; got = [_read_output(f)[0] for f in fs_by_tag['hip']]
+    for s_ in range(4):
+        assert np.array_equal(got[s_]['replica_index'], ref[s_]['replica_index']), s_
+        assert np.array_equal(got[s_]['replica_cumulative_swaps'], ref[s_]['replica_cumulative_swaps']), s_
+        assert abs(got[s_]['potential'][0, 0] - ref[s_]['potential'][0, 0]) < 1e-4 * max(1., abs(ref[s_]['potential'][0, 0]))
+        assert P.rel_rms(ref[s_]['pos'][-1], got[s_]['pos'][-1]) < 1e-3
+    assert abs(got[0]['potential'][0, 0] - got[1]['potential'][0, 0]) > 1e-3          # two Hamiltonians on one structure
+    ri = np.stack([o['replica_index'].reshape(-1) for o in got])
+    assert (ri[:, -1] != np.arange(4)).any(), 'no exchange between the two Hamiltonians was accepted'
+    # identical potentials in different files still share one engine
+    a = str(tmp_path / 'a.up'); c = str(tmp_path / 'c.up')
+    shutil.copyfile(P.fixture('proteinG56_7A'), a); shutil.copyfile(P.fixture('proteinG56_7A'), c)
+    hip.in_process_upside(['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '3', a, c], verbose=False)
+    # different atom counts cannot exchange coordinates: refused
+    d = str(tmp_path / 'd.up'); shutil.copyfile(P.fixture('trpcage20_7A'), d)
     with pytest.raises(RuntimeError):
-        hip.in_process_upside(args + [a, b], verbose=False)
-    hip.in_process_upside(args + [a, c], verbose=False)        # identical potentials, different files: fine
+        hip.in_process_upside(['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8', '--seed', '3', a, d], verbose=False)
 
 
 def test_replica_swap_next_rejects_stale_energies(hip):

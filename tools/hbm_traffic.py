@@ -33,6 +33,18 @@ def per_kernel(dbfile, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def kernel_source_stamp():
+    """sha256 over the kernel sources the counters were collected on: bench.py compares it with the sources it runs and
+    reports the table as stale instead of quoting counters of kernels that have changed since"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'upside-md_amd', 'csrc')
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(root)):
+        if fn.endswith(('.hip', '.h')):
+            h.update(fn.encode()); h.update(open(os.path.join(root, fn), 'rb').read())
+    return h.hexdigest()
+
+
 def main():
     fetch_db, write_db, workload, replicas = sys.argv[1:5]
     sq_db = sys.argv[6] if len(sys.argv) > 6 else None
@@ -56,9 +68,10 @@ def main():
             entry[label]['valu_insts_per_launch'] = q[k][0]
             if label in pairs and pairs[label] > 0:
                 entry[label]['valu_insts_per_pair'] = q[k][0] / pairs[label]
+    entry['_kernel_sources_sha256'] = kernel_source_stamp()
     tab['%s/R%s' % (workload, replicas)] = entry
     json.dump(tab, open(out, 'w'), indent=1, sort_keys=True)
-    for k, v in sorted(entry.items(), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:
+    for k, v in sorted(((k, v) for k, v in entry.items() if isinstance(v, dict)), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:
         print('%-40s read %8.1f MB  write %8.1f MB' % (k, v['fetch_bytes'] / 1e6, v['write_bytes'] / 1e6))
 
 

@@ -32,10 +32,12 @@ HBOND = float(open(os.path.join(PARAM, 'ff_1', 'hbond')).read())
 FIXTURES = {
     'trpcage20_7A': (cfg.TRP_CAGE, '7A', 'ff_1/sidechain.h5', 9.0, 11, True),
     'proteinG56_7A': (cfg.PROTEIN_G, '7A', 'ff_1/sidechain.h5', 12.5, 12, True),
-    'syn150_10A': (150, '10A', 'packing/sidechain_10A_cutoff.h5', 18.5, 13, False),
+    'syn150_10A': (150, '10A', 'packing/sidechain_10A_cutoff.h5', 19.7, 13, False),   # Rg ~ 14.8 A; 18.5 gave 13.5: steric walls ill-conditioned in fp32
     'syn300_10A': (300, '10A', 'packing/sidechain_10A_cutoff.h5', 22.0, 14, False),
     'syn300_7A': (300, '7A', 'ff_1/sidechain.h5', 22.0, 14, False),
 }
+
+TARGET_RG = {'syn150_10A': 14.8}      # fixtures taken from the collapse trajectory at a target radius of gyration
 
 NODES = ['rama_coord', 'affine_alignment', 'infer_H_O', 'placement_fixed_point_vector_only',
          'placement_fixed_point_vector_only_CB', 'placement_fixed_point_vector_scalar', 'placement_scalar',
@@ -187,9 +189,19 @@ def make(name):
         tmp = '/tmp/_compact_%s.up' % name
         cfg.write_config(tmp, fasta, pos0, cavity_radius=r_cavity, **kw)
         exe = os.path.join(REF, 'upside_' + variant)
-        subprocess.check_call([exe, '--duration', '200', '--frame-interval', '20', '--temperature', '0.9',
+        target_rg = TARGET_RG.get(name)
+        subprocess.check_call([exe, '--duration', '200', '--frame-interval', '2' if target_rg else '20', '--temperature', '0.9',
                                '--seed', '1', '--disable-recentering', tmp], stdout=subprocess.DEVNULL)
-        pos = cfg.read_last_frame(tmp).astype('f8')
+        if target_rg:      # the frame of the collapse whose radius of gyration is closest to the target (2.2 N^0.38 A):
+            with pkg.h5lite.open_file(tmp) as f:       # the fully collapsed end state sits deep in its steric walls
+                frames = f.read('output/pos', 'f4')[:, 0]
+            rgs = np.array([rg(x) for x in frames])
+            below = np.nonzero(rgs <= target_rg * 1.15)[0]
+            k = below[np.argmin(np.abs(rgs[below] - target_rg))]
+            print('%s: frame %d of %d, Rg %.2f (last frame %.2f)' % (name, k, len(frames), rgs[k], rgs[-1]))
+            pos = frames[k].astype('f8')
+        else:
+            pos = cfg.read_last_frame(tmp).astype('f8')
         pos -= pos.mean(axis=0)
         os.remove(tmp)
         np.save(coords_file, pos.astype('f4'))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Noise floor of the REFERENCE itself (build container only): the same reference sources compiled -O1 without fast-math
 (throw-away builds under /tmp, tools/build_ref_O1.sh) compared with the golden vectors of the -O3 -ffast-math build, next to the
-distance of our C restatement from both.  Writes profiles/r02_reference_noise_floor.txt (the table) and
+distance of our C restatement from both.  Writes profiles/r03_reference_noise_floor.txt (the table) and
 tests/golden/reference_noise_floor.json: per fixture and structure the relative RMS deviation of the forces and the worst one
 over the nodes' sensitivities.  The tests derive their tolerances against the golden vectors from that file (2x the floor)."""
 import sys, os, json
@@ -39,5 +39,5 @@ for name, variant in FIX:
         line += ' | oracle-vs-refO1: deriv %.2e' % P.rel_rms(a['deriv'], o['deriv'])
         table[name][tag] = entry
         lines.append(line); print(line)
-open(os.path.join(ROOT, 'profiles', 'r02_reference_noise_floor.txt'), 'w').write('\n'.join(lines) + '\n')
+open(os.path.join(ROOT, 'profiles', 'r03_reference_noise_floor.txt'), 'w').write('\n'.join(lines) + '\n')
 json.dump(table, open(os.path.join(ROOT, 'tests', 'golden', 'reference_noise_floor.json'), 'w'), indent=1, sort_keys=True)

@@ -263,11 +263,17 @@ extern "C" int upside_hip_set_temperature(DerivEngine* e, const float* temperatu
 }
 extern "C" int upside_hip_init_md(DerivEngine* e, const float* temperature, uint32_t base_seed, float thermostat_timescale, float dt,
                                   int thermostat_interval_rounds) {
+    std::vector<uint32_t> seeds(e ? e->ctx.n_system : 0);
+    for (size_t s = 0; s < seeds.size(); ++s) seeds[s] = base_seed + (uint32_t)s;   // main.cpp:459
+    return upside_hip_init_md_seeds(e, temperature, seeds.data(), thermostat_timescale, dt, thermostat_interval_rounds);
+}
+extern "C" int upside_hip_init_md_seeds(DerivEngine* e, const float* temperature, const uint32_t* seeds, float thermostat_timescale, float dt,
+                                        int thermostat_interval_rounds) {
     API_TRY
     const int S = e->ctx.n_system;
     if (thermostat_interval_rounds < 1) throw string("thermostat interval must be at least one round");
     e->thermostat_timescale = thermostat_timescale; e->dt = dt; e->thermostat_interval = thermostat_interval_rounds;
-    for (int s = 0; s < S; ++s) { e->temperature[s] = temperature[s]; e->seeds[s] = base_seed + (uint32_t)s; }   // main.cpp:459
+    for (int s = 0; s < S; ++s) { e->temperature[s] = temperature[s]; e->seeds[s] = seeds[s]; }
     e->seed.upload(e->seeds);
     e->mom.fill_bytes(0);
     e->invalidate_graph();
@@ -395,6 +401,43 @@ float h_u01(uint32_t in) {   // uniform.hpp:145-179, the product and the sum rou
     return t + 0.5f * factor;
 }
 }  // namespace
+// the Metropolis rule of main.cpp:262-272 on given log-Boltzmann differences (any mixture of Hamiltonians): a uniform of the
+// round's generator is drawn only for a rejectable pair; accepted[n_pair] = generator position after this set
+extern "C" int upside_replica_decide_lboltz(int n_pair, const float* lboltz_diff, uint32_t base_seed, uint64_t round, int draw0, int* accepted) {
+    API_TRY
+    int draw = draw0;
+    for (int p = 0; p < n_pair; ++p) {
+        int ok = 1;
+        if (lboltz_diff[p] < 0.f) {
+            const uint32_t key[4] = {base_seed, 1u /* REPLICA_EXCHANGE_RANDOM_STREAM */, 0u, 0u};
+            uint32_t X[4] = {(uint32_t)(round & 0xffffffffu), (uint32_t)(round >> 32), 0u, (uint32_t)draw};
+            h_threefry4x32_20(X, key);
+            ++draw;
+            if (expf(lboltz_diff[p]) < h_u01(X[0])) ok = 0;
+        }
+        accepted[p] = ok;
+    }
+    accepted[n_pair] = draw;
+    return 0;
+    API_CATCH(1)
+}
+// trade the coordinates of system s1 of engine e1 and system s2 of engine e2 (same atom count; device to device)
+extern "C" int upside_hip_swap_between(DerivEngine* e1, int s1, DerivEngine* e2, int s2) {
+    API_TRY
+    if (!e1 || !e2 || s1 < 0 || s2 < 0 || s1 >= e1->ctx.n_system || s2 >= e2->ctx.n_system) throw string("invalid system");
+    if (e1->pos->n_elem != e2->pos->n_elem) throw string("the two systems differ in their number of atoms");
+    if (e1 == e2 && s1 == s2) return 0;
+    const size_t row = (size_t)e1->pos->n_elem * e1->pos->stride;
+    e1->sync(); e2->sync();
+    DevBuf<float> tmp; tmp.alloc(row);
+    float* a = e1->pos->output.p + (size_t)s1 * row; float* b = e2->pos->output.p + (size_t)s2 * row;
+    hip_check(hipMemcpy(tmp.p, a, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hip_check(hipMemcpy(a, b, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hip_check(hipMemcpy(b, tmp.p, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    e1->swap_energy.clear(); e2->swap_energy.clear();
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_replica_decide(int n_pair, const int* pairs, const float* beta, const float* energy, uint32_t base_seed,
                                      uint64_t round, int draw0, int* accepted) {
     API_TRY

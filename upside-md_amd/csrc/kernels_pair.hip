@@ -306,14 +306,14 @@ struct CovRowOp2 {
     v2 xr[6], hbr, acc; int tr;
     __device__ __forceinline__ CovRowOp2(const upk_igraph_t& G_, const PairLds& L_, const PairArgs& A_, int s_) : G(G_), Q(quad_shape(G_)), L(L_), A(A_), s(s_) {}
     __device__ __forceinline__ void begin(int row) {
-        float x[8]; load_row8(x, (RS == 1 ? L.c1 : L.c2) + row * 8);
+        float x[8]; load_row8_planes(x, RS == 1 ? L.c1 : L.c2, (RS == 1 ? G.n1 : G.n2) + 1, row);
 #pragma unroll
         for (int c = 0; c < 6; ++c) xr[c] = bc2(x[c]);
         hbr = bc2(x[6]); tr = __float_as_int(x[7]); acc = bc2(0.f);
     }
     __device__ __forceinline__ void body(int, int jA, int jB, bool liveA, bool liveB) {
         float xa[8], xb[8];
-        load_row8(xa, (RS == 1 ? L.c2 : L.c1) + jA * 8); load_row8(xb, (RS == 1 ? L.c2 : L.c1) + jB * 8);
+        load_row8_planes(xa, RS == 1 ? L.c2 : L.c1, (RS == 1 ? G.n2 : G.n1) + 1, jA); load_row8_planes(xb, RS == 1 ? L.c2 : L.c1, (RS == 1 ? G.n2 : G.n1) + 1, jB);
         v2 xo[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) xo[c] = mk2(xa[c], xb[c]);
@@ -334,9 +334,8 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t 
     const int s = blockIdx.y;
     const PairLds L = pair2_lds(lds, G, A.tab_floats);
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
-    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0);
-    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, nullptr, 0);
-    stage_sentinel(L.c1, G.n1, 0.f, __int_as_float(0)); stage_sentinel(L.c2, G.n2, 0.f, __int_as_float(0));
+    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0));
+    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, nullptr, 0, 0.f, __int_as_float(0));
     if (threadIdx.x == 0) *L.counter = 0;
     const int n_rows = RS == 1 ? G.n1 : G.n2, cap = RS == 1 ? G.cap1 : G.cap2;
     stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
@@ -363,7 +362,7 @@ struct CovBackwardOp2 {
     // sensitivity (sens_mode 1 / 3) rides in a separate LDS array in front of the accumulators: L-side detail of the kernel below.
     const float* site_sens = nullptr;
     __device__ __forceinline__ void begin(int row) {
-        float x[8]; load_row8(x, (RS == 1 ? L.c1 : L.c2) + row * 8);
+        float x[8]; load_row8_planes(x, RS == 1 ? L.c1 : L.c2, (RS == 1 ? G.n1 : G.n2) + 1, row);
 #pragma unroll
         for (int c = 0; c < 6; ++c) xr[c] = bc2(x[c]);
         hbr = bc2(x[6]); tr = __float_as_int(x[7]);
@@ -373,7 +372,7 @@ struct CovBackwardOp2 {
     }
     __device__ __forceinline__ void body(int, int jA, int jB, bool liveA, bool liveB) {
         float xa[8], xb[8];
-        load_row8(xa, (RS == 1 ? L.c2 : L.c1) + jA * 8); load_row8(xb, (RS == 1 ? L.c2 : L.c1) + jB * 8);
+        load_row8_planes(xa, RS == 1 ? L.c2 : L.c1, (RS == 1 ? G.n2 : G.n1) + 1, jA); load_row8_planes(xb, RS == 1 ? L.c2 : L.c1, (RS == 1 ? G.n2 : G.n1) + 1, jB);
         v2 xo[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) xo[c] = mk2(xa[c], xb[c]);
@@ -391,13 +390,14 @@ struct CovBackwardOp2 {
         v2 od[DO];
 #pragma unroll
         for (int c = 0; c < DO; ++c) od[c] = ps * dv[c];
+        const int n_o = RS == 1 ? G.n2 : G.n1;          // accumulators as DO planes [component][element]
         if (liveA) {
 #pragma unroll
-            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + jA * DO + c, od[c].x);
+            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + c * n_o + jA, od[c].x);
         }
         if (liveB) {
 #pragma unroll
-            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + jB * DO + c, od[c].y);
+            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + c * n_o + jB, od[c].y);
         }
     }
     __device__ __forceinline__ void flush(int row) {
@@ -422,9 +422,8 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igrap
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
-    stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0);
-    stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, S2, A.sens_stride);
-    stage_sentinel(L.c1, G.n1, 0.f, __int_as_float(0)); stage_sentinel(L.c2, G.n2, 0.f, __int_as_float(0));
+    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0));
+    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, S2, A.sens_stride, 0.f, __int_as_float(0));
     if (S1) for (int t = threadIdx.x; t < G.n1; t += blockDim.x) site_sens[t] = S1[(size_t)t * A.sens_stride];
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) oacc[t] = 0ull;
     if (threadIdx.x == 0) *L.counter = 0;
@@ -443,9 +442,9 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igrap
     unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
     const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
-        const unsigned long long a = oacc[t];
-        if (!a) continue;
         const int i = t / DO, c = t - i * DO;
+        const unsigned long long a = oacc[c * n_other + i];
+        if (!a) continue;
         if (alone) osens[(size_t)oloc[i] * onode.stride + c] += from_fixed22(a);
         else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
     }

@@ -301,8 +301,9 @@ __device__ __forceinline__ RotLds rot_stage(const upk_rotamer_t& R, float* lds, 
     if (STAGED) {
         if (want_acc) { r.acc = (unsigned long long*)p; p += G.n1 * 12; for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) r.acc[t] = 0ull; }
         r.rows = p; p += (G.n1 + (SENTINEL ? 1 : 0)) * 8;
-        stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
-        if (SENTINEL) stage_sentinel((float*)r.rows, G.n1, __int_as_float(1 << 12) /* type 0, state 0 of 1 */, __int_as_float(0) /* node 0 */);
+        if (SENTINEL)     // the packed passes: two 16-byte planes + the sentinel row (type 0, state 0 of 1, node 0)
+            stage_rows_planes((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0, __int_as_float(1 << 12), __int_as_float(0));
+        else stage_rows((float*)r.rows, G.node1, s, G.loc1, G.n1, 6, R.bead_node, R.bead_meta, nullptr, 0);
     } else r.rows = R.bead_pack + (size_t)s * G.n1 * 8;
     r.range = (int*)p; r.ord = (unsigned short*)(r.range + G.n1); r.counter = r.range + PG_WALK_LDS_WORDS(G.n1);
     stage_ranges(r.range, r.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
@@ -387,7 +388,7 @@ struct RotEnergyOp2 {
     __device__ __forceinline__ RotEnergyOp2(const upk_rotamer_t& R_, const RotLds& L_, int s)
         : R(R_), Q(quad_shape(R_.G)), L(L_), P(R_.P + (size_t)s * R_.slot_cap * 36), active(R_.slot_active + (size_t)s * R_.slot_cap) {}
     __device__ __forceinline__ void begin(int row) {
-        float xr[8]; load_row8(xr, L.rows + row * 8);
+        float xr[8]; load_row8_planes(xr, L.rows, R.G.n1 + 1, row);
 #pragma unroll
         for (int c = 0; c < 6; ++c) x1[c] = bc2(xr[c]);
         mr = __float_as_int(xr[6]); a = __float_as_int(xr[7]);
@@ -402,8 +403,8 @@ struct RotEnergyOp2 {
     }
     __device__ __forceinline__ void body(int, int wA, int wB, bool liveA, bool liveB) {
         float xa[8], xb[8];
-        load_row8(xa, L.rows + (wA & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
-        load_row8(xb, L.rows + (wB & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        load_row8_planes(xa, L.rows, R.G.n1 + 1, wA & ((1 << UPK_ROT_J_BITS) - 1));
+        load_row8_planes(xb, L.rows, R.G.n1 + 1, wB & ((1 << UPK_ROT_J_BITS) - 1));
         const RotPairMeta mA = rot_pair_meta(wA, xa), mB = rot_pair_meta(wB, xb);
         v2 x2[6];
 #pragma unroll
@@ -435,7 +436,7 @@ struct RotGradOp2 {
     __device__ __forceinline__ RotGradOp2(const upk_rotamer_t& R_, const RotLds& L_, int s)
         : R(R_), Q(quad_shape(R_.G)), L(L_), marg(R_.marg + (size_t)s * R_.slot_cap * 36), nbm(R_.nb_cur + (size_t)s * R_.n_node * 6) {}
     __device__ __forceinline__ void begin(int row) {
-        float xr[8]; load_row8(xr, L.rows + row * 8);
+        float xr[8]; load_row8_planes(xr, L.rows, R.G.n1 + 1, row);
 #pragma unroll
         for (int c = 0; c < 6; ++c) { x1[c] = bc2(xr[c]); acc[c] = bc2(0.f); }
         mr = __float_as_int(xr[6]); a = __float_as_int(xr[7]);
@@ -455,8 +456,8 @@ struct RotGradOp2 {
     }
     __device__ __forceinline__ void body(int, int wA, int wB, bool liveA, bool liveB) {
         float xa[8], xb[8];
-        load_row8(xa, L.rows + (wA & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
-        load_row8(xb, L.rows + (wB & ((1 << UPK_ROT_J_BITS) - 1)) * 8);
+        load_row8_planes(xa, L.rows, R.G.n1 + 1, wA & ((1 << UPK_ROT_J_BITS) - 1));
+        load_row8_planes(xb, L.rows, R.G.n1 + 1, wB & ((1 << UPK_ROT_J_BITS) - 1));
         const RotPairMeta mA = rot_pair_meta(wA, xa), mB = rot_pair_meta(wB, xb);
         const v2 ps = mk2(sens_of(mA, liveA), sens_of(mB, liveB));
         v2 x2[6];
@@ -473,13 +474,15 @@ struct RotGradOp2 {
             od[c] = ps * dd[c]; od[3 + c] = ps * g2[c];
             acc[c] -= od[c]; acc[3 + c] = fma2(ps, g1[c], acc[3 + c]);
         }
+        // accumulators as six planes [component][bead]: the consecutive partners of a row group fall into distinct banks
+        const int n1 = R.G.n1;
         if (liveA) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + mA.j * 6 + c, od[c].x);
+            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * n1 + mA.j, od[c].x);
         }
         if (liveB) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + mB.j * 6 + c, od[c].y);
+            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * n1 + mB.j, od[c].y);
         }
     }
     __device__ __forceinline__ void flush(int row) {
@@ -488,7 +491,7 @@ struct RotGradOp2 {
         for (int c = 0; c < 6; ++c) t[c] = group_sum4(acc[c].x + acc[c].y);
         if ((threadIdx.x & (P2_LANES - 1)) != 0) return;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + row * 6 + c, t[c]);
+        for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * R.G.n1 + row, t[c]);
     }
 };
 template <bool POLY>
@@ -506,9 +509,10 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad2(upk_rotam
     unsigned long long* gacc = R.grad_acc + (size_t)s * G.n1 * 6;
     const bool alone = gridDim.x == 1;     // the system's only workgroup: its accumulators are the totals
     for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) {
-        const unsigned long long a = L.acc[t];
+        const int i = t / 6, c = t - i * 6;
+        const unsigned long long a = L.acc[c * G.n1 + i];
         if (!a) continue;
-        if (alone) { const int i = t / 6, c = t - i * 6; sens[(size_t)G.loc1[i] * G.node1.stride + c] += from_fixed22(a); }
+        if (alone) sens[(size_t)G.loc1[i] * G.node1.stride + c] += from_fixed22(a);
         else atomicAdd(gacc + t, a);       // several workgroups share the system: exact partial sums, k_rotamer_grad_finish converts
     }
     if (alone) {   // the node marginal of the bead's rotamer state goes to the 1-body parents (rotamer.cpp:968-984)
@@ -1047,6 +1051,9 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
 }
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
+#ifndef BP_NODE_ROWS_512
+#define BP_NODE_ROWS_512 4
+#endif
 
 // Pair matrices pinned in registers for the whole solve.  The edge phase is bandwidth bound (at 1024 systems every CU
 // streams ~0.6 MB per sweep, half of it exp(-E) matrices that never change during the solve), and the register file
@@ -1273,7 +1280,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 const int q = COMPACT ? (n == 6 ? 6 : 3) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
-                constexpr int ROWS = BLOCK == BP_BLOCK ? 4 : 8;
+                constexpr int ROWS = BP_NODE_ROWS_512 > 0 && BLOCK != BP_BLOCK ? BP_NODE_ROWS_512 : (BLOCK == BP_BLOCK ? 4 : 8);
                 for (int k0 = gl; k0 < deg; k0 += ROWS * BP_GROUP) {
                     float4 m0[ROWS]; float2 m1[ROWS];
 #pragma unroll

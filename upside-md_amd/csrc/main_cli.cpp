@@ -47,6 +47,7 @@ struct EArray {   // h5_support.cpp:199-274: extensible along dimension 0, chunk
     }
     void push(const void* data) { const char* c = (const char*)data; buffer.insert(buffer.end(), c, c + row_size * elem); }
     void flush() {
+        if (!row_size) return;      // (a dataset with an empty row shape never receives records)
         const size_t n_rec = buffer.size() / (row_size * elem);
         if (!n_rec) return;
         hid_t space = H5Dget_space(dset);
@@ -67,8 +68,11 @@ struct EArray {   // h5_support.cpp:199-274: extensible along dimension 0, chunk
 };
 struct OutputLogger {   // one per system / configuration file (H5Logger, state_logger.h:70-141)
     hid_t file = -1, group = -1; int n_buffered = 0;
-    EArray pos, kinetic, potential, time, temperature, replica_index, pivot_stats, jump_stats; bool log_replica = false, log_pivot = false, log_jump = false;
-    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index, bool with_pivot, bool with_jump) {
+    EArray pos, kinetic, potential, time, temperature, replica_index, replica_cumulative_swaps, pivot_stats, jump_stats; bool log_replica = false, log_pivot = false, log_jump = false;
+    // swap_partners: the other system of every swap pair this system takes part in, in swap-set order (main.cpp:203-217:
+    // `replica_swap_partner` written once, `replica_cumulative_swaps` (n_success, n_attempt) per pair and frame)
+    void open(const string& path, int n_atom, const string& invocation, bool with_replica_index, bool with_pivot, bool with_jump,
+              const vector<int>& swap_partners = vector<int>()) {
         file = H5Fopen(path.c_str(), H5F_ACC_RDWR, H5P_DEFAULT);
         if (file < 0) throw string("Unable to open configuration file at ") + path;
         if (H5Lexists(file, "output", H5P_DEFAULT) > 0) H5Ldelete(file, "/output", H5P_DEFAULT);   // main.cpp:473-477
@@ -87,7 +91,13 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
         time.create(group, "time", H5T_NATIVE_DOUBLE, 8, {});
         temperature.create(group, "temperature", H5T_NATIVE_DOUBLE, 8, {1});
         log_replica = with_replica_index;
-        if (log_replica) replica_index.create(group, "replica_index", H5T_NATIVE_INT, 4, {1});
+        if (log_replica) {
+            replica_index.create(group, "replica_index", H5T_NATIVE_INT, 4, {1});
+            EArray partner; partner.create(group, "replica_swap_partner", H5T_NATIVE_INT, 4, {});
+            for (int sp : swap_partners) partner.push(&sp);
+            partner.close();
+            replica_cumulative_swaps.create(group, "replica_cumulative_swaps", H5T_NATIVE_INT, 4, {(hsize_t)swap_partners.size(), 2});
+        }
         log_pivot = with_pivot;
         if (log_pivot) pivot_stats.create(group, "pivot_stats", H5T_NATIVE_INT, 4, {2});   // monte_carlo_sampler.h:33-37
         log_jump = with_jump;
@@ -115,15 +125,15 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
             else extra[i].push(buf.data());
         }
     }
-    void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc, const int* mcj) {
+    void sample(const float* x, double kin, double pot, double t, double temp, int rep, const int* mc, const int* mcj, const int* cum_swaps) {
         pos.push(x); kinetic.push(&kin); potential.push(&pot); time.push(&t); temperature.push(&temp);
-        if (log_replica) replica_index.push(&rep);
+        if (log_replica) { replica_index.push(&rep); if (replica_cumulative_swaps.row_size) replica_cumulative_swaps.push(cum_swaps); }
         if (log_pivot) pivot_stats.push(mc);
         if (log_jump) jump_stats.push(mcj);
         if (!(++n_buffered % 100)) flush();                       // state_logger.h:91-92
     }
     void flush() {
-        pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) replica_index.flush();
+        pos.flush(); kinetic.flush(); potential.flush(); time.flush(); temperature.flush(); if (log_replica) { replica_index.flush(); replica_cumulative_swaps.flush(); }
         if (log_pivot) pivot_stats.flush();
         if (log_jump) jump_stats.flush();
         for (auto& x : extra) x.flush();
@@ -131,7 +141,7 @@ struct OutputLogger {   // one per system / configuration file (H5Logger, state_
     }
     void close() {
         if (file < 0) return;
-        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); pivot_stats.close(); jump_stats.close();
+        pos.close(); kinetic.close(); potential.close(); time.close(); temperature.close(); replica_index.close(); replica_cumulative_swaps.close(); pivot_stats.close(); jump_stats.close();
         for (auto& x : extra) x.close();
         H5Gclose(group); H5Fclose(file); file = group = -1;
     }
@@ -243,14 +253,15 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
 
     if (anneal_duration == -1.) anneal_duration = duration;      // main.cpp:434
     const vector<float> initial_temps = temps;
-    // One engine serves every system, so all files must hold the SAME potential (the reference builds one engine per file,
-    // main.cpp:450-571, and so also runs mixtures -- e.g. Hamiltonian replica exchange; here such a run is refused rather
-    // than silently simulated under the first file's force field): /input/potential is compared by digest, node names,
-    // arguments, attributes and dataset bytes alike.  Only /input/pos (and the output) differ between the files.
+    // One engine per DISTINCT potential (the reference builds one engine per file, main.cpp:450-571, which is what Hamiltonian
+    // replica exchange and mixed runs use): the files are grouped by a digest of /input/potential -- node names, arguments,
+    // attributes and dataset bytes alike -- and every group becomes one batched engine.  Only /input/pos (and the output)
+    // differ inside a group.  The common case is one group.
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
     int n_atom = 0;
     unsigned long long potential_digest = 0;
     vector<float> all_pos;
+    vector<unsigned long long> digest_of_group; vector<vector<int>> members; vector<int> group_of(n_system), local_of(n_system);
     for (int ns = 0; ns < n_system; ++ns) {
         hid_t f = H5Fopen(files[ns].c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
         if (f < 0) throw string("unable to open ") + files[ns];
@@ -261,25 +272,51 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // (hashed only when there is something to compare with: a single-file run loads whatever the node loader accepts)
         const unsigned long long dg = (n_total > 1) ? h5u::group_digest(h5u::open_group(f, "/input/potential")) : 0ull;
         if (ns == 0) { n_atom = (int)dims[0]; potential_digest = dg; }
-        else if ((int)dims[0] != n_atom || dg != potential_digest)
-            throw string("systems must share one potential: /input/potential of ") + files[ns] + " differs from that of " + files[0] +
-                " (one engine holds all systems of a run; run different potentials as separate runs)";
+        else if ((int)dims[0] != n_atom)      // (replica exchange trades coordinates between any two systems of the run)
+            throw string("the systems of one run must have the same number of atoms: ") + files[ns] + " differs from " + files[0];
+        size_t g = 0;
+        while (g < digest_of_group.size() && digest_of_group[g] != dg) ++g;
+        if (g == digest_of_group.size()) { digest_of_group.push_back(dg); members.emplace_back(); }
+        group_of[ns] = (int)g; local_of[ns] = (int)members[g].size(); members[g].push_back(ns);
         all_pos.insert(all_pos.end(), p.begin(), p.end());
     }
-    DerivEngine* e = upside_hip_construct(n_atom, files[0].c_str(), n_system, !verbose);
-    if (!e) throw string("unable to construct the engine: ") + upside_hip_last_error();
-    struct Guard { DerivEngine* e; ~Guard() { delete e; } } guard{e};
+    const int n_group = (int)members.size();
+    if (n_group > 1 && use_comm)
+        throw string("systems must share one potential when the run is spread over several processes: /input/potential of ") + files[members[1][0]] +
+              " differs from that of " + files[0];
+    if (n_group > 1 && mc_interval > 0.) throw string("Monte-Carlo moves are not available in a run that mixes potentials");
+    vector<DerivEngine*> engines(n_group, nullptr);
+    struct Guard { vector<DerivEngine*>& v; ~Guard() { for (auto* x : v) delete x; } } guard{engines};
+    for (int g = 0; g < n_group; ++g) {
+        engines[g] = upside_hip_construct(n_atom, files[members[g][0]].c_str(), (int)members[g].size(), !verbose);
+        if (!engines[g]) throw string("unable to construct the engine: ") + upside_hip_last_error();
+    }
+    DerivEngine* e = engines[0];      // the only engine of an ordinary run
+    // per-system arrays (n floats each) <-> the engines' own orders
+    auto to_group = [&](int g, const float* all, size_t n) { vector<float> v; v.reserve(members[g].size() * n); for (int ns : members[g]) v.insert(v.end(), all + (size_t)ns * n, all + (size_t)(ns + 1) * n); return v; };
+    auto from_group = [&](int g, const vector<float>& v, float* all, size_t n) { for (size_t l = 0; l < members[g].size(); ++l) memcpy(all + (size_t)members[g][l] * n, v.data() + l * n, n * sizeof(float)); };
+    auto fleet_compute = [&](float* energy_out) {      // force pass of every system, potentials by system
+        if (n_group == 1) { if (upside_hip_compute(e, energy_out, nullptr)) throw string(upside_hip_last_error()); return; }
+        for (auto* x : engines) x->compute(PotentialAndDerivMode);          // enqueued on the engines' own streams, then collected
+        for (int g = 0; g < n_group; ++g) { engines[g]->fetch_potentials(); engines[g]->swap_energy.clear(); from_group(g, engines[g]->potential, energy_out, 1); }
+    };
     if (!set_param_file.empty()) {   // main.cpp:384-395, 498-499: one 1-D float dataset per node name
         hid_t pf = H5Fopen(set_param_file.c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);
         if (pf < 0) throw string("unable to open ") + set_param_file;
         h5u::Handle pfh(pf, H5Fclose);
         for (const string& node_name : h5u::node_names_in_group(pf)) {
             auto values = h5u::read<float>(pf, node_name, 1);
-            if (set_param((int)values.size(), values.data(), e, node_name.c_str())) throw string("--set-param: ") + upside_hip_last_error();
+            bool applied = false;      // (a mixed run: every engine that has a node of this name)
+            for (auto* x : engines) {
+                if (n_group > 1 && x->get_idx(node_name, false) < 0) continue;
+                if (set_param((int)values.size(), values.data(), x, node_name.c_str())) throw string("--set-param: ") + upside_hip_last_error();
+                applied = true;
+            }
+            if (!applied) throw string("--set-param: no node named ") + node_name;
         }
     }
     // main.cpp:548-564: recentring would fight a potential that is not translation invariant
-    for (auto& n : e->nodes) {
+    for (auto* x : engines) for (auto& n : x->nodes) {
         auto pre = [&](const char* p) { return n.name == string(p).substr(0, n.name.size()); };   // is_prefix(n.name, p), deriv_engine.cpp:72-74
         if (recenter && !xy_recenter_only && (pre("membrane_potential") || pre("z_flat_bottom") || pre("tension") || pre("AFM")))
             throw string("You have z-centering and a z-dependent potential turned on.  This is not what you want.  "
@@ -287,9 +324,16 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         if (recenter && pre("cavity_radial"))
             throw string("You have re-centering and a radial potential turned on.  This is not what you want.  Consider --disable-recentering.");
     }
-    if (upside_hip_set_pos(e, all_pos.data())) throw string(upside_hip_last_error());
     // (thermostat streams are keyed by the GLOBAL system index, main.cpp:459)
-    if (upside_hip_init_md(e, temps.data(), base_seed + (uint32_t)sys_lo, (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
+    if (n_group == 1) {
+        if (upside_hip_set_pos(e, all_pos.data())) throw string(upside_hip_last_error());
+        if (upside_hip_init_md(e, temps.data(), base_seed + (uint32_t)sys_lo, (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
+    } else for (int g = 0; g < n_group; ++g) {
+        auto gp = to_group(g, all_pos.data(), (size_t)n_atom * 3); auto gt = to_group(g, temps.data(), 1);
+        vector<uint32_t> seeds; for (int ns : members[g]) seeds.push_back(base_seed + (uint32_t)(sys_lo + ns));
+        if (upside_hip_set_pos(engines[g], gp.data())) throw string(upside_hip_last_error());
+        if (upside_hip_init_md_seeds(engines[g], gt.data(), seeds.data(), (float)thermostat_timescale, dt, thermo_rounds)) throw string(upside_hip_last_error());
+    }
 
     // swap sets (main.cpp:146-219)
     vector<vector<int>> sets;
@@ -306,7 +350,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         sets.push_back(prs);
     }
 
-    if (!use_comm)      // (inside one engine the swap sets address its own systems)
+    if (!use_comm)      // (inside one process the swap sets address its own systems)
         for (auto& st : sets) for (int x : st) if (x >= n_system) throw string("invalid system");
     if (use_comm && !sets.empty()) {
         // Rendezvous: rank 0 creates the communicator id and leaves it, with the digest of its potential, in a file every rank
@@ -350,7 +394,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     }
 
     vector<float> energy(n_system);
-    if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
+    fleet_compute(energy.data());
     if (verbose) { printf("Initial potential energy:"); for (int ns = 0; ns < n_system; ++ns) printf(" %.2f", energy[ns]); printf("\n"); }
 
     // one logger per configuration file (the engine has closed its read-only handles by now)
@@ -365,14 +409,28 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     }
     const bool have_pivot = have_mc && upside_hip_mc_loaded(e, 0), have_jump = have_mc && upside_hip_mc_loaded(e, 1);
     vector<int> mc_stats((size_t)n_system * 2, 0), mcj_stats((size_t)n_system * 2, 0);
-    if (write_output) for (int ns = 0; ns < n_system; ++ns) loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_pivot, have_jump);
-    vector<LogValue> node_loggers;      // in node order, filtered by --log-level (state_logger.h:17-27)
+    // the swap pairs every system takes part in (set order, then pair order: main.cpp:176-192) and their running counts
+    struct PairRef { int set, pair; };
+    vector<vector<PairRef>> participating(n_total);
+    vector<vector<int>> pair_success(sets.size()), pair_attempt(sets.size());
+    for (size_t k = 0; k < sets.size(); ++k) {
+        pair_success[k].assign(sets[k].size() / 2, 0); pair_attempt[k].assign(sets[k].size() / 2, 0);
+        for (size_t i = 0; i < sets[k].size() / 2; ++i) { participating[sets[k][2 * i]].push_back(PairRef{(int)k, (int)i}); participating[sets[k][2 * i + 1]].push_back(PairRef{(int)k, (int)i}); }
+    }
+    if (write_output) for (int ns = 0; ns < n_system; ++ns) {
+        vector<int> partners;
+        for (auto& pr : participating[sys_lo + ns]) { const int a = sets[pr.set][2 * pr.pair], b = sets[pr.set][2 * pr.pair + 1]; partners.push_back(a != sys_lo + ns ? a : b); }
+        loggers[ns].open(files[ns], n_atom, invocation, !sets.empty(), have_pivot, have_jump, partners);
+    }
+    vector<vector<LogValue>> node_loggers(n_group);      // per engine, in node order, filtered by --log-level (state_logger.h:17-27)
+    bool any_node_logger = false;
     if (write_output) {
-        for (auto& n : e->nodes) {
-            vector<LogValue> v; n.computation->add_loggers(v);
-            for (auto& l : v) if (l.level <= log_level) node_loggers.push_back(l);
-        }
-        for (int ns = 0; ns < n_system; ++ns) loggers[ns].add_node_loggers(node_loggers);
+        for (int g = 0; g < n_group; ++g)
+            for (auto& n : engines[g]->nodes) {
+                vector<LogValue> v; n.computation->add_loggers(v);
+                for (auto& l : v) if (l.level <= log_level) { node_loggers[g].push_back(l); any_node_logger = true; }
+            }
+        for (int ns = 0; ns < n_system; ++ns) loggers[ns].add_node_loggers(node_loggers[group_of[ns]]);
     }
     vector<int> replica_index(n_total);     // by GLOBAL slot; every rank keeps the whole table (the verdicts are identical everywhere)
     for (int ns = 0; ns < n_total; ++ns) replica_index[ns] = ns;
@@ -389,29 +447,36 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // pivots before the frame of the same round, never at t = 0 (main.cpp:626-630)
         if (have_mc && rnd && !(rnd % mc_rounds)) if (upside_hip_mc_step(e, rnd)) throw string(upside_hip_last_error());
         if (!(rnd % frame_rounds)) {   // main.cpp:633-654: recenter, energy, log, print -- before the round is integrated
-            if (recenter) upside_hip_recenter_axes(e, xy_recenter_only);
-            if (upside_hip_compute(e, energy.data(), nullptr)) throw string(upside_hip_last_error());
-            if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error());
+            if (recenter) for (auto* x : engines) upside_hip_recenter_axes(x, xy_recenter_only);
+            fleet_compute(energy.data());
+            if (n_group == 1) { if (upside_hip_get_pos(e, frame_pos.data()) || upside_hip_get_mom(e, frame_mom.data())) throw string(upside_hip_last_error()); }
+            else for (int g = 0; g < n_group; ++g) {
+                vector<float> gp(members[g].size() * (size_t)n_atom * 3), gm(gp.size());
+                if (upside_hip_get_pos(engines[g], gp.data()) || upside_hip_get_mom(engines[g], gm.data())) throw string(upside_hip_last_error());
+                from_group(g, gp, frame_pos.data(), (size_t)n_atom * 3); from_group(g, gm, frame_mom.data(), (size_t)n_atom * 3);
+            }
             if (have_pivot && upside_hip_mc_stats(e, 0, mc_stats.data(), 1)) throw string(upside_hip_last_error());   // reset per frame
             if (have_jump && upside_hip_mc_stats(e, 1, mcj_stats.data(), 1)) throw string(upside_hip_last_error());
-            if (write_output && !node_loggers.empty()) {
-                for (auto& n : e->nodes) n.computation->begin_log_frame();
-                for (int ns = 0; ns < n_system; ++ns) loggers[ns].sample_node_loggers(ns);
-                for (auto& n : e->nodes) n.computation->end_log_frame();
+            if (write_output && any_node_logger) {
+                for (auto* x : engines) for (auto& n : x->nodes) n.computation->begin_log_frame();
+                for (int ns = 0; ns < n_system; ++ns) loggers[ns].sample_node_loggers(local_of[ns]);
+                for (auto* x : engines) for (auto& n : x->nodes) n.computation->end_log_frame();
             }
             for (int ns = 0; ns < n_system; ++ns) {
                 const float* x = &frame_pos[(size_t)ns * n_atom * 3]; const float* m = &frame_mom[(size_t)ns * n_atom * 3];
                 double sum_kin = 0.;
                 for (int i = 0; i < n_atom * 3; ++i) sum_kin += (double)(m[i] * m[i]);
-                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[sys_lo + ns], &mc_stats[(size_t)ns * 2], &mcj_stats[(size_t)ns * 2]);
+                vector<int> cum;
+                for (auto& pr : participating[sys_lo + ns]) { cum.push_back(pair_success[pr.set][pr.pair]); cum.push_back(pair_attempt[pr.set][pr.pair]); }
+                if (write_output) loggers[ns].sample(x, (0.5 / n_atom) * sum_kin, (double)energy[ns], (double)(3 * dt * (float)rnd) /* fp32 product as main.cpp:540 */, (double)temps[ns], replica_index[sys_lo + ns], &mc_stats[(size_t)ns * 2], &mcj_stats[(size_t)ns * 2], cum.data());
                 double com[3] = {0, 0, 0}, rg = 0.;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) com[d] += x[i * 3 + d];
                 for (int d = 0; d < 3; ++d) com[d] /= n_atom;
                 for (int i = 0; i < n_atom; ++i) for (int d = 0; d < 3; ++d) rg += (x[i * 3 + d] - com[d]) * (x[i * 3 + d] - com[d]);
                 if (verbose) {   // the line of main.cpp:649-654, hydrogen-bond count included (get_n_hbond, main.cpp:28-35)
                     double n_hbond = 0.;
-                    for (auto& n : e->nodes) if (dynamic_cast<HBondCounter*>(n.computation.get())) {
-                        auto v = n.computation->get_param_deriv(ns);      // d(potential)/d(E_protein) = the count
+                    for (auto& n : engines[group_of[ns]]->nodes) if (dynamic_cast<HBondCounter*>(n.computation.get())) {
+                        auto v = n.computation->get_param_deriv(local_of[ns]);      // d(potential)/d(E_protein) = the count
                         if (!v.empty()) n_hbond += v[0];
                     }
                     printf("%*.0f / %*.0f elapsed %2i system %.2f temp %5.1f hbonds, Rg %5.1f A, potential % 8.2f\n", 8, rnd * 3 * double(dt), 8,
@@ -430,7 +495,10 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                     const double r = sqrt(T0) * (1. - fraction) + sqrt(T1) * fraction;
                     temps[ns] = (float)(r * r);
                 }
-                if (upside_hip_set_temperature(e, temps.data())) throw string(upside_hip_last_error());
+                for (int g = 0; g < n_group; ++g) {
+                    auto gt = n_group == 1 ? temps : to_group(g, temps.data(), 1);
+                    if (upside_hip_set_temperature(engines[g], gt.data())) throw string(upside_hip_last_error());
+                }
             }
             next = min<uint64_t>(next, (rnd / thermo_rounds + 1) * (uint64_t)thermo_rounds);
         }
@@ -438,7 +506,11 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // (main.cpp:665: nr > last_start), so with an interval of one round it attempts every second round
         if (replica_rounds) next = min<uint64_t>(next, ((sync_start + 2 + replica_rounds - 1) / replica_rounds) * (uint64_t)replica_rounds);
         if (have_mc) next = min<uint64_t>(next, (rnd / mc_rounds + 1) * (uint64_t)mc_rounds);
-        if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error());
+        if (n_group == 1) { if (upside_hip_run_md(e, (int)(next - rnd))) throw string(upside_hip_last_error()); }
+        else {      // the engines run side by side on their own streams
+            for (auto* x : engines) x->run_steps(3 * (int)(next - rnd));
+            for (auto* x : engines) x->check_device_errors();
+        }
         rnd = next;
         const bool at_sync = replica_rounds && (rnd == n_round || rnd == ((sync_start + 2 + replica_rounds - 1) / replica_rounds) * (uint64_t)replica_rounds);
         if (at_sync) sync_start = rnd;
@@ -447,7 +519,20 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             for (size_t k = 0; k < sets.size(); ++k) {
                 vector<int> acc(sets[k].size() / 2 + 1);
                 // one force evaluation per attempt: the later sets see the energies the accepted pairs traded
-                if (use_comm) {     // global indices; energies all-gathered, verdicts on the device, straddling pairs over RCCL
+                if (n_group > 1) {     // several Hamiltonians: the reference's own procedure (main.cpp:251-273), two energy passes per set
+                    const int np = (int)sets[k].size() / 2;
+                    auto log_boltzmann = [&]() { vector<float> en(n_system), lb(n_system); fleet_compute(en.data()); for (int i = 0; i < n_system; ++i) lb[i] = -(1.f / temps[i]) * en[i]; return lb; };
+                    auto coord_swap = [&](int s1, int s2) {
+                        if (upside_hip_swap_between(engines[group_of[s1]], local_of[s1], engines[group_of[s2]], local_of[s2])) throw string(upside_hip_last_error()); };
+                    const auto old_lb = log_boltzmann();
+                    for (int i = 0; i < np; ++i) coord_swap(sets[k][2 * i], sets[k][2 * i + 1]);
+                    const auto new_lb = log_boltzmann();
+                    vector<float> diff(np);
+                    for (int i = 0; i < np; ++i) { const int s1 = sets[k][2 * i], s2 = sets[k][2 * i + 1]; diff[i] = (new_lb[s1] + new_lb[s2]) - (old_lb[s1] + old_lb[s2]); }
+                    if (upside_replica_decide_lboltz(np, diff.data(), base_seed, rnd, draw, acc.data())) throw string(upside_hip_last_error());
+                    draw = acc.back();
+                    for (int i = 0; i < np; ++i) if (!acc[i]) coord_swap(sets[k][2 * i], sets[k][2 * i + 1]);      // a rejected swap is reversed
+                } else if (use_comm) {     // global indices; energies all-gathered, verdicts on the device, straddling pairs over RCCL
                     if (upside_hip_comm_replica_swap(e, (int)sets[k].size() / 2, sets[k].data(), base_seed, rnd, k == 0, acc.data()))
                         throw string(upside_hip_last_error());
                 } else {
@@ -456,13 +541,13 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                     draw = acc.back();
                 }
                 for (size_t i = 0; i < sets[k].size() / 2; ++i) {
-                    n_attempt[k]++; n_success[k] += acc[i];
+                    n_attempt[k]++; n_success[k] += acc[i]; pair_attempt[k][i]++; pair_success[k][i] += acc[i];
                     if (acc[i]) swap(replica_index[sets[k][2 * i]], replica_index[sets[k][2 * i + 1]]);
                 }
             }
         }
     }
-    e->sync();
+    for (auto* x : engines) x->sync();
     for (auto& lg : loggers) lg.close();          // buffered frames reach the files also after an early stop (and before the communicator goes)
     if (use_comm) upside_hip_comm_free(e);
     stop_signal = g_received_signal;

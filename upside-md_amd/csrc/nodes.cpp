@@ -925,7 +925,7 @@ RegisterNodeType<ZFlatBottom, 1> z_flat_bottom_node("z_flat_bottom");
 
 // contact: sidechain_radial.cpp:139-205
 struct ContactEnergy : public PotentialNode {
-    int n_contact; CoordNode& bead_pos; DevBuf<int> id; DevBuf<float> par; int src;
+    int n_contact; CoordNode& bead_pos; DevBuf<int> id; DevBuf<float> par; int src; vector<int> host_id;
     ContactEnergy(DeviceCtx* c, hid_t_compat grp, CoordNode& bead_pos_) : PotentialNode(c), bead_pos(bead_pos_) {
         check_elem_width_lower_bound(bead_pos, 3);
         vector<hsize_t> dims;
@@ -940,9 +940,18 @@ struct ContactEnergy : public PotentialNode {
             const float scale = 1.f / width[i];
             p[(size_t)i * 4] = en[i]; p[(size_t)i * 4 + 1] = dist[i]; p[(size_t)i * 4 + 2] = scale; p[(size_t)i * 4 + 3] = dist[i] + 1.f / scale;   // :171
         }
-        id.upload(ids); par.upload(p);
+        id.upload(ids); par.upload(p); host_id = ids;
         src = bead_pos.scatter.add_source(n_contact, 2, 3, ids);
         alloc_terms(n_contact);
+    }
+    void add_loggers(vector<LogValue>& out) override {   // sidechain_radial.cpp:171-183: every contact's energy, half to each of its two beads
+        LogValue l; l.name = "contact_energy"; l.dims = {(size_t)bead_pos.n_elem};
+        l.fill = [this](int sys, float* b) {
+            fill_n(b, bead_pos.n_elem, 0.f);
+            auto t = sys_slice(pot_terms, sys, (size_t)n_contact);        // of the frame's energy evaluation (zero beyond the cutoff, as the sigmoid is)
+            for (int nc = 0; nc < n_contact; ++nc) { b[host_id[nc * 2]] += 0.5f * t[nc]; b[host_id[nc * 2 + 1]] += 0.5f * t[nc]; }
+        };
+        out.push_back(l);
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_contact(&ctx->L, bead_pos.coord(), id.p, par.p, n_contact, bead_pos.scatter.source_ptr(src), bead_pos.scatter.arena_size,

@@ -37,12 +37,31 @@ __device__ __forceinline__ void lds_add_fixed22(unsigned long long* p, float v) 
     __hip_atomic_fetch_add(p, to_fixed22(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// the far-away dummy element behind the real rows of a staged side: finite everywhere in the functors, beyond every cutoff
-__device__ __forceinline__ void stage_sentinel(float* lds_rows, int n, float aux6, float aux7) {
-    if (threadIdx.x < 8) {
-        const int c = threadIdx.x;
-        lds_rows[n * 8 + c] = c < 3 ? 1.0e4f : (c == 3 ? 1.f : (c == 6 ? aux6 : (c == 7 ? aux7 : 0.f)));
+// Staged elements of the packed passes: TWO 16-byte planes per side -- [0, 4 n') the words 0..3 of every row (position, first
+// direction component), [4 n', 8 n') the words 4..7 (rest of the direction, the two metadata words), n' = n + 1 rows: the last
+// one is the SENTINEL, a far-away dummy element that is finite everywhere in the functors and beyond every cutoff.
+// A ds_read_b128 is served in lane groups of 16, one 16-byte slot of the 256-byte bank row per lane: with 32-byte rows the
+// first halves of all rows share the 8 even slots (>= 2-way conflicts for any 16 partners), with 16-byte planes row j sits in
+// slot j mod 16 and the consecutive partners a row group reads are conflict free.
+__device__ __forceinline__ void stage_rows_planes(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim,
+                                                  const int* __restrict__ meta1, const int* __restrict__ meta0,
+                                                  const float* __restrict__ sens, int sens_stride, float sentinel6, float sentinel7) {
+    const float* base = node.out + (size_t)s * node.n_elem * node.stride;
+    const int np = n + 1;
+    for (int t = threadIdx.x; t < np * 8; t += blockDim.x) {
+        const int i = t >> 3, c = t & 7;
+        float v = 0.f;
+        if (i == n) v = c < 3 ? 1.0e4f : (c == 3 ? 1.f : (c == 6 ? sentinel6 : (c == 7 ? sentinel7 : 0.f)));
+        else if (c < dim) v = base[(size_t)loc[i] * node.stride + c];
+        else if (c == 7 && meta1) v = __int_as_float(meta1[i]);
+        else if (c == 6 && sens) v = sens[(size_t)i * sens_stride];
+        else if (c == 6 && meta0) v = __int_as_float(meta0[i]);
+        lds[(c >> 2) * np * 4 + i * 4 + (c & 3)] = v;
     }
+}
+__device__ __forceinline__ void load_row8_planes(float* x, const float* planes, int np, int j) {
+    const float4 lo = *(const float4*)(planes + j * 4), hi = *(const float4*)(planes + (np + j) * 4);
+    x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
 }
 
 // one cubic piece for two pairs: value and slope of  c0 + c1 y + c2 y^2 + c3 y^3  with 5 packed FMAs
