@@ -295,9 +295,13 @@ def main():
             d = dict(bound='hbm', kernel=r[0], achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                      frac=achieved / HBM_PEAK_GBS, traffic=traffic, avg_launch_ms=avg_ms,
                      algorithmic_bytes_per_launch=bytes_per_launch)
-            if traffic is not None:      # the rate the counters saw, beside the algorithmic one
+            d['frac_model'] = d['frac']      # SURVEY 8d bytes (every sweep's re-read of the pair matrices counted) / time / peak
+            if traffic is not None:      # the rate the counters saw is the headline: achieved = HBM bytes of the PMC passes / time
                 d['traffic_source'] = PROFILE_NOTE
                 d['frac_counter'] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                d['achieved_model'] = d['achieved']
+                d['achieved'] = traffic / (avg_ms * 1e-3) / 1e9
+                d['frac'] = d['frac_counter']
             elif _TABLE_STATE.get('stale'):
                 d['traffic_source'] = 'profiles/hbm_traffic.json is STALE: the kernel sources changed after its PMC passes (rerun tools/refresh_profiles.sh pmc)'
             return d
@@ -306,28 +310,42 @@ def main():
         dom = max(rows, key=lambda r: r[1])
         roofline = entry(dom)
         # The interaction-graph kernel north_star names: the side-chain gradient pass.  It is bound by VALU issue, not by HBM
-        # (DESIGN.md section 3), so its roofline is instructions: achieved = wave-level VALU instructions per launch (PMC
-        # count of the committed profile) / the launch time measured here; peak = the issue rate a dependent scalar fp32 chain
-        # reaches on THIS device in the same launch shape (upside_hip_calibrate_valu, a known-instruction-count kernel run
-        # now).  The HBM view of the same kernel is kept under "hbm".
+        # (DESIGN.md section 3), so its roofline is arithmetic: achieved = pair evaluations of the launch (counted by the
+        # engine) x 350 flop per evaluation / the launch time measured here, against the 157.3 TFLOP/s of the
+        # fp32 vector unit WITH packed issue (MI355X_MICROARCH.md).  Beside it the instruction view: wave-level VALU
+        # instructions per launch (PMC count of the committed profile, when it belongs to these sources) / the same time,
+        # against the issue rates a fp32 chain reaches on THIS device in the same launch shape (upside_hip_calibrate_valu, a
+        # known-instruction-count kernel run now): `peak_scalar` for a dependent scalar chain, `peak` (= the packed ceiling,
+        # four independent chains compiled to v_pk_fma_f32) for packed issue.  The HBM view of the kernel is kept under "hbm".
         ig_rows = [r for r in rows if r[0].startswith('igraph')]
         ig = next((r for r in ig_rows if r[0] == 'igraph_bwd:rotamer'), max(ig_rows, key=lambda r: r[1]))
         rates = (ct.c_double * 2)()
         check(c, c.upside_hip_calibrate_valu(rates), 'calibrate_valu')
-        # instructions of this launch = pair evaluations of this launch (counted by the engine) x the instructions one
-        # evaluation costs, the latter from the PMC pass of the default workload (SQ_INSTS_VALU / pair evaluations there)
         per_pair = profiled(ig[0], 'syn300_10A', 4096, 'valu_insts_per_pair')
         pairs = ig[4] / ig[2]
         insts = per_pair * pairs if per_pair else None
         ig_ms = ig[1] / ig[2]
+        FLOP_PER_PAIR, FP32_VECTOR_PEAK_TF = 350.0, 157.3
+        achieved_tf = pairs * FLOP_PER_PAIR / (ig_ms * 1e-3) / 1e12
         achieved_valu = insts / (ig_ms * 1e-3) / 1e9 if insts else None
-        roofline['igraph'] = dict(bound='valu', kernel=ig[0], achieved=achieved_valu, peak=rates[0] / 1e9, unit='G wave-instr/s',
-                                  frac=(achieved_valu / (rates[0] / 1e9)) if achieved_valu else None, avg_launch_ms=ig_ms,
-                                  valu_insts_per_launch=insts, pair_evaluations_per_launch=pairs, valu_insts_per_pair=per_pair,
-                                  insts_source=('pair evaluations counted in this run x instructions per evaluation ' + PROFILE_NOTE) if insts else None,
-                                  peak_note='dependent scalar fp32 FMA chain, one 1024-lane workgroup per CU, measured in this run; '
-                                            'four independent chains per lane (packed issue) reach peak_ilp4',
-                                  peak_ilp4=rates[1] / 1e9, hbm=entry(ig))
+        isa = None
+        try:      # static share of packed instructions in the kernels' loop bodies (tools/isa_summary.py, build container)
+            with open(os.path.join(ROOT, 'profiles', 'isa_pk_share.json')) as f:
+                isa = json.load(f)
+        except (OSError, ValueError):
+            pass
+        roofline['igraph'] = dict(bound='valu', kernel=ig[0], achieved=achieved_tf, peak=FP32_VECTOR_PEAK_TF, unit='TFLOP/s',
+                                  frac=achieved_tf / FP32_VECTOR_PEAK_TF, flop_per_pair=FLOP_PER_PAIR, avg_launch_ms=ig_ms,
+                                  pair_evaluations_per_launch=pairs,
+                                  issue=dict(achieved=achieved_valu, unit='G wave-instr/s', peak=rates[1] / 1e9, peak_scalar=rates[0] / 1e9,
+                                             frac=(achieved_valu / (rates[1] / 1e9)) if achieved_valu else None,
+                                             frac_of_scalar_ceiling=(achieved_valu / (rates[0] / 1e9)) if achieved_valu else None,
+                                             valu_insts_per_launch=insts, valu_insts_per_pair=per_pair,
+                                             insts_source=('pair evaluations counted in this run x instructions per evaluation ' + PROFILE_NOTE) if insts
+                                             else ('stale or missing profiles/hbm_traffic.json' if _TABLE_STATE.get('stale') else None),
+                                             peak_note='peak = four independent fp32 FMA chains per lane (v_pk_fma_f32), peak_scalar = one dependent '
+                                                       'chain; one 1024-lane workgroup per CU, both measured in this run'),
+                                  packed_instruction_share=isa, hbm=entry(ig))
         roofline['kernels'] = {r[0]: dict(avg_ms=r[1] / r[2], launches=r[2],
                                           GBps=(r[3] / r[2]) / (r[1] / r[2] * 1e-3) / 1e9 if r[3] else None,
                                           pair_evaluations=(r[4] / r[2]) if r[4] else None) for r in rows}

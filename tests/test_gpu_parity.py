@@ -895,7 +895,7 @@ def test_bench_contract(tmp_path):
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['achieved'] > 0 and 'igraph' in r and r['igraph']['achieved'] > 0
+    assert r['achieved'] > 0 and 'igraph' in r and r['igraph']['achieved'] > 0 and r['igraph']['unit'] == 'TFLOP/s'
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k

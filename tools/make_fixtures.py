@@ -32,12 +32,12 @@ HBOND = float(open(os.path.join(PARAM, 'ff_1', 'hbond')).read())
 FIXTURES = {
     'trpcage20_7A': (cfg.TRP_CAGE, '7A', 'ff_1/sidechain.h5', 9.0, 11, True),
     'proteinG56_7A': (cfg.PROTEIN_G, '7A', 'ff_1/sidechain.h5', 12.5, 12, True),
-    'syn150_10A': (150, '10A', 'packing/sidechain_10A_cutoff.h5', 19.7, 13, False),   # Rg ~ 14.8 A; 18.5 gave 13.5: steric walls ill-conditioned in fp32
+    'syn150_10A': (150, '10A', 'packing/sidechain_10A_cutoff.h5', 19.7, 13, False),
     'syn300_10A': (300, '10A', 'packing/sidechain_10A_cutoff.h5', 22.0, 14, False),
     'syn300_7A': (300, '7A', 'ff_1/sidechain.h5', 22.0, 14, False),
 }
 
-TARGET_RG = {'syn150_10A': 14.8}      # fixtures taken from the collapse trajectory at a target radius of gyration
+WELL_CONDITIONED = {'syn150_10A'}      # fixtures chosen among the relaxed frames of the compaction run (see make())
 
 NODES = ['rama_coord', 'affine_alignment', 'infer_H_O', 'placement_fixed_point_vector_only',
          'placement_fixed_point_vector_only_CB', 'placement_fixed_point_vector_scalar', 'placement_scalar',
@@ -189,16 +189,35 @@ def make(name):
         tmp = '/tmp/_compact_%s.up' % name
         cfg.write_config(tmp, fasta, pos0, cavity_radius=r_cavity, **kw)
         exe = os.path.join(REF, 'upside_' + variant)
-        target_rg = TARGET_RG.get(name)
-        subprocess.check_call([exe, '--duration', '200', '--frame-interval', '2' if target_rg else '20', '--temperature', '0.9',
+        well = name in WELL_CONDITIONED
+        subprocess.check_call([exe, '--duration', '200', '--frame-interval', '2' if well else '20', '--temperature', '0.9',
                                '--seed', '1', '--disable-recentering', tmp], stdout=subprocess.DEVNULL)
-        if target_rg:      # the frame of the collapse whose radius of gyration is closest to the target (2.2 N^0.38 A):
-            with pkg.h5lite.open_file(tmp) as f:       # the fully collapsed end state sits deep in its steric walls
+        if well:
+            # A RELAXED frame (second half of the run: the collapse is over, bonded terms are thermal) on which the reference
+            # agrees with ITSELF: its -O1 build against its -O3 -ffast-math build (tools/build_ref_O1.sh) within 4e-6 relative RMS
+            # of the forces.  The equilibrium ensemble of this chain (Rg 13.0-13.8 A) also holds frames whose steric walls are
+            # ill-conditioned in fp32 (the fixture of rounds 1-2 was one: 4.5e-5); among the well-conditioned ones the most
+            # expanded is taken.  (SURVEY.md 8d's 14.8 A is not an equilibrium size of this chain at T = 0.9: a frame of that
+            # size exists only mid-collapse, with 2000 energy units of bonded strain.)
+            with pkg.h5lite.open_file(tmp) as f:
                 frames = f.read('output/pos', 'f4')[:, 0]
-            rgs = np.array([rg(x) for x in frames])
-            below = np.nonzero(rgs <= target_rg * 1.15)[0]
-            k = below[np.argmin(np.abs(rgs[below] - target_rg))]
-            print('%s: frame %d of %d, Rg %.2f (last frame %.2f)' % (name, k, len(frames), rgs[k], rgs[-1]))
+            o3 = pkg.UpsideLibrary(os.path.join(REF, 'libupside_%s.so' % variant))
+            o1 = pkg.UpsideLibrary('/tmp/refO1_%s/libupside_O1.so' % variant)
+            cand = []
+            probe = '/tmp/_probe_%s.up' % name
+            for k in range(len(frames) // 2, len(frames)):
+                x = frames[k].astype('f8'); x -= x.mean(axis=0)
+                cfg.write_config(probe, fasta, x, **kw)
+                d = []
+                for lib in (o3, o1):
+                    up = pkg.Upside(probe, library=lib); d.append(up.deriv(up.initial_pos.copy())); up.close()
+                floor = float(np.sqrt(((d[0] - d[1]) ** 2).sum() / (d[0] ** 2).sum()))
+                cand.append((k, rg(x), floor))
+            os.remove(probe)
+            good = [c for c in cand if c[2] < 4e-6] or [min(cand, key=lambda c: c[2])]
+            k, r, fl = max(good, key=lambda c: c[1])
+            print('%s: frame %d of %d (t = %g): Rg %.2f, reference-vs-reference force deviation %.1e; %d of %d relaxed frames below 4e-6, median %.1e'
+                  % (name, k, len(frames), 2. * k, r, fl, len([c for c in cand if c[2] < 4e-6]), len(cand), float(np.median([c[2] for c in cand]))))
             pos = frames[k].astype('f8')
         else:
             pos = cfg.read_last_frame(tmp).astype('f8')

@@ -116,12 +116,12 @@ __device__ __forceinline__ void load_elem(float* x, const upk_coord_t& node, int
 // right here (x, y, z and the element id in the 4th word), so the rebuild streams one float4 array per side.
 __global__ void k_pairlist_check(upk_igraph_t G) {
     __shared__ int moved;
+    __shared__ float top[2][4];              // per wavefront: the largest and second largest squared displacement
     const int s = blockIdx.y;
     if (threadIdx.x == 0) moved = 0;
     __syncthreads();
-    const float lim = sqr(0.5f * (G.cache_cutoff - G.cutoff));
     const int n_tot = G.symmetric ? G.n1 : G.n1 + G.n2;
-    bool m = false;
+    float d1 = 0.f, d2 = 0.f;                // this lane's two largest squared displacements
     for (int e = threadIdx.x; e < n_tot; e += blockDim.x) {
         const bool side1 = e < G.n1;
         const int i = side1 ? e : e - G.n1;
@@ -130,11 +130,37 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
         const float* c = (side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + (size_t)i * 4;
         const float x0 = x[0], x1 = x[1], x2 = x[2];
         const float dx = x0 - c[0], dy = x1 - c[1], dz = x2 - c[2];
-        m |= lim < dx * dx + dy * dy + dz * dz;
+        const float dd = dx * dx + dy * dy + dz * dz;
+        d2 = fmaxf(d2, fminf(d1, dd)); d1 = fmaxf(d1, dd);
         // this step's positions, packed: what upk_pairlist_refine tests against the cutoff (the same bits the pair passes read)
         ((float4*)(side1 ? G.cur_pos1 + (size_t)s * G.n1 * 4 : G.cur_pos2 + (size_t)s * G.n2 * 4))[i] = make_float4(x0, x1, x2, 0.f);
     }
-    if (m) moved = 1;   // benign race: every writer stores 1
+    // A cached list stays valid while no PAIR of elements has approached by more than the margin: |dr_i| + |dr_j| <= margin for
+    // the two largest displacements of the system.  (The reference rebuilds when ANY element has moved margin / 2,
+    // interaction_graph.h:57-90 -- sufficient, not necessary; the in-range pairs do not depend on when the cache is rebuilt, and
+    // one fast-moving bead no longer forces the rebuild that two would.)
+    {
+        // top two of the wavefront, then of the workgroup (4 wavefronts)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o1 = __shfl_xor(d1, off, UP_WAVE), o2 = __shfl_xor(d2, off, UP_WAVE);
+            const float n1 = fmaxf(d1, o1), n2 = fmaxf(fminf(d1, o1), fmaxf(d2, o2));
+            d1 = n1; d2 = n2;
+        }
+        if ((threadIdx.x & 63) == 0) { top[0][threadIdx.x >> 6] = d1; top[1][threadIdx.x >> 6] = d2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+                const float o1 = top[0][w], o2 = top[1][w];
+                const float n1 = fmaxf(a, o1), n2 = fmaxf(fminf(a, o1), fmaxf(b, o2));
+                a = n1; b = n2;
+            }
+            // (first build: the reference positions sit at 1e10, a is huge)  sqrt in fp32, compared with a slightly tightened margin
+            const float margin = G.cache_cutoff - G.cutoff;
+            if (sqrtf(a) + sqrtf(b) > 0.999f * margin) moved = 1;
+        }
+    }
     __syncthreads();
     if (moved) {
         for (int e = threadIdx.x; e < n_tot; e += blockDim.x) {
@@ -294,6 +320,19 @@ extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_
 #ifndef PLR_AHEAD
 #define PLR_AHEAD 4
 #endif
+// squared distances of two pairs at once, every operation rounded separately (no contraction): the same bits as dist2_exact,
+// from v_pk_add_f32 / v_pk_mul_f32 (3 + 3 + 2 packed instructions for the two candidates of a lane)
+typedef float plr_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ plr_v2 dist2_exact2(plr_v2 ax, plr_v2 ay, plr_v2 az, plr_v2 bx, plr_v2 by, plr_v2 bz) {
+#pragma clang fp contract(off)
+    const plr_v2 dx = ax - bx, dy = ay - by, dz = az - bz;
+    const plr_v2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const plr_v2 s = xx + yy;
+    return s + zz;
+}
+// TWO rows per wavefront trip (rows 2a and 2a+1 of the wavefront's run: one candidate of each per lane), so that the distance
+// arithmetic issues packed and the per-trip bookkeeping (loop control, ballots, list-length broadcasts) is shared: the kernel
+// is bound by instruction issue, not by the 4 bytes it reads per cached pair.
 template <bool SYM>
 __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, int side, int rows_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float plr_lds[];
@@ -323,46 +362,47 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     const float4 my_x = have ? mine[r0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int my_cnt = have ? cnt_arr[r0 + lane] : 0;
     int my_n = 0, my_lo = 0;                                      // results of row r0 + lane
-    int w0[PLR_AHEAD];                                            // first 64 list words of the next PLR_AHEAD rows
-#pragma unroll
-    for (int a = 0; a < PLR_AHEAD; ++a) {
-        const int cnt = __builtin_amdgcn_readlane(my_cnt, a);
-        w0[a] = (r0 + a < r1 && lane < cnt) ? nbr_base[(size_t)(r0 + a) * cap + lane] : 0;
-    }
-    for (int rb = r0; rb < r1; rb += PLR_AHEAD) {
-        int wcur[PLR_AHEAD];
-#pragma unroll
-        for (int a = 0; a < PLR_AHEAD; ++a) wcur[a] = w0[a];
-#pragma unroll
-        for (int a = 0; a < PLR_AHEAD; ++a) {                      // prefetch the block after this one
-            const int r = rb + PLR_AHEAD + a;
-            const int cnt = r < r1 ? __builtin_amdgcn_readlane(my_cnt, (r - r0) & 63) : 0;
-            w0[a] = lane < cnt ? nbr_base[(size_t)r * cap + lane] : 0;
+    auto bcast = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    // the first 64 list words of the next row pair are fetched while this pair is tested
+    int nA = 0, nB = 0;
+    { const int cA = __builtin_amdgcn_readlane(my_cnt, 0), cB = r0 + 1 < r1 ? __builtin_amdgcn_readlane(my_cnt, 1) : 0;
+      if (lane < cA) nA = nbr_base[(size_t)r0 * cap + lane];
+      if (lane < cB) nB = nbr_base[(size_t)(r0 + 1) * cap + lane]; }
+    for (int ra = r0; ra < r1; ra += 2) {
+        const int la = ra - r0, lb = la + 1;
+        const bool hasB = ra + 1 < r1;
+        const int cntA = __builtin_amdgcn_readlane(my_cnt, la), cntB = hasB ? __builtin_amdgcn_readlane(my_cnt, lb & 63) : 0;
+        int wA = nA, wB = nB;
+        nA = 0; nB = 0;
+        if (ra + 2 < r1) {
+            const int cA = __builtin_amdgcn_readlane(my_cnt, (la + 2) & 63), cB = ra + 3 < r1 ? __builtin_amdgcn_readlane(my_cnt, (la + 3) & 63) : 0;
+            if (lane < cA) nA = nbr_base[(size_t)(ra + 2) * cap + lane];
+            if (lane < cB) nB = nbr_base[(size_t)(ra + 3) * cap + lane];
         }
-#pragma unroll
-        for (int a = 0; a < PLR_AHEAD; ++a) {
-            const int row = rb + a;
-            if (row >= r1) break;
-            const int rl = row - r0;
-            const int cnt = __builtin_amdgcn_readlane(my_cnt, rl);
-            const float xx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.x), rl)), xy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.y), rl)),
-                        xz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_x.z), rl));
-            const int* nbr = nbr_base + (size_t)row * cap;
-            int* out = hit_base + (size_t)row * cap;
-            int n = 0, lo = 0;
-            for (int k0 = 0; k0 < cnt; k0 += 64) {
-                const int k = k0 + lane;
-                const int w = k0 == 0 ? wcur[a] : (k < cnt ? nbr[k] : 0);
-                bool hit = false;
-                const int j = w & jmask;
-                if (k < cnt) { const float4 y = oth[j]; hit = dist2_exact(xx, xy, xz, y.x, y.y, y.z) < cut2; }
-                const unsigned long long m = __ballot(hit);
-                if (hit) out[n + __popcll(m & ((1ull << lane) - 1ull))] = w;
-                n += __popcll(m);
-                if (SYM) lo += __popcll(__ballot(hit && j < row));
-            }
-            if (lane == rl) { my_n = n; my_lo = lo; }
+        plr_v2 xx, xy, xz;
+        xx.x = bcast(my_x.x, la); xy.x = bcast(my_x.y, la); xz.x = bcast(my_x.z, la);
+        xx.y = bcast(my_x.x, lb & 63); xy.y = bcast(my_x.y, lb & 63); xz.y = bcast(my_x.z, lb & 63);
+        const int* nbrA = nbr_base + (size_t)ra * cap; const int* nbrB = nbrA + cap;
+        int* outA = hit_base + (size_t)ra * cap; int* outB = outA + cap;
+        int na = 0, nb = 0, loa = 0, lob = 0;
+        const int cmax = cntA > cntB ? cntA : cntB;
+        for (int k0 = 0; k0 < cmax; k0 += 64) {
+            const int k = k0 + lane;
+            if (k0) { wA = k < cntA ? nbrA[k] : 0; wB = k < cntB ? nbrB[k] : 0; }
+            const int jA = wA & jmask, jB = wB & jmask;
+            const float4 yA = oth[k < cntA ? jA : 0], yB = oth[k < cntB ? jB : 0];
+            plr_v2 yx, yy, yz; yx.x = yA.x; yx.y = yB.x; yy.x = yA.y; yy.y = yB.y; yz.x = yA.z; yz.y = yB.z;
+            const plr_v2 d2 = dist2_exact2(xx, xy, xz, yx, yy, yz);
+            const bool hitA = k < cntA && d2.x < cut2, hitB = k < cntB && d2.y < cut2;
+            const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (hitA) outA[na + __popcll(mA & below)] = wA;
+            if (hitB) outB[nb + __popcll(mB & below)] = wB;
+            na += __popcll(mA); nb += __popcll(mB);
+            if (SYM) { loa += __popcll(__ballot(hitA && jA < ra)); lob += __popcll(__ballot(hitB && jB < ra + 1)); }
         }
+        if (lane == la) { my_n = na; my_lo = loa; }
+        if (hasB && lane == lb) { my_n = nb; my_lo = lob; }
     }
     if (have) { hcnt[r0 + lane] = my_n; if (SYM && hlo) hlo[r0 + lane] = my_lo; }
 }

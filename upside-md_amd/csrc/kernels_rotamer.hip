@@ -99,7 +99,6 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
         const int s = fl[1 + fi];
         const unsigned char* mark = R.mark + (size_t)s * G.mark_stride;
-        int* slot_of = R.slot_of + (size_t)s * NN * NN;
         __syncthreads();                                     // LDS of the previous system is no longer read
         // ---- pack the marks: wave item = (row, word); 8 loads in flight per lane
         for (int item0 = wave * 8; item0 < NN * W; item0 += n_wave * 8) {
@@ -197,7 +196,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                     const int sl = lo ? p_lo++ : p_hi++;
                     const int nb = nrot[b];
                     if (sl < R.slot_cap) {
-                        slot_a[sl] = a; slot_b[sl] = b; slot_of[(size_t)a * NN + b] = sl; slot_of[(size_t)b * NN + a] = sl;
+                        slot_a[sl] = a; slot_b[sl] = b;
                         if (na == 1 && nb > 1) {
                             const int pos = rank_below(b, a);              // 1-state partners of b below a
                             if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
@@ -207,8 +206,40 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                             slot_off[sl * 2 + 1] = (bp_s[b] + kb * (nb == 6 ? 2 : 1)) * 4;
                             if (R.slot_row) { int* sr = R.slot_row + (size_t)s * R.slot_cap * 2; sr[sl * 2] = row_of(a) + k_multi; sr[sl * 2 + 1] = row_of(b) + kb; }
                         }
-                    } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
+                    }
                     if (na > 1) ++k_multi;
+                }
+            }
+        }
+        // ---- every cached bead pair remembers its slot, in the bits of its list word above the bead index (one 4-byte word per
+        // cached pair; the pair passes read nothing else).  The slot of the residue pair (a < b) follows from the same popcounts
+        // the numbering used -- first slot of a's "same class" / "higher class" run + partners of a in (a, b) of that run -- so
+        // no node x node table is written or gathered (round 2: a 4 NN^2-byte table per system and a kernel of its own).
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+            auto slot_of_pair = [&](int a, int b) {                  // a < b
+                const int na = nrot[a];
+                const int cend = na == 1 ? e1 : (na == 3 ? e3 : NN), first = na == 1 ? 0 : (na == 3 ? e1 : e3);
+                const bool lo = b < cend;
+                const int cl = lo ? slot_class(na, na) : (na == 1 ? CL1X : (na == 3 ? CL36 : CL66));
+                const int* rowx = lo ? row_lo : row_hi;
+                int sl = cls_lds[cl] + rowx[a] - (first < NN ? rowx[first] : 0);
+                for (int c = a >> 6; c <= (b >> 6); ++c) {             // + partners of a in (a, b) of b's run
+                    unsigned long long w = bits[a * W + c] & ~below(a + 1, c) & below(b, c);
+                    w &= lo ? below(cend, c) : ~below(cend, c);
+                    sl += __popcll(w);
+                }
+                return sl;
+            };
+            for (int row = wave; row < G.n1; row += n_wave) {
+                const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+                const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+                const int nr = R.bead_node[row];
+                for (int k = lane; k < cnt; k += 64) {
+                    const int j = G.nbr1[base + k];                  // freshly built: a bare bead index
+                    const int nj = R.bead_node[j];                   // (beads sorted by node: nr < nj; the configuration's own order: either)
+                    const int sl = slot_of_pair(nr < nj ? nr : nj, nr < nj ? nj : nr);
+                    G.nbr1[base + k] = j | ((sl < R.slot_cap ? sl : UPK_ROT_SLOT_NONE) << UPK_ROT_J_BITS);
                 }
             }
         }
@@ -221,34 +252,8 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     return launch_status();
 }
 
-// rebuild step 3: every cached bead pair remembers its slot, in the bits of its list word above the bead index
-// (one 4-byte word per cached pair instead of a second array; the pair passes read nothing else)
-__global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
-    const upk_igraph_t& G = R.G;
-    const int* fl = UPK_FLAG_LIST(G);
-    const int n_flagged = fl[0];
-    const int NN = R.n_node;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
-        const int s = fl[1 + fi];
-        const int* slot_of = R.slot_of + (size_t)s * NN * NN;
-        for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
-            const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
-            const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-            const int a = R.bead_node[row];
-            for (int k = lane; k < cnt; k += 64) {
-                const int j = G.nbr1[base + k];                  // freshly built: a bare bead index
-                const int sl = slot_of[a * NN + R.bead_node[j]];
-                G.nbr1[base + k] = j | ((sl < 0 ? UPK_ROT_SLOT_NONE : sl) << UPK_ROT_J_BITS);
-            }
-        }
-    }
-}
-extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    int blocks = (R->G.n1 + 3) / 4;
-    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(256), 0, ST(L), *R);
-    return launch_status();
-}
+// rebuild step 3 (every cached bead pair remembers its slot) is part of upk_rotamer_build_slots since round 3
+extern "C" int upk_rotamer_nbr_slots(const upk_launch_t*, const upk_rotamer_t*) { return 0; }
 
 // ------------------------------------------------------------------------------------------------
 // 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256)
@@ -551,7 +556,11 @@ extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_
     int tab_floats; size_t lds; dim3 grid, block;
     static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
     if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_ROT_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
-    if (rot_pair2_enabled()) {                     // packed passes (two partners per lane)
+    // (the packed form of THIS pass is opt-in: it is bound by its scattered pair-matrix stores, and 16 rows x 4 partners per
+    //  store instruction touch 1.7x the cache lines of 8 rows x 8 partners: 1.26 ms scalar, 1.45 ms packed at 4096 systems)
+    static int packed_energy = -1;
+    if (packed_energy < 0) { const char* e = getenv("UPSIDE_HIP_PAIR2_ENERGY"); packed_energy = (e && atoi(e)) ? 1 : 0; }
+    if (rot_pair2_enabled() && packed_energy) {
         for (int poly = no_poly ? 0 : 1; poly >= 0; --poly) {
             if (poly && !R->param_tri_poly) continue;
             if (rot_geometry(L, R, false, tab_floats, lds, grid, block, poly != 0, true) != 1) continue;
@@ -848,6 +857,8 @@ __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int
 #pragma unroll
         for (int i = 0; i < NA; ++i) t += va[i] * P[i * NB + j];
         tb[j] = t; sb += t; }
+    // (tried: both products on explicit v_pk_fma_f32 pairs -- the compiler's own pairing already issues as many packed
+    //  operations, no change in time, and the re-associated row sums cost the bit-identity between the solve variants)
     const float ra = fast_rcp(sa), rb = fast_rcp(sb);
     if (WT) {
 #pragma unroll
@@ -1142,8 +1153,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
     }
     // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
-    constexpr bool PACK = K66 + K36 + K33 > 0;
-    static_assert(!COMPACT || PACK, "the compact inbox is laid out by the packing pass");
+    constexpr bool PACK = K66 + K36 + K33 > 0 || COMPACT;      // (the compact inbox is laid out by the packing pass)
     int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
     if (COMPACT) {
         // Which rows carry a message in this solve: an activity bit per cached row (LDS, in the region the messages will take),
@@ -1861,7 +1871,9 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     //  128: 0.489 vs 0.527 -- the register layout from 1/8 system per CU on)
     const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 0);
     const dim3 grid(1, L->n_system);
-    if (resident == 0 || threads != BP_BLOCK || only_fallback)
+    if (resident == 3 && !only_fallback && R->slot_row && R->row_start)      // experiment: 1024 lanes, every matrix streamed, dense inbox in LDS
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0, true>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
