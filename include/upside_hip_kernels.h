@@ -258,7 +258,7 @@ typedef struct {
     /* per system state */
     float *node_prob, *node_off, *nb_cur;               /* [S][n_node][6], off [S][n_node] */
     int slot_cap, adj_cap;
-    int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], (unused since round 3: NULL), [S][cap] */
+    int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
     unsigned char* mark;                 /* [S][n_node^2] residue pairs owning a cached bead pair (= G.mark_table) */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
@@ -285,7 +285,7 @@ typedef struct {
 
 /* pair-list rebuild of flagged systems (replaces EdgeLocator, rotamer.cpp:134-206): clear the node x node table,
  * [upk_pairlist_build marks it through G.mark_table], number the slots by class + adjacency + inbox layout, and
- * record the slot of every cached bead pair (upk_rotamer_build_slots does both; upk_rotamer_nbr_slots is a no-op kept for callers) */
+ * record the slot of every cached bead pair */
 int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R);
 int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R);
 int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R);

@@ -346,7 +346,9 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
     bool have = fetch(claim(), cur);
     while (have) {
         const bool have_next = fetch(claim(), nxt);
-        const int n_trip = __builtin_amdgcn_readfirstlane((cur.n_mine + PG_LANES - 1) / PG_LANES);   // lane 0: group 0 holds the batch's longest row
+        // (the longest row of the batch decides the trips: a wave-wide maximum, so that a row order computed a few steps ago --
+        //  nodes.cpp: IGraphHost::refine -- only costs balance, never pairs; counts are < 2^24, exact in fp32)
+        const int n_trip = __builtin_amdgcn_readfirstlane((int)wave_max((float)((cur.n_mine > 0 ? cur.n_mine : 0) + PG_LANES - 1) ) / PG_LANES);
         op.begin(cur.row);      // (groups past the last row take row 0: their lanes are never live, but evaluate like everyone else's)
         for (int t0 = 0; t0 < n_trip; t0 += PG_CHUNK) {
             int wn[PG_CHUNK];

@@ -388,16 +388,17 @@ struct CovBackwardOp2 {
 #pragma unroll
         for (int c = 0; c < DR; ++c) acc[c] = fma2(ps, dr[c], acc[c]);
         v2 od[DO];
+        const v2 pss = ps * bc2(P2_FIX_SCALE);              // (fixed-point scale folded into the sensitivity: two values per instruction)
 #pragma unroll
-        for (int c = 0; c < DO; ++c) od[c] = ps * dv[c];
+        for (int c = 0; c < DO; ++c) od[c] = pss * dv[c];
         const int n_o = RS == 1 ? G.n2 : G.n1;          // accumulators as DO planes [component][element]
         if (liveA) {
 #pragma unroll
-            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + c * n_o + jA, od[c].x);
+            for (int c = 0; c < DO; ++c) lds_add_fixed22_scaled(oacc + c * n_o + jA, od[c].x);
         }
         if (liveB) {
 #pragma unroll
-            for (int c = 0; c < DO; ++c) lds_add_fixed22(oacc + c * n_o + jB, od[c].y);
+            for (int c = 0; c < DO; ++c) lds_add_fixed22_scaled(oacc + c * n_o + jB, od[c].y);
         }
     }
     __device__ __forceinline__ void flush(int row) {

@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
         const int s = fl[1 + fi];
         const unsigned char* mark = R.mark + (size_t)s * G.mark_stride;
+        int* slot_of = R.slot_of + (size_t)s * NN * NN;
         __syncthreads();                                     // LDS of the previous system is no longer read
         // ---- pack the marks: wave item = (row, word); 8 loads in flight per lane
         for (int item0 = wave * 8; item0 < NN * W; item0 += n_wave * 8) {
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                     const int sl = lo ? p_lo++ : p_hi++;
                     const int nb = nrot[b];
                     if (sl < R.slot_cap) {
-                        slot_a[sl] = a; slot_b[sl] = b;
+                        slot_a[sl] = a; slot_b[sl] = b; slot_of[(size_t)a * NN + b] = sl; slot_of[(size_t)b * NN + a] = sl;
                         if (na == 1 && nb > 1) {
                             const int pos = rank_below(b, a);              // 1-state partners of b below a
                             if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
@@ -206,40 +207,8 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
                             slot_off[sl * 2 + 1] = (bp_s[b] + kb * (nb == 6 ? 2 : 1)) * 4;
                             if (R.slot_row) { int* sr = R.slot_row + (size_t)s * R.slot_cap * 2; sr[sl * 2] = row_of(a) + k_multi; sr[sl * 2 + 1] = row_of(b) + kb; }
                         }
-                    }
+                    } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
                     if (na > 1) ++k_multi;
-                }
-            }
-        }
-        // ---- every cached bead pair remembers its slot, in the bits of its list word above the bead index (one 4-byte word per
-        // cached pair; the pair passes read nothing else).  The slot of the residue pair (a < b) follows from the same popcounts
-        // the numbering used -- first slot of a's "same class" / "higher class" run + partners of a in (a, b) of that run -- so
-        // no node x node table is written or gathered (round 2: a 4 NN^2-byte table per system and a kernel of its own).
-        {
-            const int lane = tid & 63, wave = tid >> 6;
-            auto slot_of_pair = [&](int a, int b) {                  // a < b
-                const int na = nrot[a];
-                const int cend = na == 1 ? e1 : (na == 3 ? e3 : NN), first = na == 1 ? 0 : (na == 3 ? e1 : e3);
-                const bool lo = b < cend;
-                const int cl = lo ? slot_class(na, na) : (na == 1 ? CL1X : (na == 3 ? CL36 : CL66));
-                const int* rowx = lo ? row_lo : row_hi;
-                int sl = cls_lds[cl] + rowx[a] - (first < NN ? rowx[first] : 0);
-                for (int c = a >> 6; c <= (b >> 6); ++c) {             // + partners of a in (a, b) of b's run
-                    unsigned long long w = bits[a * W + c] & ~below(a + 1, c) & below(b, c);
-                    w &= lo ? below(cend, c) : ~below(cend, c);
-                    sl += __popcll(w);
-                }
-                return sl;
-            };
-            for (int row = wave; row < G.n1; row += n_wave) {
-                const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
-                const int cnt = G.cnt1[(size_t)s * G.n1 + row];
-                const int nr = R.bead_node[row];
-                for (int k = lane; k < cnt; k += 64) {
-                    const int j = G.nbr1[base + k];                  // freshly built: a bare bead index
-                    const int nj = R.bead_node[j];                   // (beads sorted by node: nr < nj; the configuration's own order: either)
-                    const int sl = slot_of_pair(nr < nj ? nr : nj, nr < nj ? nj : nr);
-                    G.nbr1[base + k] = j | ((sl < R.slot_cap ? sl : UPK_ROT_SLOT_NONE) << UPK_ROT_J_BITS);
                 }
             }
         }
@@ -248,12 +217,41 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rotamer_build_slots(upk_rotamer_t 
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
     if (R->n_node > 1024) return 9003;
     const size_t lds = (size_t)R->n_node * ((R->n_node + 63) / 64) * 8;
+    // (tried in round 3: stamping the slots into the list words inside this kernel from the popcounts of the bit matrix, without
+    //  the node x node table -- 1.33 ms per step against 0.53 + 0.59 for the two kernels: one workgroup per system walks its 66 k
+    //  list words through a chain of dependent loads, the separate kernel spreads them over hundreds of workgroups)
     hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < 256 ? L->n_system : 256), dim3(BP_BLOCK), lds, ST(L), *R);
     return launch_status();
 }
 
-// rebuild step 3 (every cached bead pair remembers its slot) is part of upk_rotamer_build_slots since round 3
-extern "C" int upk_rotamer_nbr_slots(const upk_launch_t*, const upk_rotamer_t*) { return 0; }
+// rebuild step 3: every cached bead pair remembers its slot, in the bits of its list word above the bead index
+// (one 4-byte word per cached pair instead of a second array; the pair passes read nothing else)
+__global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
+    const upk_igraph_t& G = R.G;
+    const int* fl = UPK_FLAG_LIST(G);
+    const int n_flagged = fl[0];
+    const int NN = R.n_node;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+        const int s = fl[1 + fi];
+        const int* slot_of = R.slot_of + (size_t)s * NN * NN;
+        for (int row = blockIdx.x * n_wave + wave; row < G.n1; row += gridDim.x * n_wave) {
+            const size_t base = ((size_t)s * G.n1 + row) * G.cap1;
+            const int cnt = G.cnt1[(size_t)s * G.n1 + row];
+            const int a = R.bead_node[row];
+            for (int k = lane; k < cnt; k += 64) {
+                const int j = G.nbr1[base + k];                  // freshly built: a bare bead index
+                const int sl = slot_of[a * NN + R.bead_node[j]];
+                G.nbr1[base + k] = j | ((sl < 0 ? UPK_ROT_SLOT_NONE : sl) << UPK_ROT_J_BITS);
+            }
+        }
+    }
+}
+extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    int blocks = (R->G.n1 + 3) / 4;
+    hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(256), 0, ST(L), *R);
+    return launch_status();
+}
 
 // ------------------------------------------------------------------------------------------------
 // 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256)
@@ -474,20 +472,21 @@ struct RotGradOp2 {
         v2 dd[3], g1[3], g2[3];
         quadspline_pair2<true, POLY>(Q, pA, pB, x1, x2, dd, g1, g2, o1A, o2A, o1B, o2B);
         v2 od[6];                                           // the partners' shares
+        const v2 pss = ps * bc2(P2_FIX_SCALE);              // (the partners' shares leave in fixed point: scaled here, two per instruction)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            od[c] = ps * dd[c]; od[3 + c] = ps * g2[c];
-            acc[c] -= od[c]; acc[3 + c] = fma2(ps, g1[c], acc[3 + c]);
+            od[c] = pss * dd[c]; od[3 + c] = pss * g2[c];
+            acc[c] = fma2(-ps, dd[c], acc[c]); acc[3 + c] = fma2(ps, g1[c], acc[3 + c]);
         }
         // accumulators as six planes [component][bead]: the consecutive partners of a row group fall into distinct banks
         const int n1 = R.G.n1;
         if (liveA) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * n1 + mA.j, od[c].x);
+            for (int c = 0; c < 6; ++c) lds_add_fixed22_scaled(L.acc + c * n1 + mA.j, od[c].x);
         }
         if (liveB) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * n1 + mB.j, od[c].y);
+            for (int c = 0; c < 6; ++c) lds_add_fixed22_scaled(L.acc + c * n1 + mB.j, od[c].y);
         }
     }
     __device__ __forceinline__ void flush(int row) {
@@ -833,14 +832,27 @@ struct BpCtx {
     __device__ __forceinline__ float* msg(int off) const { return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
 
+// One message row, wide: a row to a 3-state node is 4 floats at a 16-byte boundary (one b128 access, the 4th word unused), a
+// row to a 6-state node 6 or 8 floats at an 8-byte boundary (three b64 accesses) -- in both inbox layouts.  (Dword accesses
+// cost an LDS instruction each: the dense inbox of 3 / 6 dwords per row kept the LDS index unit busy 52 % of the solve.)
+template <int N> __device__ __forceinline__ void bp_load_row(const float* p, float* v) {
+    if (N == 3) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; }
+    else { const float2 a = ((const float2*)p)[0], b = ((const float2*)p)[1], c = ((const float2*)p)[2]; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; }
+}
+template <int N> __device__ __forceinline__ void bp_store_row(float* p, const float* v) {
+    if (N == 3) *(float4*)p = make_float4(v[0], v[1], v[2], 1.f);
+    else { ((float2*)p)[0] = make_float2(v[0], v[1]); ((float2*)p)[1] = make_float2(v[2], v[3]); ((float2*)p)[2] = make_float2(v[4], v[5]); }
+}
 // edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
 // L1 normalisation of 506-521), rewritten in place.  1-ulp hardware reciprocals: the reference itself uses the
 // 12-bit rcpps here (Float4.h:199-212).
 template <int NA, int NB, bool WT>   // WT: messages leave through 16-byte write-through stores (cluster solve)
 __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int a, int b, const float (&P)[NA * NB], const float* __restrict__ nb_old,
                                              __amdgpu_buffer_rsrc_t inbox_w) {
-    float* ma = C.msg(oa);
-    float* mb = C.msg(ob);
+    float* pa = C.msg(oa);
+    float* pb = C.msg(ob);
+    float ma[NA], mb[NB];
+    bp_load_row<NA>(pa, ma); bp_load_row<NB>(pb, mb);
     float va[NA], vb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) va[i] = nb_old[a * 6 + i] * fast_rcp(1e-10f + ma[i]);
@@ -871,9 +883,10 @@ __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int
         if (NB == 6) st_wt16(inbox_w, ob + 4, tb[NB - 2], tb[NB - 1], 1.f, 1.f);
     } else {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ma[i] = ta[i] * ra;
+        for (int i = 0; i < NA; ++i) ta[i] *= ra;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) mb[j] = tb[j] * rb;
+        for (int j = 0; j < NB; ++j) tb[j] *= rb;
+        bp_store_row<NA>(pa, ta); bp_store_row<NB>(pb, tb);
     }
 }
 // the NA x NB entries of one slot, row-major, from the [36][cap] table
@@ -995,8 +1008,8 @@ template <int NA, int NB>
 __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa, int ob, int a, int b, const float (&P)[NA * NB],
                                                   const float* __restrict__ nbm, bool want_energy) {
     float en = 0.f;
-    const float* ma = C.msg(oa);
-    const float* mb = C.msg(ob);
+    float ma[NA], mb[NB];
+    bp_load_row<NA>(C.msg(oa), ma); bp_load_row<NB>(C.msg(ob), mb);
     // the unnormalised marginals are formed twice (sum, then store) rather than kept: 36 fewer live registers next
     // to the resident matrices, and the products round identically both times
     float bc1[NA], bc2[NB], sum = 0.f;
@@ -1102,9 +1115,9 @@ struct BpResident {
     }
 };
 
-// COMPACT: the message inbox is laid out per solve for the slots ACTIVE in this evaluation only, 3 / 6 floats per row instead of
-// the cached layout's 4 / 8 for every cached residue pair (a quarter of which has no bead pair in range on a given step): 137 KB
-// instead of 244 KB for the 300-residue benchmark protein, so that all but a sliver of it stays in the LDS for all sweeps.
+// COMPACT: the message inbox is laid out per solve for the slots ACTIVE in this evaluation only, 4 / 6 floats per row instead of
+// the cached layout's 4 / 8 for every cached residue pair (a quarter of which has no bead pair in range on a given step): 151 KB
+// instead of 244 KB for the 300-residue benchmark protein, so that most of it stays in the LDS for all sweeps.
 template <int BLOCK, int K66, int K36, int K33, bool COMPACT = false>
 __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1173,15 +1186,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         {
             const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
             int sum = 0;
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) sum += __popc(rmask[w]) * (w * 32 < R6 ? 3 : 6); }
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) sum += __popc(rmask[w]) * (w * 32 < R6 ? 4 : 6); }
             int total;
             int run = block_excl_scan(sum, (int*)scratch, &total);
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { wbase[w] = run; run += __popc(rmask[w]) * (w * 32 < R6 ? 3 : 6); } }
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { wbase[w] = run; run += __popc(rmask[w]) * (w * 32 < R6 ? 4 : 6); } }
             if (tid == 0) wbase[n_words] = total;
             inbox_floats = total;
         }
         __syncthreads();
-        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? 3 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
+        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? 4 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
         int my_start[(1024 + BLOCK - 1) / BLOCK + 1];          // first message float of the nodes this lane copies (NN <= 1024)
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; my_start[k] = g <= NN ? dense(bp_start[g]) : 0; }
@@ -1204,7 +1217,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // the head of the inbox stays in LDS as far as it reaches: the rows to the 3-state nodes come first, then the rows to the
     // 6-state nodes (the boundary never cuts a row)
     {
-        constexpr int W3 = COMPACT ? 3 : 4, W6 = COMPACT ? 6 : 8;
+        constexpr int W3 = 4, W6 = COMPACT ? 6 : 8;
         int n = lds_msg_floats < inbox_floats ? lds_msg_floats : inbox_floats;
         if (n > inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / W3) * W3;
         C.lds_floats = n;
@@ -1287,7 +1300,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int q = COMPACT ? (n == 6 ? 6 : 3) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
+                const int q = COMPACT ? (n == 6 ? 6 : 4) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
                 constexpr int ROWS = BP_NODE_ROWS_512 > 0 && BLOCK != BP_BLOCK ? BP_NODE_ROWS_512 : (BLOCK == BP_BLOCK ? 4 : 8);
@@ -1298,10 +1311,10 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                         const int k = k0 + u * BP_GROUP;
                         m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
-                            if (COMPACT) {       // dense rows of 3 / 6 floats, 4-byte aligned
+                            if (COMPACT) {       // dense rows: 4 floats (16-byte aligned) to a 3-state node, 6 floats (8-byte aligned) to a 6-state node
                                 const float* m = C.msg(base + k * q);
-                                m0[u].x = m[0]; m0[u].y = m[1]; m0[u].z = m[2];
-                                if (n == 6) { m0[u].w = m[3]; m1[u].x = m[4]; m1[u].y = m[5]; }
+                                if (n == 6) { const float2 a = ((const float2*)m)[0], b = ((const float2*)m)[1]; m0[u] = make_float4(a.x, a.y, b.x, b.y); m1[u] = ((const float2*)m)[2]; }
+                                else m0[u] = *(const float4*)m;
                             } else {
                                 const float* m = C.msg((base + k * q) * 4);
                                 m0[u] = *(const float4*)m;
@@ -1871,16 +1884,21 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     //  128: 0.489 vs 0.527 -- the register layout from 1/8 system per CU on)
     const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 0);
     const dim3 grid(1, L->n_system);
-    if (resident == 3 && !only_fallback && R->slot_row && R->row_start)      // experiment: 1024 lanes, every matrix streamed, dense inbox in LDS
+    static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
+    if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
+    // (the layout pass borrows the LDS inbox for an activity bit per cached row and a prefix per 32 rows: at most two rows per slot)
+    const size_t layout_scratch = (((size_t)2 * R->slot_cap + 64) / 32 * 2 + 2) * sizeof(int);
+    const bool dense = compact && R->slot_row && R->row_start && (size_t)lds_msg_floats * sizeof(float) >= layout_scratch;
+    // (every one-workgroup variant lays its inbox out the same way: the order in which a node multiplies its messages, and with
+    //  it every bit of the result, is then the same whichever variant a batch size selects)
+    if ((resident == 0 || threads != BP_BLOCK) && !only_fallback && dense && threads == BP_BLOCK)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0, true>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else {                    // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
-        static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
-        if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
-        if (compact && R->slot_row && R->row_start)
+        if (dense)
             hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
         else hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     }

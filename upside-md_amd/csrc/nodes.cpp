@@ -1235,7 +1235,7 @@ struct RotamerSidechain : public PotentialNode {
         R.slot_cap = (int)max(1L, min(full, (long)(n_node * slot_factor)));
         R.adj_cap = min(max(n_node, 1), env_int("UPSIDE_HIP_ADJ_CAP", 256));
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
-        adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
+        slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
         bp_rec.alloc((size_t)S * R.slot_cap * 4);
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
@@ -1278,7 +1278,7 @@ struct RotamerSidechain : public PotentialNode {
         R.n_prob = (int)prob_nodes.size(); R.prob_out = d_prob_out.p; R.prob_sens = d_prob_sens.p; R.prob_stride = d_prob_stride.p;
         R.prob_sys_stride = d_prob_sys_stride.p;
         R.node_prob = node_prob.p; R.node_off = node_off.p; R.nb_cur = nb_cur.p;
-        R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = nullptr; R.slot_active = slot_active.p; R.mark = mark.p;
+        R.n_slot = n_slot.p; R.slot_a = slot_a.p; R.slot_b = slot_b.p; R.slot_of = slot_of.p; R.slot_active = slot_active.p; R.mark = mark.p;
         R.adj_cnt = adj_cnt.p; R.adj_slot = adj_slot.p; R.bp_start = bp_start.p; R.slot_off = slot_off.p;
         R.class_start = class_start.p; R.slot_active_last = slot_active_last.p; R.bead_meta = d_bead_meta.p;
         R.row_start = row_start.p; R.slot_row = slot_row.p;
@@ -1305,7 +1305,8 @@ struct RotamerSidechain : public PotentialNode {
         upk_check(upk_pairlist_check(&ctx->L, &ig.G), "pairlist_check");
         upk_check(upk_rotamer_clear_slots(&ctx->L, &R), "rotamer_clear_slots");
         upk_check(upk_pairlist_build(&ctx->L, &ig.G), "pairlist_build");
-        upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");      // (numbers the slots and stamps them into the list words)
+        upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
+        upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
         ig.refine(ig.G);
     }
     // workgroups per system of the belief-propagation solve: enough that the exp(-E) matrices of the multi-state

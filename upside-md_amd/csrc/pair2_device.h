@@ -15,7 +15,8 @@
 // branch-free and the discarded halves contribute an exact +0.
 //
 // Gradient accumulators: 64-bit integer LDS atomics as before (order-independent, bit-reproducible), but a contribution is
-// converted as round(v * 2^22) -- 4 instructions instead of the 8 of the 2^32 split (igraph_device.h: to_fixed32): resolution
+// converted as floor(v * 2^22 + 0.5) -- a packed multiply shared by two values, v_cvt_rpi_i32_f32 and a sign extension instead of the 8
+// instructions of the 2^32 split (igraph_device.h: to_fixed32): resolution
 // 2.4e-7, below the rounding of the fp32 sums it replaces; |v| >= 512 saturates (v_cvt_i32_f32), sums cannot overflow.
 #pragma once
 #include "igraph_device.h"
@@ -28,9 +29,16 @@ __device__ __forceinline__ v2 bc2(float a) { v2 r; r.x = a; r.y = a; return r; }
 __device__ __forceinline__ v2 fma2(v2 a, v2 b, v2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 #define P2_FIX_BITS 22
-__device__ __forceinline__ unsigned long long to_fixed22(float v) {
-    const int q = (int)rintf(v * (float)(1 << P2_FIX_BITS));         // v_mul, v_rndne, v_cvt_i32 (saturating)
-    return (unsigned long long)(long long)q;                           // v_ashrrev 31
+#define P2_FIX_SCALE ((float)(1 << P2_FIX_BITS))
+// vs = value * 2^22 (the callers scale two values per v_pk_mul_f32): v_cvt_rpi_i32_f32 = floor(vs + 0.5), saturating; v_ashrrev 31
+__device__ __forceinline__ unsigned long long to_fixed22_scaled(float vs) {
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(vs));
+    return (unsigned long long)(long long)q;
+}
+__device__ __forceinline__ unsigned long long to_fixed22(float v) { return to_fixed22_scaled(v * P2_FIX_SCALE); }
+__device__ __forceinline__ void lds_add_fixed22_scaled(unsigned long long* p, float vs) {
+    __hip_atomic_fetch_add(p, to_fixed22_scaled(vs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ float from_fixed22(unsigned long long a) { return (float)((double)(long long)a * (1.0 / (double)(1 << P2_FIX_BITS))); }
 __device__ __forceinline__ void lds_add_fixed22(unsigned long long* p, float v) {
@@ -224,7 +232,8 @@ __device__ __forceinline__ void group2_batch_loop(Op& op, int n_rows, const unsi
     bool have = fetch(claim(), cur);
     while (have) {
         const bool have_next = fetch(claim(), nxt);
-        const int n_trip = __builtin_amdgcn_readfirstlane((cur.n_mine + 2 * P2_LANES - 1) / (2 * P2_LANES));   // lane 0: group 0 holds the batch's longest row
+        // (wave-wide maximum: the row order may be a few steps old, igraph_device.h)
+        const int n_trip = __builtin_amdgcn_readfirstlane((int)wave_max((float)((cur.n_mine > 0 ? cur.n_mine : 0) + 2 * P2_LANES - 1)) / (2 * P2_LANES));
         op.begin(cur.row);
         for (int t0 = 0; t0 < n_trip; t0 += P2_CHUNK) {
             int na[P2_CHUNK], nb[P2_CHUNK];
