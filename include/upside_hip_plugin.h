@@ -128,10 +128,6 @@ struct DerivComputation {   // deriv_engine.h:48-80
     // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).
     virtual bool has_prepare() const { return false; }
     virtual void prepare() {}
-    // second part of the upkeep, needed by propagate_deriv() only (the hit lists of the side the backward pass gathers
-    // over): enqueued after every node's prepare(), so it runs beside the forward passes instead of in front of them
-    virtual bool has_prepare_backward() const { return false; }
-    virtual void prepare_backward() {}
     std::vector<const DerivComputation*> prepare_deps;   // parents prepare() reads (empty = all of them)
 };
 

@@ -97,3 +97,81 @@ def test_model_selection(tmp_path):
     x1 = cfg.read_pdb_backbone(f, recenter=False)[1]
     x2 = cfg.read_pdb_backbone(f, model=2, recenter=False)[1]
     assert len(x1) == len(pos) and np.abs(x1 - pos).max() < 6e-4 and np.abs(x2 - pos - 1.).max() < 6e-4
+
+
+def test_break_chains_on_a_fixture(tmp_path):
+    """py/ugly_hack_break_chain.py restated (config.break_chains): bonded terms across a junction go, the rama_coord row at the
+    junction loses the dihedral it cannot have, one jump move per chain appears -- and a configuration whose hydrogen-bond
+    sites still draw on two chains is refused, as the reference script complains (:134-139)."""
+    import shutil
+    f = str(tmp_path / 'two_chains.up')
+    shutil.copyfile(P.fixture('trpcage20_7A'), f)
+    with pytest.raises(ValueError):
+        cfg.break_chains(f, chain_first_residue=[10])          # written as ONE chain: residue 10's donor site uses C of residue 9
+    # drop the junction residues' sites by hand (what write_config(chain_first_residue=...) does), then cut
+    with P.pkg.h5lite.open_file(f, 'r+') as t:
+        pot = t.group('input/potential')
+        before = dict((nm, pot.group(nm).shape('id')[0]) for nm in ('dist_spring', 'angle_spring', 'dihedral_spring'))
+        for side in ('donors', 'acceptors'):
+            g = pot.group('infer_H_O').group(side)
+            res = g.read('residue', 'i4')
+            keep = ~np.isin(res, [9, 10])
+            for nm in ('residue', 'bond_length', 'id'):
+                arr = g.read(nm); g.delete(nm); g.write(nm, arr[keep])
+    removed = cfg.break_chains(f, chain_first_residue=[10])
+    assert removed['dist_spring'] == 1 and removed['angle_spring'] == 2 and removed['dihedral_spring'] == 1
+    with P.pkg.h5lite.open_file(f) as t:
+        inp = t.group('input'); pot = inp.group('potential')
+        assert list(inp.group('chain_break').read('chain_first_residue', 'i4')) == [10]
+        for nm in before:
+            ids = pot.group(nm).read('id', 'i4')
+            assert ids.shape[0] == before[nm] - removed[nm]
+            assert all(len(set(r // 30)) == 1 for r in ids)                     # atoms 0..29 = chain 0, 30..59 = chain 1
+            assert pot.group(nm).shape('equil_dist')[0] == ids.shape[0]
+        rama = pot.group('rama_coord').read('id', 'i4')
+        assert rama[9, 4] == -1 and rama[10, 0] == -1 and (rama[9, :4] >= 0).all() and (rama[10, 1:] >= 0).all()
+        jm = inp.group('jump_moves')
+        assert jm.read('atom_range', 'i4').tolist() == [[0, 30], [30, 60]]
+        assert np.allclose(jm.read('sigma_trans', 'f4'), 5.) and np.allclose(jm.read('sigma_rot', 'f4'), np.pi / 6.)
+    # (the C restatement of the engine loads the cut file and evaluates it; a dihedral id of -1 is the dummy angle of bonds.cpp:219-220)
+    orc = P.pkg.Upside(f, library=P.oracle_library())
+    e = orc.energy(orc.initial_pos.copy())
+    assert np.isfinite(e)
+    orc.close()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/parameters'), reason='needs the reference parameter directory (build container)')
+def test_two_chain_configuration_from_scratch(tmp_path):
+    """write_config(chain_first_residue=...) + break_chains(): the path of py/upside_config.py --chain-break-from-file followed
+    by py/ugly_hack_break_chain.py --chain-break-from-file.  The junction residues have no hydrogen-bond sites (:1445-1449), the
+    chain break is recorded, and the unmodified reference library and the C restatement agree on the resulting potential."""
+    PARAM = '/root/reference/parameters'
+    fasta = cfg.fasta_from_one_letter(cfg.PROTEIN_G[:24])
+    pos = cfg.helix_chain(24)
+    pos[36:] += np.array([0., 9., 0.])                                           # second chain (residues 12..23) moved beside the first
+    f = str(tmp_path / 'dimer.up')
+    cfg.write_config(f, fasta, pos, sidechain_lib=os.path.join(PARAM, 'ff_1', 'sidechain.h5'),
+                     environment_lib=os.path.join(PARAM, 'ff_1', 'environment.h5'),
+                     rama_ref=cfg.load_rama_reference(os.path.join(PARAM, 'common', 'rama_reference.pkl')),
+                     hbond_energy=float(open(os.path.join(PARAM, 'ff_1', 'hbond')).read()), chain_first_residue=[12])
+    with P.pkg.h5lite.open_file(f) as t:      # (no group handle outlives the block: the file is reopened for writing below)
+        don = t.group('input/potential/infer_H_O').group('donors').read('residue', 'i4')
+        acc = t.group('input/potential/infer_H_O').group('acceptors').read('residue', 'i4')
+    assert not set(don) & {11, 12} and not set(acc) & {11, 12}
+    removed = cfg.break_chains(f)                                               # chain_first_residue from the file
+    assert removed['dist_spring'] == 1 and removed['angle_spring'] == 2 and removed['dihedral_spring'] == 1
+    with P.pkg.h5lite.open_file(f) as t:
+        rama = t.group('input/potential/rama_coord').read('id', 'i4')
+    assert rama[11, 4] == -1 and rama[12, 0] == -1 and (rama[11, :4] >= 0).all() and (rama[12, 1:] >= 0).all()
+    orc = P.pkg.Upside(f, library=P.oracle_library())
+    x = orc.initial_pos.copy()
+    e_o, d_o = orc.energy(x), orc.deriv(x)
+    orc.close()
+    assert np.isfinite(e_o) and np.isfinite(d_o).all()
+    ref_lib = os.path.join(P.REF_DIR, 'libupside_7A.so')
+    if os.path.exists(ref_lib):
+        ref = P.pkg.Upside(f, library=P.pkg.UpsideLibrary(ref_lib))
+        e_r, d_r = ref.energy(x), ref.deriv(x)
+        ref.close()
+        assert abs(e_r - e_o) < 1e-4 * max(1., abs(e_r)) and P.rel_rms(d_r, d_o) < 1e-4
+        # no force crosses the junction through a bonded term: moving chain 2 rigidly far away leaves chain 1's bonded energy alone

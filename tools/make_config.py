@@ -33,20 +33,28 @@ def main():
     ap.add_argument('--cavity-radius', type=float, default=0.)
     ap.add_argument('--contacts'); ap.add_argument('--z-flat-bottom'); ap.add_argument('--tension')
     ap.add_argument('--pivot-moves', action='store_true', help='also write /input/pivot_moves (Monte-Carlo)')
+    ap.add_argument('--join-chains', action='store_true', help='keep the chains of the PDB file bonded end to end (default: cut them, '
+                    'py/upside_config.py --chain-break-from-file + py/ugly_hack_break_chain.py)')
+    ap.add_argument('--rl-chains', nargs=2, type=int, default=None, help='numbers of receptor and ligand chains: two collective jump moves')
     a = ap.parse_args()
     pkg = load_package(); cfg = pkg.config
     if not a.pdb:
         ap.error('--pdb is required')
     fasta, pos, first = cfg.read_pdb_backbone(a.pdb, chains=[c for c in a.chains.split(',') if c] or None, model=a.model,
                                               allow_unexpected_chain_breaks=a.allow_unexpected_chain_breaks)
-    if first:
-        print('note: chains are concatenated; first residues of later chains: %s (bonded terms across them are kept)' % first)
+    if first and a.join_chains:
+        print('note: chains are concatenated; first residues of later chains: %s (--join-chains: bonded terms across them are kept)' % first)
     P = a.param_dir
     sclib = 'ff_1/sidechain.h5' if a.cutoff == '7' else 'packing/sidechain_10A_cutoff.h5'
     info = cfg.write_config(a.out, fasta, pos, sidechain_lib=os.path.join(P, sclib),
                             environment_lib=os.path.join(P, 'ff_1', 'environment.h5'),
                             rama_ref=cfg.load_rama_reference(os.path.join(P, 'common', 'rama_reference.pkl')),
-                            hbond_energy=float(open(os.path.join(P, 'ff_1', 'hbond')).read()), cavity_radius=a.cavity_radius)
+                            hbond_energy=float(open(os.path.join(P, 'ff_1', 'hbond')).read()), cavity_radius=a.cavity_radius,
+                            chain_first_residue=() if a.join_chains else first)
+    if first and not a.join_chains:      # upside_config.py --chain-break-from-file + ugly_hack_break_chain.py --chain-break-from-file
+        removed = cfg.break_chains(a.out, rl_chains=a.rl_chains)
+        print('chains start at residues %s: removed across the junctions %s; one jump move per %s' %
+              ([0] + list(first), removed, 'receptor / ligand group' if a.rl_chains else 'chain'))
     extra = {}
     if a.contacts: extra['contacts'] = table(a.contacts)
     if a.z_flat_bottom: extra['z_flat_bottom'] = table(a.z_flat_bottom)

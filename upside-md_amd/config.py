@@ -130,9 +130,13 @@ def _args(g, names):
 
 def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref, hbond_energy,
                  rama_seed=0, cavity_radius=0., rotamer_damping=0.4, bond_stiffness=48.,
-                 angle_stiffness=175., per_residue_rama=True):
+                 angle_stiffness=175., per_residue_rama=True, chain_first_residue=(), hbond_exclude_residues=()):
     """fasta: array of 3-letter codes; init_pos (3*n_res,3); sidechain_lib / environment_lib: paths to
-    the parameter HDF5 libraries; rama_ref: (72,72) reference-state probabilities."""
+    the parameter HDF5 libraries; rama_ref: (72,72) reference-state probabilities.
+    chain_first_residue: first residue of every chain but the first (py/upside_config.py --chain-break-from-file,
+    :1413-1451): recorded as /input/chain_break/chain_first_residue, and the two residues at every junction join
+    hbond_exclude_residues (no donor / acceptor site inferred from atoms of two chains).  The bonded terms across the
+    junctions are removed afterwards by break_chains(), as the reference does with py/ugly_hack_break_chain.py."""
     fasta = np.asarray(fasta)
     n_res = len(fasta)
     n_atom = 3 * n_res
@@ -222,8 +226,14 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
     g.write('placement_data', placement_energy.astype('f4'))
 
     # --- hydrogen bonds -------------------------------------------------------------------
-    donor_res = np.array([i for i in range(n_res) if i > 0 and fasta[i] != 'PRO'], dtype='i4')
-    acc_res = np.array([i for i in range(n_res) if i < n_res - 1], dtype='i4')
+    chain_first_residue = [int(i) for i in chain_first_residue]
+    if any(i <= 0 or i >= n_res for i in chain_first_residue) or sorted(set(chain_first_residue)) != chain_first_residue:
+        raise ValueError('chain_first_residue must be increasing residue indices in (0, n_res)')
+    excluded = set(int(i) for i in hbond_exclude_residues) | set(i + j for i in chain_first_residue for j in (-1, 0))   # :1445-1449
+    if chain_first_residue:
+        inp.create_group('chain_break').write('chain_first_residue', np.array(chain_first_residue, dtype='i4'))
+    donor_res = np.array([i for i in range(n_res) if i > 0 and i not in excluded and fasta[i] != 'PRO'], dtype='i4')   # :190-191
+    acc_res = np.array([i for i in range(n_res) if i < n_res - 1 and i not in excluded], dtype='i4')
     n_donor, n_acceptor = len(donor_res), len(acc_res)
     g = pot.create_group('infer_H_O'); _args(g, ['pos'])
     don = g.create_group('donors'); acc = g.create_group('acceptors')
@@ -403,6 +413,95 @@ def add_pivot_moves(path):
         g.write('pivot_atom', pivot_atom[keep])
         g.write('pivot_restype', map_id[keep])
         g.write('pivot_range', np.column_stack((pivot_atom[keep][:, 4] + 1, np.full(int(keep.sum()), n_atom, 'i4'))).astype('i4'))
+
+
+def break_chains(path, chain_first_residue=None, rl_chains=None, jump_length_scale=5., jump_rotation_scale=30., remove_pivot=False):
+    """py/ugly_hack_break_chain.py restated: cut a configuration into chains at `chain_first_residue` (default: the
+    /input/chain_break/chain_first_residue that write_config recorded).
+      * bonded terms whose atoms lie in more than one chain are removed: every angle_spring and dihedral_spring row, the
+        dist_spring rows that are bonds (bonded_atoms != 0; non-bonded springs across chains are restraints and stay) (:129-131);
+      * a rama_coord row across a junction loses the dihedral it cannot have: phi of a chain's first residue (id[0] = -1),
+        psi of a chain's last (id[4] = -1) (:143-157);
+      * /input/jump_moves gets one rigid-body move per chain, or per receptor / ligand group with rl_chains = (n_receptor
+        chains, n_ligand chains) (:96-120), widths in Angstrom / degrees; remove_pivot drops /input/pivot_moves (:92-93);
+      * infer_H_O sites drawing on two chains are an error (:134-139: they must have been excluded when the file was written).
+    Returns the number of rows removed per node."""
+    with h5lite.open_file(path, 'r+') as f:
+        inp = f.group('input')
+        pot = inp.group('potential')
+        n_atom = inp.shape('pos')[0]
+        if chain_first_residue is None:
+            if 'chain_break' not in inp:
+                raise ValueError('no /input/chain_break in %s and no chain_first_residue given' % path)
+            chain_first_residue = inp.group('chain_break').read('chain_first_residue', 'i4')
+        else:
+            chain_first_residue = np.asarray(chain_first_residue, 'i4').reshape(-1)
+            if 'chain_break' in inp:
+                inp.delete('chain_break')
+            if len(chain_first_residue):
+                inp.create_group('chain_break').write('chain_first_residue', chain_first_residue)
+        if rl_chains is not None:
+            if 'chain_break' not in inp:
+                raise ValueError('rl_chains needs chain breaks')
+            g = inp.group('chain_break')
+            if 'rl_chains' in g:
+                g.delete('rl_chains')
+            g.write('rl_chains', np.asarray(rl_chains, 'i4').reshape(2))
+        elif 'chain_break' in inp and 'rl_chains' in inp.group('chain_break'):
+            rl_chains = inp.group('chain_break').read('rl_chains', 'i4')
+        starts = np.concatenate(([0], 3 * np.asarray(chain_first_residue, 'i8')))       # first atom of every chain
+        chain_of = lambda ids: (np.asarray(ids)[..., None] >= starts).sum(axis=-1)      # (negative ids: chain 0, as the reference counts them)
+        multichain = lambda ids: np.array([len(set(r)) > 1 for r in chain_of(ids)], dtype=bool)
+        removed = {}
+        # (checked before anything is modified: a refused file is left as it was)
+        if 'infer_H_O' in pot:
+            io = pot.group('infer_H_O')
+            if multichain(io.group('donors').read('id', 'i4')).any() or multichain(io.group('acceptors').read('id', 'i4')).any():
+                raise ValueError('an infer_H_O site draws on atoms of two chains: write the configuration with chain_first_residue '
+                                 '(or hbond_exclude_residues) so that the junction residues are excluded')
+
+        def cut(name, others, consider=None):
+            if name not in pot:
+                return
+            g = pot.group(name)
+            ids = g.read('id', 'i4')
+            drop = multichain(ids)
+            if consider is not None:
+                drop &= consider(g)
+            removed[name] = int(drop.sum())
+            keep = ~drop
+            for nm in ['id'] + others:
+                arr = g.read(nm)
+                g.delete(nm)
+                g.write(nm, arr[keep])
+
+        cut('angle_spring', ['equil_dist', 'spring_const'])
+        cut('dihedral_spring', ['equil_dist', 'spring_const'])
+        cut('dist_spring', ['equil_dist', 'spring_const', 'bonded_atoms'], lambda g: g.read('bonded_atoms', 'i4') != 0)
+        if 'rama_coord' in pot:
+            g = pot.group('rama_coord')
+            ids = g.read('id', 'i4')
+            n_edit = 0
+            for loc in np.nonzero(multichain(ids))[0]:
+                c = chain_of(ids[loc])
+                if not (c[1] == c[2] == c[3] and (c[0] == c[1] or c[3] == c[4])):
+                    raise ValueError('weird rama_coord row %d, unable to proceed' % loc)
+                if c[0] == c[1]:
+                    ids[loc, 4] = -1      # cut psi
+                else:
+                    ids[loc, 0] = -1      # cut phi
+                n_edit += 1
+            g.delete('id'); g.write('id', ids)
+            removed['rama_coord (dihedrals cut)'] = n_edit
+        if remove_pivot and 'pivot_moves' in inp:
+            inp.delete('pivot_moves')
+        ends = np.concatenate((starts, [n_atom]))
+        if rl_chains is None:
+            ranges = [[ends[i], ends[i + 1]] for i in range(len(starts))]
+        else:
+            ranges = [[ends[0], ends[int(rl_chains[0])]], [ends[int(rl_chains[0])], ends[-1]]]
+    add_jump_moves(path, ranges, [jump_length_scale] * len(ranges), [jump_rotation_scale * np.pi / 180.] * len(ranges))
+    return removed
 
 
 def add_jump_moves(path, atom_ranges, sigma_trans, sigma_rot):

@@ -220,7 +220,7 @@ DerivEngine::~DerivEngine() {
     invalidate_graph();
     for (auto& kv : side) {
         (void)hipStreamSynchronize(kv.second.stream);
-        (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join); (void)hipEventDestroy(kv.second.join_bwd);
+        (void)hipEventDestroy(kv.second.fork); (void)hipEventDestroy(kv.second.join);
     }
     for (auto& kv : side) if (kv.second.owns_stream) (void)hipStreamDestroy(kv.second.stream);
     nodes.clear();
@@ -340,7 +340,6 @@ void DerivEngine::finalize() {
             } else hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
             hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
-            hip_check(hipEventCreateWithFlags(&sd.join_bwd, hipEventDisableTiming), "hipEventCreate");
             side[(int)c] = sd;
         }
     }
@@ -377,29 +376,18 @@ void DerivEngine::compute(ComputeMode mode) {
             hip_check(hipStreamWaitEvent(sd.stream, sd.fork, 0), "hipStreamWaitEvent");
             on_stream(sd.stream, [&] { c->prepare(); });
             hip_check(hipEventRecord(sd.join, sd.stream), "hipEventRecord");
-            if ((int)k == last_prepare_step)   // the backward-side upkeep of every node, after all the forward-side upkeep
-                for (auto& kv : side) {
-                    auto* cb = nodes[kv.first].computation.get();
-                    if (!cb->has_prepare_backward()) continue;
-                    on_stream(kv.second.stream, [&] { cb->prepare_backward(); });
-                    hip_check(hipEventRecord(kv.second.join_bwd, kv.second.stream), "hipEventRecord");
-                }
             continue;
         }
         if (!st.backward) {
             if (c->has_prepare()) {
                 auto it = side.find(st.node);
                 if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent");
-                else { c->prepare(); if (c->has_prepare_backward()) c->prepare_backward(); }
+                else c->prepare();
             }
             c->compute_value(mode);
         } else if (!c->potential_term) {
             auto* cn = static_cast<CoordNode*>(c);
             cn->gather_contributions();
-            if (c->has_prepare_backward()) {
-                auto it = side.find(st.node);
-                if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join_bwd, 0), "hipStreamWaitEvent");
-            }
             c->propagate_deriv();
         }
     }

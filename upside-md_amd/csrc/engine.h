@@ -44,7 +44,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
     struct Step { int node; bool backward; bool prepare = false; };
     std::vector<Step> schedule;
-    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join_bwd = nullptr; bool owns_stream = true; };
+    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool owns_stream = true; };
     std::map<int, Side> side;                  // node index -> side stream of its prepare() (empty when disabled)
     int last_prepare_step = -1;                // index in `schedule` of the last prepare step
     DevBuf<float*> zero_ptrs; DevBuf<long> zero_sizes; int n_zero = 0;   // every CoordNode's sens, cleared by one launch per force pass

@@ -136,8 +136,15 @@ inline herr_t digest_attribute(hid_t obj, const char* name, const H5A_info_t*, v
     Handle a(H5Aopen(obj, name, H5P_DEFAULT), H5Aclose);
     Handle ty(H5Aget_type(a), H5Tclose);
     Handle sp(H5Aget_space(a), H5Sclose);
-    if (H5Tis_variable_str(ty) > 0) { c.error = "variable-length strings not supported"; return -1; }
     const hssize_t n = H5Sget_simple_extent_npoints(sp);
+    if (H5Tis_variable_str(ty) > 0) {      // (h5py-style metadata: hashed by content -- the pointers HDF5 hands back are not content)
+        std::vector<char*> strs((size_t)(n > 0 ? n : 0), nullptr);
+        Handle mt(H5Tcopy(H5T_C_S1), H5Tclose); H5Tset_size(mt, H5T_VARIABLE);
+        if (!strs.empty() && H5Aread(a, mt, strs.data()) < 0) { c.error = std::string("unable to read attribute ") + name; return -1; }
+        for (char* x : strs) c.text(x ? x : "");
+        if (!strs.empty()) H5Dvlen_reclaim(mt, sp, H5P_DEFAULT, strs.data());
+        return 0;
+    }
     std::vector<unsigned char> buf((size_t)(n > 0 ? n : 0) * H5Tget_size(ty));
     if (!buf.empty() && H5Aread(a, ty, buf.data()) < 0) { c.error = std::string("unable to read attribute ") + name; return -1; }
     c.bytes(buf.data(), buf.size());
@@ -158,6 +165,11 @@ inline herr_t digest_object(hid_t, const char* name, const H5O_info_t* info, voi
         if (nd > 0) H5Sget_simple_extent_dims(sp, dims.data(), NULL);
         c.bytes(dims.data(), sizeof(hsize_t) * (size_t)(nd > 0 ? nd : 0));
         const hssize_t n = H5Sget_simple_extent_npoints(sp);
+        if (H5Tdetect_class(ty, H5T_VLEN) > 0 || H5Tis_variable_str(ty) > 0) {
+            // variable-length data would be read as pointers: no node of this library reads such a dataset, its shape is its digest
+            c.text("<variable-length>");
+            return 0;
+        }
         std::vector<unsigned char> buf((size_t)(n > 0 ? n : 0) * H5Tget_size(ty));
         if (!buf.empty() && H5Dread(obj, ty, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf.data()) < 0) { c.error = std::string("unable to read ") + name; return -1; }
         c.bytes(buf.data(), buf.size());

@@ -116,7 +116,7 @@ __device__ __forceinline__ void load_elem(float* x, const upk_coord_t& node, int
 // right here (x, y, z and the element id in the 4th word), so the rebuild streams one float4 array per side.
 __global__ void k_pairlist_check(upk_igraph_t G) {
     __shared__ int moved;
-    __shared__ float top[2][4];              // per wavefront: the largest and second largest squared displacement
+    __shared__ float top[2][16];             // per wavefront: the largest and second largest squared displacement
     const int s = blockIdx.y;
     if (threadIdx.x == 0) moved = 0;
     __syncthreads();
@@ -180,7 +180,11 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
     }
 }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
-    hipLaunchKernelGGL(k_pairlist_check, dim3(1, L->n_system), dim3(256), 0, ST(L), *G);
+    // (latency bound -- every element is a chain load position -> load reference -> store packed copy: as many lanes as the
+    //  system has elements, up to a full workgroup, so that a lane walks one or two elements instead of seven)
+    const int n_tot = G->symmetric ? G->n1 : G->n1 + G->n2;
+    const int threads = n_tot <= 256 ? 256 : (n_tot <= 512 ? 512 : 1024);
+    hipLaunchKernelGGL(k_pairlist_check, dim3(1, L->n_system), dim3(threads), 0, ST(L), *G);
     return launch_status();
 }
 

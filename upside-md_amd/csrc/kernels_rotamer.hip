@@ -846,7 +846,17 @@ template <int N> __device__ __forceinline__ void bp_store_row(float* p, const fl
 // edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
 // L1 normalisation of 506-521), rewritten in place.  1-ulp hardware reciprocals: the reference itself uses the
 // 12-bit rcpps here (Float4.h:199-212).
-template <int NA, int NB, bool WT>   // WT: messages leave through 16-byte write-through stores (cluster solve)
+// a node's belief row in LDS: NS floats per node (8: one b128 for three states, + one b64 for six; 6: dword reads)
+template <int N, int NS> __device__ __forceinline__ void bp_load_nb(const float* p, float* v) {
+    if (NS == 8) {
+        const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z;
+        if (N == 6) { const float2 b = *(const float2*)(p + 4); v[3] = a.w; v[4] = b.x; v[5] = b.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+}
+template <int NA, int NB, bool WT, int NS = 6>   // WT: messages leave through 16-byte write-through stores (cluster solve)
 __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int a, int b, const float (&P)[NA * NB], const float* __restrict__ nb_old,
                                              __amdgpu_buffer_rsrc_t inbox_w) {
     float* pa = C.msg(oa);
@@ -854,10 +864,11 @@ __device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int
     float ma[NA], mb[NB];
     bp_load_row<NA>(pa, ma); bp_load_row<NB>(pb, mb);
     float va[NA], vb[NB];
+    bp_load_nb<NA, NS>(nb_old + a * NS, va); bp_load_nb<NB, NS>(nb_old + b * NS, vb);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = nb_old[a * 6 + i] * fast_rcp(1e-10f + ma[i]);
+    for (int i = 0; i < NA; ++i) va[i] *= fast_rcp(1e-10f + ma[i]);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) vb[j] = nb_old[b * 6 + j] * fast_rcp(1e-10f + mb[j]);
+    for (int j = 0; j < NB; ++j) vb[j] *= fast_rcp(1e-10f + mb[j]);
     float ta[NA], tb[NB], sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) { float t = 0.f;
@@ -900,7 +911,7 @@ __device__ __forceinline__ void bp_load_matrix(const BpCtx& C, int sl, float (&P
         else P[i * NB + 2] = ((const float*)r)[2];
     }
 }
-template <int NA, int NB, bool WT>
+template <int NA, int NB, bool WT, int NS = 6>
 __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
                                                    __amdgpu_buffer_rsrc_t inbox_w) {
     // (measured and rejected: fetching the next slot's flag and message offsets one trip ahead.  In the 6x6 instance it
@@ -911,7 +922,7 @@ __device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int h
         if (!act) continue;
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, sl, P);
-        bp_edge_slot<NA, NB, WT>(C, oa, ob, C.slot_a[sl], C.slot_b[sl], P, nb_old, inbox_w);
+        bp_edge_slot<NA, NB, WT, NS>(C, oa, ob, C.slot_a[sl], C.slot_b[sl], P, nb_old, inbox_w);
     }
 }
 // Active slots of the multi-state classes, packed once per solve: the sweeps then read one 16-byte record per ACTIVE slot
@@ -941,7 +952,7 @@ __device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict_
         __syncthreads();
     }
 }
-template <int NA, int NB>
+template <int NA, int NB, int NS = 6>
 __device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int end, const float* __restrict__ nb_old, int tid, int nt,
                                                __amdgpu_buffer_rsrc_t rs) {
 #ifndef BP_REC_AHEAD
@@ -966,7 +977,7 @@ __device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int en
             if (idx + 2 * nt < end) r2 = C.rec[idx + 2 * nt];
             float P1[NA * NB];
             bp_load_matrix<NA, NB>(C, r1.w, P1);                  // (the last trip re-reads its own matrix: harmless)
-            bp_edge_slot<NA, NB, false>(C, r0.x, r0.y, r0.z & 0xffff, r0.z >> 16, P0, nb_old, rs);
+            bp_edge_slot<NA, NB, false, NS>(C, r0.x, r0.y, r0.z & 0xffff, r0.z >> 16, P0, nb_old, rs);
             r0 = r1; r1 = r2;
 #pragma unroll
             for (int e = 0; e < NA * NB; ++e) P0[e] = P1[e];
@@ -980,13 +991,13 @@ __device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int en
         if (BP_REC_AHEAD && idx + nt < end) rn = C.rec[idx + nt];
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, r.w, P);
-        bp_edge_slot<NA, NB, false>(C, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nb_old, rs);
+        bp_edge_slot<NA, NB, false, NS>(C, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nb_old, rs);
         if (BP_REC_AHEAD) r = rn; else if (idx + nt < end) r = C.rec[idx + nt];
     }
 }
-template <int NA, int NB>
+template <int NA, int NB, int NS = 6>
 __device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
-    bp_edge_range_impl<NA, NB, false>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
+    bp_edge_range_impl<NA, NB, false, NS>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
 }
 // energies -> probabilities, in place, for slots [lo, hi) of one class (rotamer.cpp:835)
 // One slot per lane and trip: all NA*NB loads of the slot are issued before the first store, so a trip costs one
@@ -1004,7 +1015,7 @@ __device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int
 }
 
 // pair marginals and (optionally) their Bethe free-energy terms (rotamer.cpp:405-451)
-template <int NA, int NB>
+template <int NA, int NB, int NS = 6>
 __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa, int ob, int a, int b, const float (&P)[NA * NB],
                                                   const float* __restrict__ nbm, bool want_energy) {
     float en = 0.f;
@@ -1014,9 +1025,9 @@ __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa
     // to the resident matrices, and the products round identically both times
     float bc1[NA], bc2[NB], sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) bc1[i] = nbm[a * 6 + i] * rcp(1e-10f + ma[i]);
+    for (int i = 0; i < NA; ++i) bc1[i] = nbm[a * NS + i] * rcp(1e-10f + ma[i]);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) bc2[j] = nbm[b * 6 + j] * rcp(1e-10f + mb[j]);
+    for (int j = 0; j < NB; ++j) bc2[j] = nbm[b * NS + j] * rcp(1e-10f + mb[j]);
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -1028,11 +1039,11 @@ __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa
         for (int j = 0; j < NB; ++j) {
             const float pm = (P[i * NB + j] * bc1[i] * bc2[j]) * rs;
             C.marg[PIDX6(C.cap, sl, i, j)] = pm;
-            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i * NB + j] * nbm[a * 6 + i] * nbm[b * 6 + j]));
+            if (want_energy) en += pm * logf((1e-10f + pm) * rcp(1e-10f + P[i * NB + j] * nbm[a * NS + i] * nbm[b * NS + j]));
         }
     return en;
 }
-template <int NA, int NB>
+template <int NA, int NB, int NS = 6>
 __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nbm, int tid, int nt,
                                                    bool want_energy) {
     float en = 0.f;
@@ -1040,12 +1051,12 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
         if (!C.active[sl]) continue;
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, sl, P);
-        en += bp_marginal_slot<NA, NB>(C, sl, C.slot_off[sl * 2], C.slot_off[sl * 2 + 1], C.slot_a[sl], C.slot_b[sl], P, nbm, want_energy);
+        en += bp_marginal_slot<NA, NB, NS>(C, sl, C.slot_off[sl * 2], C.slot_off[sl * 2 + 1], C.slot_a[sl], C.slot_b[sl], P, nbm, want_energy);
     }
     return en;
 }
 
-template <int NA, int NB>
+template <int NA, int NB, int NS = 6>
 __device__ __forceinline__ float bp_marginal_packed(const BpCtx& C, int first, int end, const float* __restrict__ nbm, int tid, int nt, bool want_energy) {
     float en = 0.f;
     int idx = first + tid;                                         // (the next trip's record is fetched one trip ahead, as in bp_edge_packed)
@@ -1055,7 +1066,7 @@ __device__ __forceinline__ float bp_marginal_packed(const BpCtx& C, int first, i
         if (idx + nt < end) rn = C.rec[idx + nt];
         float P[NA * NB];
         bp_load_matrix<NA, NB>(C, r.w, P);
-        en += bp_marginal_slot<NA, NB>(C, r.w, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nbm, want_energy);
+        en += bp_marginal_slot<NA, NB, NS>(C, r.w, r.x, r.y, r.z & 0xffff, r.z >> 16, P, nbm, want_energy);
         r = rn;
     }
     return en;
@@ -1075,6 +1086,9 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
 }
 
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase
+#ifndef BP_NODE_STRIDE
+#define BP_NODE_STRIDE 6      // (8 = one b128 + one b64 per node row: measured equal, and 6 leaves 7 KB more of the LDS to the inbox)
+#endif
 #ifndef BP_NODE_ROWS_512
 #define BP_NODE_ROWS_512 4
 #endif
@@ -1101,16 +1115,16 @@ struct BpResident {
             }
         }
     }
-    __device__ __forceinline__ void edge(const BpCtx& C, const float* __restrict__ nb_old, __amdgpu_buffer_rsrc_t rs) const {
+    template <int NS> __device__ __forceinline__ void edge(const BpCtx& C, const float* __restrict__ nb_old, __amdgpu_buffer_rsrc_t rs) const {
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (ab[k] >= 0) bp_edge_slot<NA, NB, false>(C, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nb_old, rs);
+            if (ab[k] >= 0) bp_edge_slot<NA, NB, false, NS>(C, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nb_old, rs);
     }
-    __device__ __forceinline__ float marginal(const BpCtx& C, const float* __restrict__ nbm, bool want_energy) const {
+    template <int NS> __device__ __forceinline__ float marginal(const BpCtx& C, const float* __restrict__ nbm, bool want_energy) const {
         float en = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (ab[k] >= 0) en += bp_marginal_slot<NA, NB>(C, sl[k], oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nbm, want_energy);
+            if (ab[k] >= 0) en += bp_marginal_slot<NA, NB, NS>(C, sl[k], oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nbm, want_energy);
         return en;
     }
 };
@@ -1125,10 +1139,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
     const int NN = R.n_node;
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
-    float* nb0 = lds + NN * 6;         // [NN][6]
-    float* nb1 = lds + NN * 12;        // [NN][6]
-    float* scratch = lds + NN * 18;    // [32]
-    int* nrot = (int*)(lds + NN * 18 + 32);      // [NN]   state counts
+    constexpr int NS = BP_NODE_STRIDE;   // floats per node in the LDS belief arrays: 8, so that a node's states are one b128 (+ one b64) access
+    float* nb0 = lds + NN * NS;        // [NN][NS]
+    float* nb1 = lds + NN * 2 * NS;    // [NN][NS]
+    float* scratch = lds + NN * 3 * NS;   // [32]
+    int* nrot = (int*)(lds + NN * 3 * NS + 32);  // [NN]   state counts
     int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
     int* cls = bp_start + NN + 1;                // [N_CLASS+1]
     int* n_act = cls + N_CLASS + 1;              // [3] active slots of the 3x3 / 3x6 / 6x6 classes
@@ -1153,7 +1168,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     else for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
     if (tid < 3) n_act[tid] = 0;
-    for (int i = tid; i < NN * 6; i += nt) prob[i] = R.node_prob[(size_t)s * NN * 6 + i];
+    for (int i = tid; i < NN * 6; i += nt) prob[(i / 6) * NS + i % 6] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
 
     // energies -> probabilities for the entries each class uses (rotamer.cpp:835); 1xN rows carry up to 6 columns
@@ -1233,7 +1248,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         const int cnt = adj_cnt[g];
         float pr[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) pr[r] = prob[g * 6 + r];
+        for (int r = 0; r < 6; ++r) pr[r] = prob[g * NS + r];
         for (int k0 = 0; k0 < cnt; k0 += 4) {
             int sl[4], act[4]; float row[4][6];
 #pragma unroll
@@ -1251,10 +1266,10 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                     for (int r = 0; r < 6; ++r) if (r < n) pr[r] *= row[u][r];
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) if (r < n) prob[g * 6 + r] = pr[r];
+        for (int r = 0; r < 6; ++r) if (r < n) prob[g * NS + r] = pr[r];
     }
     __syncthreads();
-    for (int i = tid; i < NN * 6; i += nt) { nb0[i] = prob[i]; nb1[i] = prob[i]; }   // old node belief = prob (rotamer.cpp:1009-1013)
+    for (int i = tid; i < NN * NS; i += nt) { const float v = (i % NS) < 6 ? prob[i] : 0.f; nb0[i] = v; nb1[i] = v; }   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
     BpResident<3, 3, K33> r33; BpResident<3, 6, K36> r36; BpResident<6, 6, K66> r66;
     const int e33 = cls[CL33] + n_act[CL33], e36 = cls[CL36] + n_act[CL36], e66 = cls[CL66] + n_act[CL66];   // ends of the packed records
@@ -1274,15 +1289,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // ---- edge phase: every residue pair rewrites its two messages in place from the old node beliefs
         // (measured and rejected: dealing 64-slot chunks of all classes to the wavefronts round-robin, heavy classes first, to
         // even out the trip counts -- 1 % slower: the phase is limited by bytes, not by trips)
-        r33.edge(C, nb_old, inbox_rs); r36.edge(C, nb_old, inbox_rs); r66.edge(C, nb_old, inbox_rs);
+        r33.template edge<NS>(C, nb_old, inbox_rs); r36.template edge<NS>(C, nb_old, inbox_rs); r66.template edge<NS>(C, nb_old, inbox_rs);
         if (PACK) {
-            bp_edge_packed<3, 3>(C, cls[CL33] + K33 * nt, e33, nb_old, tid, nt, inbox_rs);
-            bp_edge_packed<3, 6>(C, cls[CL36] + K36 * nt, e36, nb_old, tid, nt, inbox_rs);
-            bp_edge_packed<6, 6>(C, cls[CL66] + K66 * nt, e66, nb_old, tid, nt, inbox_rs);
+            bp_edge_packed<3, 3, NS>(C, cls[CL33] + K33 * nt, e33, nb_old, tid, nt, inbox_rs);
+            bp_edge_packed<3, 6, NS>(C, cls[CL36] + K36 * nt, e36, nb_old, tid, nt, inbox_rs);
+            bp_edge_packed<6, 6, NS>(C, cls[CL66] + K66 * nt, e66, nb_old, tid, nt, inbox_rs);
         } else {
-            bp_edge_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
-            bp_edge_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_old, tid, nt);
-            bp_edge_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_old, tid, nt);
+            bp_edge_range<3, 3, NS>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
+            bp_edge_range<3, 6, NS>(C, cls[CL36], cls[CL36 + 1], nb_old, tid, nt);
+            bp_edge_range<6, 6, NS>(C, cls[CL66], cls[CL66 + 1], nb_old, tid, nt);
         }
         __syncthreads();
         if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
@@ -1358,15 +1373,15 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 // b = prob * product, then standardize (rotamer.cpp:258-273); lane gl finishes states gl and gl+4
                 float v[6], mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { v[r] = r < n ? prob[g * 6 + r] * bb[r] : 0.f; mx = fmaxf(mx, v[r]); }
+                for (int r = 0; r < 6; ++r) { v[r] = r < n ? prob[g * NS + r] * bb[r] : 0.f; mx = fmaxf(mx, v[r]); }
                 const float rm = rcp(mx);
                 const float damp = sweep < 0 ? 0.f : R.damping;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     if (r < n && (r % BP_GROUP) == gl) {
-                        const float o = nb_old[g * 6 + r];
+                        const float o = nb_old[g * NS + r];
                         const float nv = damp != 0.f ? (1.f - damp) * rm * v[r] + damp * o : rm * v[r];
-                        nb_cur[g * 6 + r] = nv;
+                        nb_cur[g * NS + r] = nv;
                         dev = fmaxf(nv - o, dev);                      // signed, rotamer.cpp:275-281
                     }
                 }
@@ -1390,24 +1405,24 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     for (int g = tid; g < NN; g += nt) {
         const int n = nrot[g];
         float sum = 0.f;
-        if (n == 1) { nb_cur[g * 6] = 1.f; for (int r = 1; r < 6; ++r) nb_cur[g * 6 + r] = 0.f; continue; }
-        for (int r = 0; r < n; ++r) sum += nb_cur[g * 6 + r];
+        if (n == 1) { nb_cur[g * NS] = 1.f; for (int r = 1; r < 6; ++r) nb_cur[g * NS + r] = 0.f; continue; }
+        for (int r = 0; r < n; ++r) sum += nb_cur[g * NS + r];
         const float rs = rcp(sum);
-        for (int r = 0; r < n; ++r) nb_cur[g * 6 + r] *= rs;
+        for (int r = 0; r < n; ++r) nb_cur[g * NS + r] *= rs;
     }
     __syncthreads();
     float en = 0.f;
-    en += r33.marginal(C, nb_cur, want_energy);
-    en += r36.marginal(C, nb_cur, want_energy);
-    en += r66.marginal(C, nb_cur, want_energy);
+    en += r33.template marginal<NS>(C, nb_cur, want_energy);
+    en += r36.template marginal<NS>(C, nb_cur, want_energy);
+    en += r66.template marginal<NS>(C, nb_cur, want_energy);
     if (PACK) {
-        en += bp_marginal_packed<3, 3>(C, cls[CL33] + K33 * nt, e33, nb_cur, tid, nt, want_energy);
-        en += bp_marginal_packed<3, 6>(C, cls[CL36] + K36 * nt, e36, nb_cur, tid, nt, want_energy);
-        en += bp_marginal_packed<6, 6>(C, cls[CL66] + K66 * nt, e66, nb_cur, tid, nt, want_energy);
+        en += bp_marginal_packed<3, 3, NS>(C, cls[CL33] + K33 * nt, e33, nb_cur, tid, nt, want_energy);
+        en += bp_marginal_packed<3, 6, NS>(C, cls[CL36] + K36 * nt, e36, nb_cur, tid, nt, want_energy);
+        en += bp_marginal_packed<6, 6, NS>(C, cls[CL66] + K66 * nt, e66, nb_cur, tid, nt, want_energy);
     } else {
-        en += bp_marginal_range<3, 3>(C, cls[CL33], cls[CL33 + 1], nb_cur, tid, nt, want_energy);
-        en += bp_marginal_range<3, 6>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
-        en += bp_marginal_range<6, 6>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
+        en += bp_marginal_range<3, 3, NS>(C, cls[CL33], cls[CL33 + 1], nb_cur, tid, nt, want_energy);
+        en += bp_marginal_range<3, 6, NS>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
+        en += bp_marginal_range<6, 6, NS>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
     }
     if (want_energy) {
         for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
@@ -1415,13 +1430,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         for (int g = tid; g < NN; g += nt) {   // node_free_energy, rotamer.cpp:292-302
             const int n = nrot[g];
             float e = R.node_off[(size_t)s * NN + g];
-            for (int r = 0; r < n; ++r) { const float b = nb_cur[g * 6 + r]; e += b * logf((1e-10f + b) * rcp(1e-10f + prob[g * 6 + r])); }
+            for (int r = 0; r < n; ++r) { const float b = nb_cur[g * NS + r]; e += b * logf((1e-10f + b) * rcp(1e-10f + prob[g * NS + r])); }
             en += e;
         }
         const float tot = block_sum(en, scratch);
         if (tid == 0) R.energy[s] = tot;
     }
-    for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[i];
+    for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[(i / 6) * NS + i % 6];
     __syncthreads();
     // leave the accumulators clean for the next force evaluation
     // (only the slots written this step: the others were left at 0 by the prologue); the flags move to active_last
@@ -1904,7 +1919,7 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     }
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
-    const size_t lds_base = ((size_t)R->n_node * 20 + 64 + 8) * sizeof(float);
+    const size_t lds_base = ((size_t)R->n_node * (3 * BP_NODE_STRIDE + 2) + 64 + 8) * sizeof(float);
     if (lds_base > 155 * 1024) return 9004;
     // LDS left over holds the messages to the 3-state nodes (at most all of the inbox: 16 floats per slot)
     static int lds_msg_kb = -1;   // UPSIDE_HIP_BP_LDS_MSG_KB (experiments): 0 keeps every message in global memory
