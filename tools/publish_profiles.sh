@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the summaries tools/refresh_profiles.sh left under gpurun_out/prof/ into profiles/ (tracked), named per round
 set -u
-R=${1:-r02}
+R=${1:-r03}
 S=gpurun_out/prof; D=profiles
 for n in 1 8 64 256 1024 4096; do [ -s $S/bench_R$n.json ] && cp $S/bench_R$n.json $D/${R}_bench_R$n.json; done
 for w in remd64_proteinG56 ens512_syn150; do [ -s $S/bench_$w.json ] && cp $S/bench_$w.json $D/${R}_bench_$w.json; done

@@ -28,7 +28,7 @@ for t in trace fetch write sq; do rm -rf "$OUT/$t"; done
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS -d "$OUT/sq" -o sq -- $CMD > "$OUT/sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$OUT/sq" -o sq -- $CMD > "$OUT/sq.log" 2>&1
 for t in trace fetch write sq; do
   db=$(find "$OUT/$t" -name "*.db" | head -1)
   [ -n "$db" ] && python3 tools/rocpd_summary.py "$db" "$OUT/${t}_summary.txt"
