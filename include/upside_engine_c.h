@@ -161,6 +161,9 @@ int upside_hip_comm_free(DerivEngine* engine);
 
 /* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */
 int upside_hip_rebuild_flags(DerivEngine* engine, const char* node_name, int* flags);
+/* diagnostics: out11 = n1, n2, cap1, cap2, cutoff, cache cutoff, then per-system means of the summed cached list lengths of
+   side 1 / side 2 and of the in-range (hit) list lengths of side 1 / side 2, and the sides the MD path walks (bit mask) */
+int upside_hip_igraph_stats(DerivEngine* engine, const char* node_name, double* out11);
 /* Parity/diagnostic access: the in-range pair list of an interaction-graph node of system `sys` after the
  * last force pass, canonical order of interaction_graph.h:122-157.  Returns n_edge or -1. */
 int upside_hip_get_pairlist(DerivEngine* engine, const char* node_name, int sys, int max_edge, int* i1, int* i2);

@@ -18,6 +18,7 @@ using namespace std;
 int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pair<int, int>>& out);
 int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters);
 int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags);
+int engine_igraph_stats(DerivEngine& e, const string& node_name, double* out);
 double engine_bp_bytes(DerivEngine& e);
 double engine_igraph_bytes(DerivEngine& e);
 int upside_main_impl(int argc, const char* const* argv, int verbose);
@@ -520,6 +521,12 @@ extern "C" int upside_hip_rebuild_flags(DerivEngine* e, const char* node_name, i
     vector<int> f;
     if (engine_rebuild_flags(*e, node_name, f)) throw string("node has no interaction graph");
     for (size_t i = 0; i < f.size(); ++i) flags[i] = f[i];
+    return 0;
+    API_CATCH(1)
+}
+extern "C" int upside_hip_igraph_stats(DerivEngine* e, const char* node_name, double* out11) {
+    API_TRY
+    if (engine_igraph_stats(*e, node_name, out11)) throw string("node has no interaction graph");
     return 0;
     API_CATCH(1)
 }

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
                                                    // rotamer passes visit a pair once and give both beads their share
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     const bool side1 = (int)blockIdx.x < blocks1;             // workgroups [0, blocks1) serve the side-1 rows
     const int rb = side1 ? blockIdx.x : blockIdx.x - blocks1;
     const int n_my = side1 ? G.n1 : G.n2, n_other = side1 ? G.n2 : G.n1;
@@ -344,14 +344,19 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     extern __shared__ __attribute__((aligned(16))) float plr_lds[];
     float4* oth = (float4*)plr_lds;
     const int s = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    // (the wavefront index is uniform, which the compiler cannot see: made scalar, row numbers, list lengths and row base addresses
+    //  stay in scalar registers and the loop control runs on the scalar unit)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G.n1 : G.n2, n_other = rows1 ? G.n2 : G.n1;
     const int cap = rows1 ? G.cap1 : G.cap2;
     const float4* src = (const float4*)((rows1 ? G.cur_pos2 : G.cur_pos1) + (size_t)s * n_other * 4);
     const float4* mine = (const float4*)((rows1 ? G.cur_pos1 : G.cur_pos2) + (size_t)s * n_rows * 4);
-    for (int j = threadIdx.x; j < n_other; j += blockDim.x) oth[j] = src[j];
+    for (int j = threadIdx.x; j <= n_other; j += blockDim.x) oth[j] = j < n_other ? src[j] : make_float4(1e18f, 1e18f, 1e18f, 0.f);
     __syncthreads();
+    // (lanes past the end of their row carry the word n_other, which names the far-away sentinel behind the staged elements: such a
+    //  lane fails the distance test by itself and the trip needs no validity masks)
+    const int dead = n_other;
     const int* nbr_base = (rows1 ? G.nbr1 : G.nbr2) + (size_t)s * n_rows * cap;
     const int* cnt_arr = (rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows;
     int* hit_base = (rows1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap;
@@ -370,7 +375,7 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     int my_n = 0, my_lo = 0;                                      // results of row r0 + lane
     auto bcast = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     // the first 64 list words of the next row pair are fetched while this pair is tested
-    int nA = 0, nB = 0;
+    int nA = dead, nB = dead;
     { const int cA = __builtin_amdgcn_readlane(my_cnt, 0), cB = r0 + 1 < r1 ? __builtin_amdgcn_readlane(my_cnt, 1) : 0;
       if (lane < cA) nA = nbr_base[(size_t)r0 * cap + lane];
       if (lane < cB) nB = nbr_base[(size_t)(r0 + 1) * cap + lane]; }
@@ -379,7 +384,7 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
         const bool hasB = ra + 1 < r1;
         const int cntA = __builtin_amdgcn_readlane(my_cnt, la), cntB = hasB ? __builtin_amdgcn_readlane(my_cnt, lb & 63) : 0;
         int wA = nA, wB = nB;
-        nA = 0; nB = 0;
+        nA = dead; nB = dead;
         if (ra + 2 < r1) {
             const int cA = __builtin_amdgcn_readlane(my_cnt, (la + 2) & 63), cB = ra + 3 < r1 ? __builtin_amdgcn_readlane(my_cnt, (la + 3) & 63) : 0;
             if (lane < cA) nA = nbr_base[(size_t)(ra + 2) * cap + lane];
@@ -394,18 +399,18 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
         const int cmax = cntA > cntB ? cntA : cntB;
         for (int k0 = 0; k0 < cmax; k0 += 64) {
             const int k = k0 + lane;
-            if (k0) { wA = k < cntA ? nbrA[k] : 0; wB = k < cntB ? nbrB[k] : 0; }
+            if (k0) { wA = k < cntA ? nbrA[k] : dead; wB = k < cntB ? nbrB[k] : dead; }
             const int jA = wA & jmask, jB = wB & jmask;
-            const float4 yA = oth[k < cntA ? jA : 0], yB = oth[k < cntB ? jB : 0];
+            const float4 yA = oth[jA], yB = oth[jB];
             plr_v2 yx, yy, yz; yx.x = yA.x; yx.y = yB.x; yy.x = yA.y; yy.y = yB.y; yz.x = yA.z; yz.y = yB.z;
             const plr_v2 d2 = dist2_exact2(xx, xy, xz, yx, yy, yz);
-            const bool hitA = k < cntA && d2.x < cut2, hitB = k < cntB && d2.y < cut2;
-            const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
+            const bool hitA = d2.x < cut2, hitB = d2.y < cut2;
+            const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA), mB = __builtin_amdgcn_ballot_w64(hitB);
             const unsigned long long below = (1ull << lane) - 1ull;
             if (hitA) outA[na + __popcll(mA & below)] = wA;
             if (hitB) outB[nb + __popcll(mB & below)] = wB;
             na += __popcll(mA); nb += __popcll(mB);
-            if (SYM) { loa += __popcll(__ballot(hitA && jA < ra)); lob += __popcll(__ballot(hitB && jB < ra + 1)); }
+            if (SYM) { loa += __popcll(__builtin_amdgcn_ballot_w64(hitA && jA < ra)); lob += __popcll(__builtin_amdgcn_ballot_w64(hitB && jB < ra + 1)); }
         }
         if (lane == la) { my_n = na; my_lo = loa; }
         if (hasB && lane == lb) { my_n = nb; my_lo = lob; }
@@ -416,7 +421,7 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G->n1 : G->n2, n_other = rows1 ? G->n2 : G->n1;
     if (n_rows < 1) return 0;
-    const size_t lds = (size_t)(n_other > 0 ? n_other : 1) * 16;
+    const size_t lds = (size_t)((n_other > 0 ? n_other : 0) + 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
     const int rows_per_wg = L->n_system >= upk_device_cu_count() ? PLR_ROWS : (L->n_system >= 16 ? 64 : 16);

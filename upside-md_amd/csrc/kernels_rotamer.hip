@@ -231,7 +231,7 @@ __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int NN = R.n_node;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
         const int s = fl[1 + fi];
         const int* slot_of = R.slot_of + (size_t)s * NN * NN;

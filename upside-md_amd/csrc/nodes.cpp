@@ -1596,6 +1596,22 @@ int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& f
     flags = ig->rebuild_flag.download();
     return 0;
 }
+int engine_igraph_stats(DerivEngine& e, const string& node_name, double* out) {
+    // diagnostics (tools/list_stats.py): sizes and per-system mean list lengths of a node's interaction graph
+    auto* c = e.get(node_name).computation.get();
+    IGraphHost* ig = nullptr;
+    if (auto* r = dynamic_cast<RotamerSidechain*>(c)) ig = &r->ig;
+    else if (auto* h = dynamic_cast<HBondCoverage*>(c)) ig = &h->ig;
+    else if (auto* en = dynamic_cast<EnvironmentCoverage*>(c)) ig = &en->ig;
+    else if (auto* p = dynamic_cast<ProteinHBond*>(c)) ig = &p->ig;
+    if (!ig) return -1;
+    e.sync();
+    const double S = e.ctx.n_system;
+    auto total = [&](DevBuf<int>& b) { double t = 0.; if (b.n) for (int v : b.download()) t += v; return t / S; };
+    out[0] = ig->G.n1; out[1] = ig->G.n2; out[2] = ig->G.cap1; out[3] = ig->G.cap2; out[4] = ig->G.cutoff; out[5] = ig->G.cache_cutoff;
+    out[6] = total(ig->cnt1); out[7] = total(ig->cnt2); out[8] = total(ig->hcnt1); out[9] = total(ig->hcnt2); out[10] = ig->md_sides;
+    return 0;
+}
 int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters) {
     for (auto& n : e.nodes)
         if (auto* r = dynamic_cast<RotamerSidechain*>(n.computation.get())) { e.sync(); iters = r->iters.download(); return 0; }
