@@ -60,39 +60,34 @@ extern "C" int upk_scale(const upk_launch_t* L, float* x, int n, float factor) {
     return launch_status();
 }
 
+// Eight lanes per target element, lane c of the group owning component c: a contribution row (3 to 8 consecutive floats) is one
+// 32-byte access of the group instead of `width` instructions that each touch 64 different rows.  Every component is still
+// summed by one lane in entry order (the same sum as one lane per element).
 __global__ void k_gather_contrib(const float* __restrict__ arena, long arena_stride, const int* __restrict__ csr_start,
                                  const int* __restrict__ csr_entry, upk_coord_t target, int width, int comp_offset) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= target.n_elem) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = g >> 3, c = g & 7;
+    if (t >= target.n_elem || c >= width) return;
     const int s = blockIdx.y;
-    const float* a = arena + (size_t)s * arena_stride;
-    float acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    const float* a = arena + (size_t)s * arena_stride + c;
+    float acc = 0.f;
     const int e0 = csr_start[t], e1 = csr_start[t + 1];
-    // four contributions per trip: their offsets, then their rows, are fetched as independent loads before the adds
-    // (same summation order as one at a time)
+    // four contributions per trip: their offsets, then their values, are fetched as independent loads before the adds
     for (int e = e0; e < e1; e += 4) {
-        int off[4]; float v[4][8];
+        int off[4]; float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) off[u] = csr_entry[e + u < e1 ? e + u : e];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) v[u] = a[off[u]];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[u][c] = c < width ? a[off[u] + c] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (e + u < e1)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) if (c < width) acc[c] += v[u][c];
+        for (int u = 0; u < 4; ++u) if (e + u < e1) acc += v[u];
     }
-    float* sens = C_SENS(target, s) + (size_t)t * target.stride + comp_offset;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) if (c < width) sens[c] += acc[c];
+    C_SENS(target, s)[(size_t)t * target.stride + comp_offset + c] += acc;
 }
 extern "C" int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_stride, const int* csr_start,
                                   const int* csr_entry, upk_coord_t target, int width, int comp_offset) {
-    hipLaunchKernelGGL(k_gather_contrib, grid1(target.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), arena, arena_stride,
+    if (width > 8) return 9010;
+    hipLaunchKernelGGL(k_gather_contrib, grid1(target.n_elem * 8, L->n_system), dim3(UPK_BLOCK), 0, ST(L), arena, arena_stride,
                        csr_start, csr_entry, target, width, comp_offset);
     return launch_status();
 }
