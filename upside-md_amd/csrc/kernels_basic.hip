@@ -206,28 +206,33 @@ __device__ void house(int n, float* x, float& beta) {   // eig.cpp:56-73
     for (int i = 1; i < n; ++i) x[i] *= rcp(s);
 }
 
-__device__ void qr_step(int n, float* d, float* u, float* rot) {   // eig.cpp:183-228; rot points at row p
-    const float dval = 0.5f * (d[n - 2] - d[n - 1]) + 1e-20f;
-    const float un = u[n - 2];
-    const float mu = d[n - 1] - un * un * rcp(dval + copysignf(sqrtf(dval * dval + un * un), dval));
-    float x = d[0] - mu, z = u[0];
-    for (int k = 0; k < n - 1; ++k) {
+// (N rows starting at row P of the tridiagonal matrix: both compile-time, so that d, u and rot are indexed by constants and stay
+//  in registers -- with run-time N and P the compiler moved the three arrays of every lane to LDS, 64 KB per workgroup)
+template <int N, int P>
+__device__ __forceinline__ void qr_step(float (&d)[4], float (&u)[3], float (&rot)[16]) {   // eig.cpp:183-228
+    const float dval = 0.5f * (d[P + N - 2] - d[P + N - 1]) + 1e-20f;
+    const float un = u[P + N - 2];
+    const float mu = d[P + N - 1] - un * un * rcp(dval + copysignf(sqrtf(dval * dval + un * un), dval));
+    float x = d[P] - mu, z = u[P];
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
         const float inv_r = rsqrt_(x * x + z * z);
         const bool trivial = (z == 0.f);
         const float c = trivial ? 1.f : x * inv_r;
         const float s = trivial ? 0.f : -z * inv_r;
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float t1 = rot[k * 4 + j], t2 = rot[(k + 1) * 4 + j];
-            rot[k * 4 + j] = c * t1 - s * t2;
-            rot[(k + 1) * 4 + j] = s * t1 + c * t2;
+            const float t1 = rot[(P + k) * 4 + j], t2 = rot[(P + k + 1) * 4 + j];
+            rot[(P + k) * 4 + j] = c * t1 - s * t2;
+            rot[(P + k + 1) * 4 + j] = s * t1 + c * t2;
         }
-        if (k > 0) u[k - 1] = c * x - s * z;
-        const float T00 = d[k], T11 = d[k + 1], T01 = u[k];
-        d[k] = T00 * c * c - T01 * 2.f * c * s + T11 * s * s;
-        d[k + 1] = T00 * s * s + T01 * 2.f * c * s + T11 * c * c;
-        u[k] = (T00 - T11) * c * s + T01 * (c * c - s * s);
-        x = u[k];
-        if (k < n - 2) { z = -u[k + 1] * s; u[k + 1] *= c; }
+        if (k > 0) u[P + k - 1] = c * x - s * z;
+        const float T00 = d[P + k], T11 = d[P + k + 1], T01 = u[P + k];
+        d[P + k] = T00 * c * c - T01 * 2.f * c * s + T11 * s * s;
+        d[P + k + 1] = T00 * s * s + T01 * 2.f * c * s + T11 * c * c;
+        u[P + k] = (T00 - T11) * c * s + T01 * (c * c - s * s);
+        x = u[P + k];
+        if (k < N - 2) { z = -u[P + k + 1] * s; u[P + k + 1] *= c; }
     }
 }
 
@@ -298,7 +303,15 @@ __global__ void k_affine_fwd(upk_coord_t pos, const int* __restrict__ atoms, con
                 const bool anyu[3] = {any0, any1, any2};
                 int p;
                 for (p = 4 - q - 1; p > 0; --p) if (!anyu[p - 1]) break;
-                qr_step(4 - q - p, d + p, u + p, rot + 4 * p);
+                switch (p * 8 + (4 - q - p)) {     // (p, rows): the six blocks a 4x4 tridiagonal matrix can deflate to
+                    case 0 * 8 + 4: qr_step<4, 0>(d, u, rot); break;
+                    case 0 * 8 + 3: qr_step<3, 0>(d, u, rot); break;
+                    case 0 * 8 + 2: qr_step<2, 0>(d, u, rot); break;
+                    case 1 * 8 + 3: qr_step<3, 1>(d, u, rot); break;
+                    case 1 * 8 + 2: qr_step<2, 1>(d, u, rot); break;
+                    case 2 * 8 + 2: qr_step<2, 2>(d, u, rot); break;
+                    default: break;
+                }
             }
         }
         if (__ballot(!done) == 0ull) break;
@@ -802,7 +815,7 @@ __global__ void __launch_bounds__(1024) k_backbone_pairs(upk_coord_t aff, const 
     __syncthreads();
     const float cutoff2_atom = 3.f * 3.f + 0.1f * 3.f;
     const float cut2 = dist_cutoff * dist_cutoff;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_wave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     int* q = queues + wave * BBP_QUEUE;
     const int qi = lane >> 4, i1 = (lane >> 2) & 3, i2 = lane & 3;
     for (int r = wave; r < BBP_ROWS; r += n_wave) {
