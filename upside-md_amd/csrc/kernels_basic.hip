@@ -787,7 +787,9 @@ __device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, flo
     float cs, dcs; compact_sigmoid(cs, dcs, r_mag2 - wall * wall, sharpness);
     v = 4.f * cs; dv_over_r = 2.f * (4.f * dcs);
 }
+#ifndef BBP_ROWS
 #define BBP_ROWS 64       // residues per workgroup (16 waves x 4)
+#endif
 #define BBP_QUEUE 72      // per-wave queue of close residues (64 new + < 4 left over)
 __global__ void __launch_bounds__(1024) k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residue, const int* __restrict__ id,
                                  const int* __restrict__ n_atom, const float* __restrict__ ref_pos, int n_res, float dist_cutoff,
