@@ -1910,6 +1910,8 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0, true>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    // (tried in round 3: 256 lanes x 2 workgroups per CU, so that the barrier stalls of one solve are filled by the other -- 10.9 ms
+    //  per launch against 6.6: half of each inbox no longer fits LDS and a lane walks twice the streamed 3x3 slots)
     else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else {                    // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
