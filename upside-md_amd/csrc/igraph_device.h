@@ -291,7 +291,15 @@ __device__ __forceinline__ void load_row8(float* x, const float* p) {   // one 3
 #ifndef PG_CHUNK
 #define PG_CHUNK 4      // trips whose list words are loaded together, one chunk ahead
 #endif
-// sum over the lanes of a group, left in all of them
+// sum over the lanes of a group of LANES, left in all of them
+template <int LANES> __device__ __forceinline__ float group_sum_n(float v) {
+    static_assert(LANES == 2 || LANES == 4 || LANES == 8 || LANES == 16, "group_sum_n: DPP steps for groups of 2, 4, 8 or 16 lanes");
+    if (LANES == 16) v += dpp_mov<UP_DPP_ROW_MIRROR>(v);
+    if (LANES >= 8) v += dpp_mov<UP_DPP_HALF_MIRROR>(v);
+    if (LANES >= 4) v += dpp_mov<UP_DPP_XOR2>(v);
+    v += dpp_mov<UP_DPP_XOR1>(v);
+    return v;
+}
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(PG_LANES == 4 || PG_LANES == 8 || PG_LANES == 16, "group_sum: DPP steps for groups of 4, 8 or 16 lanes");
     if (PG_LANES == 16) v += dpp_mov<UP_DPP_ROW_MIRROR>(v);
@@ -318,11 +326,12 @@ __device__ __forceinline__ void stage_ranges(int* lds_range, unsigned short* lds
 //   body(row, word, live) -- one hit-list word per lane; !live: the lane is past the end of its row (word 0), discard
 //   flush(row)      -- reduce over the group and write the row's results (also for rows without hits)
 // All control flow is wave-uniform except the predication of lanes past the end of their row.
-template <typename Op>
+// (LANES: lanes per row group -- 8 by default; graphs whose rows hold two or three pairs take 2, so that a trip is not 3/4 idle lanes)
+template <typename Op, int LANES = PG_LANES>
 __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsigned short* ord, const int* range,
                                                  const int* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step) {
-    const int lane = threadIdx.x & 63, gl = lane & (PG_LANES - 1), g = lane / PG_LANES;
-    const int n_batch = (n_rows + PG_PER_WAVE - 1) / PG_PER_WAVE;
+    const int lane = threadIdx.x & 63, gl = lane & (LANES - 1), g = lane / LANES;
+    const int n_batch = (n_rows + (UP_WAVE / LANES) - 1) / (UP_WAVE / LANES);
     auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
     // one batch = (row, list range, first chunk of list words) per group; the NEXT batch's is fetched while the current one
     // is processed, so a batch switch waits neither for the claim nor for the first global loads
@@ -330,7 +339,7 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
     auto fetch = [&](int i, Batch& B) -> bool {                   // returns false past the last batch (wave-uniform)
         const int b = batch_first + i * batch_step;
         if (b >= n_batch) return false;
-        const int ri = b * PG_PER_WAVE + g;
+        const int ri = b * (UP_WAVE / LANES) + g;
         B.valid = ri < n_rows;
         B.row = B.valid ? (int)ord[ri] : 0;
         const int rg = B.valid ? range[B.row] : 0;
@@ -339,7 +348,7 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
         B.hrow = hit + (size_t)B.row * cap + first + gl;
         B.n_mine = end - first - gl;                              // this lane's words sit at hrow[0], hrow[8], ...: k < n_mine
 #pragma unroll
-        for (int u = 0; u < PG_CHUNK; ++u) B.w[u] = u * PG_LANES < B.n_mine ? B.hrow[u * PG_LANES] : 0;
+        for (int u = 0; u < PG_CHUNK; ++u) B.w[u] = u * LANES < B.n_mine ? B.hrow[u * LANES] : 0;
         return true;
     };
     Batch cur, nxt;
@@ -348,19 +357,19 @@ __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsig
         const bool have_next = fetch(claim(), nxt);
         // (the longest row of the batch decides the trips: a wave-wide maximum, so that a row order computed a few steps ago --
         //  nodes.cpp: IGraphHost::refine -- only costs balance, never pairs; counts are < 2^24, exact in fp32)
-        const int n_trip = __builtin_amdgcn_readfirstlane((int)wave_max((float)((cur.n_mine > 0 ? cur.n_mine : 0) + PG_LANES - 1) ) / PG_LANES);
+        const int n_trip = __builtin_amdgcn_readfirstlane((int)wave_max((float)((cur.n_mine > 0 ? cur.n_mine : 0) + LANES - 1) ) / LANES);
         op.begin(cur.row);      // (groups past the last row take row 0: their lanes are never live, but evaluate like everyone else's)
         for (int t0 = 0; t0 < n_trip; t0 += PG_CHUNK) {
             int wn[PG_CHUNK];
 #pragma unroll
-            for (int u = 0; u < PG_CHUNK; ++u) { const int k = (t0 + PG_CHUNK + u) * PG_LANES; wn[u] = k < cur.n_mine ? cur.hrow[k] : 0; }
+            for (int u = 0; u < PG_CHUNK; ++u) { const int k = (t0 + PG_CHUNK + u) * LANES; wn[u] = k < cur.n_mine ? cur.hrow[k] : 0; }
             // Bodies are branch-free (a lane past the end of its row evaluates list word 0 and discards the result); which of
             // the PG_CHUNK unrolled copies of the functor a pair runs through depends only on its position in its row, never on
             // what else is in the batch, so results do not depend on how rows of equal length were dealt to the wavefronts.
 #pragma unroll
             for (int u = 0; u < PG_CHUNK; ++u) {
                 if (t0 + u >= n_trip) break;        // (wave-uniform)
-                op.body(cur.row, cur.w[u], (t0 + u) * PG_LANES < cur.n_mine);
+                op.body(cur.row, cur.w[u], (t0 + u) * LANES < cur.n_mine);
             }
 #pragma unroll
             for (int u = 0; u < PG_CHUNK; ++u) cur.w[u] = wn[u];

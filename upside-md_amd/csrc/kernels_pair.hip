@@ -90,7 +90,7 @@ __device__ __forceinline__ PairLds pair_lds(float* lds, const upk_igraph_t& G, i
 }
 
 // MODE 0: row sums of the value; 1: value and the UNWEIGHTED sum of d(value)/d(row element); 2: sum of sens(pair) * d(value)/d(row element)
-template <int IT, int ROW_SIDE, int MODE, bool POLY>
+template <int IT, int ROW_SIDE, int MODE, bool POLY, int LANES = PG_LANES>
 struct RowOp {
     static constexpr int NV = MODE == 0 ? 1 : 8;
     const upk_igraph_t& G; const QuadShape Q; const PairLds& L; const PairArgs& A;
@@ -125,8 +125,8 @@ struct RowOp {
     __device__ __forceinline__ void flush(int row) {
         float t[NV];
 #pragma unroll
-        for (int c = 0; c < NV; ++c) t[c] = group_sum(acc[c]);
-        if ((threadIdx.x & (PG_LANES - 1)) != 0) return;
+        for (int c = 0; c < NV; ++c) t[c] = group_sum_n<LANES>(acc[c]);
+        if ((threadIdx.x & (LANES - 1)) != 0) return;
         const int n_rows = ROW_SIDE == 1 ? G.n1 : G.n2;
         float* out_p = A.out + (size_t)s * A.out_sys_stride + (size_t)((ROW_SIDE == 1 ? A.out_row0 : A.out_row0_2) + row) * A.out_stride + A.out_comp;
         if (MODE == 0) *out_p = t[0];
@@ -165,20 +165,23 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
     // rows: [0,dim) coordinates, [6] per-element pair sensitivity (mode 2, sides with dim <= 6), [7] element type
     stage_rows(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, (MODE == 2 && G.dim1 <= 6) ? S1 : nullptr, A.sens_stride);
     stage_rows(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, (MODE == 2 && G.dim2 <= 6) ? S2 : nullptr, A.sens_stride);
+    // (backbone hydrogen bonds: a donor or acceptor has two or three partners in range -- groups of 2 lanes, 32 rows per wavefront
+    //  batch, instead of 8-lane groups of which six lanes would evaluate dead pairs: 0.28 + 0.41 -> 0.23 + 0.29 ms per step at 4096 systems)
+    constexpr int LANES = IT == UPK_IT_PROTEIN_HBOND ? 2 : PG_LANES;
     if (SIDES & 1) {
         if (threadIdx.x == 0) *L.counter = 0;
         stage_ranges(L.range, L.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
         __syncthreads();
-        RowOp<IT, 1, MODE, POLY> op(G, L, A, s);
-        group_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
+        RowOp<IT, 1, MODE, POLY, LANES> op(G, L, A, s);
+        group_batch_loop<RowOp<IT, 1, MODE, POLY, LANES>, LANES>(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
     }
     if (SIDES & 2) {
         if (SIDES == 3) __syncthreads();
         if (threadIdx.x == 0) *L.counter = 0;
         stage_ranges(L.range, L.ord, G.hcnt2 + (size_t)s * G.n2, nullptr, G.ord2 + (size_t)s * G.n2, G.n2);
         __syncthreads();
-        RowOp<IT, 2, MODE, POLY> op(G, L, A, s);
-        group_batch_loop(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, blockIdx.x, gridDim.x);
+        RowOp<IT, 2, MODE, POLY, LANES> op(G, L, A, s);
+        group_batch_loop<RowOp<IT, 2, MODE, POLY, LANES>, LANES>(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, blockIdx.x, gridDim.x);
     }
 }
 
@@ -545,6 +548,13 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
         return launch_status();
     }
     pair_geometry(L->n_system, n_rows, bps, threads);
+    // (a few hundred rows of two or three pairs: the pass is the latency of staging the system, which several small workgroups
+    //  per CU overlap: 1024 lanes 0.29 + 0.23 ms, 512: 0.25 + 0.18, 256: 0.23 + 0.17, 128: 0.29 + 0.20 -- UPSIDE_HIP_HB_THREADS, experiments; the environment graph, 300 rows of ~40 pairs, is best left at 1024)
+    if (G->itype == UPK_IT_PROTEIN_HBOND && bps == 1) {
+        static int hb_threads = 0;
+        if (!hb_threads) { const char* e = getenv("UPSIDE_HIP_HB_THREADS"); hb_threads = e ? atoi(e) : 256; if (hb_threads < 64 || hb_threads > 1024) hb_threads = 256; }
+        threads = hb_threads;
+    }
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
         case UPK_IT_HBOND_COVERAGE:
