@@ -417,10 +417,43 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     }
     if (have) { hcnt[r0 + lane] = my_n; if (SYM && hlo) hlo[r0 + lane] = my_lo; }
 }
+// Rows of a handful of cached neighbours (backbone hydrogen bonds: three per donor or acceptor): one LANE per row walks its list --
+// the row-pair machinery above costs a fixed ~100 instructions and a dependent chain per pair of rows, 0.19 ms per launch for
+// 840 cached pairs per system.  Same hit lists, in the same order.
+__global__ void __launch_bounds__(256) k_pairlist_refine_short(upk_igraph_t G, int side) {
+    const int s = blockIdx.y, row = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool rows1 = side == 1;
+    const int n_rows = rows1 ? G.n1 : G.n2, n_other = rows1 ? G.n2 : G.n1;
+    if (row >= n_rows) return;
+    const int cap = rows1 ? G.cap1 : G.cap2;
+    const float4* src = (const float4*)((rows1 ? G.cur_pos2 : G.cur_pos1) + (size_t)s * n_other * 4);
+    const float4 x = ((const float4*)((rows1 ? G.cur_pos1 : G.cur_pos2) + (size_t)s * n_rows * 4))[row];
+    const int* nbr = (rows1 ? G.nbr1 : G.nbr2) + ((size_t)s * n_rows + row) * cap;
+    int* hit = (rows1 ? G.hit1 : G.hit2) + ((size_t)s * n_rows + row) * cap;
+    const int cnt = ((rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows)[row];
+    const float cut2 = G.cutoff * G.cutoff;
+    const int jmask = G.nbr_j_bits ? (1 << G.nbr_j_bits) - 1 : 0x7fffffff;
+    int n = 0;
+    for (int k0 = 0; k0 < cnt; k0 += 4) {          // four words, then their four positions, in flight together
+        int w[4]; float4 y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = nbr[k0 + u < cnt ? k0 + u : k0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = src[w[u] & jmask];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < cnt && dist2_exact(x.x, x.y, x.z, y[u].x, y[u].y, y[u].z) < cut2) hit[n++] = w[u];
+    }
+    ((rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows)[row] = n;
+}
 extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side) {
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G->n1 : G->n2, n_other = rows1 ? G->n2 : G->n1;
     if (n_rows < 1) return 0;
+    if (G->itype == UPK_IT_PROTEIN_HBOND && !G->symmetric) {
+        hipLaunchKernelGGL(k_pairlist_refine_short, dim3((n_rows + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side);
+        return launch_status();
+    }
     const size_t lds = (size_t)((n_other > 0 ? n_other : 0) + 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
