@@ -128,8 +128,9 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
         const upk_coord_t& node = side1 ? G.node1 : G.node2;
         const float* x = C_OUT(node, s) + (size_t)(side1 ? G.loc1[i] : G.loc2[i]) * node.stride;
         const float* c = (side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + (size_t)i * 4;
-        const float x0 = x[0], x1 = x[1], x2 = x[2];
-        const float dx = x0 - c[0], dy = x1 - c[1], dz = x2 - c[2];
+        const float4 xv = *(const float4*)x, cv = *(const float4*)c;     // (rows of a coordinate node are padded to multiples of 4 floats)
+        const float x0 = xv.x, x1 = xv.y, x2 = xv.z;
+        const float dx = x0 - cv.x, dy = x1 - cv.y, dz = x2 - cv.z;
         const float dd = dx * dx + dy * dy + dz * dz;
         d2 = fmaxf(d2, fminf(d1, dd)); d1 = fmaxf(d1, dd);
         // this step's positions, packed: what upk_pairlist_refine tests against the cutoff (the same bits the pair passes read)
@@ -457,7 +458,13 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
     const size_t lds = (size_t)((n_other > 0 ? n_other : 0) + 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
-    const int rows_per_wg = L->n_system >= upk_device_cu_count() ? PLR_ROWS : (L->n_system >= 16 ? 64 : 16);
+    int rows_per_wg = L->n_system >= upk_device_cu_count() ? PLR_ROWS : (L->n_system >= 16 ? 64 : 16);
+    {   // a side of a few hundred rows (environment graph: 300): smaller workgroups, or one of its two would walk 256 rows as 32
+        // dependent row pairs per wavefront while the other has 44 (0.30 -> 0.24 ms; UPSIDE_HIP_PLR_ROWS_SMALL: experiments, 0 = off)
+        static int small_rows = -1;
+        if (small_rows < 0) { const char* e = getenv("UPSIDE_HIP_PLR_ROWS_SMALL"); small_rows = e ? atoi(e) : 128; }
+        if (small_rows > 0 && n_rows <= 512 && rows_per_wg > small_rows) rows_per_wg = small_rows;
+    }
     const dim3 grid((n_rows + rows_per_wg - 1) / rows_per_wg, L->n_system);
     if (G->symmetric) hipLaunchKernelGGL(k_pairlist_refine<true>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
     else hipLaunchKernelGGL(k_pairlist_refine<false>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
