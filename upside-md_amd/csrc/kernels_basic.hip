@@ -72,15 +72,19 @@ __global__ void k_gather_contrib(const float* __restrict__ arena, long arena_str
     const float* a = arena + (size_t)s * arena_stride + c;
     float acc = 0.f;
     const int e0 = csr_start[t], e1 = csr_start[t + 1];
-    // four contributions per trip: their offsets, then their values, are fetched as independent loads before the adds
-    for (int e = e0; e < e1; e += 4) {
-        int off[4]; float v[4];
+    // GC_UNROLL contributions per trip: their offsets, then their values, are fetched as independent loads before the adds (a trip is
+    // two dependent round trips; an atom of `pos` gathers 15-20 contributions)
+#ifndef GC_UNROLL
+#define GC_UNROLL 8
+#endif
+    for (int e = e0; e < e1; e += GC_UNROLL) {
+        int off[GC_UNROLL]; float v[GC_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) off[u] = csr_entry[e + u < e1 ? e + u : e];
+        for (int u = 0; u < GC_UNROLL; ++u) off[u] = csr_entry[e + u < e1 ? e + u : e];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = a[off[u]];
+        for (int u = 0; u < GC_UNROLL; ++u) v[u] = a[off[u]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (e + u < e1) acc += v[u];
+        for (int u = 0; u < GC_UNROLL; ++u) if (e + u < e1) acc += v[u];
     }
     C_SENS(target, s)[(size_t)t * target.stride + comp_offset + c] += acc;
 }
