@@ -371,6 +371,40 @@ def test_cached_pairlist_path_after_md(hip):
     c.free_deriv_engine(ct.c_void_p(eng))
 
 
+def test_list_statistics_agree_with_the_pair_lists(hip):
+    """upside_hip_igraph_stats (diagnostics, tools/list_stats.py): after MD steps the per-system sums of the in-range (hit) list
+    lengths of every graph equal the sizes of its canonical pair list -- the rows the pair passes walk hold exactly the
+    reference's edges (interaction_graph.h:201-257) --, cached lists are at least as long, capacities are not exceeded."""
+    name = 'proteinG56_7A'
+    c = hip.calc
+    c.upside_hip_igraph_stats.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_void_p]
+    g = P.golden(name); n_atom = g['pos'].shape[0]
+    S = 3
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), S, True)
+    pos = np.ascontiguousarray(np.stack([g['pos'], g['pos2'], g['pos']]).astype('f4'))
+    c.upside_hip_set_pos(eng, pos.ctypes.data)
+    temps = np.full(S, 0.85, 'f4')
+    c.upside_hip_init_md(eng, temps.ctypes.data, 3, 5.0, 0.009, 1)
+    assert c.upside_hip_run_md(eng, 12) == 0
+    en = np.zeros(S, 'f4')
+    assert c.upside_hip_compute(eng, en.ctypes.data, None) == 0
+    up_view = type('V', (), {'calc': c, 'engine': ct.c_void_p(eng)})
+    out = np.zeros(11)
+    for node in IGRAPH_NODES:
+        assert c.upside_hip_igraph_stats(eng, node.encode(), out.ctypes.data) == 0, node
+        n1, n2, cap1, cap2, cut, cache_cut, c1, c2, h1, h2, sides = out
+        assert cache_cut > cut > 0 and n1 > 0 and n2 > 0
+        edges = sum(len(hip_pairlist(up_view, node, sys=k)) for k in range(S)) / S
+        symmetric = node == 'rotamer'
+        for side, (cached, hits, n_rows, cap) in enumerate(((c1, h1, n1, cap1), (c2, h2, n2, cap2)), 1):
+            if not (int(sides) & side) or (symmetric and side == 2):
+                continue
+            assert abs(hits - edges) < 1e-6 * max(edges, 1.), (node, side, hits, edges)     # (each pair once per walked side)
+            assert cached >= hits and cached <= n_rows * cap
+    assert c.upside_hip_igraph_stats(eng, b'pos', out.ctypes.data) != 0      # not an interaction-graph node
+    c.free_deriv_engine(ct.c_void_p(eng))
+
+
 def test_benchmark_size_properties(hip):
     """BASELINE-size checks that need no oracle run: translation invariance (sum of forces ~ 0), rigid-rotation
     invariance of the energy, energy conservation trend of the leapfrog integrator without thermostat noise,
