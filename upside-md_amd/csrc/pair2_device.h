@@ -188,16 +188,15 @@ __device__ __forceinline__ v2 quadspline_pair2(const QuadShape& Q, const float* 
 }
 
 // ---- 4-lane groups, two hit-list words per lane and trip ---------------------------------------------------------------
-#define P2_LANES 4
+#ifndef P2_LANES
+#define P2_LANES 4      // (measured at 4096 systems: 8 lanes within 0.5 %, 16 lanes -4.5 %: the LDS bank conflicts of the partner gathers --
+                        //  two thirds of the LDS-active cycles -- are not what bounds the passes)
+#endif
 #define P2_ROWS (UP_WAVE / P2_LANES)
 #ifndef P2_CHUNK
 #define P2_CHUNK 2      // trips whose list words are loaded together, one chunk ahead (a trip = 8 words of a row)
 #endif
-__device__ __forceinline__ float group_sum4(float v) {
-    v += dpp_mov<UP_DPP_XOR2>(v);
-    v += dpp_mov<UP_DPP_XOR1>(v);
-    return v;
-}
+__device__ __forceinline__ float group_sum4(float v) { return group_sum_n<P2_LANES>(v); }     // (sum over the P2_LANES lanes of a row group)
 // As group_batch_loop (igraph_device.h), for batches of 16 rows.  Op provides
 //   begin(row)                       -- load the row element, reset the row accumulators
 //   body(row, wA, wB, liveA, liveB)  -- two hit-list words per lane; a dead half carries `dead_word` (the sentinel element)
