@@ -275,7 +275,7 @@ typedef struct {
     int* n_bad;                          /* [S] solves that ran into max_iter (rotamer.cpp:784-785), counted on the device */
     int* bp_rec;                         /* [S][slot_cap][4] scratch of the one-workgroup solve: per class, the slots active this step
                                             packed as {offset a, offset b, node a | node b << 16, slot} */
-    long long* bp_trace;                 /* [S][16] 100 MHz phase clocks of the last solve, or NULL (diagnostics) */
+    long long* bp_trace;                 /* [S][32] 100 MHz phase clocks of the last solve ([16..24): sub-phase stamps), or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */
     int bp_C, bp_resident;               /* workgroups per system; 1 = matrices resident in LDS (512 lanes), 0 = split solve over global memory */

@@ -16,7 +16,7 @@ lib = E.default_library()
 if S == 1:
     e = E.Upside(up, library=lib)
     for _ in range(3): e.energy(pos)
-    t = e.get_value_by_name((16,), "rotamer", "bp_trace")
+    t = e.get_value_by_name((32,), "rotamer", "bp_trace")
 else:
     c = lib.calc
     import ctypes as ct
@@ -29,9 +29,13 @@ else:
     c.upside_hip_set_pos(eng, allpos.ctypes.data)
     en = np.zeros(S, np.float32)
     for _ in range(3): c.upside_hip_compute(eng, en.ctypes.data, None)
-    t = np.zeros(16, np.float32)
-    c.get_value_by_name(16, t.ctypes.data, eng, b"rotamer", b"bp_trace")
+    t = np.zeros(32, np.float32)
+    c.get_value_by_name(32, t.ctypes.data, eng, b"rotamer", b"bp_trace")
 names = ["prologue", "loop", "epilogue", "edge_phase", "node_phase"]
 for n_, v in zip(names, t[:5]): print("%-12s %8.1f us" % (n_, v * 0.01))
 print("sweeps %d  n_slot %d  inbox rows %d  class starts %s" % (t[5], t[6], t[7], t[8:14].astype(int)))
 print("per sweep: edge %.2f us  node %.2f us" % (t[3] * 0.01 / (t[5] + 1), t[4] * 0.01 / (t[5] + 1)))
+
+sub = ["setup", "layout+pack", "msg init", "fold+nb init", "resident load", "resident marginals", "packed marginals", "energy+beliefs out"]
+print("stamps since kernel start (us): " + ", ".join("%s %.1f" % (n_, v * 0.01) for n_, v in zip(sub, t[16:24])))
+print("loop end at %.1f us, kernel end at %.1f us" % ((t[0] + t[1]) * 0.01, (t[0] + t[1] + t[2]) * 0.01))

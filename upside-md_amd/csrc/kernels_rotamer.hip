@@ -29,7 +29,12 @@ static inline int launch_status() { return (int)hipGetLastError(); }
 // row are contiguous (one 24-byte record), records of consecutive slots are adjacent.  The pair passes, whose neighbouring
 // lanes hold the rotamer states j = 0..5 of one partner residue, then touch one cache line where an entry-major layout
 // touched six; the solve, whose neighbouring lanes hold consecutive slots, still reads contiguous memory.
+#ifdef PIDX_SLOT_MAJOR      // (experiment, round 3: one 144-byte record per slot -- belief propagation 8.1 instead of 6.4 ms, the energy pass 1.5 instead
+                            //  of 1.27: lanes walk consecutive SLOTS, which the [row][slot] planes keep contiguous)
+#define PIDX6(cap, sl, i, j) ((((size_t)(sl)) * 6 + (i)) * 6 + (j))
+#else
 #define PIDX6(cap, sl, i, j) ((((size_t)(i)) * (cap) + (sl)) * 6 + (j))
+#endif
 #define PIDX(R, sl, e) PIDX6((R).slot_cap, sl, (e) / 6, (e) % 6)
 
 // slot classes in storage order
@@ -471,7 +476,7 @@ struct RotGradOp2 {
         const bool both1 = na == 1 && nb == 1, multi = na > 1 && nb > 1, no_slot = multi && m.sl == UPK_ROT_SLOT_NONE;
         // (selects on integers, no divergent address code: the two tables differ in base and offset only)
         const bool lo = a < m.b;
-        const int off_m = ((lo ? ra : rb) * R.slot_cap + (no_slot ? 0 : m.sl)) * 6 + (lo ? rb : ra);       // PIDX6
+        const int off_m = (int)PIDX6(R.slot_cap, no_slot ? 0 : m.sl, lo ? ra : rb, lo ? rb : ra);
         const int off_n = na == 1 ? m.b * 6 + rb : a * 6 + ra;
         const uintptr_t base = multi ? (uintptr_t)marg : (uintptr_t)nbm;
         const float pv = ((const float*)base)[multi ? off_m : off_n];
@@ -1171,6 +1176,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     long long tr_t0 = 0, tr_edge = 0, tr_node = 0, tr_pro = 0, tr_loop = 0;
     const bool trace = R.bp_trace != nullptr && tid == 0;
     if (trace) tr_t0 = wall_clock64();
+    long long* TX = R.bp_trace ? R.bp_trace + (size_t)s * 32 + 16 : nullptr;     // sub-phase stamps since the kernel's start (diagnostics)
+#define BP_STAMP(k) do { if (trace) TX[k] = wall_clock64() - tr_t0; } while (0)
     BpCtx C;
     C.cap = R.slot_cap;
     C.slot_a = R.slot_a + (size_t)s * R.slot_cap;
@@ -1200,6 +1207,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         exp_class<1, 1>(C.P, C.cap, cls[CL11], cls[CL11 + 1], tid, nt, C.active);
         exp_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], tid, nt, C.active);
     }
+    BP_STAMP(0);
     // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
     constexpr bool PACK = K66 + K36 + K33 > 0 || COMPACT;      // (the compact inbox is laid out by the packing pass)
     int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
@@ -1212,12 +1220,60 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         int* wbase = (int*)(rmask + n_words);          // [n_words + 1]
         for (int i = tid; i < n_words; i += nt) rmask[i] = 0u;
         __syncthreads();
-        for (int sl = cls[CL33] + tid; sl < cls[CL66 + 1]; sl += nt)
-            if (C.active[sl]) {
-                const int ra = C.slot_row[sl * 2], rb = C.slot_row[sl * 2 + 1];
-                atomicOr(&rmask[ra >> 5], 1u << (ra & 31)); atomicOr(&rmask[rb >> 5], 1u << (rb & 31));
+        // The slots are visited in the 64-slot chunks of the packing (chunk ch belongs to wavefront ch mod n_wave): ONE pass loads the
+        // activity flags -- four chunks' flags in flight per lane, then their row pairs --, counts each chunk, marks the rows and keeps
+        // the flags as a bit per visit; the records are written from those bits once the layout is known.  (The first form walked the
+        // slots three times, every visit a dependent global round trip: 36 -> 21 us of the solve's 430; all visits in flight at once,
+        // kept in registers for the record pass, measured no better: 24 us.)
+        constexpr int PK_MAXIT = 16, PK_UNR = 4;
+        const int pk_lane = tid & 63, pk_wave = tid >> 6, pk_nwave = nt >> 6;
+        const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
+        const int n_chunk = nc0 + nc1 + nc2, n_it = (n_chunk + pk_nwave - 1) / pk_nwave;
+        const bool fast_pack = n_it <= PK_MAXIT && 2 * n_chunk <= NN * NS;
+        int* chunk_cnt = (int*)nb0; int* chunk_base = chunk_cnt + n_chunk;     // (nb0 / nb1 are filled after the fold below)
+        auto chunk_of = [&](int it, int& ch, int& c, int& first, int& sl) -> bool {       // visit `it` of this wavefront; false past the last chunk
+            ch = pk_wave + it * pk_nwave;
+            c = ch < nc0 ? CL33 : (ch < nc0 + nc1 ? CL36 : CL66);
+            first = c == CL33 ? 0 : (c == CL36 ? nc0 : nc0 + nc1);
+            sl = cls[c] + (ch - first) * 64 + pk_lane;
+            return ch < n_chunk;
+        };
+        unsigned actbits = 0u;
+        if (fast_pack) {
+#pragma unroll
+            for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
+                if (it0 >= n_it) break;
+                int ch[PK_UNR], sl[PK_UNR], fl[PK_UNR]; bool ok[PK_UNR]; int2 rr[PK_UNR];
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) { int c, first; ok[u] = chunk_of(it0 + u, ch[u], c, first, sl[u]); ok[u] = ok[u] && sl[u] < cls[c + 1]; }
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) fl[u] = ok[u] ? C.active[sl[u]] : 0;
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) rr[u] = fl[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) {
+                    const unsigned long long b = __ballot(fl[u] != 0);
+                    if (pk_lane == 0 && ch[u] < n_chunk) chunk_cnt[ch[u]] = __popcll(b);
+                    if (fl[u]) {
+                        actbits |= 1u << (it0 + u);
+                        atomicOr(&rmask[rr[u].x >> 5], 1u << (rr[u].x & 31)); atomicOr(&rmask[rr[u].y >> 5], 1u << (rr[u].y & 31));
+                    }
+                }
             }
+        } else {
+            for (int sl = cls[CL33] + tid; sl < cls[CL66 + 1]; sl += nt)
+                if (C.active[sl]) {
+                    const int ra = C.slot_row[sl * 2], rb = C.slot_row[sl * 2 + 1];
+                    atomicOr(&rmask[ra >> 5], 1u << (ra & 31)); atomicOr(&rmask[rb >> 5], 1u << (rb & 31));
+                }
+        }
         __syncthreads();
+        if (fast_pack && tid < n_chunk) {          // records of the class in front of chunk tid
+            const int first = tid < nc0 ? 0 : (tid < nc0 + nc1 ? nc0 : nc0 + nc1);
+            int before = 0;
+            for (int k = first; k < tid; ++k) before += chunk_cnt[k];
+            chunk_base[tid] = before;
+        }
         {
             const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
             int sum = 0;
@@ -1236,7 +1292,31 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         inbox_floats3 = dense(R6);
         int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
         C.rec = rec;
-        bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return dense(C.slot_row[sl * 2 + side]); });   // (ends with a barrier)
+        if (fast_pack) {
+#pragma unroll
+            for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
+                if (it0 >= n_it) break;
+                int ch[PK_UNR], cc[PK_UNR], sl[PK_UNR], sa[PK_UNR], sb[PK_UNR]; bool act[PK_UNR]; int2 rr[PK_UNR];
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) { int first; chunk_of(it0 + u, ch[u], cc[u], first, sl[u]); act[u] = (actbits >> (it0 + u)) & 1u; }
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) {
+                    rr[u] = act[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
+                    sa[u] = act[u] ? C.slot_a[sl[u]] : 0; sb[u] = act[u] ? C.slot_b[sl[u]] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < PK_UNR; ++u) {
+                    if (ch[u] >= n_chunk) continue;                              // (wave-uniform)
+                    const unsigned long long b = __ballot(act[u]);
+                    const int base = chunk_base[ch[u]];
+                    if (act[u]) rec[cls[cc[u]] + base + __popcll(b & ((1ull << pk_lane) - 1ull))] = make_int4(dense(rr[u].x), dense(rr[u].y), sa[u] | (sb[u] << 16), sl[u]);
+                    const int last = cc[u] == CL33 ? nc0 - 1 : (cc[u] == CL36 ? nc0 + nc1 - 1 : n_chunk - 1);
+                    if (pk_lane == 0 && ch[u] == last) n_act[cc[u]] = base + __popcll(b);
+                }
+            }
+            __syncthreads();
+        } else
+            bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return dense(C.slot_row[sl * 2 + side]); });   // (ends with a barrier)
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; if (g <= NN) bp_start[g] = my_start[k]; }   // rows -> floats
     } else {
@@ -1258,8 +1338,10 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         C.lds_floats = n;
     }
     __syncthreads();       // (bp_start holds float offsets now; the scratch of the compact layout is dead)
+    BP_STAMP(1);
     for (int i = tid; i < inbox_floats; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
+    BP_STAMP(2);
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     // (four partners per trip: slot ids, then flags, then the rows, each as one batch of loads; same product order)
     for (int g = tid; g < NN; g += nt) {
@@ -1291,9 +1373,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     __syncthreads();
     for (int i = tid; i < NN * NS; i += nt) { const float v = (i % NS) < 6 ? prob[i] : 0.f; nb0[i] = v; nb1[i] = v; }   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
+    BP_STAMP(3);
     BpResident<3, 3, K33> r33; BpResident<3, 6, K36> r36; BpResident<6, 6, K66> r66;
     const int e33 = cls[CL33] + n_act[CL33], e36 = cls[CL36] + n_act[CL36], e66 = cls[CL66] + n_act[CL66];   // ends of the packed records
     r33.load(C, cls[CL33], e33, tid, nt); r36.load(C, cls[CL36], e36, tid, nt); r66.load(C, cls[CL66], e66, tid, nt);
+    BP_STAMP(4);
     const __amdgpu_buffer_rsrc_t inbox_rs = make_rsrc(C.inbox, 0u);
 
     float* nb_old = nb0; float* nb_cur = nb1;
@@ -1432,9 +1516,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     __syncthreads();
     float en = 0.f;
+    // (measured and rejected in round 3: retiring a slot's matrix right behind its marginals instead of in a pass of its own -- the second
+    //  store stream in the marginal loops costs more than the pass saves, epilogue 75 -> 100 us; fetching the next slot's matrix one trip
+    //  ahead in the marginal loops -- no change: the epilogue is bound by its scattered 12- and 24-byte stores)
     en += r33.template marginal<NS>(C, nb_cur, want_energy);
     en += r36.template marginal<NS>(C, nb_cur, want_energy);
     en += r66.template marginal<NS>(C, nb_cur, want_energy);
+    BP_STAMP(5);
     if (PACK) {
         en += bp_marginal_packed<3, 3, NS>(C, cls[CL33] + K33 * nt, e33, nb_cur, tid, nt, want_energy);
         en += bp_marginal_packed<3, 6, NS>(C, cls[CL36] + K36 * nt, e36, nb_cur, tid, nt, want_energy);
@@ -1444,6 +1532,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         en += bp_marginal_range<3, 6, NS>(C, cls[CL36], cls[CL36 + 1], nb_cur, tid, nt, want_energy);
         en += bp_marginal_range<6, 6, NS>(C, cls[CL66], cls[CL66 + 1], nb_cur, tid, nt, want_energy);
     }
+    BP_STAMP(6);
     if (want_energy) {
         for (int sl = cls[CL11] + tid; sl < cls[CL11 + 1]; sl += nt)   // 1-1 edges (rotamer.cpp:861)
             if (C.active[sl]) en += -logf(C.P[PIDX6(C.cap, sl, 0, 0)]);
@@ -1458,6 +1547,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     for (int i = tid; i < NN * 6; i += nt) R.nb_cur[(size_t)s * NN * 6 + i] = nb_cur[(i / 6) * NS + i % 6];
     __syncthreads();
+    BP_STAMP(7);
     // leave the accumulators clean for the next force evaluation
     // (only the slots written this step: the others were left at 0 by the prologue); the flags move to active_last
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
@@ -1477,7 +1567,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     retire_class<1, 6>(C.P, C.cap, cls[CL1X], cls[CL1X + 1], active_w, active_last, tid, nt, rest);
     for (int i = cls[N_CLASS] + tid; i < n_slot; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }   // (no slot lies outside the classes)
     if (trace) {
-        long long* T = R.bp_trace + (size_t)s * 16;
+        long long* T = R.bp_trace + (size_t)s * 32;
         T[0] = tr_pro - tr_t0; T[1] = tr_loop - tr_pro; T[2] = wall_clock64() - tr_loop; T[3] = tr_edge; T[4] = tr_node;
         T[5] = iter; T[6] = n_slot; T[7] = COMPACT ? C.lds_floats : bp_start[NN];
         for (int c = 0; c <= N_CLASS; ++c) T[8 + c] = cls[c];

@@ -1296,7 +1296,7 @@ struct RotamerSidechain : public PotentialNode {
         }
         R.bp_trace = nullptr;
         prepare_deps.push_back(ig.node1);   // the list upkeep reads the bead positions only, not the 1-body energies
-        if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 16); R.bp_trace = bp_trace.p; }
+        if (getenv("UPSIDE_HIP_BP_TRACE")) { bp_trace.alloc((size_t)ctx->n_system * 32); R.bp_trace = bp_trace.p; }
     }
     bool has_prepare() const override { return true; }
     void prepare() override {   // pair list + residue-pair slots of the systems that moved (depends on the bead positions only)
@@ -1514,7 +1514,7 @@ struct RotamerSidechain : public PotentialNode {
         }
         if (!strcmp(log_name, "bp_trace")) {   // diagnostics: phase clocks (10 ns units) of system 0's last solve
             if (!R.bp_trace) throw string("set UPSIDE_HIP_BP_TRACE=1 before constructing the engine");
-            auto t = bp_trace.download(); return vector<float>(t.begin(), t.begin() + 16);
+            auto t = bp_trace.download(); return vector<float>(t.begin(), t.begin() + 32);
         }
         if (!strcmp(log_name, "read n_bad_solve") || !strcmp(log_name, "read n_bad_solve and reset")) {   // rotamer.cpp:764-770
             vector<float> r(1, float(head(n_bad, 1)[0]));
