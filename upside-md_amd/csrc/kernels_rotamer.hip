@@ -1411,6 +1411,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // spill to global memory, those of the 3-state nodes all sit in LDS: the 6-state nodes go first, in rounds of their own
         // (one round for the 128 of the benchmark protein), instead of being spread over every round; 1-state nodes have no
         // inbox and take no slot.  (Node order in the arrays: 1-state, 3-state, 6-state.)
+        // (tried in round 3: the 140 3-state nodes of the benchmark protein in ONE round -- 116 on four lanes, 24 on two -- instead of 128 + 12:
+        //  the round then waits for the two-lane nodes' longer row loops, node phase 6.9 -> 8.0 us per sweep)
         const int e1n = R.n_node1, e3n = R.n_node1 + R.n_node3;
         for (int part = 0; part < 2; ++part)
         for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += n_grp) {
