@@ -1110,7 +1110,15 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
     for (int sl = lo + tid; sl < hi; sl += nt) { active_last[sl] = active_w[sl]; active_w[sl] = 0; }
 }
 
-#define BP_GROUP 4   // lanes cooperating on one node in the node phase
+#define BP_GROUP 4   // lanes cooperating on one node in the node phase (upper bound: the combine is the butterfly of a quad)
+// ... on a 6-state / a 3-state node.  The 140 3-state nodes of the benchmark protein need two rounds at four lanes each (128 + 12) and
+// one at two; measured at 4096 systems, solve in ms by (6-state, 3-state) lanes: (4,4) 6.36, (4,2) 6.14, (4,1) 6.66, (2,2) 7.28, (2,1) 6.92
+#ifndef BP_GROUP6
+#define BP_GROUP6 4
+#endif
+#ifndef BP_GROUP3
+#define BP_GROUP3 2
+#endif
 #ifndef BP_NODE_STRIDE
 #define BP_NODE_STRIDE 6      // (8 = one b128 + one b64 per node row: measured equal, and 6 leaves 7 KB more of the LDS to the inbox)
 #endif
@@ -1411,12 +1419,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // spill to global memory, those of the 3-state nodes all sit in LDS: the 6-state nodes go first, in rounds of their own
         // (one round for the 128 of the benchmark protein), instead of being spread over every round; 1-state nodes have no
         // inbox and take no slot.  (Node order in the arrays: 1-state, 3-state, 6-state.)
-        // (tried in round 3: the 140 3-state nodes of the benchmark protein in ONE round -- 116 on four lanes, 24 on two -- instead of 128 + 12:
-        //  the round then waits for the two-lane nodes' longer row loops, node phase 6.9 -> 8.0 us per sweep)
+        // (tried in round 3: the 3-state nodes in one round as a MIX -- 116 on four lanes, 24 on two: slower, the round waits for the
+        //  two-lane nodes; ALL of them on two lanes is what won)
         const int e1n = R.n_node1, e3n = R.n_node1 + R.n_node3;
         for (int part = 0; part < 2; ++part)
-        for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += n_grp) {
-            const int g = g0 + tid / BP_GROUP;
+        for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += part == 0 ? nt / BP_GROUP6 : nt / BP_GROUP3) {
+            const int grp = part == 0 ? BP_GROUP6 : BP_GROUP3, glx = tid & (grp - 1);
+            const int g = g0 + tid / grp;
             const bool live = g < g_hi;
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -1425,11 +1434,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
                 constexpr int ROWS = BP_NODE_ROWS_512 > 0 && BLOCK != BP_BLOCK ? BP_NODE_ROWS_512 : (BLOCK == BP_BLOCK ? 4 : 8);
-                for (int k0 = gl; k0 < deg; k0 += ROWS * BP_GROUP) {
+                for (int k0 = glx; k0 < deg; k0 += ROWS * grp) {
                     float4 m0[ROWS]; float2 m1[ROWS];
 #pragma unroll
                     for (int u = 0; u < ROWS; ++u) {
-                        const int k = k0 + u * BP_GROUP;
+                        const int k = k0 + u * grp;
                         m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
                             if (COMPACT) {       // dense rows: 4 floats (16-byte aligned) to a 3-state node, 6 floats (8-byte aligned) to a 6-state node
@@ -1445,7 +1454,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                     }
 #pragma unroll
                     for (int u = 0; u < ROWS; ++u) {
-                        if (k0 + u * BP_GROUP >= deg) break;
+                        if (k0 + u * grp >= deg) break;
                         bb[0] *= m0[u].x; bb[1] *= m0[u].y; bb[2] *= m0[u].z;
                         if (n == 6) { bb[3] *= m0[u].w; bb[4] *= m1[u].x; bb[5] *= m1[u].y; }
                         if (u & 1) {                    // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
@@ -1462,7 +1471,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             {
                 float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { bb[r] *= dpp_mov<UP_DPP_XOR2>(bb[r]); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR2>(bb[r]); bb[r] *= grp == 4 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }   // (a pair has no lane^2 partner)
                 const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
@@ -1470,7 +1479,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             {
                 float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { bb[r] *= dpp_mov<UP_DPP_XOR1>(bb[r]); mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR1>(bb[r]); bb[r] *= grp >= 2 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
                 const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
@@ -1484,7 +1493,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 const float damp = sweep < 0 ? 0.f : R.damping;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
-                    if (r < n && (r % BP_GROUP) == gl) {
+                    if (r < n && (r & (grp - 1)) == glx) {
                         const float o = nb_old[g * NS + r];
                         const float nv = damp != 0.f ? (1.f - damp) * rm * v[r] + damp * o : rm * v[r];
                         nb_cur[g * NS + r] = nv;
