@@ -1116,6 +1116,9 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
 #ifndef BP_GROUP6
 #define BP_GROUP6 4
 #endif
+#ifndef BP_EDGE_REVERSE
+#define BP_EDGE_REVERSE 1
+#endif
 #ifndef BP_GROUP3
 #define BP_GROUP3 2
 #endif
@@ -1403,8 +1406,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // even out the trip counts -- 1 % slower: the phase is limited by bytes, not by trips)
         r33.template edge<NS>(C, nb_old, inbox_rs); r36.template edge<NS>(C, nb_old, inbox_rs); r66.template edge<NS>(C, nb_old, inbox_rs);
         if (PACK) {
-            bp_edge_packed<3, 3, NS>(C, cls[CL33] + K33 * nt, e33, nb_old, tid, nt, inbox_rs);
-            bp_edge_packed<3, 6, NS>(C, cls[CL36] + K36 * nt, e36, nb_old, tid, nt, inbox_rs);
+            // (no barrier separates the classes: a wavefront's edge phase is the sum of its trips through all of them.  A class of
+            //  n slots gives its first n mod nt lanes one slot more; dealt from lane 0 in every class the extra trips pile up on the
+            //  first wavefronts -- 8 trips there, 5 on the last one for the benchmark protein.  The streamed 3x3 and 3x6 classes are
+            //  dealt from the LAST lane instead: 7 at most.  Which lane serves a slot changes nothing in its arithmetic.)
+            const int tid_r = BP_EDGE_REVERSE ? nt - 1 - tid : tid;
+            bp_edge_packed<3, 3, NS>(C, cls[CL33] + K33 * nt, e33, nb_old, tid_r, nt, inbox_rs);
+            bp_edge_packed<3, 6, NS>(C, cls[CL36] + K36 * nt, e36, nb_old, tid_r, nt, inbox_rs);
             bp_edge_packed<6, 6, NS>(C, cls[CL66] + K66 * nt, e66, nb_old, tid, nt, inbox_rs);
         } else {
             bp_edge_range<3, 3, NS>(C, cls[CL33], cls[CL33 + 1], nb_old, tid, nt);
@@ -1433,7 +1441,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 const int q = COMPACT ? (n == 6 ? 6 : 4) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
-                constexpr int ROWS = BP_NODE_ROWS_512 > 0 && BLOCK != BP_BLOCK ? BP_NODE_ROWS_512 : (BLOCK == BP_BLOCK ? 4 : 8);
+                constexpr int ROWS = BP_NODE_ROWS_512;      // (one value for every variant: the renormalisation points of the product follow it)
                 for (int k0 = glx; k0 < deg; k0 += ROWS * grp) {
                     float4 m0[ROWS]; float2 m1[ROWS];
 #pragma unroll
