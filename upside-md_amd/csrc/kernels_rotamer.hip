@@ -854,6 +854,8 @@ struct BpCtx {
     // the first lds_floats floats of the inbox (messages to the 3-state nodes come first) may live in LDS instead of
     // global memory: the one-workgroup solve re-reads and rewrites them every sweep
     float* inbox_lds = nullptr; int lds_floats = 0;
+    // (a pointer selected between two address spaces: FLAT accesses.  Round 3 instantiated the rest of the solve a second time for an inbox
+    //  that fits LDS as a whole -- plain ds_read / ds_write there --, the branch taken once per solve: 6.01 against 5.98 ms, no gain)
     __device__ __forceinline__ float* msg(int off) const { return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
 
