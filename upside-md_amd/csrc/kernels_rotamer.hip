@@ -1396,7 +1396,6 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     float* nb_old = nb0; float* nb_cur = nb1;
     int iter = 0;
     float maxdev = 1e10f;
-    const int gl = tid % BP_GROUP, n_grp = nt / BP_GROUP;
     // sweep -1 is calculate_new_beliefs(0.f, true): only its messages survive and the "old" node belief becomes
     // prob / max(prob) (rotamer.cpp:1034 with the swap at 995-1001)
     if (trace) tr_pro = wall_clock64();
@@ -1425,7 +1424,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         if (trace) { tr_b = wall_clock64(); tr_edge += tr_b - tr_a; }
         // ---- node phase: BP_GROUP lanes per node stream the node's inbox, multiply, and combine by shuffles
         float dev = 0.f;
-        // Rounds of n_grp nodes; a round waits for its slowest load.  The inbox rows of the 6-state nodes are the ones that
+        // Rounds of nt / (lanes per node) nodes; a round waits for its slowest load.  The inbox rows of the 6-state nodes are the ones that
         // spill to global memory, those of the 3-state nodes all sit in LDS: the 6-state nodes go first, in rounds of their own
         // (one round for the 128 of the benchmark protein), instead of being spread over every round; 1-state nodes have no
         // inbox and take no slot.  (Node order in the arrays: 1-state, 3-state, 6-state.)
@@ -1495,7 +1494,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
             }
             if (live) {
-                // b = prob * product, then standardize (rotamer.cpp:258-273); lane gl finishes states gl and gl+4
+                // b = prob * product, then standardize (rotamer.cpp:258-273); lane glx of the node finishes states glx, glx + grp, ...
                 float v[6], mx = 0.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) { v[r] = r < n ? prob[g * NS + r] * bb[r] : 0.f; mx = fmaxf(mx, v[r]); }
