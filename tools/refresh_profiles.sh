@@ -2,8 +2,8 @@
 # Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh [all|pmc|bench|configs]'): regenerates the raw material of
 # profiles/ under gpurun_out/prof/.  Each rocprofv3 pass profiles the program itself (no shell hop after --), PMC passes
 # are separate from each other and carry no trace domains beyond the kernel trace.
+#   pmc      kernel trace + the FETCH_SIZE / WRITE_SIZE / SQ passes of the default command, hbm_traffic.json (first: the bench lines use it)
 #   bench    bench.py lines at 1 .. 4096 replicas per GPU
-#   pmc      kernel trace + the FETCH_SIZE / WRITE_SIZE / SQ passes of the default command, hbm_traffic.json
 #   configs  the other BASELINE configurations (throughput table, REMD and ensemble lines on one GPU)
 set -u
 export TMPDIR=/tmp
@@ -11,13 +11,6 @@ MODE=${1:-all}
 OUT=$PWD/gpurun_out/prof
 mkdir -p "$OUT"
 want() { [ "$MODE" = all ] || [ "$MODE" = "$1" ]; }
-
-if want bench; then
-for R in 1 8 64 256 1024 4096; do
-  st=100; [ $R -le 64 ] && st=300
-  python3 bench.py --replicas $R --steps $st --warmup 30 2>"$OUT/bench_R$R.err" | grep '^{' | tail -1 > "$OUT/bench_R$R.json"
-done
-fi
 
 if want pmc; then
 [ -s "$OUT/bench_R4096.json" ] || python3 bench.py --steps 100 --warmup 30 --no-cpu-baseline 2>"$OUT/bench_R4096.err" | grep '^{' | tail -1 > "$OUT/bench_R4096.json"
@@ -40,6 +33,15 @@ rm -f "$OUT/hbm_traffic.json"
 python3 tools/hbm_traffic.py "$fdb" "$wdb" syn300_10A 4096 "$OUT/hbm_traffic.json" "$sdb" "$PAIRS" > "$OUT/hbm_traffic.txt" 2>&1
 # keep the merge small: drop the databases
 find "$OUT" -name "*.db" -delete
+# the bench lines below (mode all) then read THIS table: bench.py takes profiles/hbm_traffic.json, stamped with the sources it was measured on
+[ -s "$OUT/hbm_traffic.json" ] && cp "$OUT/hbm_traffic.json" profiles/hbm_traffic.json
+fi
+
+if want bench; then
+for R in 1 8 64 256 1024 4096; do
+  st=100; [ $R -le 64 ] && st=300
+  python3 bench.py --replicas $R --steps $st --warmup 30 2>"$OUT/bench_R$R.err" | grep '^{' | tail -1 > "$OUT/bench_R$R.json"
+done
 fi
 
 if want configs; then

@@ -2057,9 +2057,9 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
     static int lds_msg_kb = -1;   // UPSIDE_HIP_BP_LDS_MSG_KB (experiments): 0 keeps every message in global memory
     if (lds_msg_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_MSG_KB"); lds_msg_kb = e ? atoi(e) : 160; }
     size_t msg_bytes = (size_t)lds_msg_kb * 1024;
-    // LDS of the one-workgroup solve, beliefs + inbox: all 160 KB of the CU (the kernel has no static LDS) -- the dense inbox of the benchmark
-    // protein, 130 KB, then fits whole, and no sweep waits for message rows in global memory (solve at 4096 systems: 140 KB 6.16 ms,
-    // 150 KB 6.04, 156-160 KB 5.98).  UPSIDE_HIP_BP_LDS_CAP_KB: experiments.
+    // LDS of the one-workgroup solve, beliefs + inbox: all 160 KB of the CU (the kernel has no static LDS) -- 140 instead of 126 KB of the
+    // benchmark protein's 151 KB dense inbox, fewer message rows in global memory for a sweep to wait for (solve at 4096 systems:
+    // 140 KB 6.16 ms, 150 KB 6.04, 156-160 KB 5.98).  UPSIDE_HIP_BP_LDS_CAP_KB: experiments.
     static int lds_cap_kb = -1;
     if (lds_cap_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_CAP_KB"); lds_cap_kb = e ? atoi(e) : 160; if (lds_cap_kb < 32 || lds_cap_kb > 160) lds_cap_kb = 160; }
     if (lds_base + msg_bytes > (size_t)lds_cap_kb * 1024) msg_bytes = (size_t)lds_cap_kb * 1024 - lds_base;
