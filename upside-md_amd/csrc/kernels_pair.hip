@@ -185,6 +185,23 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
     }
 }
 
+// End of a backward pass whose workgroup is the system's only one: the other side's totals leave the LDS accumulators ELEMENT by element --
+// one lane loads the element's row index, its DO sums and its sens row (16-byte accesses: rows of a coordinate node are padded to
+// multiples of 4 floats), adds and stores.  (The first form walked the DO * n accumulators one by one: six or seven trips per lane, each
+// a chain of two dependent global loads, 12-24 us at the end of a 94 us workgroup.)  get(c, i): the total of component c of element i.
+template <int DO, typename Get>
+__device__ __forceinline__ void flush_other_side(float* __restrict__ osens, const int* __restrict__ oloc, int stride, int n_other, Get get) {
+    for (int i = threadIdx.x; i < n_other; i += blockDim.x) {
+        float add[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) add[c] = c < DO ? get(c, i) : 0.f;
+        float4* row = (float4*)(osens + (size_t)oloc[i] * stride);
+        float4 r0 = row[0];
+        r0.x += add[0]; r0.y += add[1]; r0.z += add[2]; r0.w += add[3];
+        if (DO > 4) { float4 r1 = row[1]; r1.x += add[4]; r1.y += add[5]; r1.z += add[6]; r1.w += add[7]; row[1] = r1; }
+        row[0] = r0;
+    }
+}
 // ---- backward, ONE visit per pair over the rows of side RS (the side the forward pass ran over): the row element's gradient
 // accumulates in registers; the other element's goes through 64-bit integer LDS atomics as exact fixed point (igraph_device.h:
 // to_fixed32), so its total does not depend on the order in which the pairs arrive -- results stay bit-reproducible
@@ -262,6 +279,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
     float* osens = C_SENS(onode, s);
     unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
     const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    if (alone && (onode.stride & 3) == 0) { flush_other_side<DO>(osens, oloc, onode.stride, n_other, [&](int c, int i) { return from_fixed32(oacc[i * DO + c]); }); return; }
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
         const unsigned long long a = oacc[t];
         if (!a) continue;
@@ -445,6 +463,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igrap
     float* osens = C_SENS(onode, s);
     unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
     const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    if (alone && (onode.stride & 3) == 0) { flush_other_side<DO>(osens, oloc, onode.stride, n_other, [&](int c, int i) { return from_fixed22(oacc[c * n_other + i]); }); return; }
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
         const int i = t / DO, c = t - i * DO;
         const unsigned long long a = oacc[c * n_other + i];

@@ -537,6 +537,19 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad2(upk_rotam
     float* sens = C_SENS(G.node1, s);
     unsigned long long* gacc = R.grad_acc + (size_t)s * G.n1 * 6;
     const bool alone = gridDim.x == 1;     // the system's only workgroup: its accumulators are the totals
+    if (alone && (G.node1.stride & 3) == 0) {
+        // (element by element: the bead's row index, its six sums, one 16-byte read-modify-write pair of its sens row -- the first form walked
+        //  the 6 n accumulators one by one, seven trips per lane, each a chain of two dependent global loads)
+        for (int i = threadIdx.x; i < G.n1; i += blockDim.x) {
+            float add[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) add[c] = from_fixed22(L.acc[c * G.n1 + i]);
+            float4* row = (float4*)(sens + (size_t)G.loc1[i] * G.node1.stride);
+            float4 r0 = row[0], r1 = row[1];
+            r0.x += add[0]; r0.y += add[1]; r0.z += add[2]; r0.w += add[3]; r1.x += add[4]; r1.y += add[5];
+            row[0] = r0; row[1] = r1;
+        }
+    } else
     for (int t = threadIdx.x; t < G.n1 * 6; t += blockDim.x) {
         const int i = t / 6, c = t - i * 6;
         const unsigned long long a = L.acc[c * G.n1 + i];
