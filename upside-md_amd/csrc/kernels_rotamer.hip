@@ -562,7 +562,21 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_grad2(upk_rotam
         for (int i = threadIdx.x; i < G.n1; i += blockDim.x) {
             const float mg = nbm[R.bead_node[i] * 6 + ((R.bead_meta[i] >> 8) & 0xF)];
             const int loc = G.loc1[i];
-            for (int k = 0; k < R.n_prob; ++k) R.prob_sens[k][(size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k]] += mg;
+            // (the parents' values first, then the stores: the arrays may alias as far as the compiler knows, which made every parent a
+            //  load -> store chain of its own)
+            constexpr int KB = 4;
+            for (int k0 = 0; k0 < R.n_prob; k0 += KB) {
+                float* q[KB]; float v[KB];
+#pragma unroll
+                for (int u = 0; u < KB; ++u) {
+                    const int k = k0 + u < R.n_prob ? k0 + u : k0;
+                    q[u] = R.prob_sens[k] + (size_t)s * R.prob_sys_stride[k] + (size_t)loc * R.prob_stride[k];
+                }
+#pragma unroll
+                for (int u = 0; u < KB; ++u) v[u] = *q[u];
+#pragma unroll
+                for (int u = 0; u < KB; ++u) if (k0 + u < R.n_prob) *q[u] = v[u] + mg;
+            }
         }
     }
 }
