@@ -74,6 +74,7 @@ int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, con
 int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
                    float* contrib, long contrib_stride);
 /* rama_coord (src/bonds.cpp:205-247): jac [S][n_res][2][5][3] */
+#define UPK_RAMA_JAC 32   /* floats per residue in the Jacobian buffer of upk_rama_fwd / _bwd: 30 used, a 128-byte row */
 int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
                  float* jac);
 int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride);

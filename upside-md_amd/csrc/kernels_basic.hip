@@ -418,14 +418,24 @@ __global__ void k_rama_fwd(upk_coord_t pos, const int* __restrict__ atom, const 
     f3 p[5];
     for (int a = 0; a < 5; ++a) p[a] = ld3(x + (size_t)atom[nt * 5 + a] * pos.stride);
     float* o = C_OUT(out, s) + (size_t)nt * out.stride;
-    float* j = jac + ((size_t)s * n_res + nt) * 30;
+    // the Jacobian of a residue: 2 angles x 5 atoms x 3 = 30 floats in a 128-byte row (UPK_RAMA_JAC floats), stored as eight 16-byte words
+    // instead of thirty dwords at a 120-byte stride
+    float jv[UPK_RAMA_JAC];
+#pragma unroll
+    for (int k = 0; k < UPK_RAMA_JAC; ++k) jv[k] = 0.f;
+#pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
         f3 d[5];
+#pragma unroll
         for (int a = 0; a < 5; ++a) d[a] = mk3(0.f, 0.f, 0.f);
         if (dummy[nt * 2 + pp]) o[pp] = -1.3963f;
         else o[pp] = dihedral_germ(p[0 + pp], p[1 + pp], p[2 + pp], p[3 + pp], d[0 + pp], d[1 + pp], d[2 + pp], d[3 + pp]);
-        for (int a = 0; a < 5; ++a) { j[(pp * 5 + a) * 3 + 0] = d[a].x; j[(pp * 5 + a) * 3 + 1] = d[a].y; j[(pp * 5 + a) * 3 + 2] = d[a].z; }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) { jv[(pp * 5 + a) * 3 + 0] = d[a].x; jv[(pp * 5 + a) * 3 + 1] = d[a].y; jv[(pp * 5 + a) * 3 + 2] = d[a].z; }
     }
+    float4* j = (float4*)(jac + ((size_t)s * n_res + nt) * UPK_RAMA_JAC);
+#pragma unroll
+    for (int k = 0; k < UPK_RAMA_JAC / 4; ++k) j[k] = make_float4(jv[4 * k], jv[4 * k + 1], jv[4 * k + 2], jv[4 * k + 3]);
 }
 extern "C" int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
                             float* jac) {
@@ -437,7 +447,7 @@ __global__ void k_rama_bwd(upk_coord_t rama, const float* __restrict__ jac, int 
     if (idx >= n_res * 5) return;
     const int s = blockIdx.y, nt = idx / 5, a = idx % 5;
     const float* sn = C_SENS(rama, s) + (size_t)nt * rama.stride;
-    const float* j = jac + ((size_t)s * n_res + nt) * 30;
+    const float* j = jac + ((size_t)s * n_res + nt) * UPK_RAMA_JAC;
     float* o = contrib + (size_t)s * contrib_stride + (size_t)idx * 3;
     for (int c = 0; c < 3; ++c) o[c] = sn[0] * j[(0 * 5 + a) * 3 + c] + sn[1] * j[(1 * 5 + a) * 3 + c];
 }
@@ -699,11 +709,13 @@ __global__ void k_weighted_pos_bwd(upk_coord_t pos, upk_coord_t energy, const in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= self.n_elem) return;
     const int s = blockIdx.y;
-    const float* sn = C_SENS(self, s) + (size_t)i * self.stride;
-    const float* o = C_OUT(self, s) + (size_t)i * self.stride;
+    // (rows of a coordinate node are padded to multiples of 4 floats: one 16-byte access per row instead of three or four dwords)
+    const float4 sn = *(const float4*)(C_SENS(self, s) + (size_t)i * self.stride);
+    const float o3 = (C_OUT(self, s) + (size_t)i * self.stride)[3];
     float* ps = C_SENS(pos, s) + (size_t)index_pos[i] * pos.stride;      // index_pos / index_weight are injective (checked on the host)
-    ps[0] += sn[0]; ps[1] += sn[1]; ps[2] += sn[2];
-    C_SENS(energy, s)[(size_t)index_weight[i] * energy.stride] -= o[3] * sn[3];
+    if ((pos.stride & 3) == 0) { float4 v = *(float4*)ps; v.x += sn.x; v.y += sn.y; v.z += sn.z; *(float4*)ps = v; }
+    else { ps[0] += sn.x; ps[1] += sn.y; ps[2] += sn.z; }
+    C_SENS(energy, s)[(size_t)index_weight[i] * energy.stride] -= o3 * sn.w;
 }
 extern "C" int upk_weighted_pos_bwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
                                     const int* index_weight, upk_coord_t self) {
@@ -747,10 +759,11 @@ __global__ void k_protein_hbond_finish(upk_coord_t infer, upk_coord_t out) {
     const int nv = blockIdx.x * blockDim.x + threadIdx.x;
     if (nv >= out.n_elem) return;
     const int s = blockIdx.y;
-    const float* h = C_OUT(infer, s) + (size_t)nv * infer.stride;
-    float* o = C_OUT(out, s) + (size_t)nv * out.stride;
-    for (int c = 0; c < 6; ++c) o[c] = h[c];
-    o[6] = 1.f - expf(-o[6]);
+    const float4* h = (const float4*)(C_OUT(infer, s) + (size_t)nv * infer.stride);      // (6 of 8 floats)
+    float4* o = (float4*)(C_OUT(out, s) + (size_t)nv * out.stride);                          // (7 of 8 floats: [6] = the bond count so far)
+    const float4 h0 = h[0], h1 = h[1], o1 = o[1];
+    o[0] = h0;
+    o[1] = make_float4(h1.x, h1.y, 1.f - expf(-o1.z), o1.w);
 }
 extern "C" int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out) {
     hipLaunchKernelGGL(k_protein_hbond_finish, grid1(out.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), infer, out);
@@ -772,9 +785,12 @@ __global__ void k_protein_hbond_passthrough(upk_coord_t self, upk_coord_t infer,
     if (nv >= n1 + n2) return;
     const int s = blockIdx.y;
     const int tgt = nv < n1 ? loc1[nv] : loc2[nv - n1];
-    const float* sn = C_SENS(self, s) + (size_t)nv * self.stride;
-    float* t = C_SENS(infer, s) + (size_t)tgt * infer.stride;
-    for (int c = 0; c < 6; ++c) t[c] += sn[c];
+    const float4* sn = (const float4*)(C_SENS(self, s) + (size_t)nv * self.stride);     // (rows of 8 floats: 7 and 6 used)
+    float4* t = (float4*)(C_SENS(infer, s) + (size_t)tgt * infer.stride);
+    const float4 s0 = sn[0], s1 = sn[1];
+    float4 t0 = t[0], t1 = t[1];
+    t0.x += s0.x; t0.y += s0.y; t0.z += s0.z; t0.w += s0.w; t1.x += s1.x; t1.y += s1.y;
+    t[0] = t0; t[1] = t1;
 }
 extern "C" int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_coord_t infer, const int* loc1, int n1,
                                              const int* loc2, int n2) {

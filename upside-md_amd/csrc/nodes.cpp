@@ -105,7 +105,7 @@ struct RamaCoord : public CoordNode {
         }
         for (int x : a) if (x < 0 || x >= pos.n_elem) throw string("atom index out of range");
         atom.upload(a); dummy.upload(dm);
-        jac.alloc((size_t)c->n_system * n_elem * 30);
+        jac.alloc((size_t)c->n_system * n_elem * UPK_RAMA_JAC);
         src = pos.scatter.add_source(n_elem, 5, 3, a);
     }
     void compute_value(ComputeMode) override { upk_check(upk_rama_fwd(&ctx->L, pos.coord(), atom.p, dummy.p, n_elem, coord(), jac.p), "rama_fwd"); }
