@@ -240,6 +240,28 @@ __device__ __forceinline__ void stage_rows(float* lds, const upk_coord_t& node, 
                                            const int* __restrict__ meta1, const int* __restrict__ meta0,
                                            const float* __restrict__ sens, int sens_stride) {
     const float* base = node.out + (size_t)s * node.n_elem * node.stride;
+    // one lane per ELEMENT (row index and metadata in one round of loads, the row as one or two 16-byte loads, two 16-byte LDS stores)
+    // instead of one lane per word, which made nine trips of two dependent global loads per lane for 1200 elements
+    if ((node.stride & 3) == 0) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int l = loc[i];
+            const int m1 = meta1 ? meta1[i] : 0, m0 = meta0 ? meta0[i] : 0;
+            const float sv = sens ? sens[(size_t)i * sens_stride] : 0.f;
+            const float4* row = (const float4*)(base + (size_t)l * node.stride);
+            const float4 r0 = row[0];
+            float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dim > 4) r1 = row[1];
+            const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = c < dim ? r[c] : 0.f;
+            if (dim <= 7 && meta1) v[7] = __int_as_float(m1);
+            if (dim <= 6) { if (sens) v[6] = sv; else if (meta0) v[6] = __int_as_float(m0); }
+            ((float4*)lds)[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+            ((float4*)lds)[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < n * 8; t += blockDim.x) {
         const int i = t >> 3, c = t & 7;
         float v = 0.f;

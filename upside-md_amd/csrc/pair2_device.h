@@ -56,6 +56,32 @@ __device__ __forceinline__ void stage_rows_planes(float* lds, const upk_coord_t&
                                                   const float* __restrict__ sens, int sens_stride, float sentinel6, float sentinel7) {
     const float* base = node.out + (size_t)s * node.n_elem * node.stride;
     const int np = n + 1;
+    // one lane per ELEMENT: its row index and metadata in one round of loads, its row as one or two 16-byte loads, two 16-byte LDS stores.
+    // (The first form dealt the 8 words of an element to 8 lanes: nine trips per lane for 1200 elements, each a chain of two dependent
+    //  global loads in front of the pair loop.)  Rows of a coordinate node are padded to multiples of 4 floats.
+    if ((node.stride & 3) == 0) {
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (i == n) { v[0] = v[1] = v[2] = 1.0e4f; v[3] = 1.f; v[6] = sentinel6; v[7] = sentinel7; }
+            else {
+                const int l = loc[i];
+                const int m1 = meta1 ? meta1[i] : 0, m0 = meta0 ? meta0[i] : 0;
+                const float sv = sens ? sens[(size_t)i * sens_stride] : 0.f;
+                const float4* row = (const float4*)(base + (size_t)l * node.stride);
+                const float4 r0 = row[0];
+                float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dim > 4) r1 = row[1];
+                const float r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = c < dim ? r[c] : 0.f;
+                if (dim <= 7 && meta1) v[7] = __int_as_float(m1);
+                if (dim <= 6) { if (sens) v[6] = sv; else if (meta0) v[6] = __int_as_float(m0); }
+            }
+            ((float4*)lds)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            ((float4*)lds)[np + i] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < np * 8; t += blockDim.x) {
         const int i = t >> 3, c = t & 7;
         float v = 0.f;
