@@ -134,8 +134,17 @@ __device__ __forceinline__ void clamped_deBoor_vd_scalar(float& val, float& der,
 }
 
 // bicubic patch: spline.h:60-80
-__device__ __forceinline__ void bicubic_vd(float& value, float& dx, float& dy, const float* __restrict__ c,
+__device__ __forceinline__ void bicubic_vd(float& value, float& dx, float& dy, const float* __restrict__ cp,
                                            float fx, float fy) {
+    // (a patch is 16 floats at a 64-byte boundary of its table: four 16-byte loads instead of sixteen dwords)
+    float c[16];
+    if ((((size_t)cp) & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float4 q = ((const float4*)cp)[k]; c[4 * k] = q.x; c[4 * k + 1] = q.y; c[4 * k + 2] = q.z; c[4 * k + 3] = q.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = cp[k];
+    }
     const float fx2 = fx * fx, fx3 = fx * fx2, fy2 = fy * fy;
     const float vx0 = c[0] + fy * (c[1] + fy * (c[2] + fy * c[3]));
     const float vx1 = c[4] + fy * (c[5] + fy * (c[6] + fy * c[7]));
