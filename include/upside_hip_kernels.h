@@ -14,7 +14,17 @@
 extern "C" {
 #endif
 
-typedef struct { int n_system; void* stream; } upk_launch_t;
+/* fuse: the engine's queue of fused per-element ops (upk_fuse_create) or NULL.  Per-element launchers (marked "fusable" below)
+ * append an op to it instead of launching; every other launcher runs the queue first (upk_fuse_flush), so the order of calls is
+ * the order of effects.  A caller that enqueues its own work on `stream` must call upk_fuse_flush(L) first. */
+typedef struct { int n_system; void* stream; void* fuse; } upk_launch_t;
+void* upk_fuse_create(int n_system);
+void upk_fuse_destroy(void* fuse);
+int upk_fuse_flush(const upk_launch_t* L);          /* one launch for the pending ops (no-op when nothing is pending) */
+int upk_fuse_pending(const upk_launch_t* L);        /* number of ops waiting */
+long upk_fuse_launch_count(const upk_launch_t* L);  /* fused launches so far (diagnostics) */
+int upk_fuse_table_size(const upk_launch_t* L);     /* distinct ops registered so far: constant once every op of the MD loop has been seen */
+#define UPK_FLUSH(L) do { const int r_ = upk_fuse_flush(L); if (r_) return r_; } while (0)
 
 /* A CoordNode's storage (src/deriv_engine.h:83-96): out/sens are [S][n_elem][stride] */
 typedef struct { float* out; float* sens; int n_elem; int width; int stride; } upk_coord_t;
@@ -58,9 +68,8 @@ int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy,
 /* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
 int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
                           float max_force);
-/* n_invocations is common to all systems (they are thermalised at the same rounds) and lives on the device: the
- * launcher reads it and then increments it in stream order, so a captured MD graph replays correctly;
- * mom is [S][n_atom][4] */
+/* n_invocations[S] lives on the device, one (equal) entry per system -- all systems are thermalised at the same rounds --:
+ * the op reads its system's entry and then advances it, so a captured MD graph replays correctly; mom is [S][n_atom][4] */
 int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,
                    const float* mom_scale, const float* noise_scale);
 int upk_recenter(const upk_launch_t* L, upk_coord_t pos, int xy_only);
@@ -73,8 +82,9 @@ int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, con
 /* writes per-residue 3 atoms x 3 comps into contrib[s][res*9 ...] */
 int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
                    float* contrib, long contrib_stride);
-/* rama_coord (src/bonds.cpp:205-247): jac [S][n_res][2][5][3] */
-#define UPK_RAMA_JAC 32   /* floats per residue in the Jacobian buffer of upk_rama_fwd / _bwd: 30 used, a 128-byte row */
+/* rama_coord (src/bonds.cpp:205-247): jac [S][n_res][UPK_RAMA_JAC] -- the 2 x 5 x 3 derivatives of a residue in the first 30 floats
+ * of a 128-byte row (written as eight 16-byte words: the buffer must be 16-byte aligned and hold UPK_RAMA_JAC floats per residue) */
+#define UPK_RAMA_JAC 32
 int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
                  float* jac);
 int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride);
@@ -174,7 +184,7 @@ typedef struct {
     const float* param_poly; int n_poly;
     int sens_overlap;                    /* node1 and node2 are one node AND some element is listed on both sides (set by the host) */
 } upk_igraph_t;
-#define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8192 beads, < 2^19 - 1 slots */
+#define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8191 beads (bead index n1 is the refine kernel's sentinel), < 2^19 - 1 slots */
 #define UPK_ROT_SLOT_NONE 0x7FFFF        /* slot field of a cached bead pair whose residue pair got no slot (capacity overflow) */
 
 /* K1: flag[s] |= any element moved more than (cache_cutoff-cutoff)/2 since the last build

@@ -81,6 +81,9 @@ struct DeviceCtx {
     void begin(const std::string& fam);
     void end(const std::string& fam, double algorithmic_bytes, double pair_evaluations = 0.);
     void flush_profile();
+    // run the queued per-element ops (upside_hip_kernels.h: upk_launch_t::fuse).  A node that enqueues its OWN work on `stream`
+    // (kernels, copies, events) calls this first; the launchers of upside_hip_kernels.h do it themselves.
+    void flush();
 };
 
 // deferred derivative contributions gathered into a CoordNode's sens (see upk_gather_contrib)
@@ -123,6 +126,12 @@ struct DerivComputation {   // deriv_engine.h:48-80
     virtual void begin_log_frame() {}
     virtual void end_log_frame() {}
     virtual bool capturable() const { return true; }   // false: kernel arguments change from step to step (no hipGraph replay)
+    // true: compute_value / propagate_deriv / prepare enqueue work through the launchers of upside_hip_kernels.h ONLY (which keep
+    // the fused-op queue in order themselves); false (the default, any plug-in node): the engine runs the queue before every call
+    bool library_launchers_only = false;
+    // compute_value (fused_forward) / gather + propagate_deriv (fused_backward) enqueue fused per-element ops ONLY: the engine orders
+    // the sweep so that such steps run back to back and share launches (DerivEngine::finalize)
+    bool fused_forward = false, fused_backward = false;
     // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).
     // The engine enqueues it on a side stream as soon as the last parent is computed, so a straggling rebuild of a
     // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).

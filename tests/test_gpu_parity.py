@@ -608,6 +608,11 @@ ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes
+    {'UPSIDE_HIP_FUSE': '0'},                # every per-element op launched on its own instead of through the fused-op queue
+    {'UPSIDE_HIP_FUSE_THREADS': '1024'},     # fused launches with 1024-lane workgroups (the instance that spills the alignment ops)
+    {'UPSIDE_HIP_FUSE_THREADS': '128'},      # ... and with two wavefronts per system
+    {'UPSIDE_HIP_PAIR2': '0'},               # scalar (one partner per lane) forms of the side-chain gradient and coverage passes
+    {'UPSIDE_HIP_PAIR2_ENERGY': '1'},        # packed form of the side-chain energy pass
 ]
 
 

@@ -24,8 +24,10 @@ void upk_check(int code, const char* what) {
 }
 
 // ---- DeviceCtx profiling --------------------------------------------------------------------------
+void DeviceCtx::flush() { upk_check(upk_fuse_flush(&L), "fuse_flush"); }
 void DeviceCtx::begin(const std::string& fam) {
     if (!profile) return;
+    flush();      // the bracket times the launches made inside it
     hipEvent_t a, b;
     hip_check(hipEventCreate(&a), "hipEventCreate"); hip_check(hipEventCreate(&b), "hipEventCreate");
     hip_check(hipEventRecord(a, stream), "hipEventRecord");
@@ -33,6 +35,7 @@ void DeviceCtx::begin(const std::string& fam) {
 }
 void DeviceCtx::end(const std::string& fam, double algorithmic_bytes, double pair_evaluations) {
     if (!profile) return;
+    flush();
     auto& f = families[fam];
     hip_check(hipEventRecord(f.pending.back().second, stream), "hipEventRecord");
     f.launches += 1; f.bytes += algorithmic_bytes; f.pairs += pair_evaluations;
@@ -206,6 +209,8 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
     ctx.n_system = n_system;
     hip_check(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking), "hipStreamCreate");   // (stream priorities were tried: a low-priority upkeep stream delays the joins, -10 to -27 %)
     ctx.L.n_system = n_system; ctx.L.stream = (void*)ctx.stream;
+    ctx.L.fuse = upk_fuse_create(n_system);      // queue of fused per-element ops (kernels_basic.hip)
+    if (!ctx.L.fuse) throw string("cannot allocate the fused-op table");
     ctx.error_flag.alloc(1);
     potential.assign(n_system, 0.f);
     Node n; n.name = "pos"; n.computation.reset(new Pos(&ctx, n_atom));
@@ -224,6 +229,7 @@ DerivEngine::~DerivEngine() {
     }
     for (auto& kv : side) if (kv.second.owns_stream) (void)hipStreamDestroy(kv.second.stream);
     nodes.clear();
+    upk_fuse_destroy(ctx.L.fuse); ctx.L.fuse = nullptr;
     if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
 }
 void DerivEngine::add_node(const string& name, unique_ptr<DerivComputation> fcn, vector<string> argument_names) {
@@ -252,6 +258,44 @@ void DerivEngine::finalize() {
     // Unroll the level-synchronous sweep of deriv_engine.cpp:124-169 once; the order of events is static.
     schedule.clear();
     for (auto& n : nodes) n.germ_exec_level = n.deriv_exec_level = -1;
+    // Order of the sweep.  Any order that runs a node after its parents (forward) / after its children (backward) computes the
+    // same graph; the reference walks it level by level.  Here steps that only enqueue fused per-element ops are drawn together:
+    // forward, every such step whose parents are done, then ONE other step, and so on; then the same backward.  The per-element
+    // work of a force pass then reaches the device in a handful of launches instead of one per level.  UPSIDE_HIP_SCHEDULE=bfs
+    // keeps the reference's level order (tests).
+    const char* sched_env = getenv("UPSIDE_HIP_SCHEDULE");
+    const bool grouped = !(sched_env && !strcmp(sched_env, "bfs"));
+    if (grouped) {
+        const size_t N = nodes.size();
+        std::vector<char> done(N, 0);
+        auto sweep = [&](bool backward) {
+            std::fill(done.begin(), done.end(), 0);
+            auto ready = [&](size_t i) {
+                const auto& deps = backward ? nodes[i].children : nodes[i].parents;
+                return !done[i] && all_of(begin(deps), end(deps), [&](size_t d) { return done[d] != 0; });
+            };
+            auto fused = [&](size_t i) { auto* c = nodes[i].computation.get(); return backward ? c->fused_backward : c->fused_forward; };
+            int lvl = 0;
+            for (size_t n_done = 0; n_done < N;) {
+                bool progress = true;
+                while (progress) {
+                    progress = false;
+                    for (size_t i = 0; i < N; ++i) if (fused(i) && ready(i)) {
+                        schedule.push_back(Step{(int)i, backward}); done[i] = 1; ++n_done; progress = true;
+                        (backward ? nodes[i].deriv_exec_level : nodes[i].germ_exec_level) = lvl;
+                    }
+                }
+                ++lvl;
+                for (size_t i = 0; i < N; ++i) if (ready(i)) {
+                    schedule.push_back(Step{(int)i, backward}); done[i] = 1; ++n_done;
+                    (backward ? nodes[i].deriv_exec_level : nodes[i].germ_exec_level) = lvl;
+                    break;
+                }
+                ++lvl;
+            }
+        };
+        sweep(false); sweep(true);
+    } else
     for (int lvl = 0, not_finished = 1;; ++lvl, not_finished = 0) {
         for (size_t i = 0; i < nodes.size(); ++i) {
             auto& n = nodes[i];
@@ -356,22 +400,24 @@ void DerivEngine::finalize() {
         }
 }
 
-void DerivEngine::compute(ComputeMode mode) {
+void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
     ++n_compute;
     // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
     // node's sens before that node's own forward step
     upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
-    auto on_stream = [&](hipStream_t st, const std::function<void()>& f) {
+    auto on_stream = [&](hipStream_t st, const std::function<void()>& f) {     // (the fused-op queue is empty on entry; what f queues runs on st)
         hipStream_t main_stream = ctx.stream;
         ctx.stream = st; ctx.L.stream = (void*)st;
-        try { f(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
+        try { f(); ctx.flush(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
         ctx.stream = main_stream; ctx.L.stream = (void*)main_stream;
     };
     for (size_t k = 0; k < schedule.size(); ++k) {
         const Step& st = schedule[k];
         auto* c = nodes[st.node].computation.get();
+        if (!c->library_launchers_only) ctx.flush();       // a node that may enqueue work of its own on the stream
         if (st.prepare) {   // fork: side stream waits for everything enqueued so far, runs the upkeep, records `join`
             Side& sd = side[st.node];
+            ctx.flush();
             hip_check(hipEventRecord(sd.fork, ctx.stream), "hipEventRecord");
             hip_check(hipStreamWaitEvent(sd.stream, sd.fork, 0), "hipStreamWaitEvent");
             on_stream(sd.stream, [&] { c->prepare(); });
@@ -381,16 +427,18 @@ void DerivEngine::compute(ComputeMode mode) {
         if (!st.backward) {
             if (c->has_prepare()) {
                 auto it = side.find(st.node);
-                if (it != side.end()) hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent");
+                if (it != side.end()) { ctx.flush(); hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent"); }
                 else c->prepare();
             }
             c->compute_value(mode);
         } else if (!c->potential_term) {
             auto* cn = static_cast<CoordNode*>(c);
             cn->gather_contributions();
+            if (!c->library_launchers_only) ctx.flush();       // (the gather is a fused op; the node may read its sens through the stream)
             c->propagate_deriv();
         }
     }
+    if (!keep_pending) ctx.flush();       // callers outside the MD loop find the queue empty
 }
 
 void DerivEngine::fetch_potentials() {
@@ -408,7 +456,7 @@ void DerivEngine::integration_stage(int stage, float dt_, float max_force) {
     const float a = 1.f / 6.f, b = 1.f / 3.f;   // Verlet
     const float mom_update[] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
     const float pos_update[] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
-    compute(DerivMode);
+    compute(DerivMode, true);       // the tail of the backward sweep, the leapfrog update and the head of the next force pass share a launch
     upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force), "integration_stage");
 }
 void DerivEngine::integration_cycle(float dt_, float max_force) {
@@ -417,10 +465,10 @@ void DerivEngine::integration_cycle(float dt_, float max_force) {
 
 void DerivEngine::set_invocations(uint64_t n) {
     n_invocations = n;
-    if (!n_invocations_dev.n) n_invocations_dev.alloc(1);
-    unsigned long long v = n;
+    if (!n_invocations_dev.n) n_invocations_dev.alloc(ctx.n_system);
+    std::vector<unsigned long long> v(ctx.n_system, (unsigned long long)n);     // one copy per system (kernels_basic.hip: c_thermostat)
     sync();
-    hip_check(hipMemcpy(n_invocations_dev.p, &v, sizeof(v), hipMemcpyHostToDevice), "H2D");
+    hip_check(hipMemcpy(n_invocations_dev.p, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice), "H2D");
 }
 void DerivEngine::md_step() {
     if (stage_num == 0 && !(round_num % thermostat_interval)) {   // main.cpp:657-662
@@ -440,10 +488,11 @@ bool DerivEngine::capture_md_graph() {
     invalidate_graph();
     const int sn = stage_num; const uint64_t rn = round_num, ni = n_invocations, sd = steps_done, nc = n_compute;
     static const bool debug = getenv("UPSIDE_HIP_GRAPH_DEBUG") != nullptr;
+    ctx.flush();
     hipError_t err = hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeGlobal);
     if (err != hipSuccess) { if (debug) fprintf(stderr, "graph: begin capture failed: %s\n", hipGetErrorString(err)); (void)hipGetLastError(); return false; }
     bool ok = true;
-    try { for (int i = 0; i < 6; ++i) md_step(); }
+    try { for (int i = 0; i < 6; ++i) md_step(); ctx.flush(); }
     catch (const string& e) { ok = false; if (debug) fprintf(stderr, "graph: capture threw: %s\n", e.c_str()); }
     catch (...) { ok = false; }
     hipGraph_t g = nullptr;
@@ -465,12 +514,14 @@ void DerivEngine::run_steps(int n_step) {
         const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;
         if (use_graph && !graph_failed && aligned && left >= 6 && (!md_graph_ready || md_graph_parity == (int)(n_compute & 1))) {
             if (!md_graph_ready && !capture_md_graph()) { graph_failed = true; md_step(); --left; continue; }
+            ctx.flush();
             hip_check(hipGraphLaunch(md_graph_exec, ctx.stream), "hipGraphLaunch");
             round_num += 2; n_invocations += 2; steps_done += 6; n_compute += 6; left -= 6;
             continue;
         }
         md_step(); --left;
     }
+    ctx.flush();
 }
 void DerivEngine::load_pivot_moves(hid_t_compat input_group_) {
     const hid_t input = (hid_t)input_group_;
@@ -553,7 +604,7 @@ void DerivEngine::mc_step(uint64_t round) {   // MultipleMonteCarloSampler::exec
         sync();
     }
 }
-void DerivEngine::sync() { hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
+void DerivEngine::sync() { ctx.flush(); hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
 
 void DerivEngine::check_device_errors() {
     sync();
@@ -564,6 +615,8 @@ void DerivEngine::check_device_errors() {
             throw string("belief propagation: a workgroup of a solve cluster never arrived (the cluster solve needs all its workgroups "
                          "co-resident; something else occupied the device): the forces of this step are not valid.  Set UPSIDE_HIP_BP_CLUSTER=1 "
                          "to use the one-workgroup solve");
+        if (f[0] == 8)   // kernels_rotamer.hip: RotGradOp2::flush
+            throw string("side-chain gradient: a bead's gradient is not finite (NaN or overflow in the pair pass): the forces of this step are not valid");
         throw string("device capacity overflow (code ") + to_string(f[0]) +
             "): raise UPSIDE_HIP_NBR_CAP / UPSIDE_HIP_SLOT_FACTOR (1 = neighbour list, 2 = residue-pair slots, 3 = node adjacency)";
     }

@@ -15,7 +15,7 @@
 
 struct Pos : public CoordNode {   // deriv_engine.h:122-141
     int n_atom;
-    Pos(DeviceCtx* c, int n_atom_) : CoordNode(c, n_atom_, 3), n_atom(n_atom_) {}
+    Pos(DeviceCtx* c, int n_atom_) : CoordNode(c, n_atom_, 3), n_atom(n_atom_) { library_launchers_only = true; fused_forward = fused_backward = true; }
     void compute_value(ComputeMode) override {}
     void propagate_deriv() override {}
 };
@@ -38,7 +38,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     std::vector<float> temperature; std::vector<uint32_t> seeds;
     float thermostat_timescale = 5.f, dt = 0.009f; int thermostat_interval = 1;
     uint64_t n_invocations = 0, round_num = 0;      // host mirrors; the thermostat reads the device copy below
-    DevBuf<unsigned long long> n_invocations_dev;   // [1]
+    DevBuf<unsigned long long> n_invocations_dev;   // [S] (equal entries: each system's workgroup advances its own)
     void set_invocations(uint64_t n);
 
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
@@ -60,7 +60,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
         return dynamic_cast<T&>(*c);
     }
     void finalize();
-    void compute(ComputeMode mode);            // enqueue; no synchronisation
+    void compute(ComputeMode mode, bool keep_pending = false);   // enqueue; no synchronisation.  keep_pending: leave queued fused ops for the caller to extend (MD loop)
     void fetch_potentials();                   // D2H of every PotentialNode::potential + engine total
     void integration_cycle(float dt, float max_force = 0.f);   // deriv_engine.cpp:172-192 (Verlet weights)
     void integration_stage(int stage, float dt, float max_force);   // one force evaluation + leapfrog sub-step (deriv_engine.cpp:172-192)

@@ -4,6 +4,12 @@
 // gathers deterministically (upk_gather_contrib) -- no float atomics anywhere in the force pass.
 #include "device_math.h"
 #include "../../include/upside_hip_kernels.h"
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <type_traits>
+#include <unordered_map>
+#include <vector>
 
 using namespace up;
 
@@ -17,38 +23,90 @@ static inline int launch_status() { return (int)hipGetLastError(); }
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
 
 // ------------------------------------------------------------------------------------------------
+// Fused per-element passes.  A force pass holds ~45 per-element steps (coordinate nodes, bonded terms, derivative gathers, the
+// integrator) of a few hundred to a few thousand elements per system each.  As kernels of their own they cost a dependent launch
+// apiece: 4.9 us of host time per eager launch on this platform, 1.7 us per node of a replayed hipGraph -- against 0.25-0.7 us for
+// the same dependent step as a PHASE of a resident workgroup (tools/ubench/launch_chain.hip).  The launchers below therefore do not
+// launch: they append an op record (kind + the argument block the kernel used to take) to the engine's queue
+// (upk_launch_t::fuse), and the queue is run by ONE launch of k_fused_list -- one workgroup per system walks the ops in order, a
+// workgroup barrier between consecutive ops; what an op writes for a later one travels through global memory inside one CU
+// (L2 hits; workgroup-scope visibility needs no cache maintenance on gfx950).  Everything that is not fusable (pair passes,
+// list upkeep, belief propagation, memory copies, events) flushes the queue first, so program order is the order of effects.
+// Op records live in a device table that only grows: an op is registered the first time its (kind, arguments) are seen (a
+// blocking upload) and referred to by a 16-bit id afterwards; a launch takes the ids of its ops as a kernel argument, so the
+// steady state has no copies and can be captured into a hipGraph.
+// UPSIDE_HIP_FUSE=0: every op is launched on its own (one workgroup per system), the order of effects is the same.
+#define FUSE_PAYLOAD 232
+#define FUSE_MAX_PENDING 224
+struct FusedOp { int kind, n, lds_bytes, flags; unsigned char payload[FUSE_PAYLOAD]; };   // flags bit 0: no barrier needed in front of this op
+struct FusedIds { int n; unsigned short id[FUSE_MAX_PENDING]; };
+static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, int flags);
+// An op is looked up by the BYTES of its argument block, padding included: launchers fill a zeroed block field by field (FARGS),
+// nested structs through cz / pz, which rebuild them member by member (a struct copy may carry the source's padding along).
+template <typename A>
+static inline int fuse_submit(const upk_launch_t* L, int kind, const A& args, int n, int lds_bytes = 0, int flags = 0) {
+    static_assert(sizeof(A) <= FUSE_PAYLOAD, "fused-op argument block too large");
+    static_assert(std::is_trivially_copyable<A>::value, "fused-op arguments are copied bytewise");
+    return fuse_submit_raw(L, kind, &args, sizeof(A), n, lds_bytes, flags);
+}
+#define FARGS(T, a) T a; memset((void*)&a, 0, sizeof(a))
+static inline upk_coord_t cz(const upk_coord_t& c) {
+    upk_coord_t r; memset((void*)&r, 0, sizeof(r));
+    r.out = c.out; r.sens = c.sens; r.n_elem = c.n_elem; r.width = c.width; r.stride = c.stride;
+    return r;
+}
+static inline upk_placement_t pz(const upk_placement_t& p) {
+    upk_placement_t r; memset((void*)&r, 0, sizeof(r));
+    r.n_elem = p.n_elem; r.n_pos_dim = p.n_pos_dim; r.n_sig = p.n_sig; r.sig[0] = p.sig[0]; r.sig[1] = p.sig[1]; r.sig[2] = p.sig[2];
+    r.affine_residue = p.affine_residue; r.layer = p.layer; r.rama_residue = p.rama_residue; r.is_rama = p.is_rama;
+    r.fixed_data = p.fixed_data; r.spline_coeff = p.spline_coeff; r.nx = p.nx; r.ny = p.ny;
+    return r;
+}
+enum { FOP_ZERO_MANY = 1, FOP_REDUCE_SUM, FOP_GATHER_CONTRIB, FOP_INTEGRATION_STAGE, FOP_THERMOSTAT, FOP_AFFINE_FWD, FOP_AFFINE_BWD,
+       FOP_RAMA_FWD, FOP_RAMA_BWD, FOP_INFER_FWD, FOP_INFER_BWD, FOP_SPRING, FOP_PLACEMENT_FWD, FOP_PLACEMENT_BWD, FOP_RAMA_MAP_POT,
+       FOP_WEIGHTED_POS_FWD, FOP_WEIGHTED_POS_BWD, FOP_NONLINEAR_COUPLING, FOP_HBOND_ENERGY, FOP_PROTEIN_HBOND_FINISH,
+       FOP_PROTEIN_HBOND_BWD_PRE, FOP_PROTEIN_HBOND_PASSTHROUGH, FOP_BACKBONE_PAIRS, FOP_N };
+
+// ------------------------------------------------------------------------------------------------
 // generic
-__global__ void k_reduce_sum(const float* __restrict__ in, int n, float* __restrict__ out, int accumulate) {
-    __shared__ float part[UPK_BLOCK / UP_WAVE];
-    const int s = blockIdx.y;
-    const float* p = in + (size_t)s * n;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += p[i];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+// out[s] (+)= sum of in[s][0..n): ALWAYS summed as 256 strided partial sums (lane t of a virtual 256-lane block takes i = t, t + 256, ...)
+// combined wave by wave in order, whatever the size of the workgroup that runs it: the value does not depend on the launch shape
+struct ReduceSumArgs { const float* in; int n; float* out; int accumulate; };
+__device__ __forceinline__ void c_reduce_sum(const ReduceSumArgs& A, int s, float* part /* LDS, 4 floats */) {
+    const float* p = A.in + (size_t)s * A.n;
+    for (int v = threadIdx.x; v < UPK_BLOCK; v += blockDim.x) {      // virtual lane v (whole wavefronts make the same trips)
+        float acc = 0.f;
+        for (int i = v; i < A.n; i += UPK_BLOCK) acc += p[i];
+        acc = wave_sum(acc);
+        if ((v & 63) == 0) part[v >> 6] = acc;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[w];
-        out[s] = accumulate ? out[s] + t : t;
+        A.out[s] = A.accumulate ? A.out[s] + t : t;
     }
 }
-__global__ void k_zero_many(float* const* __restrict__ ptrs, const long* __restrict__ sizes) {
-    float4* p = (float4*)ptrs[blockIdx.y];
-    const long n4 = sizes[blockIdx.y] >> 2;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) p[i] = z;
-    const long tail = sizes[blockIdx.y] & 3;
-    if (blockIdx.x == 0 && threadIdx.x < tail) ptrs[blockIdx.y][(n4 << 2) + threadIdx.x] = 0.f;
+// every buffer holds n_system equal slices: a workgroup clears the slices of its system
+struct ZeroManyArgs { float* const* ptrs; const long* sizes; int n_buf, n_system; };
+__device__ __forceinline__ void c_zero_many(const ZeroManyArgs& A, int s) {
+    for (int b = 0; b < A.n_buf; ++b) {
+        const long per = A.sizes[b] / A.n_system;
+        float* p = A.ptrs[b] + (size_t)s * per;
+        if ((per & 3) == 0 && (((size_t)p) & 15) == 0) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (long i = threadIdx.x; i < (per >> 2); i += blockDim.x) ((float4*)p)[i] = z;
+        } else for (long i = threadIdx.x; i < per; i += blockDim.x) p[i] = 0.f;
+    }
 }
 extern "C" int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf) {
     if (n_buf <= 0) return 0;
-    hipLaunchKernelGGL(k_zero_many, dim3(128, n_buf), dim3(256), 0, ST(L), ptrs, sizes);
-    return launch_status();
+    FARGS(ZeroManyArgs, a); a.ptrs = ptrs; a.sizes = sizes; a.n_buf = n_buf; a.n_system = L->n_system;
+    return fuse_submit(L, FOP_ZERO_MANY, a, 0);
 }
 extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate) {
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, n, out, accumulate);
-    return launch_status();
+    FARGS(ReduceSumArgs, a); a.in = in; a.n = n; a.out = out; a.accumulate = accumulate;
+    return fuse_submit(L, FOP_REDUCE_SUM, a, 0);
 }
 
 __global__ void k_scale(float* __restrict__ x, int n, float f) {
@@ -56,6 +114,7 @@ __global__ void k_scale(float* __restrict__ x, int n, float f) {
     if (i < n) x[i] *= f;
 }
 extern "C" int upk_scale(const upk_launch_t* L, float* x, int n, float factor) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_scale, grid1(n, 1), dim3(UPK_BLOCK), 0, ST(L), x, n, factor);
     return launch_status();
 }
@@ -63,12 +122,11 @@ extern "C" int upk_scale(const upk_launch_t* L, float* x, int n, float factor) {
 // Eight lanes per target element, lane c of the group owning component c: a contribution row (3 to 8 consecutive floats) is one
 // 32-byte access of the group instead of `width` instructions that each touch 64 different rows.  Every component is still
 // summed by one lane in entry order (the same sum as one lane per element).
-__global__ void k_gather_contrib(const float* __restrict__ arena, long arena_stride, const int* __restrict__ csr_start,
-                                 const int* __restrict__ csr_entry, upk_coord_t target, int width, int comp_offset) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+struct GatherContribArgs { const float* arena; long arena_stride; const int* csr_start; const int* csr_entry; upk_coord_t target; int width, comp_offset; };
+__device__ __forceinline__ void b_gather_contrib(const int g, const int s, const float* __restrict__ arena, long arena_stride, const int* __restrict__ csr_start,
+                                                 const int* __restrict__ csr_entry, upk_coord_t target, int width, int comp_offset) {
     const int t = g >> 3, c = g & 7;
     if (t >= target.n_elem || c >= width) return;
-    const int s = blockIdx.y;
     const float* a = arena + (size_t)s * arena_stride + c;
     float acc = 0.f;
     const int e0 = csr_start[t], e1 = csr_start[t + 1];
@@ -91,17 +149,15 @@ __global__ void k_gather_contrib(const float* __restrict__ arena, long arena_str
 extern "C" int upk_gather_contrib(const upk_launch_t* L, const float* arena, long arena_stride, const int* csr_start,
                                   const int* csr_entry, upk_coord_t target, int width, int comp_offset) {
     if (width > 8) return 9010;
-    hipLaunchKernelGGL(k_gather_contrib, grid1(target.n_elem * 8, L->n_system), dim3(UPK_BLOCK), 0, ST(L), arena, arena_stride,
-                       csr_start, csr_entry, target, width, comp_offset);
-    return launch_status();
+    FARGS(GatherContribArgs, a); a.arena = arena; a.arena_stride = arena_stride; a.csr_start = csr_start; a.csr_entry = csr_entry; a.target = cz(target); a.width = width; a.comp_offset = comp_offset;
+    return fuse_submit(L, FOP_GATHER_CONTRIB, a, target.n_elem * 8);
 }
 
 // ------------------------------------------------------------------------------------------------
 // integrator (deriv_engine.cpp:11-35), thermostat (thermostat.cpp:9-18), recenter (deriv_engine.cpp:37-48)
-__global__ void k_integration_stage(float* __restrict__ mom, upk_coord_t pos, float vel_factor, float pos_factor, float max_force) {
-    const int na = blockIdx.x * blockDim.x + threadIdx.x;
+struct IntegrationStageArgs { float* mom; upk_coord_t pos; float vel_factor, pos_factor, max_force; };
+__device__ __forceinline__ void b_integration_stage(const int na, const int s, float* __restrict__ mom, upk_coord_t pos, float vel_factor, float pos_factor, float max_force) {
     if (na >= pos.n_elem) return;
-    const int s = blockIdx.y;
     const float* d_ = C_SENS(pos, s) + (size_t)na * pos.stride;
     float* x = C_OUT(pos, s) + (size_t)na * pos.stride;
     float* m = mom + ((size_t)s * pos.n_elem + na) * 4;
@@ -117,18 +173,17 @@ __global__ void k_integration_stage(float* __restrict__ mom, upk_coord_t pos, fl
 }
 extern "C" int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
                                      float max_force) {
-    hipLaunchKernelGGL(k_integration_stage, grid1(pos.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, pos, vel_factor,
-                       pos_factor, max_force);
-    return launch_status();
+    FARGS(IntegrationStageArgs, a); a.mom = mom; a.pos = cz(pos); a.vel_factor = vel_factor; a.pos_factor = pos_factor; a.max_force = max_force;
+    return fuse_submit(L, FOP_INTEGRATION_STAGE, a, pos.n_elem);
 }
 
-__global__ void k_thermostat(float* __restrict__ mom, int n_atom, const uint32_t* __restrict__ seed,
-                             const unsigned long long* __restrict__ n_inv, const float* __restrict__ mom_scale,
-                             const float* __restrict__ noise_scale) {
-    const int na = blockIdx.x * blockDim.x + threadIdx.x;
+struct ThermostatArgs { float* mom; int n_atom; const uint32_t* seed; unsigned long long* n_inv; const float* mom_scale; const float* noise_scale; };
+__device__ __forceinline__ void b_thermostat(const int na, const int s, float* __restrict__ mom, int n_atom, const uint32_t* __restrict__ seed,
+                                             const unsigned long long* __restrict__ n_inv, const float* __restrict__ mom_scale,
+                                             const float* __restrict__ noise_scale) {
     if (na >= n_atom) return;
-    const int s = blockIdx.y;
-    const uint64_t t = *n_inv;   // invocation counter lives on the device so that a captured graph can be replayed
+    const uint64_t t = n_inv[s];   // the invocation counter lives on the device (a captured graph can be replayed), one copy per system: the
+                                   // workgroup that runs a system's ops reads it here and advances it behind a barrier (c_thermostat)
     const uint32_t key[4] = {seed[s], 0u /* THERMOSTAT_RANDOM_STREAM, random.h:25 */, 0u, 0u};
     uint32_t X[4] = {(uint32_t)(t & 0xffffffffu), (uint32_t)(t >> 32), (uint32_t)na, 0u};
     threefry4x32_20(X, key);
@@ -139,13 +194,15 @@ __global__ void k_thermostat(float* __restrict__ mom, int n_atom, const uint32_t
     const float ms = mom_scale[s], ns = noise_scale[s];
     m[0] = ms * m[0] + ns * n0; m[1] = ms * m[1] + ns * n1; m[2] = ms * m[2] + ns * n2;
 }
-__global__ void k_counter_add(unsigned long long* ctr, unsigned long long inc) { if (threadIdx.x == 0 && blockIdx.x == 0) *ctr += inc; }
+__device__ __forceinline__ void c_thermostat(const ThermostatArgs& A, int s) {
+    for (int i = threadIdx.x; i < A.n_atom; i += blockDim.x) b_thermostat(i, s, A.mom, A.n_atom, A.seed, A.n_inv, A.mom_scale, A.noise_scale);
+    __syncthreads();                       // every lane has read the counter
+    if (threadIdx.x == 0) A.n_inv[s] += 1ull;
+}
 extern "C" int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,
                               const float* mom_scale, const float* noise_scale) {
-    hipLaunchKernelGGL(k_thermostat, grid1(n_atom, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, n_atom, seed, n_invocations,
-                       mom_scale, noise_scale);
-    hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(64), 0, ST(L), n_invocations, 1ull);   // after every lane has read it (stream order)
-    return launch_status();
+    FARGS(ThermostatArgs, a); a.mom = mom; a.n_atom = n_atom; a.seed = seed; a.n_inv = n_invocations; a.mom_scale = mom_scale; a.noise_scale = noise_scale;
+    return fuse_submit(L, FOP_THERMOSTAT, a, 0);
 }
 
 __global__ void k_recenter(upk_coord_t pos, int xy_only) {
@@ -166,6 +223,7 @@ __global__ void k_recenter(upk_coord_t pos, int xy_only) {
     for (int i = threadIdx.x; i < pos.n_elem; i += blockDim.x) for (int c = 0; c < 3; ++c) x[(size_t)i * pos.stride + c] -= center[c];
 }
 extern "C" int upk_recenter(const upk_launch_t* L, upk_coord_t pos, int xy_only) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_recenter, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, xy_only);
     return launch_status();
 }
@@ -181,6 +239,7 @@ __global__ void k_kinetic(const float* __restrict__ mom, int n_atom, float* __re
     if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < UPK_BLOCK / UP_WAVE; ++w) t += part[w]; kin[s] = 0.5f * t / (float)n_atom; }
 }
 extern "C" int upk_kinetic(const upk_launch_t* L, const float* mom, int n_atom, float* kin) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_kinetic, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), mom, n_atom, kin);
     return launch_status();
 }
@@ -240,10 +299,10 @@ __device__ __forceinline__ void qr_step(float (&d)[4], float (&u)[3], float (&ro
     }
 }
 
-__global__ void k_affine_fwd(upk_coord_t pos, const int* __restrict__ atoms, const float* __restrict__ ref_geom, int n_res,
-                             upk_coord_t out, float* __restrict__ eig) {
-    const int lane_res = blockIdx.x * blockDim.x + threadIdx.x;
-    const int s = blockIdx.y;
+struct AffineFwdArgs { upk_coord_t pos; const int* atoms; const float* ref_geom; int n_res; upk_coord_t out; float* eig; };
+// (called by ALL lanes of a wavefront with consecutive lane_res: the interpreter rounds the loop bound up to whole wavefronts)
+__device__ __forceinline__ void b_affine_fwd(const int lane_res, const int s, upk_coord_t pos, const int* __restrict__ atoms, const float* __restrict__ ref_geom, int n_res,
+                                             upk_coord_t out, float* __restrict__ eig) {
     const int n_pad = (n_res + 3) & ~3;
     // every lane of a wave must reach the ballots; lanes beyond n_pad replay residue 0 and are discarded
     const bool in_pad = lane_res < n_pad;
@@ -336,15 +395,14 @@ __global__ void k_affine_fwd(upk_coord_t pos, const int* __restrict__ atoms, con
 }
 extern "C" int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, const float* ref_geom, int n_res,
                               upk_coord_t out, float* eig) {
-    hipLaunchKernelGGL(k_affine_fwd, grid1((n_res + 3) & ~3, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atoms, ref_geom, n_res, out, eig);
-    return launch_status();
+    FARGS(AffineFwdArgs, a); a.pos = cz(pos); a.atoms = atoms; a.ref_geom = ref_geom; a.n_res = n_res; a.out = cz(out); a.eig = eig;
+    return fuse_submit(L, FOP_AFFINE_FWD, a, (n_res + 63) & ~63);
 }
 
-__global__ void k_affine_bwd(upk_coord_t aff, const float* __restrict__ ref_geom, const float* __restrict__ eig, int n_res,
-                             float* __restrict__ contrib, long contrib_stride) {   // eig.cpp:388-470
-    const int nr = blockIdx.x * blockDim.x + threadIdx.x;
+struct AffineBwdArgs { upk_coord_t aff; const float* ref_geom; const float* eig; int n_res; float* contrib; long contrib_stride; };
+__device__ __forceinline__ void b_affine_bwd(const int nr, const int s, upk_coord_t aff, const float* __restrict__ ref_geom, const float* __restrict__ eig, int n_res,
+                                             float* __restrict__ contrib, long contrib_stride) {   // eig.cpp:388-470
     if (nr >= n_res) return;
-    const int s = blockIdx.y;
     const float* e = eig + ((size_t)s * n_res + nr) * 20;
     const float* evals = e; const float* ev = e + 4;
 #define EV(k, i) ev[(k) * 4 + (i)]
@@ -403,17 +461,16 @@ __global__ void k_affine_bwd(upk_coord_t aff, const float* __restrict__ ref_geom
 }
 extern "C" int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
                               float* contrib, long contrib_stride) {
-    hipLaunchKernelGGL(k_affine_bwd, grid1(n_res, L->n_system), dim3(UPK_BLOCK), 0, ST(L), aff, ref_geom, eig, n_res, contrib, contrib_stride);
-    return launch_status();
+    FARGS(AffineBwdArgs, a); a.aff = cz(aff); a.ref_geom = ref_geom; a.eig = eig; a.n_res = n_res; a.contrib = contrib; a.contrib_stride = contrib_stride;
+    return fuse_submit(L, FOP_AFFINE_BWD, a, n_res);
 }
 
 // ------------------------------------------------------------------------------------------------
 // rama_coord (bonds.cpp:205-247)
-__global__ void k_rama_fwd(upk_coord_t pos, const int* __restrict__ atom, const int* __restrict__ dummy, int n_res,
-                           upk_coord_t out, float* __restrict__ jac) {
-    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+struct RamaFwdArgs { upk_coord_t pos; const int* atom; const int* dummy; int n_res; upk_coord_t out; float* jac; };
+__device__ __forceinline__ void b_rama_fwd(const int nt, const int s, upk_coord_t pos, const int* __restrict__ atom, const int* __restrict__ dummy, int n_res,
+                                           upk_coord_t out, float* __restrict__ jac) {
     if (nt >= n_res) return;
-    const int s = blockIdx.y;
     const float* x = C_OUT(pos, s);
     f3 p[5];
     for (int a = 0; a < 5; ++a) p[a] = ld3(x + (size_t)atom[nt * 5 + a] * pos.stride);
@@ -439,30 +496,30 @@ __global__ void k_rama_fwd(upk_coord_t pos, const int* __restrict__ atom, const 
 }
 extern "C" int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
                             float* jac) {
-    hipLaunchKernelGGL(k_rama_fwd, grid1(n_res, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atom, dummy, n_res, out, jac);
-    return launch_status();
+    FARGS(RamaFwdArgs, a); a.pos = cz(pos); a.atom = atom; a.dummy = dummy; a.n_res = n_res; a.out = cz(out); a.jac = jac;
+    return fuse_submit(L, FOP_RAMA_FWD, a, n_res);
 }
-__global__ void k_rama_bwd(upk_coord_t rama, const float* __restrict__ jac, int n_res, float* __restrict__ contrib, long contrib_stride) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // (residue, atom slot)
+struct RamaBwdArgs { upk_coord_t rama; const float* jac; int n_res; float* contrib; long contrib_stride; };
+__device__ __forceinline__ void b_rama_bwd(const int idx /* (residue, atom slot) */, const int s, upk_coord_t rama, const float* __restrict__ jac, int n_res,
+                                           float* __restrict__ contrib, long contrib_stride) {
     if (idx >= n_res * 5) return;
-    const int s = blockIdx.y, nt = idx / 5, a = idx % 5;
+    const int nt = idx / 5, a = idx % 5;
     const float* sn = C_SENS(rama, s) + (size_t)nt * rama.stride;
     const float* j = jac + ((size_t)s * n_res + nt) * UPK_RAMA_JAC;
     float* o = contrib + (size_t)s * contrib_stride + (size_t)idx * 3;
     for (int c = 0; c < 3; ++c) o[c] = sn[0] * j[(0 * 5 + a) * 3 + c] + sn[1] * j[(1 * 5 + a) * 3 + c];
 }
 extern "C" int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride) {
-    hipLaunchKernelGGL(k_rama_bwd, grid1(n_res * 5, L->n_system), dim3(UPK_BLOCK), 0, ST(L), rama, jac, n_res, contrib, contrib_stride);
-    return launch_status();
+    FARGS(RamaBwdArgs, a); a.rama = cz(rama); a.jac = jac; a.n_res = n_res; a.contrib = contrib; a.contrib_stride = contrib_stride;
+    return fuse_submit(L, FOP_RAMA_BWD, a, n_res * 5);
 }
 
 // ------------------------------------------------------------------------------------------------
 // infer_H_O (hbond.cpp:59-119)
-__global__ void k_infer_fwd(upk_coord_t pos, const int* __restrict__ atom, const float* __restrict__ bond_length, int n_virtual,
-                            upk_coord_t out, float* __restrict__ dfd) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct InferFwdArgs { upk_coord_t pos; const int* atom; const float* bond_length; int n_virtual; upk_coord_t out; float* dfd; };
+__device__ __forceinline__ void b_infer_fwd(const int nv, const int s, upk_coord_t pos, const int* __restrict__ atom, const float* __restrict__ bond_length, int n_virtual,
+                                            upk_coord_t out, float* __restrict__ dfd) {
     if (nv >= n_virtual) return;
-    const int s = blockIdx.y;
     const float* x = C_OUT(pos, s);
     const f3 prev_c = ld3(x + (size_t)atom[nv * 3] * pos.stride), curr_c = ld3(x + (size_t)atom[nv * 3 + 1] * pos.stride),
              next_c = ld3(x + (size_t)atom[nv * 3 + 2] * pos.stride);
@@ -480,14 +537,13 @@ __global__ void k_infer_fwd(upk_coord_t pos, const int* __restrict__ atom, const
 }
 extern "C" int upk_infer_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const float* bond_length, int n_virtual,
                              upk_coord_t out, float* dfd) {
-    hipLaunchKernelGGL(k_infer_fwd, grid1(n_virtual, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, atom, bond_length, n_virtual, out, dfd);
-    return launch_status();
+    FARGS(InferFwdArgs, a); a.pos = cz(pos); a.atom = atom; a.bond_length = bond_length; a.n_virtual = n_virtual; a.out = cz(out); a.dfd = dfd;
+    return fuse_submit(L, FOP_INFER_FWD, a, n_virtual);
 }
-__global__ void k_infer_bwd(upk_coord_t infer, const float* __restrict__ bond_length, const float* __restrict__ dfd, int n_virtual,
-                            float* __restrict__ contrib, long contrib_stride) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct InferBwdArgs { upk_coord_t infer; const float* bond_length; const float* dfd; int n_virtual; float* contrib; long contrib_stride; };
+__device__ __forceinline__ void b_infer_bwd(const int nv, const int s, upk_coord_t infer, const float* __restrict__ bond_length, const float* __restrict__ dfd, int n_virtual,
+                                            float* __restrict__ contrib, long contrib_stride) {
     if (nv >= n_virtual) return;
-    const int s = blockIdx.y;
     const float* sn = C_SENS(infer, s) + (size_t)nv * infer.stride;
     const f3 sens_pos = ld3(sn), sens_dir = ld3(sn + 3);
     const f3 snu = sens_dir + bond_length[nv] * sens_pos;
@@ -505,18 +561,17 @@ __global__ void k_infer_bwd(upk_coord_t infer, const float* __restrict__ bond_le
 }
 extern "C" int upk_infer_bwd(const upk_launch_t* L, upk_coord_t infer, const float* bond_length, const float* dfd, int n_virtual,
                              float* contrib, long contrib_stride) {
-    hipLaunchKernelGGL(k_infer_bwd, grid1(n_virtual, L->n_system), dim3(UPK_BLOCK), 0, ST(L), infer, bond_length, dfd, n_virtual, contrib, contrib_stride);
-    return launch_status();
+    FARGS(InferBwdArgs, a); a.infer = cz(infer); a.bond_length = bond_length; a.dfd = dfd; a.n_virtual = n_virtual; a.contrib = contrib; a.contrib_stride = contrib_stride;
+    return fuse_submit(L, FOP_INFER_BWD, a, n_virtual);
 }
 
 // ------------------------------------------------------------------------------------------------
 // bonded springs (bonds.cpp:297-318, 457-487, 519-545)
-__global__ void k_spring(int kind, upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ equil,
-                         const float* __restrict__ kk, int n, float* __restrict__ contrib, long contrib_stride,
-                         float* __restrict__ pot_terms) {
-    const int nt = blockIdx.x * blockDim.x + threadIdx.x;
+struct SpringArgs { int kind; upk_coord_t pos; const int* id; const float* equil; const float* kk; int n; float* contrib; long contrib_stride; float* pot_terms; };
+__device__ __forceinline__ void b_spring(const int nt, const int s, int kind, upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ equil,
+                                         const float* __restrict__ kk, int n, float* __restrict__ contrib, long contrib_stride,
+                                         float* __restrict__ pot_terms) {
     if (nt >= n) return;
-    const int s = blockIdx.y;
     const float* x = C_OUT(pos, s);
     float* o = contrib + (size_t)s * contrib_stride + (size_t)nt * kind * 3;
     float pot;
@@ -554,8 +609,8 @@ __global__ void k_spring(int kind, upk_coord_t pos, const int* __restrict__ id, 
 }
 extern "C" int upk_spring(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* equil, const float* k, int n,
                           float* contrib, long contrib_stride, float* pot_terms) {
-    hipLaunchKernelGGL(k_spring, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), kind, pos, id, equil, k, n, contrib, contrib_stride, pot_terms);
-    return launch_status();
+    FARGS(SpringArgs, a); a.kind = kind; a.pos = cz(pos); a.id = id; a.equil = equil; a.kk = k; a.n = n; a.contrib = contrib; a.contrib_stride = contrib_stride; a.pot_terms = pot_terms;
+    return fuse_submit(L, FOP_SPRING, a, n);
 }
 
 __global__ void k_cavity(upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ radius, const float* __restrict__ kk,
@@ -577,16 +632,16 @@ __global__ void k_cavity(upk_coord_t pos, const int* __restrict__ id, const floa
 }
 extern "C" int upk_cavity_radial(const upk_launch_t* L, upk_coord_t pos, const int* id, const float* radius, const float* k, int n,
                                  float* contrib, long contrib_stride, float* pot_terms) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_cavity, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, id, radius, k, n, contrib, contrib_stride, pot_terms);
     return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // placement (placement.cpp:264-307; RamaPlacement 60-92; FixedPlacement 139-141)
-__global__ void k_placement_fwd(upk_placement_t P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out, float* __restrict__ rama_deriv) {
-    const int ne = blockIdx.x * blockDim.x + threadIdx.x;
+struct PlacementFwdArgs { upk_placement_t P; upk_coord_t aff, rama, out; float* rama_deriv; };
+__device__ __forceinline__ void b_placement_fwd(const int ne, const int s, const upk_placement_t& P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out, float* __restrict__ rama_deriv) {
     if (ne >= P.n_elem) return;
-    const int s = blockIdx.y;
     const int ar = P.affine_residue[ne];
     const float* a = C_OUT(aff, s) + (size_t)ar * aff.stride;
     const f3 t = ld3(a);
@@ -617,15 +672,14 @@ __global__ void k_placement_fwd(upk_placement_t P, upk_coord_t aff, upk_coord_t 
 }
 extern "C" int upk_placement_fwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out,
                                  float* rama_deriv) {
-    hipLaunchKernelGGL(k_placement_fwd, grid1(P->n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *P, aff, rama, out, rama_deriv);
-    return launch_status();
+    FARGS(PlacementFwdArgs, a); a.P = pz(*P); a.aff = cz(aff); a.rama = cz(rama); a.out = cz(out); a.rama_deriv = rama_deriv;
+    return fuse_submit(L, FOP_PLACEMENT_FWD, a, P->n_elem);
 }
 
-__global__ void k_placement_bwd(upk_placement_t P, upk_coord_t aff, upk_coord_t out, const float* __restrict__ rama_deriv,
-                                float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ rama_contrib, long rama_stride) {
-    const int ne = blockIdx.x * blockDim.x + threadIdx.x;
+struct PlacementBwdArgs { upk_placement_t P; upk_coord_t aff, out; const float* rama_deriv; float* aff_contrib; long aff_stride; float* rama_contrib; long rama_stride; };
+__device__ __forceinline__ void b_placement_bwd(const int ne, const int s, const upk_placement_t& P, upk_coord_t aff, upk_coord_t out, const float* __restrict__ rama_deriv,
+                                                float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ rama_contrib, long rama_stride) {
     if (ne >= P.n_elem) return;
-    const int s = blockIdx.y;
     const int ar = P.affine_residue[ne];
     const float* a = C_OUT(aff, s) + (size_t)ar * aff.stride;
     const f3 t = ld3(a);
@@ -659,18 +713,16 @@ __global__ void k_placement_bwd(upk_placement_t P, upk_coord_t aff, upk_coord_t 
 }
 extern "C" int upk_placement_bwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out,
                                  const float* rama_deriv, float* aff_contrib, long aff_stride, float* rama_contrib, long rama_stride) {
-    hipLaunchKernelGGL(k_placement_bwd, grid1(P->n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *P, aff, out, rama_deriv, aff_contrib,
-                       aff_stride, rama_contrib, rama_stride);
-    return launch_status();
+    FARGS(PlacementBwdArgs, a); a.P = pz(*P); a.aff = cz(aff); a.out = cz(out); a.rama_deriv = rama_deriv; a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.rama_contrib = rama_contrib; a.rama_stride = rama_stride;
+    return fuse_submit(L, FOP_PLACEMENT_BWD, a, P->n_elem);
 }
 
 // ------------------------------------------------------------------------------------------------
 // rama_map_pot (rama_map_pot.cpp:57-82)
-__global__ void k_rama_map_pot(upk_coord_t rama, const int* __restrict__ residue, const int* __restrict__ map_id, int n,
-                               const float* __restrict__ coeff, int nx, float* __restrict__ pot_terms) {
-    const int nr = blockIdx.x * blockDim.x + threadIdx.x;
+struct RamaMapPotArgs { upk_coord_t rama; const int* residue; const int* map_id; int n; const float* coeff; int nx; float* pot_terms; };
+__device__ __forceinline__ void b_rama_map_pot(const int nr, const int s, upk_coord_t rama, const int* __restrict__ residue, const int* __restrict__ map_id, int n,
+                                               const float* __restrict__ coeff, int nx, float* __restrict__ pot_terms) {
     if (nr >= n) return;
-    const int s = blockIdx.y;
     const float scale = nx * (0.5f / UP_PI_F - 1e-7f);
     const int r = residue[nr];
     const float* rc = C_OUT(rama, s) + (size_t)r * rama.stride;
@@ -684,16 +736,15 @@ __global__ void k_rama_map_pot(upk_coord_t rama, const int* __restrict__ residue
 }
 extern "C" int upk_rama_map_pot(const upk_launch_t* L, upk_coord_t rama, const int* residue, const int* map_id, int n,
                                 const float* coeff, int nx, float* pot_terms) {
-    hipLaunchKernelGGL(k_rama_map_pot, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), rama, residue, map_id, n, coeff, nx, pot_terms);
-    return launch_status();
+    FARGS(RamaMapPotArgs, a); a.rama = cz(rama); a.residue = residue; a.map_id = map_id; a.n = n; a.coeff = coeff; a.nx = nx; a.pot_terms = pot_terms;
+    return fuse_submit(L, FOP_RAMA_MAP_POT, a, n);
 }
 
 // weighted_pos (environment.cpp:132-154)
-__global__ void k_weighted_pos_fwd(upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
-                                   const int* __restrict__ index_weight, upk_coord_t out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+struct WeightedPosArgs { upk_coord_t pos, energy; const int* index_pos; const int* index_weight; upk_coord_t self; };
+__device__ __forceinline__ void b_weighted_pos_fwd(const int i, const int s, upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
+                                                   const int* __restrict__ index_weight, upk_coord_t out) {
     if (i >= out.n_elem) return;
-    const int s = blockIdx.y;
     const float* p = C_OUT(pos, s) + (size_t)index_pos[i] * pos.stride;
     float* o = C_OUT(out, s) + (size_t)i * out.stride;
     o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
@@ -701,14 +752,12 @@ __global__ void k_weighted_pos_fwd(upk_coord_t pos, upk_coord_t energy, const in
 }
 extern "C" int upk_weighted_pos_fwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
                                     const int* index_weight, upk_coord_t out) {
-    hipLaunchKernelGGL(k_weighted_pos_fwd, grid1(out.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, energy, index_pos, index_weight, out);
-    return launch_status();
+    FARGS(WeightedPosArgs, a); a.pos = cz(pos); a.energy = cz(energy); a.index_pos = index_pos; a.index_weight = index_weight; a.self = cz(out);
+    return fuse_submit(L, FOP_WEIGHTED_POS_FWD, a, out.n_elem);
 }
-__global__ void k_weighted_pos_bwd(upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
-                                   const int* __restrict__ index_weight, upk_coord_t self) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void b_weighted_pos_bwd(const int i, const int s, upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
+                                                   const int* __restrict__ index_weight, upk_coord_t self) {
     if (i >= self.n_elem) return;
-    const int s = blockIdx.y;
     // (rows of a coordinate node are padded to multiples of 4 floats: one 16-byte access per row instead of three or four dwords)
     const float4 sn = *(const float4*)(C_SENS(self, s) + (size_t)i * self.stride);
     const float o3 = (C_OUT(self, s) + (size_t)i * self.stride)[3];
@@ -719,16 +768,15 @@ __global__ void k_weighted_pos_bwd(upk_coord_t pos, upk_coord_t energy, const in
 }
 extern "C" int upk_weighted_pos_bwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
                                     const int* index_weight, upk_coord_t self) {
-    hipLaunchKernelGGL(k_weighted_pos_bwd, grid1(self.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, energy, index_pos, index_weight, self);
-    return launch_status();
+    FARGS(WeightedPosArgs, a); a.pos = cz(pos); a.energy = cz(energy); a.index_pos = index_pos; a.index_weight = index_weight; a.self = cz(self);
+    return fuse_submit(L, FOP_WEIGHTED_POS_BWD, a, self.n_elem);
 }
 
 // nonlinear_coupling (environment.cpp:358-369)
-__global__ void k_nonlinear_coupling(upk_coord_t input, const int* __restrict__ types, const float* __restrict__ coeff, int n_coeff,
-                                     float offset, float inv_dx, float* __restrict__ pot_terms) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+struct NonlinearCouplingArgs { upk_coord_t input; const int* types; const float* coeff; int n_coeff; float offset, inv_dx; float* pot_terms; };
+__device__ __forceinline__ void b_nonlinear_coupling(const int i, const int s, upk_coord_t input, const int* __restrict__ types, const float* __restrict__ coeff, int n_coeff,
+                                                     float offset, float inv_dx, float* __restrict__ pot_terms) {
     if (i >= input.n_elem) return;
-    const int s = blockIdx.y;
     const float coord = (C_OUT(input, s)[(size_t)i * input.stride] - offset) * inv_dx;
     float v, dv;
     clamped_deBoor_vd_scalar(v, dv, coeff + types[i] * n_coeff, coord, n_coeff);
@@ -737,28 +785,26 @@ __global__ void k_nonlinear_coupling(upk_coord_t input, const int* __restrict__ 
 }
 extern "C" int upk_nonlinear_coupling(const upk_launch_t* L, upk_coord_t input, const int* types, const float* coeff, int n_coeff,
                                       float offset, float inv_dx, float* pot_terms) {
-    hipLaunchKernelGGL(k_nonlinear_coupling, grid1(input.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), input, types, coeff, n_coeff, offset, inv_dx, pot_terms);
-    return launch_status();
+    FARGS(NonlinearCouplingArgs, a); a.input = cz(input); a.types = types; a.coeff = coeff; a.n_coeff = n_coeff; a.offset = offset; a.inv_dx = inv_dx; a.pot_terms = pot_terms;
+    return fuse_submit(L, FOP_NONLINEAR_COUPLING, a, input.n_elem);
 }
 
 // hbond_energy (hbond.cpp:430-444)
-__global__ void k_hbond_energy(upk_coord_t ph, float Ep, float* __restrict__ pot_terms) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct HBondEnergyArgs { upk_coord_t ph; float Ep; float* pot_terms; };
+__device__ __forceinline__ void b_hbond_energy(const int nv, const int s, upk_coord_t ph, float Ep, float* __restrict__ pot_terms) {
     if (nv >= ph.n_elem) return;
-    const int s = blockIdx.y;
     C_SENS(ph, s)[(size_t)nv * ph.stride + 6] += Ep;
     if (pot_terms) pot_terms[(size_t)s * ph.n_elem + nv] = C_OUT(ph, s)[(size_t)nv * ph.stride + 6] * Ep;
 }
 extern "C" int upk_hbond_energy(const upk_launch_t* L, upk_coord_t protein_hbond, float E_protein, float* pot_terms) {
-    hipLaunchKernelGGL(k_hbond_energy, grid1(protein_hbond.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), protein_hbond, E_protein, pot_terms);
-    return launch_status();
+    FARGS(HBondEnergyArgs, a); a.ph = cz(protein_hbond); a.Ep = E_protein; a.pot_terms = pot_terms;
+    return fuse_submit(L, FOP_HBOND_ENERGY, a, protein_hbond.n_elem);
 }
 
 // protein_hbond helpers (hbond.cpp:320-335, 343-365)
-__global__ void k_protein_hbond_finish(upk_coord_t infer, upk_coord_t out) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct ProteinHBondFinishArgs { upk_coord_t infer, out; };
+__device__ __forceinline__ void b_protein_hbond_finish(const int nv, const int s, upk_coord_t infer, upk_coord_t out) {
     if (nv >= out.n_elem) return;
-    const int s = blockIdx.y;
     const float4* h = (const float4*)(C_OUT(infer, s) + (size_t)nv * infer.stride);      // (6 of 8 floats)
     float4* o = (float4*)(C_OUT(out, s) + (size_t)nv * out.stride);                          // (7 of 8 floats: [6] = the bond count so far)
     const float4 h0 = h[0], h1 = h[1], o1 = o[1];
@@ -766,24 +812,22 @@ __global__ void k_protein_hbond_finish(upk_coord_t infer, upk_coord_t out) {
     o[1] = make_float4(h1.x, h1.y, 1.f - expf(-o1.z), o1.w);
 }
 extern "C" int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out) {
-    hipLaunchKernelGGL(k_protein_hbond_finish, grid1(out.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), infer, out);
-    return launch_status();
+    FARGS(ProteinHBondFinishArgs, a); a.infer = cz(infer); a.out = cz(out);
+    return fuse_submit(L, FOP_PROTEIN_HBOND_FINISH, a, out.n_elem);
 }
-__global__ void k_protein_hbond_bwd_pre(upk_coord_t self, float* __restrict__ sens_scaled) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct ProteinHBondBwdPreArgs { upk_coord_t self; float* sens_scaled; };
+__device__ __forceinline__ void b_protein_hbond_bwd_pre(const int nv, const int s, upk_coord_t self, float* __restrict__ sens_scaled) {
     if (nv >= self.n_elem) return;
-    const int s = blockIdx.y;
     sens_scaled[(size_t)s * self.n_elem + nv] = C_SENS(self, s)[(size_t)nv * self.stride + 6] * (1.f - C_OUT(self, s)[(size_t)nv * self.stride + 6]);
 }
 extern "C" int upk_protein_hbond_bwd_pre(const upk_launch_t* L, upk_coord_t self, float* sens_scaled) {
-    hipLaunchKernelGGL(k_protein_hbond_bwd_pre, grid1(self.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, sens_scaled);
-    return launch_status();
+    FARGS(ProteinHBondBwdPreArgs, a); a.self = cz(self); a.sens_scaled = sens_scaled;
+    return fuse_submit(L, FOP_PROTEIN_HBOND_BWD_PRE, a, self.n_elem);
 }
-__global__ void k_protein_hbond_passthrough(upk_coord_t self, upk_coord_t infer, const int* __restrict__ loc1, int n1,
-                                            const int* __restrict__ loc2, int n2) {
-    const int nv = blockIdx.x * blockDim.x + threadIdx.x;
+struct ProteinHBondPassthroughArgs { upk_coord_t self, infer; const int* loc1; int n1; const int* loc2; int n2; };
+__device__ __forceinline__ void b_protein_hbond_passthrough(const int nv, const int s, upk_coord_t self, upk_coord_t infer, const int* __restrict__ loc1, int n1,
+                                                            const int* __restrict__ loc2, int n2) {
     if (nv >= n1 + n2) return;
-    const int s = blockIdx.y;
     const int tgt = nv < n1 ? loc1[nv] : loc2[nv - n1];
     const float4* sn = (const float4*)(C_SENS(self, s) + (size_t)nv * self.stride);     // (rows of 8 floats: 7 and 6 used)
     float4* t = (float4*)(C_SENS(infer, s) + (size_t)tgt * infer.stride);
@@ -794,8 +838,8 @@ __global__ void k_protein_hbond_passthrough(upk_coord_t self, upk_coord_t infer,
 }
 extern "C" int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_coord_t infer, const int* loc1, int n1,
                                              const int* loc2, int n2) {
-    hipLaunchKernelGGL(k_protein_hbond_passthrough, grid1(n1 + n2, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, infer, loc1, n1, loc2, n2);
-    return launch_status();
+    FARGS(ProteinHBondPassthroughArgs, a); a.self = cz(self); a.infer = cz(infer); a.loc1 = loc1; a.n1 = n1; a.loc2 = loc2; a.n2 = n2;
+    return fuse_submit(L, FOP_PROTEIN_HBOND_PASSTHROUGH, a, n1 + n2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,18 +851,18 @@ __device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, flo
     float cs, dcs; compact_sigmoid(cs, dcs, r_mag2 - wall * wall, sharpness);
     v = 4.f * cs; dv_over_r = 2.f * (4.f * dcs);
 }
-#ifndef BBP_ROWS
-#define BBP_ROWS 64       // residues per workgroup (16 waves x 4)
-#endif
 #define BBP_QUEUE 72      // per-wave queue of close residues (64 new + < 4 left over)
-__global__ void __launch_bounds__(1024) k_backbone_pairs(upk_coord_t aff, const int* __restrict__ residue, const int* __restrict__ id,
-                                 const int* __restrict__ n_atom, const float* __restrict__ ref_pos, int n_res, float dist_cutoff,
-                                 float* __restrict__ aff_contrib, long aff_stride, float* __restrict__ pot_terms) {
+struct BackbonePairsArgs { upk_coord_t aff; const int* residue; const int* id; const int* n_atom; const float* ref_pos; int n_res; float dist_cutoff;
+                           float* aff_contrib; long aff_stride; float* pot_terms; };
+// collective op of the system's workgroup (any number of wavefronts); lds: (n_res * 17 + waves * BBP_QUEUE) floats
+__device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, const int s, float* lds) {
+    const upk_coord_t aff = A.aff; const int* __restrict__ residue = A.residue; const int* __restrict__ id = A.id; const int* __restrict__ n_atom = A.n_atom;
+    const float* __restrict__ ref_pos = A.ref_pos; const int n_res = A.n_res; const float dist_cutoff = A.dist_cutoff;
+    float* __restrict__ aff_contrib = A.aff_contrib; const long aff_stride = A.aff_stride; float* __restrict__ pot_terms = A.pot_terms;
     // One wavefront per residue: 64 lanes test 64 partner residues at a time (centre distance, sequence separation),
     // close partners are compacted into a small LDS queue and evaluated four at a time, one lane per atom pair
     // (4 partners x 4 x 4 atoms), so the steric kernel runs with dense lanes; wave reduction, no scatter.
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // per residue: 4 atoms x 3 + centre 3 + (n_atom,id) as int bits
-    const int s = blockIdx.y;
+    // lds per residue: 4 atoms x 3 + centre 3 + (n_atom,id) as int bits
     float* atoms = lds;                       // [n_res][12]
     float* ctr = lds + (size_t)n_res * 12;    // [n_res][3]
     int* meta = (int*)(ctr + (size_t)n_res * 3);   // [n_res][2]
@@ -840,9 +884,7 @@ __global__ void __launch_bounds__(1024) k_backbone_pairs(upk_coord_t aff, const 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     int* q = queues + wave * BBP_QUEUE;
     const int qi = lane >> 4, i1 = (lane >> 2) & 3, i2 = lane & 3;
-    for (int r = wave; r < BBP_ROWS; r += n_wave) {
-        const int nr1 = blockIdx.x * BBP_ROWS + r;
-        if (nr1 >= n_res) break;
+    for (int nr1 = wave; nr1 < n_res; nr1 += n_wave) {
         const f3 t1 = ld3(ctr + nr1 * 3);
         const int na1 = meta[nr1 * 2], id1 = meta[nr1 * 2 + 1];
         const f3 x1 = ld3(atoms + nr1 * 12 + i1 * 3);
@@ -903,10 +945,8 @@ extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const 
                                   float* pot_terms) {
     const size_t lds = ((size_t)n_res * (12 + 3 + 2) + 16 * BBP_QUEUE) * sizeof(float);
     if (lds > 150 * 1024) return 9001;   // > ~2200 residues: needs the tiled variant
-    const int blocks = (n_res + BBP_ROWS - 1) / BBP_ROWS;
-    hipLaunchKernelGGL(k_backbone_pairs, dim3(blocks, L->n_system), dim3(1024), lds, ST(L), aff, residue, id, n_atom, ref_pos, n_res,
-                       dist_cutoff, aff_contrib, aff_stride, pot_terms);
-    return launch_status();
+    FARGS(BackbonePairsArgs, a); a.aff = cz(aff); a.residue = residue; a.id = id; a.n_atom = n_atom; a.ref_pos = ref_pos; a.n_res = n_res; a.dist_cutoff = dist_cutoff; a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.pot_terms = pot_terms;
+    return fuse_submit(L, FOP_BACKBONE_PAIRS, a, 0, (int)lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,6 +1014,7 @@ __global__ void k_pivot_propose(upk_coord_t pos, float* __restrict__ pos_copy, u
 }
 extern "C" int upk_pivot_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_pivot_t* P, const uint32_t* seed,
                                  uint64_t round, float* delta_lprob) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_pivot_propose, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, *P, seed, round, delta_lprob);
     return launch_status();
 }
@@ -1035,6 +1076,7 @@ __global__ void k_jump_propose(upk_coord_t pos, float* __restrict__ pos_copy, up
 }
 extern "C" int upk_jump_propose(const upk_launch_t* L, upk_coord_t pos, float* pos_copy, const upk_jump_t* J, const uint32_t* seed,
                                 uint64_t round, float* delta_lprob) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_jump_propose, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, *J, seed, round, delta_lprob);
     return launch_status();
 }
@@ -1064,6 +1106,7 @@ __global__ void k_mc_accept(upk_coord_t pos, const float* __restrict__ pos_copy,
 extern "C" int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy, const float* e_old, const float* e_new,
                              const float* delta_lprob, const float* temperature, const uint32_t* seed, uint64_t round, int stream,
                              int accept_draw, int* stats) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_mc_accept, dim3(1, L->n_system), dim3(UPK_BLOCK), 0, ST(L), pos, pos_copy, e_old, e_new, delta_lprob, temperature,
                        seed, round, stream, accept_draw, stats);
     return launch_status();
@@ -1105,6 +1148,7 @@ __global__ void k_replica_swap(upk_coord_t pos, const float* __restrict__ energy
 }
 extern "C" int upk_replica_swap(const upk_launch_t* L, upk_coord_t pos, const float* energy, const float* beta, int n_pair,
                                 const int* pairs, uint32_t seed, uint64_t round, int draw0, int* accepted) {
+    UPK_FLUSH(L);
     if (n_pair > 1024) return 9002;
     hipLaunchKernelGGL(k_replica_swap, dim3(1), dim3(UPK_BLOCK), 0, ST(L), pos, energy, beta, n_pair, pairs, seed, round, draw0, accepted);
     return launch_status();
@@ -1121,6 +1165,7 @@ __global__ void k_sum_potentials(const float* const* __restrict__ node_pot, int 
     out[s] = t;
 }
 extern "C" int upk_sum_potentials(const upk_launch_t* L, const float* const* node_pot, int n_node, float* out) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_sum_potentials, grid1(L->n_system, 1), dim3(UPK_BLOCK), 0, ST(L), node_pot, n_node, L->n_system, out);
     return launch_status();
 }
@@ -1150,6 +1195,7 @@ __global__ void k_replica_decide(float* __restrict__ energy_all, const float* __
 }
 extern "C" int upk_replica_decide(const upk_launch_t* L, float* energy_all, const float* beta_all, int n_pair, const int* pairs,
                                   uint32_t seed, uint64_t round, int* draw_io, int* accepted) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_replica_decide, dim3(1), dim3(64), 0, ST(L), energy_all, beta_all, n_pair, pairs, seed, round, draw_io, accepted);
     return launch_status();
 }
@@ -1165,6 +1211,7 @@ __global__ void k_replica_apply(upk_coord_t pos, int n_pair, const int* __restri
     else if (kind == 2) { const float* in = staging + (size_t)b * n; for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) xa[i] = in[i]; }
 }
 extern "C" int upk_replica_apply(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* plan, const int* accepted, const float* staging) {
+    UPK_FLUSH(L);
     if (n_pair <= 0) return 0;
     const int n = pos.n_elem * pos.stride;
     hipLaunchKernelGGL(k_replica_apply, dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)n_pair), dim3(UPK_BLOCK), 0, ST(L), pos, n_pair, plan, accepted, staging);
@@ -1179,6 +1226,7 @@ __global__ void k_swap_system_pairs(upk_coord_t pos, const int* __restrict__ pai
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float t = a[i]; a[i] = b[i]; b[i] = t; }
 }
 extern "C" int upk_swap_system_pairs(const upk_launch_t* L, upk_coord_t pos, int n_pair, const int* pairs) {
+    UPK_FLUSH(L);
     if (n_pair <= 0) return 0;
     const int n = pos.n_elem * pos.stride;
     hipLaunchKernelGGL(k_swap_system_pairs, dim3((unsigned)((n + UPK_BLOCK - 1) / UPK_BLOCK), (unsigned)n_pair), dim3(UPK_BLOCK), 0, ST(L), pos, pairs);
@@ -1210,6 +1258,7 @@ __global__ void k_placement_param_deriv(upk_placement_t P, upk_coord_t aff, upk_
 }
 extern "C" int upk_placement_param_deriv(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out, int system,
                                          float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_placement_param_deriv, grid1(P->n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), *P, aff, out, system, table);
     return launch_status();
@@ -1237,6 +1286,7 @@ __global__ void k_nonlinear_coupling_param_deriv(upk_coord_t input, const int* _
 }
 extern "C" int upk_nonlinear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t input, const int* types, int n_coeff, float offset,
                                                   float inv_dx, int system, float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_nonlinear_coupling_param_deriv, grid1(input.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), input, types, n_coeff, offset,
                        inv_dx, system, table);
@@ -1250,6 +1300,7 @@ __global__ void k_column_sum(upk_coord_t c, int comp, int s, float* __restrict__
     atomicAdd(out, C_OUT(c, s)[(size_t)i * c.stride + comp]);
 }
 extern "C" int upk_column_sum(const upk_launch_t* L, upk_coord_t c, int comp, int system, float* out) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_column_sum, grid1(c.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), c, comp, system, out);
     return launch_status();
@@ -1296,6 +1347,7 @@ __global__ void k_point_potential(int kind, upk_coord_t pos, const int* __restri
 }
 extern "C" int upk_point_potential(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* par, int n, float time,
                                    float* contrib, long contrib_stride, float* pot_terms) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_point_potential, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), kind, pos, id, par, n, time, contrib,
                        contrib_stride, pot_terms);
     return launch_status();
@@ -1324,6 +1376,7 @@ __global__ void k_contact(upk_coord_t bead, const int* __restrict__ id, const fl
 }
 extern "C" int upk_contact(const upk_launch_t* L, upk_coord_t bead, const int* id, const float* par, int n, float* contrib,
                            long contrib_stride, float* pot_terms) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_contact, grid1(n, L->n_system), dim3(UPK_BLOCK), 0, ST(L), bead, id, par, n, contrib, contrib_stride, pot_terms);
     return launch_status();
 }
@@ -1336,6 +1389,7 @@ __global__ void k_broadcast_rows(const float* __restrict__ value, upk_coord_t ou
     C_OUT(out, blockIdx.y)[(size_t)ne * out.stride + d] = value[i];
 }
 extern "C" int upk_broadcast_rows(const upk_launch_t* L, const float* value, upk_coord_t out) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_broadcast_rows, grid1(out.n_elem * out.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), value, out);
     return launch_status();
 }
@@ -1346,6 +1400,7 @@ __global__ void k_slice_fwd(upk_coord_t in, const int* __restrict__ id, upk_coor
     C_OUT(out, s)[(size_t)na * out.stride + d] = C_OUT(in, s)[(size_t)id[na] * in.stride + d];
 }
 extern "C" int upk_slice_fwd(const upk_launch_t* L, upk_coord_t in, const int* id, upk_coord_t out) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_slice_fwd, grid1(out.n_elem * out.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, id, out);
     return launch_status();
 }
@@ -1357,6 +1412,7 @@ __global__ void k_slice_bwd(upk_coord_t self, float* __restrict__ contrib, long 
     contrib[(size_t)s * contrib_stride + i] = C_SENS(self, s)[(size_t)na * self.stride + d];
 }
 extern "C" int upk_slice_bwd(const upk_launch_t* L, upk_coord_t self, float* contrib, long contrib_stride) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_slice_bwd, grid1(self.n_elem * self.width, L->n_system), dim3(UPK_BLOCK), 0, ST(L), self, contrib, contrib_stride);
     return launch_status();
 }
@@ -1374,6 +1430,7 @@ __global__ void k_uniform_transform_fwd(upk_coord_t in, const float* __restrict_
 }
 extern "C" int upk_uniform_transform_fwd(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset, float inv_dx,
                                          upk_coord_t out, float* jac) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_uniform_transform_fwd, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, coeff, n_coeff, offset, inv_dx, out, jac);
     return launch_status();
 }
@@ -1384,6 +1441,7 @@ __global__ void k_uniform_transform_bwd(upk_coord_t in, upk_coord_t self, const 
     C_SENS(in, s)[(size_t)i * in.stride] += jac[(size_t)s * in.n_elem + i] * C_SENS(self, s)[(size_t)i * self.stride];
 }
 extern "C" int upk_uniform_transform_bwd(const upk_launch_t* L, upk_coord_t in, upk_coord_t self, const float* jac) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_uniform_transform_bwd, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, self, jac);
     return launch_status();
 }
@@ -1409,6 +1467,7 @@ __global__ void k_uniform_transform_param_deriv(upk_coord_t in, const float* __r
 }
 extern "C" int upk_uniform_transform_param_deriv(const upk_launch_t* L, upk_coord_t in, const float* coeff, int n_coeff, float offset,
                                                  float inv_dx, int system, float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_uniform_transform_param_deriv, grid1(in.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), in, coeff, n_coeff, offset, inv_dx, system, table);
     return launch_status();
@@ -1429,6 +1488,7 @@ __global__ void k_linear_coupling(upk_coord_t in, const int* __restrict__ types,
 }
 extern "C" int upk_linear_coupling(const upk_launch_t* L, upk_coord_t in, const int* types, const float* couplings, upk_coord_t inact,
                                    int has_inact, int inact_dim, float* pot_terms) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_linear_coupling, grid1(in.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), in, types, couplings, inact, has_inact,
                        inact_dim, pot_terms);
     return launch_status();
@@ -1443,6 +1503,7 @@ __global__ void k_linear_coupling_param_deriv(upk_coord_t in, const int* __restr
 }
 extern "C" int upk_linear_coupling_param_deriv(const upk_launch_t* L, upk_coord_t in, const int* types, upk_coord_t inact, int has_inact,
                                                int inact_dim, int system, float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_linear_coupling_param_deriv, grid1(in.n_elem, 1), dim3(UPK_BLOCK), 0, ST(L), in, types, inact, has_inact, inact_dim, system, table);
     return launch_status();
@@ -1488,6 +1549,183 @@ __global__ void k_membrane(upk_membrane_t M, upk_coord_t cb, upk_coord_t env, up
     if (pot_terms) pot_terms[(size_t)s * n_term + i] = pot;
 }
 extern "C" int upk_membrane(const upk_launch_t* L, const upk_membrane_t* M, upk_coord_t cb, upk_coord_t env, upk_coord_t hb, float* pot_terms) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_membrane, grid1(M->n_res + hb.n_elem, L->n_system), dim3(UPK_BLOCK), 0, ST(L), *M, cb, env, hb, pot_terms);
     return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused-op interpreter (see the top of this file) and its host-side queue.
+template <typename A> __device__ __forceinline__ const A& fop_args(const FusedOp& op) { return *(const A*)op.payload; }
+#define FOP_LOOP(i, n) for (int i = threadIdx.x; i < (n); i += blockDim.x)
+// HEAVY: the instance that also holds the affine-alignment backward op, whose unrolled tables want ~200 registers per lane (every
+// other op fits 64); launches without that op take the light instance and its occupancy
+template <bool HEAVY>
+__device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, float* lds) {
+    const int n = op.n;
+    switch (op.kind) {       // (wave-uniform: op is the same record for the whole workgroup)
+        case FOP_ZERO_MANY: c_zero_many(fop_args<ZeroManyArgs>(op), s); break;
+        case FOP_REDUCE_SUM: c_reduce_sum(fop_args<ReduceSumArgs>(op), s, lds); break;
+        case FOP_THERMOSTAT: c_thermostat(fop_args<ThermostatArgs>(op), s); break;
+        case FOP_BACKBONE_PAIRS: c_backbone_pairs(fop_args<BackbonePairsArgs>(op), s, lds); break;
+        case FOP_GATHER_CONTRIB: { const auto& a = fop_args<GatherContribArgs>(op);
+            FOP_LOOP(i, n) b_gather_contrib(i, s, a.arena, a.arena_stride, a.csr_start, a.csr_entry, a.target, a.width, a.comp_offset); } break;
+        case FOP_INTEGRATION_STAGE: { const auto& a = fop_args<IntegrationStageArgs>(op);
+            FOP_LOOP(i, n) b_integration_stage(i, s, a.mom, a.pos, a.vel_factor, a.pos_factor, a.max_force); } break;
+        case FOP_AFFINE_FWD: { const auto& a = fop_args<AffineFwdArgs>(op);      // n is a multiple of 64: whole wavefronts reach the ballots
+            FOP_LOOP(i, n) b_affine_fwd(i, s, a.pos, a.atoms, a.ref_geom, a.n_res, a.out, a.eig); } break;
+        case FOP_AFFINE_BWD: if constexpr (HEAVY) { const auto& a = fop_args<AffineBwdArgs>(op);
+            FOP_LOOP(i, n) b_affine_bwd(i, s, a.aff, a.ref_geom, a.eig, a.n_res, a.contrib, a.contrib_stride); } break;
+        case FOP_RAMA_FWD: { const auto& a = fop_args<RamaFwdArgs>(op);
+            FOP_LOOP(i, n) b_rama_fwd(i, s, a.pos, a.atom, a.dummy, a.n_res, a.out, a.jac); } break;
+        case FOP_RAMA_BWD: { const auto& a = fop_args<RamaBwdArgs>(op);
+            FOP_LOOP(i, n) b_rama_bwd(i, s, a.rama, a.jac, a.n_res, a.contrib, a.contrib_stride); } break;
+        case FOP_INFER_FWD: { const auto& a = fop_args<InferFwdArgs>(op);
+            FOP_LOOP(i, n) b_infer_fwd(i, s, a.pos, a.atom, a.bond_length, a.n_virtual, a.out, a.dfd); } break;
+        case FOP_INFER_BWD: { const auto& a = fop_args<InferBwdArgs>(op);
+            FOP_LOOP(i, n) b_infer_bwd(i, s, a.infer, a.bond_length, a.dfd, a.n_virtual, a.contrib, a.contrib_stride); } break;
+        case FOP_SPRING: { const auto& a = fop_args<SpringArgs>(op);
+            FOP_LOOP(i, n) b_spring(i, s, a.kind, a.pos, a.id, a.equil, a.kk, a.n, a.contrib, a.contrib_stride, a.pot_terms); } break;
+        case FOP_PLACEMENT_FWD: { const auto& a = fop_args<PlacementFwdArgs>(op);
+            FOP_LOOP(i, n) b_placement_fwd(i, s, a.P, a.aff, a.rama, a.out, a.rama_deriv); } break;
+        case FOP_PLACEMENT_BWD: { const auto& a = fop_args<PlacementBwdArgs>(op);
+            FOP_LOOP(i, n) b_placement_bwd(i, s, a.P, a.aff, a.out, a.rama_deriv, a.aff_contrib, a.aff_stride, a.rama_contrib, a.rama_stride); } break;
+        case FOP_RAMA_MAP_POT: { const auto& a = fop_args<RamaMapPotArgs>(op);
+            FOP_LOOP(i, n) b_rama_map_pot(i, s, a.rama, a.residue, a.map_id, a.n, a.coeff, a.nx, a.pot_terms); } break;
+        case FOP_WEIGHTED_POS_FWD: { const auto& a = fop_args<WeightedPosArgs>(op);
+            FOP_LOOP(i, n) b_weighted_pos_fwd(i, s, a.pos, a.energy, a.index_pos, a.index_weight, a.self); } break;
+        case FOP_WEIGHTED_POS_BWD: { const auto& a = fop_args<WeightedPosArgs>(op);
+            FOP_LOOP(i, n) b_weighted_pos_bwd(i, s, a.pos, a.energy, a.index_pos, a.index_weight, a.self); } break;
+        case FOP_NONLINEAR_COUPLING: { const auto& a = fop_args<NonlinearCouplingArgs>(op);
+            FOP_LOOP(i, n) b_nonlinear_coupling(i, s, a.input, a.types, a.coeff, a.n_coeff, a.offset, a.inv_dx, a.pot_terms); } break;
+        case FOP_HBOND_ENERGY: { const auto& a = fop_args<HBondEnergyArgs>(op);
+            FOP_LOOP(i, n) b_hbond_energy(i, s, a.ph, a.Ep, a.pot_terms); } break;
+        case FOP_PROTEIN_HBOND_FINISH: { const auto& a = fop_args<ProteinHBondFinishArgs>(op);
+            FOP_LOOP(i, n) b_protein_hbond_finish(i, s, a.infer, a.out); } break;
+        case FOP_PROTEIN_HBOND_BWD_PRE: { const auto& a = fop_args<ProteinHBondBwdPreArgs>(op);
+            FOP_LOOP(i, n) b_protein_hbond_bwd_pre(i, s, a.self, a.sens_scaled); } break;
+        case FOP_PROTEIN_HBOND_PASSTHROUGH: { const auto& a = fop_args<ProteinHBondPassthroughArgs>(op);
+            FOP_LOOP(i, n) b_protein_hbond_passthrough(i, s, a.self, a.infer, a.loc1, a.n1, a.loc2, a.n2); } break;
+        default: break;
+    }
+}
+// one workgroup per system walks the ops of the launch in order
+// (T = the largest workgroup the instance may be launched with)
+template <bool HEAVY, int T>
+__global__ void __launch_bounds__(T) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.x;
+    for (int k = 0; k < ids.n; ++k) {
+        const FusedOp& op = table[ids.id[k]];
+        if (k && !(op.flags & 1)) __syncthreads();     // what the ops before wrote (global memory, this CU) is visible; LDS scratch is free again
+        run_fused_op<HEAVY>(op, s, lds);
+    }
+}
+template <bool HEAVY, int T>
+__global__ void __launch_bounds__(T) k_fused_one(FusedOp op) {       // an op on its own (no queue, or UPSIDE_HIP_FUSE=0)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    run_fused_op<HEAVY>(op, blockIdx.x, lds);
+}
+
+namespace {
+struct FuseQueue {
+    int n_system = 1, threads = 1024;
+    bool enabled = true;
+    FusedOp* table_dev = nullptr; int cap = 4096;
+    std::vector<FusedOp> table;                                   // host mirror of the registered ops
+    std::unordered_map<unsigned long long, std::vector<int>> index;   // hash of (kind, n, lds, flags, payload) -> ids
+    FusedIds pending; int pending_lds = 0; bool pending_heavy = false;
+    long n_launch = 0, n_ops_run = 0;
+};
+unsigned long long fuse_hash(const FusedOp& op) {
+    const unsigned char* b = (const unsigned char*)&op;
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(FusedOp); i += 8) { unsigned long long w; memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    return h;
+}
+// workgroup size of a fused launch: enough lanes for the per-element loops of a system (a few hundred to a few thousand items) in a
+// small batch, several systems resident per CU in a large one
+int fuse_threads(int n_system) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("UPSIDE_HIP_FUSE_THREADS"); forced = e ? atoi(e) : 0; if (forced % 64 || forced > 1024) forced = 0; }
+    if (forced) return forced;
+    return n_system >= 256 ? 256 : 1024;
+}
+template <bool LIST, typename... Args>
+void fuse_launch(bool heavy, int threads, int n_system, size_t lds, hipStream_t st, Args... args) {
+    const dim3 g(n_system);
+    if (heavy && threads > 512) threads = 512;           // (the heavy instances are built for at most 512 lanes)
+    const dim3 b(threads);
+    if constexpr (LIST) {
+        if (heavy) { if (threads <= 256) hipLaunchKernelGGL((k_fused_list<true, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<true, 512>), g, b, lds, st, args...); }
+        else { if (threads <= 256) hipLaunchKernelGGL((k_fused_list<false, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<false, 1024>), g, b, lds, st, args...); }
+    } else {
+        if (heavy) { if (threads <= 256) hipLaunchKernelGGL((k_fused_one<true, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_one<true, 512>), g, b, lds, st, args...); }
+        else { if (threads <= 256) hipLaunchKernelGGL((k_fused_one<false, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_one<false, 1024>), g, b, lds, st, args...); }
+    }
+}
+}  // namespace
+static_assert(sizeof(FusedOp) == 16 + FUSE_PAYLOAD && sizeof(FusedOp) % 8 == 0, "FusedOp layout");
+
+extern "C" void* upk_fuse_create(int n_system) {
+    FuseQueue* q = new FuseQueue;
+    q->n_system = n_system; q->threads = fuse_threads(n_system);
+    const char* e = getenv("UPSIDE_HIP_FUSE");
+    q->enabled = !(e && !atoi(e));
+    q->pending.n = 0;
+    if (hipMalloc((void**)&q->table_dev, (size_t)q->cap * sizeof(FusedOp)) != hipSuccess) { delete q; return nullptr; }
+    q->table.reserve(256);
+    return q;
+}
+extern "C" int upk_fuse_table_size(const upk_launch_t* L) { return L->fuse ? (int)((FuseQueue*)L->fuse)->table.size() : 0; }
+extern "C" void upk_fuse_destroy(void* fuse) {
+    FuseQueue* q = (FuseQueue*)fuse;
+    if (!q) return;
+    if (getenv("UPSIDE_HIP_FUSE_STATS")) fprintf(stderr, "fused ops: %ld launches, %ld ops, %zu distinct ops registered\n", q->n_launch, q->n_ops_run, q->table.size());
+    if (q->table_dev) (void)hipFree(q->table_dev);
+    delete q;
+}
+extern "C" int upk_fuse_pending(const upk_launch_t* L) { return L->fuse ? ((FuseQueue*)L->fuse)->pending.n : 0; }
+extern "C" long upk_fuse_launch_count(const upk_launch_t* L) { return L->fuse ? ((FuseQueue*)L->fuse)->n_launch : 0; }
+extern "C" int upk_fuse_flush(const upk_launch_t* L) {
+    FuseQueue* q = (FuseQueue*)L->fuse;
+    if (!q || !q->pending.n) return 0;
+    size_t lds = (size_t)q->pending_lds; if (lds < 64) lds = 64;      // (c_reduce_sum's partial sums)
+    fuse_launch<true>(q->pending_heavy, q->threads, q->n_system, lds, ST(L), (const FusedOp*)q->table_dev, q->pending);
+    q->n_launch += 1; q->n_ops_run += q->pending.n;
+    q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false;
+    return launch_status();
+}
+static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, int flags) {
+    FusedOp op; memset(&op, 0, sizeof(op));
+    op.kind = kind; op.n = n; op.lds_bytes = lds_bytes; op.flags = flags;
+    memcpy(op.payload, args, bytes);
+    FuseQueue* q = (FuseQueue*)L->fuse;
+    auto alone = [&]() {
+        size_t lds = (size_t)lds_bytes; if (lds < 64) lds = 64;
+        fuse_launch<false>(kind == FOP_AFFINE_BWD, q ? q->threads : fuse_threads(L->n_system), L->n_system, lds, ST(L), op);
+        return launch_status();
+    };
+    if (!q) return alone();
+    if (!q->enabled) { UPK_FLUSH(L); return alone(); }
+    // look the op up; register it on first sight (blocking upload of one record: in-flight launches read older records only)
+    const unsigned long long h = fuse_hash(op);
+    int id = -1;
+    auto& bucket = q->index[h];
+    for (int cand : bucket) if (!memcmp(&q->table[cand], &op, sizeof(op))) { id = cand; break; }
+    if (id < 0) {
+        if ((int)q->table.size() >= q->cap || (int)q->table.size() >= 65535) { UPK_FLUSH(L); return alone(); }   // (arguments that change every step)
+        id = (int)q->table.size();
+        if (hipMemcpy(q->table_dev + id, &op, sizeof(op), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); UPK_FLUSH(L); return alone(); }
+        q->table.push_back(op); bucket.push_back(id);
+    }
+    if (q->pending.n == FUSE_MAX_PENDING) UPK_FLUSH(L);
+    if (kind == FOP_AFFINE_BWD) {
+        // a large batch runs the register-hungry op in a launch of its own: the ops around it keep the light instance's occupancy
+        if (q->n_system >= 256) { UPK_FLUSH(L); q->pending.id[q->pending.n++] = (unsigned short)id; q->pending_heavy = true; return upk_fuse_flush(L); }
+        q->pending_heavy = true;
+    }
+    q->pending.id[q->pending.n++] = (unsigned short)id;
+    if (lds_bytes > q->pending_lds) q->pending_lds = lds_bytes;
+    return 0;
 }

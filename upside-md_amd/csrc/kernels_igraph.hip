@@ -181,6 +181,7 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
     }
 }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
+    UPK_FLUSH(L);
     // (latency bound -- every element is a chain load position -> load reference -> store packed copy: as many lanes as the
     //  system has elements, up to a full workgroup, so that a lane walks one or two elements instead of seven)
     const int n_tot = G->symmetric ? G->n1 : G->n1 + G->n2;
@@ -288,8 +289,10 @@ static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, 
     if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1, rows);
     else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1, rows);
 }
-extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) { return upk_pairlist_build_sides(L, G, 3); }
+extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
+    UPK_FLUSH(L); return upk_pairlist_build_sides(L, G, 3); }
 extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_t* G, int sides) {
+    UPK_FLUSH(L);
     const int rows = plb_rows(L->n_system);
     const int blocks1 = (sides & 1) ? (G->n1 + rows - 1) / rows : 0;
     const int blocks2 = (G->symmetric || !(sides & 2)) ? 0 : (G->n2 + rows - 1) / rows;
@@ -448,6 +451,7 @@ __global__ void __launch_bounds__(256) k_pairlist_refine_short(upk_igraph_t G, i
     ((rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows)[row] = n;
 }
 extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side) {
+    UPK_FLUSH(L);
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G->n1 : G->n2, n_other = rows1 ? G->n2 : G->n1;
     if (n_rows < 1) return 0;
@@ -512,6 +516,7 @@ __global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int
     }
 }
 extern "C" int upk_pairlist_order(const upk_launch_t* L, const upk_igraph_t* G, int side) {
+    UPK_FLUSH(L);
     const int n_rows = side == 1 ? G->n1 : G->n2;
     if (n_rows < 1) return 0;
     if (n_rows > 65535) return 9009;   // (16-bit row ids; larger systems take the list-walking kernels, which need no order)
@@ -565,6 +570,7 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
 }
 extern "C" int upk_igraph_rowsum(const upk_launch_t* L, const upk_igraph_t* G, int side, float* out, long out_sys_stride,
                                  int out_stride, int out_comp, int out_row0, float* own_grad) {
+    UPK_FLUSH(L);
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_rowsum, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
                        out, out_sys_stride, out_stride, out_comp, out_row0, own_grad);
@@ -626,6 +632,7 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
 }
 extern "C" int upk_igraph_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, int sens_mode, const float* sens1,
                                const float* sens2, long sens_sys_stride, int sens_stride) {
+    UPK_FLUSH(L);
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_grad, dim3(rows_grid(n_rows), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, side,
                        sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
@@ -651,6 +658,7 @@ __global__ void k_igraph_inrange(upk_igraph_t G, unsigned char* __restrict__ fla
     }
 }
 extern "C" int upk_igraph_inrange(const upk_launch_t* L, const upk_igraph_t* G, unsigned char* flags) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_igraph_inrange, dim3(rows_grid(G->n1), L->n_system), dim3(IG_BLOCK), 0, ST(L), *G, flags);
     return launch_status();
 }
@@ -704,6 +712,7 @@ __global__ void k_igraph_param_deriv(upk_igraph_t G, int s, int sens_mode, const
 }
 extern "C" int upk_igraph_param_deriv(const upk_launch_t* L, const upk_igraph_t* G, int system, int sens_mode, const float* sens1,
                                       const float* sens2, long sens_sys_stride, int sens_stride, float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     if (G->itype == UPK_IT_ROTAMER) return 9102;   // upk_rotamer_param_deriv owns the pair sensitivities of that graph
     hipLaunchKernelGGL(k_igraph_param_deriv, dim3(rows_grid(G->n1)), dim3(IG_BLOCK), 0, ST(L), *G, system,

@@ -527,6 +527,7 @@ static int pair_table_choice(const upk_igraph_t* G, size_t extra, int& tab_float
 }
 
 extern "C" int upk_igraph_passes_staged(const upk_launch_t* L, const upk_igraph_t* G, int row_side) {
+    UPK_FLUSH(L);
     (void)L;
     if (row_side != 1 && row_side != 2) return 0;
     const int n_other = row_side == 1 ? G->n2 : G->n1;
@@ -538,6 +539,7 @@ extern "C" int upk_igraph_passes_staged(const upk_launch_t* L, const upk_igraph_
 extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride,
                                int out_stride, int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode,
                                const float* sens1, const float* sens2, long sens_sys_stride, int sens_stride) {
+    UPK_FLUSH(L);
     if (side < 1 || side > 3 || mode < 0 || mode > 2 || (mode == 1 && (!own_grad || side == 3))) return 9007;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp;
@@ -589,6 +591,7 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
 
 extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
                                    const float* sens2, long sens_sys_stride, int sens_stride) {
+    UPK_FLUSH(L);
     if (row_side != 1 && row_side != 2) return 9007;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
@@ -664,6 +667,7 @@ __global__ void k_igraph_apply_own_grad(upk_igraph_t G, int side, const float* _
 }
 extern "C" int upk_igraph_apply_own_grad(const upk_launch_t* L, const upk_igraph_t* G, int side, const float* own_grad,
                                          const float* sens, long sens_sys_stride, int sens_stride) {
+    UPK_FLUSH(L);
     const int n_rows = side == 1 ? G->n1 : G->n2;
     hipLaunchKernelGGL(k_igraph_apply_own_grad, dim3((n_rows * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side, own_grad,
                        sens, sens_sys_stride, sens_stride);

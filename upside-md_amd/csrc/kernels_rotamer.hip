@@ -57,6 +57,7 @@ __global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
     }
 }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     const int n16 = (R->n_node * R->n_node + 15) / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(1024), 0, ST(L), *R);
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(BP_BLOCK, SLOT_WAVES) k_rotamer_build_slots(up
     }
 }
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     if (R->n_node > 1024) return 9003;
     const size_t lds = (size_t)R->n_node * ((R->n_node + 63) / 64) * 8;
     // (tried in round 3: stamping the slots into the list words inside this kernel from the popcounts of the bit matrix, without
@@ -273,6 +275,7 @@ __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
     }
 }
 extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     int blocks = (R->G.n1 + 15) / 16;          // 4 wavefronts x 4 rows
     hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(256), 0, ST(L), *R);
     return launch_status();
@@ -305,6 +308,7 @@ __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
     R.node_off[(size_t)s * R.n_node + g] = off;
 }
 extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_rotamer_node_prob, dim3((R->n_node + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
     return launch_status();
 }
@@ -520,7 +524,10 @@ struct RotGradOp2 {
         for (int c = 0; c < 6; ++c) t[c] = group_sum4(acc[c].x + acc[c].y);
         if ((threadIdx.x & (P2_LANES - 1)) != 0) return;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) lds_add_fixed22(L.acc + c * R.G.n1 + row, t[c]);
+        for (int c = 0; c < 6; ++c) {
+            if (!(fabsf(t[c]) < 1e30f)) *R.G.error_flag = 8;     // NaN / overflow would vanish in the integer conversion: report the step
+            lds_add_fixed22_wide(L.acc + c * R.G.n1 + row, t[c]);
+        }
     }
 };
 template <bool POLY>
@@ -604,6 +611,7 @@ static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want
     return staged;
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     int tab_floats; size_t lds; dim3 grid, block;
     static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
     if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_ROT_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
@@ -738,6 +746,7 @@ __global__ void k_rotamer_grad_finish(upk_rotamer_t R, double unit) {   // unit:
 }
 
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
+    UPK_FLUSH(L);
     int tab_floats; size_t lds; dim3 grid, block;
     const double unit32 = 1.0 / 4294967296.0, unit22 = 1.0 / (double)(1 << P2_FIX_BITS);
     if (rot_pair2_enabled()) {                     // packed passes: polynomial table if it fits beside the accumulators, else spline coefficients
@@ -801,6 +810,7 @@ __global__ void k_rotamer_param_deriv(upk_rotamer_t R, int s, float* __restrict_
     }
 }
 extern "C" int upk_rotamer_param_deriv(const upk_launch_t* L, const upk_rotamer_t* R, int system, float* table) {
+    UPK_FLUSH(L);
     if (system < 0 || system >= L->n_system) return 9101;
     hipLaunchKernelGGL(k_rotamer_param_deriv, dim3((R->G.n1 + 3) / 4), dim3(256), 0, ST(L), *R, system, table);
     return launch_status();
@@ -2078,6 +2088,7 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     }
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
+    UPK_FLUSH(L);
     const size_t lds_base = ((size_t)R->n_node * (3 * BP_NODE_STRIDE + 2) + 64 + 8) * sizeof(float);
     if (lds_base > 155 * 1024) return 9004;
     // LDS left over holds the messages to the 3-state nodes (at most all of the inbox: 16 floats per slot)
@@ -2089,7 +2100,7 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
     // 140 KB 6.16 ms, 150 KB 6.04, 156-160 KB 5.98).  UPSIDE_HIP_BP_LDS_CAP_KB: experiments.
     static int lds_cap_kb = -1;
     if (lds_cap_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_CAP_KB"); lds_cap_kb = e ? atoi(e) : 160; if (lds_cap_kb < 32 || lds_cap_kb > 160) lds_cap_kb = 160; }
-    if (lds_base + msg_bytes > (size_t)lds_cap_kb * 1024) msg_bytes = (size_t)lds_cap_kb * 1024 - lds_base;
+    if (lds_base + msg_bytes > (size_t)lds_cap_kb * 1024) msg_bytes = lds_base >= (size_t)lds_cap_kb * 1024 ? 0 : (size_t)lds_cap_kb * 1024 - lds_base;
     if (msg_bytes > (size_t)R->slot_cap * 64) msg_bytes = (size_t)R->slot_cap * 64;
     msg_bytes &= ~(size_t)15;
     const int lds_msg_floats = (int)(msg_bytes / sizeof(float));

@@ -298,7 +298,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     auto fleet_compute = [&](float* energy_out) {      // force pass of every system, potentials by system
         if (n_group == 1) { if (upside_hip_compute(e, energy_out, nullptr)) throw string(upside_hip_last_error()); return; }
         for (auto* x : engines) x->compute(PotentialAndDerivMode);          // enqueued on the engines' own streams, then collected
-        for (int g = 0; g < n_group; ++g) { engines[g]->fetch_potentials(); engines[g]->swap_energy.clear(); from_group(g, engines[g]->potential, energy_out, 1); }
+        for (int g = 0; g < n_group; ++g) { engines[g]->check_device_errors(); engines[g]->fetch_potentials(); engines[g]->swap_energy.clear(); from_group(g, engines[g]->potential, energy_out, 1); }
     };
     if (!set_param_file.empty()) {   // main.cpp:384-395, 498-499: one 1-D float dataset per node name
         hid_t pf = H5Fopen(set_param_file.c_str(), H5F_ACC_RDONLY, H5P_DEFAULT);

@@ -17,6 +17,12 @@ namespace {
 
 inline hid_t H(hid_t_compat g) { return (hid_t)g; }
 
+// A node type of this file enqueues device work through the launchers of upside_hip_kernels.h only: the engine need not run the
+// fused-op queue in front of its methods (include/upside_hip_plugin.h: library_launchers_only)
+template <class T> struct Builtin : T {
+    template <class... A> Builtin(A&&... a) : T(std::forward<A>(a)...) { this->library_launchers_only = true; }
+};
+
 vector<int> iota_targets(int n) { vector<int> v(n); for (int i = 0; i < n; ++i) v[i] = i; return v; }
 
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -52,6 +58,7 @@ struct SpringNode : public PotentialNode {
         k.upload(read<float>(H(grp), "spring_const", 1));
         src = pos.scatter.add_source(n_elem, kind, 3, ids);
         alloc_terms(n_elem);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_spring(&ctx->L, kind, pos.coord(), id.p, equil.p, k.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size,
@@ -65,9 +72,9 @@ struct SpringNode : public PotentialNode {
 struct DistSpring : SpringNode { DistSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 2) {} };
 struct AngleSpring : SpringNode { AngleSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 3) {} };
 struct DihedralSpring : SpringNode { DihedralSpring(DeviceCtx* c, hid_t_compat g, CoordNode& p) : SpringNode(c, g, p, 4) {} };
-RegisterNodeType<DistSpring, 1> dist_spring_node("dist_spring");
-RegisterNodeType<AngleSpring, 1> angle_spring_node("angle_spring");
-RegisterNodeType<DihedralSpring, 1> dihedral_spring_node("dihedral_spring");
+RegisterNodeType<Builtin<DistSpring>, 1> dist_spring_node("dist_spring");
+RegisterNodeType<Builtin<AngleSpring>, 1> angle_spring_node("angle_spring");
+RegisterNodeType<Builtin<DihedralSpring>, 1> dihedral_spring_node("dihedral_spring");
 
 // cavity_radial: bonds.cpp:323-374 (used to compact synthetic chains)
 struct CavityRadial : public PotentialNode {
@@ -87,7 +94,7 @@ struct CavityRadial : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
-RegisterNodeType<CavityRadial, 1> cavity_radial_node("cavity_radial");
+RegisterNodeType<Builtin<CavityRadial>, 1> cavity_radial_node("cavity_radial");
 
 // ---------------------------------------------------------------------------------------------------
 // rama_coord: bonds.cpp:171-249
@@ -107,13 +114,14 @@ struct RamaCoord : public CoordNode {
         atom.upload(a); dummy.upload(dm);
         jac.alloc((size_t)c->n_system * n_elem * UPK_RAMA_JAC);
         src = pos.scatter.add_source(n_elem, 5, 3, a);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode) override { upk_check(upk_rama_fwd(&ctx->L, pos.coord(), atom.p, dummy.p, n_elem, coord(), jac.p), "rama_fwd"); }
     void add_loggers(vector<LogValue>& out) override;   // bonds.cpp:199-202
     void propagate_deriv() override {
         upk_check(upk_rama_bwd(&ctx->L, coord(), jac.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size), "rama_bwd"); }
 };
-RegisterNodeType<RamaCoord, 1> rama_coord_node("rama_coord");
+RegisterNodeType<Builtin<RamaCoord>, 1> rama_coord_node("rama_coord");
 
 // affine_alignment: eig.cpp:277-473
 struct AffineAlignment : public CoordNode {
@@ -127,12 +135,13 @@ struct AffineAlignment : public CoordNode {
         atoms.upload(a); ref_geom.upload(read<float>(H(grp), "ref_geom", 3));
         eig.alloc((size_t)c->n_system * n_elem * 20);
         src = pos.scatter.add_source(n_elem, 3, 3, a);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode) override { upk_check(upk_affine_fwd(&ctx->L, pos.coord(), atoms.p, ref_geom.p, n_elem, coord(), eig.p), "affine_fwd"); }
     void propagate_deriv() override {
         upk_check(upk_affine_bwd(&ctx->L, coord(), ref_geom.p, eig.p, n_elem, pos.scatter.source_ptr(src), pos.scatter.arena_size), "affine_bwd"); }
 };
-RegisterNodeType<AffineAlignment, 1> affine_alignment_node("affine_alignment");
+RegisterNodeType<Builtin<AffineAlignment>, 1> affine_alignment_node("affine_alignment");
 
 // infer_H_O: hbond.cpp:14-121
 struct Infer_H_O : public CoordNode {
@@ -152,12 +161,13 @@ struct Infer_H_O : public CoordNode {
         atom.upload(a); bond_length.upload(b);
         dfd.alloc((size_t)c->n_system * n_virtual * 12);
         src = pos.scatter.add_source(n_virtual, 3, 3, a);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode) override { upk_check(upk_infer_fwd(&ctx->L, pos.coord(), atom.p, bond_length.p, n_virtual, coord(), dfd.p), "infer_fwd"); }
     void propagate_deriv() override {
         upk_check(upk_infer_bwd(&ctx->L, coord(), bond_length.p, dfd.p, n_virtual, pos.scatter.source_ptr(src), pos.scatter.arena_size), "infer_bwd"); }
 };
-RegisterNodeType<Infer_H_O, 1> infer_node("infer_H_O");
+RegisterNodeType<Builtin<Infer_H_O>, 1> infer_node("infer_H_O");
 
 // elements [sys*n, (sys+1)*n) of a per-system device array
 template <typename T>
@@ -248,6 +258,7 @@ struct PlacementNode : public CoordNode {
         if (has_geometry) src_aff = alignment.scatter.add_source(n_elem, 1, 6, ar);
         P.affine_residue = affine_residue.p; P.layer = layer.p; P.rama_residue = rama_residue.p;
         P.fixed_data = fixed_data.p; P.spline_coeff = spline_coeff.p;
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode) override {
         upk_coord_t rc; memset(&rc, 0, sizeof(rc));
@@ -289,13 +300,13 @@ struct PlPointVector : PlacementNode { PlPointVector(DeviceCtx* c, hid_t_compat 
 struct PlFixedPointVector : PlacementNode { PlFixedPointVector(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {2, 1}) {} };
 struct PlFixedPointVectorScalar : PlacementNode { PlFixedPointVectorScalar(DeviceCtx* c, hid_t_compat g, CoordNode& a) : PlacementNode(c, g, a, nullptr, {2, 1, 0}) {} };
 // same seven registrations as placement.cpp:319-325
-RegisterNodeType<PlScalar, 2> pl1("placement_scalar");
-RegisterNodeType<PlFixedScalar, 1> pl2("placement_fixed_scalar");
-RegisterNodeType<PlPointOnly, 2> pl3("placement_point_only");
-RegisterNodeType<PlFixedPointOnly, 1> pl4("placement_fixed_point_only");
-RegisterNodeType<PlPointVector, 2> pl5("placement_point_vector_only");
-RegisterNodeType<PlFixedPointVector, 1> pl6("placement_fixed_point_vector_only");
-RegisterNodeType<PlFixedPointVectorScalar, 1> pl7("placement_fixed_point_vector_scalar");
+RegisterNodeType<Builtin<PlScalar>, 2> pl1("placement_scalar");
+RegisterNodeType<Builtin<PlFixedScalar>, 1> pl2("placement_fixed_scalar");
+RegisterNodeType<Builtin<PlPointOnly>, 2> pl3("placement_point_only");
+RegisterNodeType<Builtin<PlFixedPointOnly>, 1> pl4("placement_fixed_point_only");
+RegisterNodeType<Builtin<PlPointVector>, 2> pl5("placement_point_vector_only");
+RegisterNodeType<Builtin<PlFixedPointVector>, 1> pl6("placement_fixed_point_vector_only");
+RegisterNodeType<Builtin<PlFixedPointVectorScalar>, 1> pl7("placement_fixed_point_vector_scalar");
 
 // ---------------------------------------------------------------------------------------------------
 // rama_map_pot: rama_map_pot.cpp:15-93
@@ -318,6 +329,7 @@ struct RamaMapPot : public PotentialNode {
         coeff.upload(fit_layered_periodic_spline2d(raw, (int)dims[0], nx, nx, 1));
         alloc_terms(n_residue);
         log_pot = attr<int>(H(grp), ".", "log_pot", 1) != 0;   // rama_map_pot.cpp:34
+        fused_forward = fused_backward = true;
     }
     bool log_pot = true;
     void add_loggers(vector<LogValue>& out) override {   // rama_map_pot.cpp:50-54
@@ -332,7 +344,7 @@ struct RamaMapPot : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
-RegisterNodeType<RamaMapPot, 1> rama_map_pot_node("rama_map_pot");
+RegisterNodeType<Builtin<RamaMapPot>, 1> rama_map_pot_node("rama_map_pot");
 
 // ---------------------------------------------------------------------------------------------------
 // backbone_pairs: backbone_steric.cpp:38-147
@@ -356,6 +368,7 @@ struct BackbonePairs : public PotentialNode {
         id.upload(ids); n_atom.upload(na); ref_pos.upload(rp);
         src = alignment.scatter.add_source(n_residue, 1, 6, ids);
         alloc_terms(n_residue);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_backbone_pairs(&ctx->L, alignment.coord(), id.p, id.p, n_atom.p, ref_pos.p, n_residue, dist_cutoff,
@@ -364,7 +377,7 @@ struct BackbonePairs : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
-RegisterNodeType<BackbonePairs, 1> backbone_pairs_node("backbone_pairs");
+RegisterNodeType<Builtin<BackbonePairs>, 1> backbone_pairs_node("backbone_pairs");
 
 // ---------------------------------------------------------------------------------------------------
 // interaction graph host side: interaction_graph.h:261-398
@@ -534,7 +547,7 @@ struct IGraphHost {
         }
         rebuild_flag.alloc(S);
         G.nbr_j_bits = itype == UPK_IT_ROTAMER ? UPK_ROT_J_BITS : 0;
-        if (G.nbr_j_bits && G.n1 > (1 << G.nbr_j_bits)) throw string("rotamer pair lists pack the bead index into ") + to_string(G.nbr_j_bits) + " bits: at most 8192 beads";
+        if (G.nbr_j_bits && G.n1 >= (1 << G.nbr_j_bits)) throw string("rotamer pair lists pack the bead index into ") + to_string(G.nbr_j_bits) + " bits (one value is the sentinel): at most 8191 beads";
         cur_pos1.alloc((size_t)S * G.n1 * 4);
         if (!G.symmetric) cur_pos2.alloc((size_t)S * G.n2 * 4);
         if (itype != UPK_IT_RADIAL && itype != UPK_IT_HBOND_SC_RADIAL) {   // (the radial potentials walk the cached lists themselves)
@@ -710,7 +723,7 @@ struct ProteinHBond : public CoordNode {
     }
     // no get_param_deriv: the reference's ProteinHBond does not override it either (hbond.cpp:290-368) -> empty
 };
-RegisterNodeType<ProteinHBond, 1> hbond_node("protein_hbond");
+RegisterNodeType<Builtin<ProteinHBond>, 1> hbond_node("protein_hbond");
 
 // hbond_coverage: hbond.cpp:371-414
 struct HBondCoverage : public CoordNode {
@@ -760,7 +773,7 @@ struct HBondCoverage : public CoordNode {
         throw string("Value ") + log_name + string(" not implemented");
     }
 };
-RegisterNodeType<HBondCoverage, 2> coverage_node("hbond_coverage");
+RegisterNodeType<Builtin<HBondCoverage>, 2> coverage_node("hbond_coverage");
 
 // environment_coverage: environment.cpp:71-109
 struct EnvironmentCoverage : public CoordNode {
@@ -787,7 +800,7 @@ struct EnvironmentCoverage : public CoordNode {
             upk_check(upk_igraph_param_deriv(&ctx->L, &ig.G, system, 1, sens.p, nullptr, sys_stride(), stride, t), "environment_coverage param_deriv"); });
     }
 };
-RegisterNodeType<EnvironmentCoverage, 2> environment_coverage_node("environment_coverage");
+RegisterNodeType<Builtin<EnvironmentCoverage>, 2> environment_coverage_node("environment_coverage");
 
 // hbond_energy: hbond.cpp:417-456
 struct HBondEnergy : public HBondCounter {
@@ -795,6 +808,7 @@ struct HBondEnergy : public HBondCounter {
     HBondEnergy(DeviceCtx* c, hid_t_compat grp, CoordNode& ph) : HBondCounter(c), protein_hbond(ph), E_protein(attr<float>(H(grp), ".", "protein_hbond_energy")) {
         check_elem_width(ph, 7);
         alloc_terms(ph.n_elem);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_hbond_energy(&ctx->L, protein_hbond.coord(), E_protein, mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "hbond_energy");
@@ -809,7 +823,7 @@ struct HBondEnergy : public HBondCounter {
         E_protein = p[0];
     }
 };
-RegisterNodeType<HBondEnergy, 1> hbond_energy_node("hbond_energy");
+RegisterNodeType<Builtin<HBondEnergy>, 1> hbond_energy_node("hbond_energy");
 
 // weighted_pos: environment.cpp:112-156
 struct WeightedPos : public CoordNode {
@@ -822,11 +836,12 @@ struct WeightedPos : public CoordNode {
         require_injective(ip, pos.n_elem, "weighted_pos index_pos");
         require_injective(iw, energy.n_elem, "weighted_pos index_weight");
         index_pos.upload(ip); index_weight.upload(iw);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode) override { upk_check(upk_weighted_pos_fwd(&ctx->L, pos.coord(), energy.coord(), index_pos.p, index_weight.p, coord()), "weighted_pos_fwd"); }
     void propagate_deriv() override { upk_check(upk_weighted_pos_bwd(&ctx->L, pos.coord(), energy.coord(), index_pos.p, index_weight.p, coord()), "weighted_pos_bwd"); }
 };
-RegisterNodeType<WeightedPos, 2> weighted_pos_node("weighted_pos");
+RegisterNodeType<Builtin<WeightedPos>, 2> weighted_pos_node("weighted_pos");
 
 // nonlinear_coupling: environment.cpp:324-397
 struct NonlinearCoupling : public PotentialNode {
@@ -843,6 +858,7 @@ struct NonlinearCoupling : public PotentialNode {
         for (int i : t) if (i < 0 || i >= n_restype) throw string("invalid coupling type");
         d_coeff.upload(coeff); types.upload(t);
         alloc_terms(input.n_elem);
+        fused_forward = fused_backward = true;
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_nonlinear_coupling(&ctx->L, input.coord(), types.p, d_coeff.p, n_coeff, spline_offset, spline_inv_dx,
@@ -864,7 +880,7 @@ struct NonlinearCoupling : public PotentialNode {
         coeff = p; hip_check(hipMemcpy(d_coeff.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
     }
 };
-RegisterNodeType<NonlinearCoupling, 1> nonlinear_coupling_node("nonlinear_coupling");
+RegisterNodeType<Builtin<NonlinearCoupling>, 1> nonlinear_coupling_node("nonlinear_coupling");
 
 // ---------------------------------------------------------------------------------------------------
 // Optional restraint / external-field nodes (not emitted for the README force field)
@@ -925,10 +941,10 @@ struct PosSpring : PointPotential { PosSpring(DeviceCtx* c, hid_t_compat g, Coor
 struct TensionPotential : PointPotential { TensionPotential(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 1) {} };
 struct AFMPotential : PointPotential { AFMPotential(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 2) {} };
 struct ZFlatBottom : PointPotential { ZFlatBottom(DeviceCtx* c, hid_t_compat g, CoordNode& p) : PointPotential(c, g, p, 3) {} };
-RegisterNodeType<PosSpring, 1> pos_spring_node("atom_pos_spring");
-RegisterNodeType<TensionPotential, 1> tension_node("tension");
-RegisterNodeType<AFMPotential, 1> AFM_node("AFM");
-RegisterNodeType<ZFlatBottom, 1> z_flat_bottom_node("z_flat_bottom");
+RegisterNodeType<Builtin<PosSpring>, 1> pos_spring_node("atom_pos_spring");
+RegisterNodeType<Builtin<TensionPotential>, 1> tension_node("tension");
+RegisterNodeType<Builtin<AFMPotential>, 1> AFM_node("AFM");
+RegisterNodeType<Builtin<ZFlatBottom>, 1> z_flat_bottom_node("z_flat_bottom");
 
 // contact: sidechain_radial.cpp:139-205
 struct ContactEnergy : public PotentialNode {
@@ -966,7 +982,7 @@ struct ContactEnergy : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
-RegisterNodeType<ContactEnergy, 1> contact_node("contact");
+RegisterNodeType<Builtin<ContactEnergy>, 1> contact_node("contact");
 
 // radial (symmetric, sidechain_radial.cpp:81-104) and hbond_sc_radial (two nodes, :107-136): the sum over in-range pairs of
 // a clamped spline of their distance; every pair has sensitivity 1.  Old-style potentials without shipped parameters:
@@ -996,8 +1012,8 @@ struct RadialPairs : public PotentialNode {
 };
 struct SidechainRadialPairs : RadialPairs { SidechainRadialPairs(DeviceCtx* c, hid_t_compat g, CoordNode& a) : RadialPairs(c, g, a, nullptr) {} };
 struct HBondSidechainRadialPairs : RadialPairs { HBondSidechainRadialPairs(DeviceCtx* c, hid_t_compat g, CoordNode& a, CoordNode& b) : RadialPairs(c, g, a, &b) {} };
-RegisterNodeType<SidechainRadialPairs, 1> radial_node("radial");
-RegisterNodeType<HBondSidechainRadialPairs, 2> hbond_sc_radial_node("hbond_sc_radial");
+RegisterNodeType<Builtin<SidechainRadialPairs>, 1> radial_node("radial");
+RegisterNodeType<Builtin<HBondSidechainRadialPairs>, 2> hbond_sc_radial_node("hbond_sc_radial");
 
 // constant: bonds.cpp:550-587
 struct ConstantCoord : public CoordNode {
@@ -1014,7 +1030,7 @@ struct ConstantCoord : public CoordNode {
         value = p; hip_check(hipMemcpy(d_value.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice), "H2D");
     }
 };
-RegisterNodeType<ConstantCoord, 0> constant_coord_node("constant");
+RegisterNodeType<Builtin<ConstantCoord>, 0> constant_coord_node("constant");
 
 // slice: bonds.cpp:589-621
 struct Slice : public CoordNode {
@@ -1028,7 +1044,7 @@ struct Slice : public CoordNode {
     void compute_value(ComputeMode) override { upk_check(upk_slice_fwd(&ctx->L, pos.coord(), id.p, coord()), "slice_fwd"); }
     void propagate_deriv() override { upk_check(upk_slice_bwd(&ctx->L, coord(), pos.scatter.source_ptr(src), pos.scatter.arena_size), "slice_bwd"); }
 };
-RegisterNodeType<Slice, 1> slice_node("slice");
+RegisterNodeType<Builtin<Slice>, 1> slice_node("slice");
 
 // uniform_transform: environment.cpp:158-235
 struct UniformTransform : public CoordNode {
@@ -1055,7 +1071,7 @@ struct UniformTransform : public CoordNode {
         coeff.assign(p.begin() + 2, p.end()); d_coeff.upload(coeff);
     }
 };
-RegisterNodeType<UniformTransform, 1> uniform_transform_node("uniform_transform");
+RegisterNodeType<Builtin<UniformTransform>, 1> uniform_transform_node("uniform_transform");
 
 // linear_coupling_uniform / linear_coupling_with_inactivation: environment.cpp:237-321
 struct LinearCoupling : public PotentialNode {
@@ -1101,8 +1117,8 @@ struct LinearCoupling : public PotentialNode {
 struct LinearCouplingUniform : LinearCoupling { LinearCouplingUniform(DeviceCtx* c, hid_t_compat g, CoordNode& in) : LinearCoupling(c, g, in, nullptr) {} };
 struct LinearCouplingInactivation : LinearCoupling {
     LinearCouplingInactivation(DeviceCtx* c, hid_t_compat g, CoordNode& in, CoordNode& inact) : LinearCoupling(c, g, in, &inact) {} };
-RegisterNodeType<LinearCouplingUniform, 1> linear_coupling_node1("linear_coupling_uniform");
-RegisterNodeType<LinearCouplingInactivation, 2> linear_coupling_node2("linear_coupling_with_inactivation");
+RegisterNodeType<Builtin<LinearCouplingUniform>, 1> linear_coupling_node1("linear_coupling_uniform");
+RegisterNodeType<Builtin<LinearCouplingInactivation>, 2> linear_coupling_node2("linear_coupling_with_inactivation");
 
 // membrane_potential: membrane_potential.cpp:13-155
 struct MembranePotential : public PotentialNode {
@@ -1149,7 +1165,7 @@ struct MembranePotential : public PotentialNode {
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
-RegisterNodeType<MembranePotential, 3> membrane_potential_node("membrane_potential");
+RegisterNodeType<Builtin<MembranePotential>, 3> membrane_potential_node("membrane_potential");
 
 // ---------------------------------------------------------------------------------------------------
 // rotamer: rotamer.cpp:581-1082
@@ -1314,6 +1330,7 @@ struct RotamerSidechain : public PotentialNode {
     // back to the one-workgroup kernel on the device).  Decided once, from the first pair list.
     void choose_bp_cluster() {
         bp_C_chosen = true;
+        ctx->flush();
         const int want = env_int("UPSIDE_HIP_BP_CLUSTER", -1);   // 1 disables, >1 forces
         R.bp_resident = 1;
         if (want == 1) { R.bp_C = 1; set_matrix_form(); return; }
@@ -1528,7 +1545,7 @@ struct RegisterRotamer {
     RegisterRotamer(string name_prefix) {
         add_node_creation_function(name_prefix, [name_prefix](DeviceCtx* c, hid_t_compat grp, const ArgList& args) -> DerivComputation* {
             if (args.size() < 1u) throw string("node " + name_prefix + " needs at least 1 arg");
-            return new RotamerSidechain(c, grp, args); });
+            auto* node = new RotamerSidechain(c, grp, args); node->library_launchers_only = true; return node; });
     }
 };
 RegisterRotamer rotamer_node("rotamer");

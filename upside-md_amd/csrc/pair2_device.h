@@ -40,6 +40,12 @@ __device__ __forceinline__ unsigned long long to_fixed22(float v) { return to_fi
 __device__ __forceinline__ void lds_add_fixed22_scaled(unsigned long long* p, float vs) {
     __hip_atomic_fetch_add(p, to_fixed22_scaled(vs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// a ROW's own total (one conversion per row and component, not per pair): the full 64-bit range instead of the saturating
+// 32-bit conversion above -- a badly clashing start structure can push a row total past 512
+__device__ __forceinline__ unsigned long long to_fixed22_wide(float v) { return (unsigned long long)__float2ll_rn(v * P2_FIX_SCALE); }
+__device__ __forceinline__ void lds_add_fixed22_wide(unsigned long long* p, float v) {
+    __hip_atomic_fetch_add(p, to_fixed22_wide(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ float from_fixed22(unsigned long long a) { return (float)((double)(long long)a * (1.0 / (double)(1 << P2_FIX_BITS))); }
 __device__ __forceinline__ void lds_add_fixed22(unsigned long long* p, float v) {
     __hip_atomic_fetch_add(p, to_fixed22(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
