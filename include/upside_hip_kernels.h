@@ -17,7 +17,17 @@ extern "C" {
 /* fuse: the engine's queue of fused per-element ops (upk_fuse_create) or NULL.  Per-element launchers (marked "fusable" below)
  * append an op to it instead of launching; every other launcher runs the queue first (upk_fuse_flush), so the order of calls is
  * the order of effects.  A caller that enqueues its own work on `stream` must call upk_fuse_flush(L) first. */
-typedef struct { int n_system; void* stream; void* fuse; } upk_launch_t;
+typedef struct { int n_system; void* stream; void* fuse; void* batch; } upk_launch_t;
+/* batch: merged launches (csrc/kernels_batch.h) or NULL.  Between upk_batch_begin and upk_batch_end the launchers of the list
+ * upkeep and of the pair passes that have a batch form append to the chain named by upk_batch_chain instead of launching; launches
+ * of one chain keep their order, the k-th launches of all chains run side by side as ONE launch.  The caller promises that
+ * different chains do not depend on each other.  Any other launcher runs what the batch holds first. */
+void* upk_batch_create(void);
+void upk_batch_destroy(void* batch);
+int upk_batch_begin(const upk_launch_t* L);
+void upk_batch_chain(const upk_launch_t* L, int chain);
+int upk_batch_run(const upk_launch_t* L);
+int upk_batch_end(const upk_launch_t* L);
 void* upk_fuse_create(int n_system);
 void upk_fuse_destroy(void* fuse);
 int upk_fuse_flush(const upk_launch_t* L);          /* one launch for the pending ops (no-op when nothing is pending) */

@@ -609,6 +609,10 @@ ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes
     {'UPSIDE_HIP_FUSE': '0'},                # every per-element op launched on its own instead of through the fused-op queue
+    {'UPSIDE_HIP_BATCH': '0'},               # no merged launches: every upkeep kernel and pair pass as a launch of its own, upkeep on side streams
+    {'UPSIDE_HIP_BATCH': '1'},               # merged launches whatever the batch size
+    {'UPSIDE_HIP_FUSE_BARRIERS': '1'},       # a workgroup barrier in front of every fused op (no dependency analysis)
+    {'UPSIDE_HIP_SCHEDULE': 'bfs'},          # the reference's level-by-level order of the sweep instead of the grouped one
     {'UPSIDE_HIP_FUSE_THREADS': '1024'},     # fused launches with 1024-lane workgroups (the instance that spills the alignment ops)
     {'UPSIDE_HIP_FUSE_THREADS': '128'},      # ... and with two wavefronts per system
     {'UPSIDE_HIP_PAIR2': '0'},               # scalar (one partner per lane) forms of the side-chain gradient and coverage passes

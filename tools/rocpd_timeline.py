@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timeline of one MD step from a rocprofv3 rocpd database: kernels between two consecutive k_integration_stage
-launches with start offset, duration, queue and grid.  usage: rocpd_timeline.py results.db [step_index] [out.txt]"""
+"""Timeline of one MD step from a rocprofv3 rocpd database: kernels between two consecutive belief-propagation solves
+(one per force pass) with start offset, duration, queue and grid.  usage: rocpd_timeline.py results.db [step_index] [out.txt]"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 idx = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -8,7 +8,8 @@ out = open(sys.argv[3], 'w') if len(sys.argv) > 3 else sys.stdout
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 want = [c for c in ('name', 'start', 'end', 'queue_id', 'stream_id', 'grid_x', 'grid_y', 'workgroup_x', 'lds_size') if c in cols]
 rows = db.execute("select %s from kernels order by start" % ','.join(want)).fetchall()
-marks = [i for i, r in enumerate(rows) if r[0].startswith('k_integration_stage')]
+marks = [i for i, r in enumerate(rows) if 'k_rotamer_bp<' in r[0] or 'k_rotamer_bp_cluster<true>' in r[0]]
+marks = [m for k, m in enumerate(marks) if k == 0 or m - marks[k - 1] > 3]      # (a cluster solve is followed by its fallback launch)
 a, b = marks[idx], marks[idx + 1]
 t0 = rows[a][2]
 out.write('columns: %s\n' % want)

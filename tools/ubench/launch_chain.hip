@@ -6,6 +6,7 @@
 // Prints microseconds per step.  Used to size the fused per-element passes.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <vector>
 
@@ -45,6 +46,20 @@ __global__ void __launch_bounds__(1024) k_phases_lds(float* a, const int* __rest
         float* t = in; in = out; out = t;
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = in[i];
+}
+
+// shader clock under a given load: one wavefront per workgroup runs a chain of dependent FMAs (4 cycles each) and times it with the
+// constant 100 MHz wall clock
+__global__ void k_clock(float* out, long long* ticks, int iters) {
+    float x = threadIdx.x * 1e-3f;
+    const long long t0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) x = __builtin_fmaf(x, 1.0001f, 0.5f);
+    }
+    const long long t1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
 int main() {
@@ -110,6 +125,20 @@ int main() {
         CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep == 2) printf("resident phases, LDS intermediates:    %.3f us per phase\n", ms * 1e3 / n_step);
+    }
+    {
+        float* o; long long* tk; CHECK(hipMalloc(&o, 1024 * 64 * 4)); CHECK(hipMalloc(&tk, 1024 * 8));
+        const int iters = 20000;     // 1.28 M dependent FMAs = 5.12 M cycles
+        for (int wgs : {1, 8, 64, 256, 1024}) {
+            for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(k_clock, dim3(wgs), dim3(64), 0, st, o, tk, iters); CHECK(hipStreamSynchronize(st)); }
+            long long t; CHECK(hipMemcpy(&t, tk, 8, hipMemcpyDeviceToHost));
+            printf("shader clock with %4d one-wave workgroups resident: %.0f MHz (dependent-FMA chain, 4 cycles each)\n", wgs, 4.0 * 64 * iters / (t * 10e-9) / 1e6);
+        }
+        // right after an idle gap
+        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+        hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, st, o, tk, 2000); CHECK(hipStreamSynchronize(st));
+        long long t; CHECK(hipMemcpy(&t, tk, 8, hipMemcpyDeviceToHost));
+        printf("shader clock of a 0.25 ms kernel after 200 ms idle: %.0f MHz\n", 4.0 * 64 * 2000 / (t * 10e-9) / 1e6);
     }
     printf("done\n");
     return 0;

@@ -211,6 +211,11 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
     ctx.L.n_system = n_system; ctx.L.stream = (void*)ctx.stream;
     ctx.L.fuse = upk_fuse_create(n_system);      // queue of fused per-element ops (kernels_basic.hip)
     if (!ctx.L.fuse) throw string("cannot allocate the fused-op table");
+    // merged launches (kernels_batch.h) for batches that are chains of dependent launches rather than work: measured on one MI355X,
+    // system-steps/s with / without -- 56 residues: 1 system 3.79 k / 3.18 k, 8: 25.9 k / 23.1 k; 300 residues: 1 system 1.83 k / 1.69 k,
+    // 64: 56 k / 62 k, 4096: 149 k / 184 k (there the upkeep kernels want their own launch shapes and the side streams).
+    // UPSIDE_HIP_BATCH=1 / 0 forces them on / off.
+    { const char* e = getenv("UPSIDE_HIP_BATCH"); const bool on = e ? atoi(e) != 0 : n_system <= 16; ctx.L.batch = on ? upk_batch_create() : nullptr; }
     ctx.error_flag.alloc(1);
     potential.assign(n_system, 0.f);
     Node n; n.name = "pos"; n.computation.reset(new Pos(&ctx, n_atom));
@@ -230,6 +235,7 @@ DerivEngine::~DerivEngine() {
     for (auto& kv : side) if (kv.second.owns_stream) (void)hipStreamDestroy(kv.second.stream);
     nodes.clear();
     upk_fuse_destroy(ctx.L.fuse); ctx.L.fuse = nullptr;
+    upk_batch_destroy(ctx.L.batch); ctx.L.batch = nullptr;
     if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
 }
 void DerivEngine::add_node(const string& name, unique_ptr<DerivComputation> fcn, vector<string> argument_names) {
@@ -268,6 +274,7 @@ void DerivEngine::finalize() {
     if (grouped) {
         const size_t N = nodes.size();
         std::vector<char> done(N, 0);
+        n_batch_group = 0;
         auto sweep = [&](bool backward) {
             std::fill(done.begin(), done.end(), 0);
             auto ready = [&](size_t i) {
@@ -286,10 +293,25 @@ void DerivEngine::finalize() {
                     }
                 }
                 ++lvl;
+                // then every other step that is ready: they do not depend on each other, so their kernels may share launches
+                // (kernels_batch.h); without merged launches, one at a time
+                // A backward step (and the forward step of a potential term) ADDS into the sensitivities of its parents with plain
+                // read-modify-writes: two steps share launches only if they have no parent in common
+                std::vector<size_t> group;
                 for (size_t i = 0; i < N; ++i) if (ready(i)) {
-                    schedule.push_back(Step{(int)i, backward}); done[i] = 1; ++n_done;
+                    bool clash = false;
+                    if (backward || nodes[i].computation->potential_term)
+                        for (size_t j : group) for (size_t pa : nodes[i].parents)
+                            if (std::find(begin(nodes[j].parents), end(nodes[j].parents), pa) != end(nodes[j].parents)) clash = true;
+                    if (clash) continue;
+                    group.push_back(i);
+                    if (!ctx.L.batch) break;
+                }
+                const int gid = group.size() > 1 ? n_batch_group++ : -1;
+                for (size_t i : group) {
+                    Step st{(int)i, backward}; st.batch = gid;
+                    schedule.push_back(st); done[i] = 1; ++n_done;
                     (backward ? nodes[i].deriv_exec_level : nodes[i].germ_exec_level) = lvl;
-                    break;
                 }
                 ++lvl;
             }
@@ -328,8 +350,38 @@ void DerivEngine::finalize() {
     }
     // hoist prepare() of the nodes that have one to just after the forward step of the last parent it reads, on a
     // side stream
+    if (ctx.L.batch && grouped) {
+        // Merged launches: the list upkeep of ALL graphs as one group, placed behind the last forward step any of it reads (the
+        // graphs' lists do not depend on each other: check / rebuild / refine of the five graphs run side by side in a handful of
+        // launches, kernels_batch.h).  On the main stream: the per-element steps it could overlap with are one fused launch now.
+        std::vector<size_t> prep;
+        for (size_t i = 0; i < nodes.size(); ++i) if (nodes[i].computation->has_prepare()) prep.push_back(i);
+        if (!prep.empty()) {
+            std::vector<char> is_dep(nodes.size(), 0);
+            for (size_t i : prep) {
+                auto& named = nodes[i].computation->prepare_deps;
+                if (named.empty()) for (size_t ip : nodes[i].parents) is_dep[ip] = 1;
+                else for (size_t j = 0; j < nodes.size(); ++j)
+                    if (std::find(begin(named), end(named), nodes[j].computation.get()) != end(named)) is_dep[j] = 1;
+            }
+            size_t last = 0;
+            for (size_t k = 0; k < schedule.size(); ++k) if (!schedule[k].backward && is_dep[schedule[k].node]) last = k;
+            // (a fused step behind `last` that nobody waits for stays behind the upkeep; the forward steps of the graphs come later anyway)
+            std::vector<Step> out(schedule.begin(), schedule.begin() + last + 1);
+            const int gid = prep.size() > 1 ? n_batch_group++ : -1;
+            for (size_t i : prep) { Step ps{(int)i, false}; ps.prepare = true; ps.batch = gid; out.push_back(ps); }
+            for (size_t k = last + 1; k < schedule.size(); ++k) {
+                Step st = schedule[k];
+                if (!st.backward && nodes[st.node].computation->has_prepare()) st.skip_prepare = true;
+                out.push_back(st);
+            }
+            schedule.swap(out);
+        }
+        print_schedule();
+        return;
+    }
     const char* env = getenv("UPSIDE_HIP_ASYNC_PREPARE");
-    if (env && atoi(env) == 0) return;
+    if (env && atoi(env) == 0) { print_schedule(); return; }
     // nodes a prepare() reads: the ones it names (any node of the graph, e.g. a grandparent whose output a parent copies
     // through), else all its parents
     std::vector<std::vector<size_t>> deps_of(nodes.size());
@@ -390,14 +442,18 @@ void DerivEngine::finalize() {
     schedule.swap(hoisted);
     last_prepare_step = -1;
     for (size_t k = 0; k < schedule.size(); ++k) if (schedule[k].prepare) last_prepare_step = (int)k;
-    if (getenv("UPSIDE_HIP_PRINT_SCHEDULE"))
-        for (auto& st : schedule) {
-            auto& n = nodes[st.node];
-            fprintf(stderr, "%-8s L%-2d %-44s parents:", st.prepare ? "prepare" : (st.backward ? "backward" : "forward"),
-                    st.backward ? n.deriv_exec_level : n.germ_exec_level, n.name.c_str());
-            for (size_t ip : n.parents) fprintf(stderr, " %s", nodes[ip].name.c_str());
-            fprintf(stderr, "\n");
-        }
+    print_schedule();
+}
+void DerivEngine::print_schedule() {
+    if (!getenv("UPSIDE_HIP_PRINT_SCHEDULE")) return;
+    for (auto& st : schedule) {
+        auto& n = nodes[st.node];
+        fprintf(stderr, "%-8s L%-2d batch %-2d %s%-44s parents:", st.prepare ? "prepare" : (st.backward ? "backward" : "forward"),
+                st.backward ? n.deriv_exec_level : n.germ_exec_level, st.batch,
+                (st.backward ? n.computation->fused_backward : n.computation->fused_forward) && !st.prepare ? "[fused] " : "        ", n.name.c_str());
+        for (size_t ip : n.parents) fprintf(stderr, " %s", nodes[ip].name.c_str());
+        fprintf(stderr, "\n");
+    }
 }
 
 void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
@@ -411,10 +467,23 @@ void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
         try { f(); ctx.flush(); } catch (...) { ctx.stream = main_stream; ctx.L.stream = (void*)main_stream; throw; }
         ctx.stream = main_stream; ctx.L.stream = (void*)main_stream;
     };
+    int open_batch = -1, chain = 0;
     for (size_t k = 0; k < schedule.size(); ++k) {
         const Step& st = schedule[k];
         auto* c = nodes[st.node].computation.get();
+        // merged launches: the steps of a group append to their own chains; the group's launches go out at its end
+        const int want_batch = ctx.profile ? -1 : st.batch;      // (profiling brackets single launches with events: no merged launches then)
+        if (want_batch != open_batch) {
+            if (open_batch >= 0) upk_check(upk_batch_end(&ctx.L), "batch_end");
+            open_batch = want_batch; chain = 0;
+            if (open_batch >= 0) upk_check(upk_batch_begin(&ctx.L), "batch_begin");
+        }
+        if (open_batch >= 0) {
+            if (!c->library_launchers_only) { upk_check(upk_batch_run(&ctx.L), "batch_run"); }
+            upk_batch_chain(&ctx.L, chain++);
+        }
         if (!c->library_launchers_only) ctx.flush();       // a node that may enqueue work of its own on the stream
+        if (st.prepare && side.find(st.node) == side.end()) { c->prepare(); continue; }     // (merged launches: upkeep inline, see finalize)
         if (st.prepare) {   // fork: side stream waits for everything enqueued so far, runs the upkeep, records `join`
             Side& sd = side[st.node];
             ctx.flush();
@@ -425,7 +494,7 @@ void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
             continue;
         }
         if (!st.backward) {
-            if (c->has_prepare()) {
+            if (c->has_prepare() && !st.skip_prepare) {
                 auto it = side.find(st.node);
                 if (it != side.end()) { ctx.flush(); hip_check(hipStreamWaitEvent(ctx.stream, it->second.join, 0), "hipStreamWaitEvent"); }
                 else c->prepare();
@@ -438,6 +507,7 @@ void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
             c->propagate_deriv();
         }
     }
+    if (open_batch >= 0) upk_check(upk_batch_end(&ctx.L), "batch_end");
     if (!keep_pending) ctx.flush();       // callers outside the MD loop find the queue empty
 }
 

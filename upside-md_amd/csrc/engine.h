@@ -42,7 +42,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     void set_invocations(uint64_t n);
 
     // execution order of one force pass, fixed at finalize() (the BFS of deriv_engine.cpp:124-169 unrolled)
-    struct Step { int node; bool backward; bool prepare = false; };
+    struct Step { int node; bool backward; bool prepare = false; int batch = -1; bool skip_prepare = false; };   // batch: steps of one merged-launch group (consecutive, mutually independent)
     std::vector<Step> schedule;
     struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool owns_stream = true; };
     std::map<int, Side> side;                  // node index -> side stream of its prepare() (empty when disabled)
@@ -60,6 +60,8 @@ struct DerivEngine {   // deriv_engine.h:145-237
         return dynamic_cast<T&>(*c);
     }
     void finalize();
+    void print_schedule();
+    int n_batch_group = 0;
     void compute(ComputeMode mode, bool keep_pending = false);   // enqueue; no synchronisation.  keep_pending: leave queued fused ops for the caller to extend (MD loop)
     void fetch_potentials();                   // D2H of every PotentialNode::potential + engine total
     void integration_cycle(float dt, float max_force = 0.f);   // deriv_engine.cpp:172-192 (Verlet weights)

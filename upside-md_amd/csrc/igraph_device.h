@@ -25,6 +25,10 @@
 
 #include <cstdlib>
 
+// block coordinates of a kernel body: those of its own launch, or its range of a merged launch (kernels_batch.h)
+struct BX { int bx, gx, by, gy; };
+#define BX_REAL (BX{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y})
+
 namespace up {
 
 // uniform cubic B-spline in basis form: value and derivative from the 4-coefficient window starting at c[bin-1]

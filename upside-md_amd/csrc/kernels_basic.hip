@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <initializer_list>
 #include <type_traits>
 #include <unordered_map>
 #include <vector>
@@ -32,22 +33,34 @@ static inline int launch_status() { return (int)hipGetLastError(); }
 // workgroup barrier between consecutive ops; what an op writes for a later one travels through global memory inside one CU
 // (L2 hits; workgroup-scope visibility needs no cache maintenance on gfx950).  Everything that is not fusable (pair passes,
 // list upkeep, belief propagation, memory copies, events) flushes the queue first, so program order is the order of effects.
-// Op records live in a device table that only grows: an op is registered the first time its (kind, arguments) are seen (a
-// blocking upload) and referred to by a 16-bit id afterwards; a launch takes the ids of its ops as a kernel argument, so the
+// Op records live in a device table that only grows: an op is registered the first time its (kind, arguments) are seen (an
+// upload through the launch stream, drained) and referred to by a 16-bit id afterwards; a launch takes the ids of its ops as a kernel argument, so the
 // steady state has no copies and can be captured into a hipGraph.
 // UPSIDE_HIP_FUSE=0: every op is launched on its own (one workgroup per system), the order of effects is the same.
 #define FUSE_PAYLOAD 232
 #define FUSE_MAX_PENDING 224
 struct FusedOp { int kind, n, lds_bytes, flags; unsigned char payload[FUSE_PAYLOAD]; };   // flags bit 0: no barrier needed in front of this op
 struct FusedIds { int n; unsigned short id[FUSE_MAX_PENDING]; };
-static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, int flags);
+// What an op reads and writes, so that the queue knows where a workgroup barrier is needed: ops that touch disjoint data run without one
+// (every wavefront walks the op list at its own pace, and the latencies of independent ops overlap).  A region is the per-system
+// slice [lo + s * stride, + len) of a device array (lo = NULL: an absent optional buffer); FUSE_ALL: everything; FUSE_LDS: the workgroup's LDS scratch.
+struct FuseRegion { const char* lo; size_t len, stride; bool write; };
+#define FUSE_LDS ((const char*)1)
+#define FUSE_ALL ((const char*)2)
+static inline FuseRegion r_slice(const void* p, size_t len_bytes, size_t stride_bytes, bool w) { FuseRegion r = {(const char*)p, len_bytes, stride_bytes, w}; return r; }
+static inline FuseRegion r_buf(const void* p, size_t per_system_bytes, bool w) { return r_slice(p, per_system_bytes, per_system_bytes, w); }
+static inline FuseRegion r_out(const upk_coord_t& c, bool w) { return r_buf(c.out, (size_t)c.n_elem * c.stride * sizeof(float), w); }
+static inline FuseRegion r_sens(const upk_coord_t& c, bool w) { return r_buf(c.sens, (size_t)c.n_elem * c.stride * sizeof(float), w); }
+static inline FuseRegion r_all() { return r_slice(FUSE_ALL, 0, 0, true); }
+static inline FuseRegion r_lds() { return r_slice(FUSE_LDS, 0, 0, true); }
+static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, const FuseRegion* regs, int n_regs);
 // An op is looked up by the BYTES of its argument block, padding included: launchers fill a zeroed block field by field (FARGS),
 // nested structs through cz / pz, which rebuild them member by member (a struct copy may carry the source's padding along).
 template <typename A>
-static inline int fuse_submit(const upk_launch_t* L, int kind, const A& args, int n, int lds_bytes = 0, int flags = 0) {
+static inline int fuse_submit(const upk_launch_t* L, int kind, const A& args, int n, std::initializer_list<FuseRegion> regs, int lds_bytes = 0) {
     static_assert(sizeof(A) <= FUSE_PAYLOAD, "fused-op argument block too large");
     static_assert(std::is_trivially_copyable<A>::value, "fused-op arguments are copied bytewise");
-    return fuse_submit_raw(L, kind, &args, sizeof(A), n, lds_bytes, flags);
+    return fuse_submit_raw(L, kind, &args, sizeof(A), n, lds_bytes, regs.begin(), (int)regs.size());
 }
 #define FARGS(T, a) T a; memset((void*)&a, 0, sizeof(a))
 static inline upk_coord_t cz(const upk_coord_t& c) {
@@ -102,11 +115,11 @@ __device__ __forceinline__ void c_zero_many(const ZeroManyArgs& A, int s) {
 extern "C" int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf) {
     if (n_buf <= 0) return 0;
     FARGS(ZeroManyArgs, a); a.ptrs = ptrs; a.sizes = sizes; a.n_buf = n_buf; a.n_system = L->n_system;
-    return fuse_submit(L, FOP_ZERO_MANY, a, 0);
+    return fuse_submit(L, FOP_ZERO_MANY, a, 0, {r_all()});
 }
 extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate) {
     FARGS(ReduceSumArgs, a); a.in = in; a.n = n; a.out = out; a.accumulate = accumulate;
-    return fuse_submit(L, FOP_REDUCE_SUM, a, 0);
+    return fuse_submit(L, FOP_REDUCE_SUM, a, 0, {r_buf(in, (size_t)n * 4, false), r_buf(out, 4, true), r_lds()});
 }
 
 __global__ void k_scale(float* __restrict__ x, int n, float f) {
@@ -150,7 +163,7 @@ extern "C" int upk_gather_contrib(const upk_launch_t* L, const float* arena, lon
                                   const int* csr_entry, upk_coord_t target, int width, int comp_offset) {
     if (width > 8) return 9010;
     FARGS(GatherContribArgs, a); a.arena = arena; a.arena_stride = arena_stride; a.csr_start = csr_start; a.csr_entry = csr_entry; a.target = cz(target); a.width = width; a.comp_offset = comp_offset;
-    return fuse_submit(L, FOP_GATHER_CONTRIB, a, target.n_elem * 8);
+    return fuse_submit(L, FOP_GATHER_CONTRIB, a, target.n_elem * 8, {r_buf(arena, (size_t)arena_stride * 4, false), r_sens(target, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -174,7 +187,7 @@ __device__ __forceinline__ void b_integration_stage(const int na, const int s, f
 extern "C" int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
                                      float max_force) {
     FARGS(IntegrationStageArgs, a); a.mom = mom; a.pos = cz(pos); a.vel_factor = vel_factor; a.pos_factor = pos_factor; a.max_force = max_force;
-    return fuse_submit(L, FOP_INTEGRATION_STAGE, a, pos.n_elem);
+    return fuse_submit(L, FOP_INTEGRATION_STAGE, a, pos.n_elem, {r_buf(mom, (size_t)pos.n_elem * 16, true), r_sens(pos, false), r_out(pos, true)});
 }
 
 struct ThermostatArgs { float* mom; int n_atom; const uint32_t* seed; unsigned long long* n_inv; const float* mom_scale; const float* noise_scale; };
@@ -202,7 +215,7 @@ __device__ __forceinline__ void c_thermostat(const ThermostatArgs& A, int s) {
 extern "C" int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,
                               const float* mom_scale, const float* noise_scale) {
     FARGS(ThermostatArgs, a); a.mom = mom; a.n_atom = n_atom; a.seed = seed; a.n_inv = n_invocations; a.mom_scale = mom_scale; a.noise_scale = noise_scale;
-    return fuse_submit(L, FOP_THERMOSTAT, a, 0);
+    return fuse_submit(L, FOP_THERMOSTAT, a, 0, {r_buf(mom, (size_t)n_atom * 16, true), r_buf(n_invocations, 8, true)});
 }
 
 __global__ void k_recenter(upk_coord_t pos, int xy_only) {
@@ -396,7 +409,7 @@ __device__ __forceinline__ void b_affine_fwd(const int lane_res, const int s, up
 extern "C" int upk_affine_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atoms, const float* ref_geom, int n_res,
                               upk_coord_t out, float* eig) {
     FARGS(AffineFwdArgs, a); a.pos = cz(pos); a.atoms = atoms; a.ref_geom = ref_geom; a.n_res = n_res; a.out = cz(out); a.eig = eig;
-    return fuse_submit(L, FOP_AFFINE_FWD, a, (n_res + 63) & ~63);
+    return fuse_submit(L, FOP_AFFINE_FWD, a, (n_res + 63) & ~63, {r_out(pos, false), r_out(out, true), r_buf(eig, (size_t)n_res * 80, true)});
 }
 
 struct AffineBwdArgs { upk_coord_t aff; const float* ref_geom; const float* eig; int n_res; float* contrib; long contrib_stride; };
@@ -462,7 +475,7 @@ __device__ __forceinline__ void b_affine_bwd(const int nr, const int s, upk_coor
 extern "C" int upk_affine_bwd(const upk_launch_t* L, upk_coord_t aff, const float* ref_geom, const float* eig, int n_res,
                               float* contrib, long contrib_stride) {
     FARGS(AffineBwdArgs, a); a.aff = cz(aff); a.ref_geom = ref_geom; a.eig = eig; a.n_res = n_res; a.contrib = contrib; a.contrib_stride = contrib_stride;
-    return fuse_submit(L, FOP_AFFINE_BWD, a, n_res);
+    return fuse_submit(L, FOP_AFFINE_BWD, a, n_res, {r_sens(aff, false), r_buf(eig, (size_t)n_res * 80, false), r_slice(contrib, (size_t)n_res * 36, (size_t)contrib_stride * 4, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,7 +510,7 @@ __device__ __forceinline__ void b_rama_fwd(const int nt, const int s, upk_coord_
 extern "C" int upk_rama_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const int* dummy, int n_res, upk_coord_t out,
                             float* jac) {
     FARGS(RamaFwdArgs, a); a.pos = cz(pos); a.atom = atom; a.dummy = dummy; a.n_res = n_res; a.out = cz(out); a.jac = jac;
-    return fuse_submit(L, FOP_RAMA_FWD, a, n_res);
+    return fuse_submit(L, FOP_RAMA_FWD, a, n_res, {r_out(pos, false), r_out(out, true), r_buf(jac, (size_t)n_res * UPK_RAMA_JAC * 4, true)});
 }
 struct RamaBwdArgs { upk_coord_t rama; const float* jac; int n_res; float* contrib; long contrib_stride; };
 __device__ __forceinline__ void b_rama_bwd(const int idx /* (residue, atom slot) */, const int s, upk_coord_t rama, const float* __restrict__ jac, int n_res,
@@ -511,7 +524,7 @@ __device__ __forceinline__ void b_rama_bwd(const int idx /* (residue, atom slot)
 }
 extern "C" int upk_rama_bwd(const upk_launch_t* L, upk_coord_t rama, const float* jac, int n_res, float* contrib, long contrib_stride) {
     FARGS(RamaBwdArgs, a); a.rama = cz(rama); a.jac = jac; a.n_res = n_res; a.contrib = contrib; a.contrib_stride = contrib_stride;
-    return fuse_submit(L, FOP_RAMA_BWD, a, n_res * 5);
+    return fuse_submit(L, FOP_RAMA_BWD, a, n_res * 5, {r_sens(rama, false), r_buf(jac, (size_t)n_res * UPK_RAMA_JAC * 4, false), r_slice(contrib, (size_t)n_res * 60, (size_t)contrib_stride * 4, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,7 +551,7 @@ __device__ __forceinline__ void b_infer_fwd(const int nv, const int s, upk_coord
 extern "C" int upk_infer_fwd(const upk_launch_t* L, upk_coord_t pos, const int* atom, const float* bond_length, int n_virtual,
                              upk_coord_t out, float* dfd) {
     FARGS(InferFwdArgs, a); a.pos = cz(pos); a.atom = atom; a.bond_length = bond_length; a.n_virtual = n_virtual; a.out = cz(out); a.dfd = dfd;
-    return fuse_submit(L, FOP_INFER_FWD, a, n_virtual);
+    return fuse_submit(L, FOP_INFER_FWD, a, n_virtual, {r_out(pos, false), r_out(out, true), r_buf(dfd, (size_t)n_virtual * 48, true)});
 }
 struct InferBwdArgs { upk_coord_t infer; const float* bond_length; const float* dfd; int n_virtual; float* contrib; long contrib_stride; };
 __device__ __forceinline__ void b_infer_bwd(const int nv, const int s, upk_coord_t infer, const float* __restrict__ bond_length, const float* __restrict__ dfd, int n_virtual,
@@ -562,7 +575,7 @@ __device__ __forceinline__ void b_infer_bwd(const int nv, const int s, upk_coord
 extern "C" int upk_infer_bwd(const upk_launch_t* L, upk_coord_t infer, const float* bond_length, const float* dfd, int n_virtual,
                              float* contrib, long contrib_stride) {
     FARGS(InferBwdArgs, a); a.infer = cz(infer); a.bond_length = bond_length; a.dfd = dfd; a.n_virtual = n_virtual; a.contrib = contrib; a.contrib_stride = contrib_stride;
-    return fuse_submit(L, FOP_INFER_BWD, a, n_virtual);
+    return fuse_submit(L, FOP_INFER_BWD, a, n_virtual, {r_sens(infer, false), r_buf(dfd, (size_t)n_virtual * 48, false), r_slice(contrib, (size_t)n_virtual * 36, (size_t)contrib_stride * 4, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,7 +623,7 @@ __device__ __forceinline__ void b_spring(const int nt, const int s, int kind, up
 extern "C" int upk_spring(const upk_launch_t* L, int kind, upk_coord_t pos, const int* id, const float* equil, const float* k, int n,
                           float* contrib, long contrib_stride, float* pot_terms) {
     FARGS(SpringArgs, a); a.kind = kind; a.pos = cz(pos); a.id = id; a.equil = equil; a.kk = k; a.n = n; a.contrib = contrib; a.contrib_stride = contrib_stride; a.pot_terms = pot_terms;
-    return fuse_submit(L, FOP_SPRING, a, n);
+    return fuse_submit(L, FOP_SPRING, a, n, {r_out(pos, false), r_slice(contrib, (size_t)n * kind * 12, (size_t)contrib_stride * 4, true), r_buf(pot_terms, pot_terms ? (size_t)n * 4 : 0, true)});
 }
 
 __global__ void k_cavity(upk_coord_t pos, const int* __restrict__ id, const float* __restrict__ radius, const float* __restrict__ kk,
@@ -673,7 +686,7 @@ __device__ __forceinline__ void b_placement_fwd(const int ne, const int s, const
 extern "C" int upk_placement_fwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t rama, upk_coord_t out,
                                  float* rama_deriv) {
     FARGS(PlacementFwdArgs, a); a.P = pz(*P); a.aff = cz(aff); a.rama = cz(rama); a.out = cz(out); a.rama_deriv = rama_deriv;
-    return fuse_submit(L, FOP_PLACEMENT_FWD, a, P->n_elem);
+    return fuse_submit(L, FOP_PLACEMENT_FWD, a, P->n_elem, {r_out(aff, false), r_out(rama, false), r_out(out, true), r_buf(rama_deriv, P->is_rama ? (size_t)P->n_elem * 2 * P->n_pos_dim * 4 : 0, true)});
 }
 
 struct PlacementBwdArgs { upk_placement_t P; upk_coord_t aff, out; const float* rama_deriv; float* aff_contrib; long aff_stride; float* rama_contrib; long rama_stride; };
@@ -714,7 +727,8 @@ __device__ __forceinline__ void b_placement_bwd(const int ne, const int s, const
 extern "C" int upk_placement_bwd(const upk_launch_t* L, const upk_placement_t* P, upk_coord_t aff, upk_coord_t out,
                                  const float* rama_deriv, float* aff_contrib, long aff_stride, float* rama_contrib, long rama_stride) {
     FARGS(PlacementBwdArgs, a); a.P = pz(*P); a.aff = cz(aff); a.out = cz(out); a.rama_deriv = rama_deriv; a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.rama_contrib = rama_contrib; a.rama_stride = rama_stride;
-    return fuse_submit(L, FOP_PLACEMENT_BWD, a, P->n_elem);
+    return fuse_submit(L, FOP_PLACEMENT_BWD, a, P->n_elem, {r_out(aff, false), r_sens(out, false), r_out(out, false), r_buf(rama_deriv, P->is_rama ? (size_t)P->n_elem * 2 * P->n_pos_dim * 4 : 0, false),
+                        r_slice(aff_contrib, (size_t)P->n_elem * 24, (size_t)aff_stride * 4, true), r_slice(rama_contrib, rama_contrib ? (size_t)P->n_elem * 8 : 0, (size_t)rama_stride * 4, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -737,7 +751,7 @@ __device__ __forceinline__ void b_rama_map_pot(const int nr, const int s, upk_co
 extern "C" int upk_rama_map_pot(const upk_launch_t* L, upk_coord_t rama, const int* residue, const int* map_id, int n,
                                 const float* coeff, int nx, float* pot_terms) {
     FARGS(RamaMapPotArgs, a); a.rama = cz(rama); a.residue = residue; a.map_id = map_id; a.n = n; a.coeff = coeff; a.nx = nx; a.pot_terms = pot_terms;
-    return fuse_submit(L, FOP_RAMA_MAP_POT, a, n);
+    return fuse_submit(L, FOP_RAMA_MAP_POT, a, n, {r_out(rama, false), r_sens(rama, true), r_buf(pot_terms, pot_terms ? (size_t)n * 4 : 0, true)});
 }
 
 // weighted_pos (environment.cpp:132-154)
@@ -753,7 +767,7 @@ __device__ __forceinline__ void b_weighted_pos_fwd(const int i, const int s, upk
 extern "C" int upk_weighted_pos_fwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
                                     const int* index_weight, upk_coord_t out) {
     FARGS(WeightedPosArgs, a); a.pos = cz(pos); a.energy = cz(energy); a.index_pos = index_pos; a.index_weight = index_weight; a.self = cz(out);
-    return fuse_submit(L, FOP_WEIGHTED_POS_FWD, a, out.n_elem);
+    return fuse_submit(L, FOP_WEIGHTED_POS_FWD, a, out.n_elem, {r_out(pos, false), r_out(energy, false), r_out(out, true)});
 }
 __device__ __forceinline__ void b_weighted_pos_bwd(const int i, const int s, upk_coord_t pos, upk_coord_t energy, const int* __restrict__ index_pos,
                                                    const int* __restrict__ index_weight, upk_coord_t self) {
@@ -769,7 +783,7 @@ __device__ __forceinline__ void b_weighted_pos_bwd(const int i, const int s, upk
 extern "C" int upk_weighted_pos_bwd(const upk_launch_t* L, upk_coord_t pos, upk_coord_t energy, const int* index_pos,
                                     const int* index_weight, upk_coord_t self) {
     FARGS(WeightedPosArgs, a); a.pos = cz(pos); a.energy = cz(energy); a.index_pos = index_pos; a.index_weight = index_weight; a.self = cz(self);
-    return fuse_submit(L, FOP_WEIGHTED_POS_BWD, a, self.n_elem);
+    return fuse_submit(L, FOP_WEIGHTED_POS_BWD, a, self.n_elem, {r_sens(self, false), r_out(self, false), r_sens(pos, true), r_sens(energy, true)});
 }
 
 // nonlinear_coupling (environment.cpp:358-369)
@@ -786,7 +800,7 @@ __device__ __forceinline__ void b_nonlinear_coupling(const int i, const int s, u
 extern "C" int upk_nonlinear_coupling(const upk_launch_t* L, upk_coord_t input, const int* types, const float* coeff, int n_coeff,
                                       float offset, float inv_dx, float* pot_terms) {
     FARGS(NonlinearCouplingArgs, a); a.input = cz(input); a.types = types; a.coeff = coeff; a.n_coeff = n_coeff; a.offset = offset; a.inv_dx = inv_dx; a.pot_terms = pot_terms;
-    return fuse_submit(L, FOP_NONLINEAR_COUPLING, a, input.n_elem);
+    return fuse_submit(L, FOP_NONLINEAR_COUPLING, a, input.n_elem, {r_out(input, false), r_sens(input, true), r_buf(pot_terms, pot_terms ? (size_t)input.n_elem * 4 : 0, true)});
 }
 
 // hbond_energy (hbond.cpp:430-444)
@@ -798,7 +812,7 @@ __device__ __forceinline__ void b_hbond_energy(const int nv, const int s, upk_co
 }
 extern "C" int upk_hbond_energy(const upk_launch_t* L, upk_coord_t protein_hbond, float E_protein, float* pot_terms) {
     FARGS(HBondEnergyArgs, a); a.ph = cz(protein_hbond); a.Ep = E_protein; a.pot_terms = pot_terms;
-    return fuse_submit(L, FOP_HBOND_ENERGY, a, protein_hbond.n_elem);
+    return fuse_submit(L, FOP_HBOND_ENERGY, a, protein_hbond.n_elem, {r_out(protein_hbond, false), r_sens(protein_hbond, true), r_buf(pot_terms, pot_terms ? (size_t)protein_hbond.n_elem * 4 : 0, true)});
 }
 
 // protein_hbond helpers (hbond.cpp:320-335, 343-365)
@@ -813,7 +827,7 @@ __device__ __forceinline__ void b_protein_hbond_finish(const int nv, const int s
 }
 extern "C" int upk_protein_hbond_finish(const upk_launch_t* L, upk_coord_t infer, upk_coord_t out) {
     FARGS(ProteinHBondFinishArgs, a); a.infer = cz(infer); a.out = cz(out);
-    return fuse_submit(L, FOP_PROTEIN_HBOND_FINISH, a, out.n_elem);
+    return fuse_submit(L, FOP_PROTEIN_HBOND_FINISH, a, out.n_elem, {r_out(infer, false), r_out(out, true)});
 }
 struct ProteinHBondBwdPreArgs { upk_coord_t self; float* sens_scaled; };
 __device__ __forceinline__ void b_protein_hbond_bwd_pre(const int nv, const int s, upk_coord_t self, float* __restrict__ sens_scaled) {
@@ -822,7 +836,7 @@ __device__ __forceinline__ void b_protein_hbond_bwd_pre(const int nv, const int 
 }
 extern "C" int upk_protein_hbond_bwd_pre(const upk_launch_t* L, upk_coord_t self, float* sens_scaled) {
     FARGS(ProteinHBondBwdPreArgs, a); a.self = cz(self); a.sens_scaled = sens_scaled;
-    return fuse_submit(L, FOP_PROTEIN_HBOND_BWD_PRE, a, self.n_elem);
+    return fuse_submit(L, FOP_PROTEIN_HBOND_BWD_PRE, a, self.n_elem, {r_sens(self, false), r_out(self, false), r_buf(sens_scaled, (size_t)self.n_elem * 4, true)});
 }
 struct ProteinHBondPassthroughArgs { upk_coord_t self, infer; const int* loc1; int n1; const int* loc2; int n2; };
 __device__ __forceinline__ void b_protein_hbond_passthrough(const int nv, const int s, upk_coord_t self, upk_coord_t infer, const int* __restrict__ loc1, int n1,
@@ -839,7 +853,7 @@ __device__ __forceinline__ void b_protein_hbond_passthrough(const int nv, const 
 extern "C" int upk_protein_hbond_passthrough(const upk_launch_t* L, upk_coord_t self, upk_coord_t infer, const int* loc1, int n1,
                                              const int* loc2, int n2) {
     FARGS(ProteinHBondPassthroughArgs, a); a.self = cz(self); a.infer = cz(infer); a.loc1 = loc1; a.n1 = n1; a.loc2 = loc2; a.n2 = n2;
-    return fuse_submit(L, FOP_PROTEIN_HBOND_PASSTHROUGH, a, n1 + n2);
+    return fuse_submit(L, FOP_PROTEIN_HBOND_PASSTHROUGH, a, n1 + n2, {r_sens(self, false), r_sens(infer, true)});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -855,7 +869,9 @@ __device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, flo
 struct BackbonePairsArgs { upk_coord_t aff; const int* residue; const int* id; const int* n_atom; const float* ref_pos; int n_res; float dist_cutoff;
                            float* aff_contrib; long aff_stride; float* pot_terms; };
 // collective op of the system's workgroup (any number of wavefronts); lds: (n_res * 17 + waves * BBP_QUEUE) floats
-__device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, const int s, float* lds) {
+// rows [row0, row1) of the system (the whole system as a fused op; a range of BBP_ROWS per workgroup in a launch of its own)
+#define BBP_ROWS 64
+__device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, const int s, float* lds, const int row0 = 0, int row1 = 1 << 30) {
     const upk_coord_t aff = A.aff; const int* __restrict__ residue = A.residue; const int* __restrict__ id = A.id; const int* __restrict__ n_atom = A.n_atom;
     const float* __restrict__ ref_pos = A.ref_pos; const int n_res = A.n_res; const float dist_cutoff = A.dist_cutoff;
     float* __restrict__ aff_contrib = A.aff_contrib; const long aff_stride = A.aff_stride; float* __restrict__ pot_terms = A.pot_terms;
@@ -884,7 +900,8 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
     int* q = queues + wave * BBP_QUEUE;
     const int qi = lane >> 4, i1 = (lane >> 2) & 3, i2 = lane & 3;
-    for (int nr1 = wave; nr1 < n_res; nr1 += n_wave) {
+    if (row1 > n_res) row1 = n_res;
+    for (int nr1 = row0 + wave; nr1 < row1; nr1 += n_wave) {
         const f3 t1 = ld3(ctr + nr1 * 3);
         const int na1 = meta[nr1 * 2], id1 = meta[nr1 * 2 + 1];
         const f3 x1 = ld3(atoms + nr1 * 12 + i1 * 3);
@@ -940,13 +957,26 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
         }
     }
 }
+__global__ void __launch_bounds__(1024) k_backbone_pairs(BackbonePairsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float bbp_lds[];
+    c_backbone_pairs(A, blockIdx.y, bbp_lds, blockIdx.x * BBP_ROWS, (blockIdx.x + 1) * BBP_ROWS);
+}
 extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
                                   const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
                                   float* pot_terms) {
     const size_t lds = ((size_t)n_res * (12 + 3 + 2) + 16 * BBP_QUEUE) * sizeof(float);
     if (lds > 150 * 1024) return 9001;   // > ~2200 residues: needs the tiled variant
+    // a system of more than a hundred residues gets several workgroups (each stages all centres, serves BBP_ROWS rows): as an op of the
+    // fused list its N^2 / 2 centre tests would sit on the 16 wavefronts of one workgroup
+    if (n_res > 2 * BBP_ROWS) {
+        UPK_FLUSH(L);
+        FARGS(BackbonePairsArgs, b); b.aff = cz(aff); b.residue = residue; b.id = id; b.n_atom = n_atom; b.ref_pos = ref_pos; b.n_res = n_res; b.dist_cutoff = dist_cutoff;
+        b.aff_contrib = aff_contrib; b.aff_stride = aff_stride; b.pot_terms = pot_terms;
+        hipLaunchKernelGGL(k_backbone_pairs, dim3((n_res + BBP_ROWS - 1) / BBP_ROWS, L->n_system), dim3(1024), lds, ST(L), b);
+        return launch_status();
+    }
     FARGS(BackbonePairsArgs, a); a.aff = cz(aff); a.residue = residue; a.id = id; a.n_atom = n_atom; a.ref_pos = ref_pos; a.n_res = n_res; a.dist_cutoff = dist_cutoff; a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.pot_terms = pot_terms;
-    return fuse_submit(L, FOP_BACKBONE_PAIRS, a, 0, (int)lds);
+    return fuse_submit(L, FOP_BACKBONE_PAIRS, a, 0, {r_out(aff, false), r_slice(aff_contrib, (size_t)n_res * 24, (size_t)aff_stride * 4, true), r_buf(pot_terms, pot_terms ? (size_t)n_res * 4 : 0, true), r_lds()}, (int)lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1635,6 +1665,8 @@ struct FuseQueue {
     std::vector<FusedOp> table;                                   // host mirror of the registered ops
     std::unordered_map<unsigned long long, std::vector<int>> index;   // hash of (kind, n, lds, flags, payload) -> ids
     FusedIds pending; int pending_lds = 0; bool pending_heavy = false;
+    std::vector<FuseRegion> live;                                 // regions touched since the last barrier of the pending list
+    bool elide = true;                                            // UPSIDE_HIP_FUSE_BARRIERS=1: a barrier in front of every op
     long n_launch = 0, n_ops_run = 0;
 };
 unsigned long long fuse_hash(const FusedOp& op) {
@@ -1673,6 +1705,7 @@ extern "C" void* upk_fuse_create(int n_system) {
     const char* e = getenv("UPSIDE_HIP_FUSE");
     q->enabled = !(e && !atoi(e));
     q->pending.n = 0;
+    { const char* b = getenv("UPSIDE_HIP_FUSE_BARRIERS"); q->elide = !(b && atoi(b)); }
     if (hipMalloc((void**)&q->table_dev, (size_t)q->cap * sizeof(FusedOp)) != hipSuccess) { delete q; return nullptr; }
     q->table.reserve(256);
     return q;
@@ -1691,16 +1724,39 @@ extern "C" int upk_fuse_flush(const upk_launch_t* L) {
     FuseQueue* q = (FuseQueue*)L->fuse;
     if (!q || !q->pending.n) return 0;
     size_t lds = (size_t)q->pending_lds; if (lds < 64) lds = 64;      // (c_reduce_sum's partial sums)
+    static const bool debug = getenv("UPSIDE_HIP_FUSE_DEBUG") != nullptr;
+    if (debug) { fprintf(stderr, "fused launch (%s):", q->pending_heavy ? "heavy" : "light"); for (int k = 0; k < q->pending.n; ++k) fprintf(stderr, " %d%s", q->table[q->pending.id[k]].kind, (q->table[q->pending.id[k]].flags & 1) ? "" : "|"); fprintf(stderr, "\n"); }
     fuse_launch<true>(q->pending_heavy, q->threads, q->n_system, lds, ST(L), (const FusedOp*)q->table_dev, q->pending);
     q->n_launch += 1; q->n_ops_run += q->pending.n;
-    q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false;
+    q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false; q->live.clear();
     return launch_status();
 }
-static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, int flags) {
+static bool fuse_overlap(const FuseRegion& a, const FuseRegion& b, int n_system) {
+    if (!a.write && !b.write) return false;
+    if (!a.lo || !b.lo) return false;                                  // an optional buffer that is not there
+    if (a.lo == FUSE_ALL || b.lo == FUSE_ALL) return true;
+    if (a.lo == FUSE_LDS || b.lo == FUSE_LDS) return a.lo == b.lo;
+    if (!a.len || !b.len) return false;
+    const size_t d = a.lo < b.lo ? (size_t)(b.lo - a.lo) : (size_t)(a.lo - b.lo);
+    if (a.stride == b.stride && d < a.stride) return a.lo < b.lo ? d < a.len : d < b.len;       // the same per-system layout: compare system 0's slices
+    const char* ae = a.lo + (size_t)(n_system - 1) * a.stride + a.len; const char* be = b.lo + (size_t)(n_system - 1) * b.stride + b.len;   // else the hulls
+    return a.lo < be && b.lo < ae;
+}
+static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, size_t bytes, int n, int lds_bytes, const FuseRegion* regs, int n_regs) {
     FusedOp op; memset(&op, 0, sizeof(op));
-    op.kind = kind; op.n = n; op.lds_bytes = lds_bytes; op.flags = flags;
+    op.kind = kind; op.n = n; op.lds_bytes = lds_bytes; op.flags = 0;
     memcpy(op.payload, args, bytes);
     FuseQueue* q = (FuseQueue*)L->fuse;
+    if (L->batch) { const int r_ = upk_batch_run(L); if (r_) return r_; }      // an open merged launch (kernels_batch.h) runs first
+    if (q && q->enabled) {
+        if (q->pending.n == FUSE_MAX_PENDING) UPK_FLUSH(L);
+        // barrier in front of this op?  only if it touches something an op since the last barrier touched, one of them writing
+        bool conflict = !q->elide;
+        for (int i = 0; i < n_regs && !conflict; ++i)
+            for (const FuseRegion& r : q->live) if (fuse_overlap(regs[i], r, q->n_system)) { conflict = true; break; }
+        if (conflict) q->live.clear(); else op.flags |= 1;
+        q->live.insert(q->live.end(), regs, regs + n_regs);
+    }
     auto alone = [&]() {
         size_t lds = (size_t)lds_bytes; if (lds < 64) lds = 64;
         fuse_launch<false>(kind == FOP_AFFINE_BWD, q ? q->threads : fuse_threads(L->n_system), L->n_system, lds, ST(L), op);
@@ -1716,13 +1772,17 @@ static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, si
     if (id < 0) {
         if ((int)q->table.size() >= q->cap || (int)q->table.size() >= 65535) { UPK_FLUSH(L); return alone(); }   // (arguments that change every step)
         id = (int)q->table.size();
-        if (hipMemcpy(q->table_dev + id, &op, sizeof(op), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); UPK_FLUSH(L); return alone(); }
+        // (a blocking copy from pageable memory may return while the DMA is still in flight, and the engine's streams do not order against
+        //  the NULL stream: the record goes through the launch's own stream, which is then drained -- once per distinct op)
+        if (hipMemcpyAsync(q->table_dev + id, &op, sizeof(op), hipMemcpyHostToDevice, ST(L)) != hipSuccess || hipStreamSynchronize(ST(L)) != hipSuccess) {
+            (void)hipGetLastError(); UPK_FLUSH(L); return alone();
+        }
         q->table.push_back(op); bucket.push_back(id);
     }
-    if (q->pending.n == FUSE_MAX_PENDING) UPK_FLUSH(L);
     if (kind == FOP_AFFINE_BWD) {
-        // a large batch runs the register-hungry op in a launch of its own: the ops around it keep the light instance's occupancy
-        if (q->n_system >= 256) { UPK_FLUSH(L); q->pending.id[q->pending.n++] = (unsigned short)id; q->pending_heavy = true; return upk_fuse_flush(L); }
+        // a large batch, or a system whose other ops want all 1024 lanes, runs the register-hungry op in a launch of its own: the ops
+        // around it keep the light instance (its occupancy, its workgroup size)
+        if (q->n_system >= 256 || n > 64) { UPK_FLUSH(L); q->pending.id[q->pending.n++] = (unsigned short)id; q->pending_heavy = true; return upk_fuse_flush(L); }
         q->pending_heavy = true;
     }
     q->pending.id[q->pending.n++] = (unsigned short)id;

@@ -17,7 +17,10 @@ using namespace up;
 #define ST(L) ((hipStream_t)(L)->stream)
 #define ROWS_PER_BLOCK 4
 #define IG_BLOCK (ROWS_PER_BLOCK * UP_WAVE)
+#ifndef UPK_LAUNCH_STATUS_DEFINED
+#define UPK_LAUNCH_STATUS_DEFINED
 static inline int launch_status() { return (int)hipGetLastError(); }
+#endif
 static inline unsigned rows_grid(int n_rows) { return n_rows > 0 ? (unsigned)((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) : 1u; }   // an empty side still needs a non-zero grid
 
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
@@ -114,10 +117,10 @@ __device__ __forceinline__ void load_elem(float* x, const upk_coord_t& node, int
 // K1: one workgroup per system decides whether the cached lists are still valid (interaction_graph.h:57-90).  A
 // system that moved too far is appended to this step's flagged list and its reference positions are refreshed
 // right here (x, y, z and the element id in the 4th word), so the rebuild streams one float4 array per side.
-__global__ void k_pairlist_check(upk_igraph_t G) {
+__device__ __forceinline__ void d_pairlist_check(const upk_igraph_t& G, const BX B, float* lds_unused) {
     __shared__ int moved;
     __shared__ float top[2][16];             // per wavefront: the largest and second largest squared displacement
-    const int s = blockIdx.y;
+    const int s = B.by;
     if (threadIdx.x == 0) moved = 0;
     __syncthreads();
     const int n_tot = G.symmetric ? G.n1 : G.n1 + G.n2;
@@ -180,7 +183,9 @@ __global__ void k_pairlist_check(upk_igraph_t G) {
         if (s == 0) G.flagged[(size_t)(G.parity ^ 1) * G.flag_stride] = 0;
     }
 }
+__global__ void k_pairlist_check(upk_igraph_t G)  { d_pairlist_check(G, BX_REAL, nullptr); }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
+    if (batch_add(L, BK_CHECK, 1, L->n_system, 0, G, sizeof(*G))) return 0;
     UPK_FLUSH(L);
     // (latency bound -- every element is a chain load position -> load reference -> store packed copy: as many lanes as the
     //  system has elements, up to a full workgroup, so that a lane walks one or two elements instead of seven)
@@ -213,22 +218,21 @@ __device__ __forceinline__ int plb_node_of(const upk_igraph_t& G, int id) {
     return (id >> 8) + ((-(int)(nr == 6) & G.mark_start6) | (-(int)(nr == 3) & G.mark_start3));
 }
 template <bool STAGED, int IT>
-__global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1, int rows_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float plb_lds[];
-    float4* oth = (float4*)plb_lds;
+__device__ __forceinline__ void d_pairlist_build(const upk_igraph_t& G, int blocks1, int rows_per_wg, const BX B, float* plb_lds) {
+        float4* oth = (float4*)plb_lds;
     constexpr bool SYM = IT == UPK_IT_ROTAMER || IT == UPK_IT_RADIAL;
     constexpr bool UPPER = IT == UPK_IT_ROTAMER;   // each bead pair once (partner above the row, i1 < i2 as in the reference's edge list): the
                                                    // rotamer passes visit a pair once and give both beads their share
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
-    const bool side1 = (int)blockIdx.x < blocks1;             // workgroups [0, blocks1) serve the side-1 rows
-    const int rb = side1 ? blockIdx.x : blockIdx.x - blocks1;
+    const bool side1 = (int)B.bx < blocks1;             // workgroups [0, blocks1) serve the side-1 rows
+    const int rb = side1 ? B.bx : B.bx - blocks1;
     const int n_my = side1 ? G.n1 : G.n2, n_other = side1 ? G.n2 : G.n1;
     const int n_pad = (n_other + 63) & ~63;
     const int cap = side1 ? G.cap1 : G.cap2;
     const float cut2 = G.cache_cutoff * G.cache_cutoff;
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         const int s = fl[1 + fi];
         const float4* src = (const float4*)((side1 ? G.cache_pos2 : G.cache_pos1) + (size_t)s * n_other * 4);
         const float4* mine = (const float4*)((side1 ? G.cache_pos1 : G.cache_pos2) + (size_t)s * n_my * 4);
@@ -283,16 +287,19 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
         }
     }
 }
+template <bool STAGED, int IT>
+__global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blocks1, int rows_per_wg)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_pairlist_build<STAGED, IT>(G, blocks1, rows_per_wg, BX_REAL, lds_dyn_);
+}
 template <int IT>
 static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, size_t lds, bool staged, int blocks1) {
     const int rows = plb_rows(L->n_system);
     if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1, rows);
     else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1, rows);
 }
-extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) {
-    UPK_FLUSH(L); return upk_pairlist_build_sides(L, G, 3); }
+extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) { return upk_pairlist_build_sides(L, G, 3); }
 extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_t* G, int sides) {
-    UPK_FLUSH(L);
     const int rows = plb_rows(L->n_system);
     const int blocks1 = (sides & 1) ? (G->n1 + rows - 1) / rows : 0;
     const int blocks2 = (G->symmetric || !(sides & 2)) ? 0 : (G->n2 + rows - 1) / rows;
@@ -303,6 +310,12 @@ extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_
     static int force_unstaged = -1;   // UPSIDE_HIP_PLB_UNSTAGED=1 exercises the path of systems whose elements do not fit LDS
     if (force_unstaged < 0) { const char* e = getenv("UPSIDE_HIP_PLB_UNSTAGED"); force_unstaged = (e && atoi(e)) ? 1 : 0; }
     const bool staged = lds <= 150 * 1024 && !force_unstaged;
+    if (staged) {       // merged launch (kernels_batch.h)
+        const int bk = G->itype == UPK_IT_ROTAMER ? BK_BUILD_ROT : G->itype == UPK_IT_HBOND_COVERAGE ? BK_BUILD_COV : G->itype == UPK_IT_ENVIRONMENT ? BK_BUILD_ENV
+                     : G->itype == UPK_IT_PROTEIN_HBOND ? BK_BUILD_HB : 0;
+        if (bk && batch_add(L, bk, (int)grid.x, (int)grid.y, lds, G, sizeof(*G), nullptr, 0, blocks1, rows)) return 0;
+    }
+    UPK_FLUSH(L);
     switch (G->itype) {
         case UPK_IT_ROTAMER: plb_launch<UPK_IT_ROTAMER>(L, G, grid, lds, staged, blocks1); break;
         case UPK_IT_HBOND_COVERAGE: plb_launch<UPK_IT_HBOND_COVERAGE>(L, G, grid, lds, staged, blocks1); break;
@@ -344,10 +357,9 @@ __device__ __forceinline__ plr_v2 dist2_exact2(plr_v2 ax, plr_v2 ay, plr_v2 az, 
 // arithmetic issues packed and the per-trip bookkeeping (loop control, ballots, list-length broadcasts) is shared: the kernel
 // is bound by instruction issue, not by the 4 bytes it reads per cached pair.
 template <bool SYM>
-__global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, int side, int rows_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) float plr_lds[];
-    float4* oth = (float4*)plr_lds;
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int side, int rows_per_wg, const BX B, float* plr_lds) {
+        float4* oth = (float4*)plr_lds;
+    const int s = B.by;
     // (the wavefront index is uniform, which the compiler cannot see: made scalar, row numbers, list lengths and row base addresses
     //  stay in scalar registers and the loop control runs on the scalar unit)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
@@ -370,8 +382,8 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     const int jmask = G.nbr_j_bits ? (1 << G.nbr_j_bits) - 1 : 0x7fffffff;
     // this wavefront's rows: a contiguous run of at most 64 (lane r holds row r0 + r's position and list length)
     const int per_wave = (rows_per_wg + n_wave - 1) / n_wave;     // <= 64 (launcher)
-    const int r0 = blockIdx.x * rows_per_wg + wave * per_wave;
-    int r1 = r0 + per_wave; { const int wg_end = (blockIdx.x + 1) * rows_per_wg; if (r1 > wg_end) r1 = wg_end; if (r1 > n_rows) r1 = n_rows; }
+    const int r0 = B.bx * rows_per_wg + wave * per_wave;
+    int r1 = r0 + per_wave; { const int wg_end = (B.bx + 1) * rows_per_wg; if (r1 > wg_end) r1 = wg_end; if (r1 > n_rows) r1 = n_rows; }
     if (r0 >= r1) return;
     const bool have = r0 + lane < r1;
     const float4 my_x = have ? mine[r0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -421,11 +433,16 @@ __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, i
     }
     if (have) { hcnt[r0 + lane] = my_n; if (SYM && hlo) hlo[r0 + lane] = my_lo; }
 }
+template <bool SYM>
+__global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, int side, int rows_per_wg)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_pairlist_refine<SYM>(G, side, rows_per_wg, BX_REAL, lds_dyn_);
+}
 // Rows of a handful of cached neighbours (backbone hydrogen bonds: three per donor or acceptor): one LANE per row walks its list --
 // the row-pair machinery above costs a fixed ~100 instructions and a dependent chain per pair of rows, 0.19 ms per launch for
 // 840 cached pairs per system.  Same hit lists, in the same order.
-__global__ void __launch_bounds__(256) k_pairlist_refine_short(upk_igraph_t G, int side) {
-    const int s = blockIdx.y, row = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_pairlist_refine_short(const upk_igraph_t& G, int side, const BX B, float* lds_unused) {
+    const int s = B.by, row = B.bx * blockDim.x + threadIdx.x;
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G.n1 : G.n2, n_other = rows1 ? G.n2 : G.n1;
     if (row >= n_rows) return;
@@ -450,12 +467,14 @@ __global__ void __launch_bounds__(256) k_pairlist_refine_short(upk_igraph_t G, i
     }
     ((rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows)[row] = n;
 }
+__global__ void __launch_bounds__(256) k_pairlist_refine_short(upk_igraph_t G, int side)  { d_pairlist_refine_short(G, side, BX_REAL, nullptr); }
 extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G, int side) {
-    UPK_FLUSH(L);
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G->n1 : G->n2, n_other = rows1 ? G->n2 : G->n1;
     if (n_rows < 1) return 0;
     if (G->itype == UPK_IT_PROTEIN_HBOND && !G->symmetric) {
+        if (batch_add(L, BK_REFINE_SHORT, (n_rows + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, side)) return 0;
+        UPK_FLUSH(L);
         hipLaunchKernelGGL(k_pairlist_refine_short, dim3((n_rows + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side);
         return launch_status();
     }
@@ -469,6 +488,11 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
         if (small_rows < 0) { const char* e = getenv("UPSIDE_HIP_PLR_ROWS_SMALL"); small_rows = e ? atoi(e) : 128; }
         if (small_rows > 0 && n_rows <= 512 && rows_per_wg > small_rows) rows_per_wg = small_rows;
     }
+    {   // merged launch: 1024-lane workgroups, four times the wavefronts -- four times the rows, so that a wavefront keeps its run of row pairs
+        const int rows_b = rows_per_wg * 4;
+        if (batch_add(L, G->symmetric ? BK_REFINE_SYM : BK_REFINE, (n_rows + rows_b - 1) / rows_b, L->n_system, lds, G, sizeof(*G), nullptr, 0, side, rows_b)) return 0;
+    }
+    UPK_FLUSH(L);
     const dim3 grid((n_rows + rows_per_wg - 1) / rows_per_wg, L->n_system);
     if (G->symmetric) hipLaunchKernelGGL(k_pairlist_refine<true>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
     else hipLaunchKernelGGL(k_pairlist_refine<false>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
@@ -501,9 +525,9 @@ __device__ __forceinline__ void order_rows(unsigned short* __restrict__ ord, int
     for (int r = threadIdx.x; r < n_rows; r += blockDim.x) ord[atomicAdd(&hist[PLO_BINS - 1 - key(r)], 1)] = (unsigned short)r;
     __syncthreads();
 }
-__global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int side) {
+__device__ __forceinline__ void d_pairlist_order(const upk_igraph_t& G, int side, const BX B, float* lds_unused) {
     __shared__ int hist[PLO_BINS], scratch[16];
-    const int s = blockIdx.x;
+    const int s = B.bx;
     const bool rows1 = side == 1;
     const int n_rows = rows1 ? G.n1 : G.n2;
     const int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
@@ -515,11 +539,13 @@ __global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int
                    [&](int r) { const int c = hcnt[r] - hlo[r]; return c < PLO_BINS ? c : PLO_BINS - 1; }, hist, scratch);
     }
 }
+__global__ void __launch_bounds__(PLO_BINS) k_pairlist_order(upk_igraph_t G, int side)  { d_pairlist_order(G, side, BX_REAL, nullptr); }
 extern "C" int upk_pairlist_order(const upk_launch_t* L, const upk_igraph_t* G, int side) {
-    UPK_FLUSH(L);
     const int n_rows = side == 1 ? G->n1 : G->n2;
     if (n_rows < 1) return 0;
     if (n_rows > 65535) return 9009;   // (16-bit row ids; larger systems take the list-walking kernels, which need no order)
+    if (batch_add(L, BK_ORDER, L->n_system, 1, 0, G, sizeof(*G), nullptr, 0, side)) return 0;
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_pairlist_order, dim3(L->n_system), dim3(PLO_BINS), 0, ST(L), *G, side);
     return launch_status();
 }

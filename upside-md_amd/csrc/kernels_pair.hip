@@ -13,7 +13,10 @@
 using namespace up;
 
 #define ST(L) ((hipStream_t)(L)->stream)
+#ifndef UPK_LAUNCH_STATUS_DEFINED
+#define UPK_LAUNCH_STATUS_DEFINED
 static inline int launch_status() { return (int)hipGetLastError(); }
+#endif
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
 
 struct PairArgs {
@@ -155,9 +158,8 @@ struct RowOp {
 
 // SIDES: 1 or 2 = the rows of that side; 3 = side 1, then side 2 (protein_hbond: both row sets in one launch)
 template <int IT, int SIDES, int MODE, bool POLY>
-__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t G, PairArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_pair_rows(const upk_igraph_t& G, const PairArgs& A, const BX B, float* lds) {
+        const int s = B.by;
     const PairLds L = pair_lds(lds, G, A.tab_floats);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
         stage_ranges(L.range, L.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
         __syncthreads();
         RowOp<IT, 1, MODE, POLY, LANES> op(G, L, A, s);
-        group_batch_loop<RowOp<IT, 1, MODE, POLY, LANES>, LANES>(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x);
+        group_batch_loop<RowOp<IT, 1, MODE, POLY, LANES>, LANES>(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, B.bx, B.gx);
     }
     if (SIDES & 2) {
         if (SIDES == 3) __syncthreads();
@@ -181,8 +183,13 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t 
         stage_ranges(L.range, L.ord, G.hcnt2 + (size_t)s * G.n2, nullptr, G.ord2 + (size_t)s * G.n2, G.n2);
         __syncthreads();
         RowOp<IT, 2, MODE, POLY, LANES> op(G, L, A, s);
-        group_batch_loop<RowOp<IT, 2, MODE, POLY, LANES>, LANES>(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, blockIdx.x, gridDim.x);
+        group_batch_loop<RowOp<IT, 2, MODE, POLY, LANES>, LANES>(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, B.bx, B.gx);
     }
+}
+template <int IT, int SIDES, int MODE, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_rows(upk_igraph_t G, PairArgs A)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_pair_rows<IT, SIDES, MODE, POLY>(G, A, BX_REAL, lds_dyn_);
 }
 
 // End of a backward pass whose workgroup is the system's only one: the other side's totals leave the LDS accumulators ELEMENT by element --
@@ -251,10 +258,9 @@ struct BackwardOp {
 };
 
 template <int IT, int RS, bool POLY>
-__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igraph_t G, PairArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int DO = BackwardOp<IT, RS, POLY>::DO;
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_pair_backward(const upk_igraph_t& G, const PairArgs& A, const BX B, float* lds) {
+        constexpr int DO = BackwardOp<IT, RS, POLY>::DO;
+    const int s = B.by;
     const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
     const PairLds L = pair_lds(lds, G, A.tab_floats);
     unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
@@ -271,14 +277,14 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
     {
         BackwardOp<IT, RS, POLY> op(G, L, oacc, A.sens_mode, s);
         const int cap = RS == 1 ? G.cap1 : G.cap2;
-        group_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x);
+        group_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx);
     }
     __syncthreads();
     const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;
     const int* oloc = RS == 1 ? G.loc2 : G.loc1;
     float* osens = C_SENS(onode, s);
     unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
-    const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    const bool alone = B.gx == 1;        // the system's only workgroup: its accumulators are the totals
     if (alone && (onode.stride & 3) == 0) { flush_other_side<DO>(osens, oloc, onode.stride, n_other, [&](int c, int i) { return from_fixed32(oacc[i * DO + c]); }); return; }
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
         const unsigned long long a = oacc[t];
@@ -287,6 +293,11 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igrap
         if (alone) osens[(size_t)oloc[i] * onode.stride + c] += from_fixed32(a);
         else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
     }
+}
+template <int IT, int RS, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_pair_backward(upk_igraph_t G, PairArgs A)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_pair_backward<IT, RS, POLY>(G, A, BX_REAL, lds_dyn_);
 }
 // ---- packed passes of the hbond_coverage graphs (pair2_device.h): two partners per lane, 4-lane row groups ----------------
 // x1 is always the side-1 element (H-bond site, 7 components: [6] = its bond probability), x2 the side-2 element (bead).
@@ -350,9 +361,8 @@ struct CovRowOp2 {
     }
 };
 template <int RS, bool POLY>
-__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t G, PairArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_cov_rows2(const upk_igraph_t& G, const PairArgs& A, const BX B, float* lds) {
+        const int s = B.by;
     const PairLds L = pair2_lds(lds, G, A.tab_floats);
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
     stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0));
@@ -362,7 +372,12 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t 
     stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
     __syncthreads();
     CovRowOp2<RS, POLY> op(G, L, A, s);
-    group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x, RS == 1 ? G.n2 : G.n1);
+    group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, RS == 1 ? G.n2 : G.n1);
+}
+template <int RS, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t G, PairArgs A)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_cov_rows2<RS, POLY>(G, A, BX_REAL, lds_dyn_);
 }
 
 // backward over the rows of side RS, ONE visit per pair: the row element's gradient in registers, the partner's through the
@@ -433,10 +448,9 @@ struct CovBackwardOp2 {
     }
 };
 template <int RS, bool POLY>
-__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igraph_t G, PairArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int DO = CovBackwardOp2<RS, POLY>::DO;
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_cov_backward2(const upk_igraph_t& G, const PairArgs& A, const BX B, float* lds) {
+        constexpr int DO = CovBackwardOp2<RS, POLY>::DO;
+    const int s = B.by;
     const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
     const PairLds L = pair2_lds(lds, G, A.tab_floats);
     unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
@@ -455,14 +469,14 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igrap
         CovBackwardOp2<RS, POLY> op(G, L, oacc, A.sens_mode, s);
         op.site_sens = site_sens;
         const int cap = RS == 1 ? G.cap1 : G.cap2;
-        group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, blockIdx.x, gridDim.x, n_other);
+        group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, n_other);
     }
     __syncthreads();
     const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;
     const int* oloc = RS == 1 ? G.loc2 : G.loc1;
     float* osens = C_SENS(onode, s);
     unsigned long long* gacc = G.gacc ? G.gacc + (size_t)s * n_other * 8 : nullptr;
-    const bool alone = gridDim.x == 1;        // the system's only workgroup: its accumulators are the totals
+    const bool alone = B.gx == 1;        // the system's only workgroup: its accumulators are the totals
     if (alone && (onode.stride & 3) == 0) { flush_other_side<DO>(osens, oloc, onode.stride, n_other, [&](int c, int i) { return from_fixed22(oacc[c * n_other + i]); }); return; }
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) {
         const int i = t / DO, c = t - i * DO;
@@ -472,6 +486,11 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igrap
         else atomicAdd(gacc + i * 8 + c, a);   // exact partial sums of the system's workgroups; k_pair_backward_finish converts
     }
 }
+template <int RS, bool POLY>
+__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_backward2(upk_igraph_t G, PairArgs A)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_cov_backward2<RS, POLY>(G, A, BX_REAL, lds_dyn_);
+}
 static bool pair2_enabled() {          // UPSIDE_HIP_PAIR2=0: the scalar passes (one partner per lane) -- A/B and tests
     static int v = -1;
     if (v < 0) { const char* e = getenv("UPSIDE_HIP_PAIR2"); v = (e && !atoi(e)) ? 0 : 1; }
@@ -479,20 +498,21 @@ static bool pair2_enabled() {          // UPSIDE_HIP_PAIR2=0: the scalar passes 
 }
 
 // global accumulators (several workgroups per system) -> the other side's sens; cleared for the next evaluation
-__global__ void k_pair_backward_finish(upk_igraph_t G, int other_side, double unit) {   // unit: value of one accumulator count
-    const int s = blockIdx.y;
+__device__ __forceinline__ void d_pair_backward_finish(const upk_igraph_t& G, int other_side, double unit, const BX B, float* lds_unused) {   // unit: value of one accumulator count
+    const int s = B.by;
     const int n_other = other_side == 1 ? G.n1 : G.n2, dim = other_side == 1 ? G.dim1 : G.dim2;
     const upk_coord_t& onode = other_side == 1 ? G.node1 : G.node2;
     const int* oloc = other_side == 1 ? G.loc1 : G.loc2;
     float* osens = C_SENS(onode, s);
     unsigned long long* gacc = G.gacc + (size_t)s * n_other * 8;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_other * 8; t += gridDim.x * blockDim.x) {
+    for (int t = B.bx * blockDim.x + threadIdx.x; t < n_other * 8; t += B.gx * blockDim.x) {
         const int i = t >> 3, c = t & 7;
         if (c >= dim) continue;
         const unsigned long long a = gacc[t];
         if (a) { osens[(size_t)oloc[i] * onode.stride + c] += (float)((double)(long long)a * unit); gacc[t] = 0ull; }
     }
 }
+__global__ void k_pair_backward_finish(upk_igraph_t G, int other_side, double unit)  { d_pair_backward_finish(G, other_side, unit, BX_REAL, nullptr); }
 
 // LDS bytes of a staged pair pass; false when the system does not fit (callers fall back to the list-walking kernels)
 static bool pair_lds_bytes(const upk_igraph_t* G, bool poly, int& tab_floats, size_t& bytes) {
@@ -539,7 +559,6 @@ extern "C" int upk_igraph_passes_staged(const upk_launch_t* L, const upk_igraph_
 extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int side, int mode, float* out, long out_sys_stride,
                                int out_stride, int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode,
                                const float* sens1, const float* sens2, long sens_sys_stride, int sens_stride) {
-    UPK_FLUSH(L);
     if (side < 1 || side > 3 || mode < 0 || mode > 2 || (mode == 1 && (!own_grad || side == 3))) return 9007;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp;
@@ -550,6 +569,7 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     size_t lds;
     const int table = pair_table_choice(G, 0, A.tab_floats, lds);
     if (!table) {                                      // list-walking kernels, one side at a time
+        UPK_FLUSH(L);
         int r = 0;
         for (int sd = 1; sd <= 2 && !r; ++sd) {
             if (!(side & sd)) continue;
@@ -563,6 +583,8 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     int bps, threads;
     if (G->itype == UPK_IT_HBOND_COVERAGE && mode == 0 && side != 3 && pair2_enabled() && lds + 64 <= 158 * 1024) {   // packed pass
         pair2_geometry(L->n_system, n_rows, bps, threads);
+        if (side == 2 && batch_add(L, table == 2 ? BK_COV_ROWS2_POLY : BK_COV_ROWS2, bps, L->n_system, lds + 64, G, sizeof(*G), &A, sizeof(A))) return 0;
+        UPK_FLUSH(L);
         const dim3 grid2(bps, L->n_system), block2(threads);
         if (side == 1) { if (table == 2) hipLaunchKernelGGL((k_cov_rows2<1, true>), grid2, block2, lds + 64, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_rows2<1, false>), grid2, block2, lds + 64, ST(L), *G, A); }
         else { if (table == 2) hipLaunchKernelGGL((k_cov_rows2<2, true>), grid2, block2, lds + 64, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_rows2<2, false>), grid2, block2, lds + 64, ST(L), *G, A); }
@@ -576,6 +598,12 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
         if (!hb_threads) { const char* e = getenv("UPSIDE_HIP_HB_THREADS"); hb_threads = e ? atoi(e) : 256; if (hb_threads < 64 || hb_threads > 1024) hb_threads = 256; }
         threads = hb_threads;
     }
+    {   // merged launch (kernels_batch.h): the instances the README force field uses
+        const int bk = (G->itype == UPK_IT_PROTEIN_HBOND && side == 3 && mode == 0) ? BK_ROWS_HB_FWD : (G->itype == UPK_IT_PROTEIN_HBOND && side == 3 && mode == 2) ? BK_ROWS_HB_BWD
+                     : (G->itype == UPK_IT_ENVIRONMENT && side == 1 && mode == 0) ? BK_ROWS_ENV_FWD : 0;
+        if (bk && batch_add(L, bk, bps, L->n_system, lds, G, sizeof(*G), &A, sizeof(A))) return 0;
+    }
+    UPK_FLUSH(L);
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
         case UPK_IT_HBOND_COVERAGE:
@@ -591,7 +619,6 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
 
 extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
                                    const float* sens2, long sens_sys_stride, int sens_stride) {
-    UPK_FLUSH(L);
     if (row_side != 1 && row_side != 2) return 9007;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
@@ -604,6 +631,7 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     const int table = pair_table_choice(G, acc_bytes, A.tab_floats, lds);
     lds += acc_bytes;
     if (!table) {      // list-walking kernels, one side at a time (they need no hit lists)
+        UPK_FLUSH(L);
         int r = upk_igraph_grad(L, G, 1, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
         if (!r) r = upk_igraph_grad(L, G, 2, sens_mode, sens1, sens2, sens_sys_stride, sens_stride);
         return r;
@@ -617,6 +645,11 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
             A.tab_floats = tf; lds2 += acc_bytes + extra;
             pair2_geometry(L->n_system, n_rows, bps, threads);
             if (!G->gacc) bps = 1;
+            if (row_side == 2 && batch_add(L, table2 == 2 ? BK_COV_BWD2_POLY : BK_COV_BWD2, bps, L->n_system, lds2, G, sizeof(*G), &A, sizeof(A))) {
+                if (bps > 1) batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / (double)(1 << P2_FIX_BITS));
+                return 0;
+            }
+            UPK_FLUSH(L);
             const dim3 grid2(bps, L->n_system), block2(threads);
             if (row_side == 1) { if (table2 == 2) hipLaunchKernelGGL((k_cov_backward2<1, true>), grid2, block2, lds2, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_backward2<1, false>), grid2, block2, lds2, ST(L), *G, A); }
             else { if (table2 == 2) hipLaunchKernelGGL((k_cov_backward2<2, true>), grid2, block2, lds2, ST(L), *G, A); else hipLaunchKernelGGL((k_cov_backward2<2, false>), grid2, block2, lds2, ST(L), *G, A); }
@@ -626,6 +659,11 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     }
     pair_geometry(L->n_system, n_rows, bps, threads);
     if (!G->gacc) bps = 1;
+    if (G->itype == UPK_IT_ENVIRONMENT && row_side == 1 && batch_add(L, BK_ENV_BWD, bps, L->n_system, lds, G, sizeof(*G), &A, sizeof(A))) {
+        if (bps > 1) batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / 4294967296.0);
+        return 0;
+    }
+    UPK_FLUSH(L);
     const dim3 grid(bps, L->n_system), block(threads);
     switch (G->itype) {
         case UPK_IT_HBOND_COVERAGE:

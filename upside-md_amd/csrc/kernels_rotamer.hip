@@ -22,7 +22,10 @@ using namespace up;
 
 #define ST(L) ((hipStream_t)(L)->stream)
 #define BP_BLOCK 1024
+#ifndef UPK_LAUNCH_STATUS_DEFINED
+#define UPK_LAUNCH_STATUS_DEFINED
 static inline int launch_status() { return (int)hipGetLastError(); }
+#endif
 #define C_OUT(c, s)  ((c).out  + (size_t)(s) * (c).n_elem * (c).stride)
 #define C_SENS(c, s) ((c).sens + (size_t)(s) * (c).n_elem * (c).stride)
 // Slot matrices (pair energies / exp(-E), pair marginals): entry (i, j) of slot sl at [i][sl][j] -- the 6 entries of a matrix
@@ -47,19 +50,21 @@ __device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
 
 // ------------------------------------------------------------------------------------------------
 // rebuild step 0: clear the node x node mark table of the flagged systems (before the list build marks it)
-__global__ void k_rotamer_clear_slots(upk_rotamer_t R) {
+__device__ __forceinline__ void d_rotamer_clear_slots(const upk_rotamer_t& R, const BX B, float* lds_unused) {
     const int* fl = UPK_FLAG_LIST(R.G);
     const int n_flagged = fl[0];
     const int n16 = (R.n_node * R.n_node + 15) / 16;          // the table is padded to a multiple of 16 bytes
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         uint4* m = (uint4*)(R.mark + (size_t)fl[1 + fi] * R.G.mark_stride);
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
+        for (int i = B.bx * blockDim.x + threadIdx.x; i < n16; i += B.gx * blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
     }
 }
+__global__ void k_rotamer_clear_slots(upk_rotamer_t R)  { d_rotamer_clear_slots(R, BX_REAL, nullptr); }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    UPK_FLUSH(L);
     const int n16 = (R->n_node * R->n_node + 15) / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
+    if (batch_add(L, BK_CLEAR_SLOTS, blocks, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_rotamer_clear_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(1024), 0, ST(L), *R);
     return launch_status();
 }
@@ -85,9 +90,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* scratch, int* total) 
 #ifndef SLOT_WAVES
 #define SLOT_WAVES 8
 #endif
-__global__ void __launch_bounds__(BP_BLOCK, SLOT_WAVES) k_rotamer_build_slots(upk_rotamer_t R) {   // (8 waves per SIMD = 64 VGPRs: two workgroups per CU)
-    extern __shared__ unsigned long long bits[];            // [NN][W]
-    __shared__ int row_lo[1024], row_hi[1024], deg1[1024], bp_s[1025], scratch[17], cls_lds[N_CLASS + 1];
+__device__ __forceinline__ void d_rotamer_build_slots(const upk_rotamer_t& R, const BX B, float* bits_lds) {
+    unsigned long long* bits = (unsigned long long*)bits_lds;            // [NN][W]   // (8 waves per SIMD = 64 VGPRs: two workgroups per CU)
+        __shared__ int row_lo[1024], row_hi[1024], deg1[1024], bp_s[1025], scratch[17], cls_lds[N_CLASS + 1];
     const upk_igraph_t& G = R.G;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(BP_BLOCK, SLOT_WAVES) k_rotamer_build_slots(up
         for (int c = 0; c * 64 < x && c < W; ++c) n += __popcll(bits[g * W + c] & below(x, c));
         return n;
     };
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         const int s = fl[1 + fi];
         const unsigned char* mark = R.mark + (size_t)s * G.mark_stride;
         int* slot_of = R.slot_of + (size_t)s * NN * NN;
@@ -223,8 +228,11 @@ __global__ void __launch_bounds__(BP_BLOCK, SLOT_WAVES) k_rotamer_build_slots(up
         }
     }
 }
+__global__ void __launch_bounds__(BP_BLOCK, SLOT_WAVES) k_rotamer_build_slots(upk_rotamer_t R)  {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
+    d_rotamer_build_slots(R, BX_REAL, lds_dyn_);
+}
 extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    UPK_FLUSH(L);
     if (R->n_node > 1024) return 9003;
     const size_t lds = (size_t)R->n_node * ((R->n_node + 63) / 64) * 8;
     // (tried in round 3: stamping the slots into the list words inside this kernel from the popcounts of the bit matrix, without
@@ -232,25 +240,27 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     //  list words through a chain of dependent loads, the separate kernel spreads them over hundreds of workgroups)
     static int wgs = 0;   // UPSIDE_HIP_SLOT_WGS (experiments): workgroups looping over the flagged systems
     if (!wgs) { const char* e = getenv("UPSIDE_HIP_SLOT_WGS"); wgs = e ? atoi(e) : 1024; if (wgs < 1) wgs = 1024; }
+    if (batch_add(L, BK_BUILD_SLOTS, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) return 0;
+    UPK_FLUSH(L);
     hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < wgs ? L->n_system : wgs), dim3(BP_BLOCK), lds, ST(L), *R);
     return launch_status();
 }
 
 // rebuild step 3: every cached bead pair remembers its slot, in the bits of its list word above the bead index
 // (one 4-byte word per cached pair instead of a second array; the pair passes read nothing else)
-__global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
+__device__ __forceinline__ void d_rotamer_nbr_slots(const upk_rotamer_t& R, const BX B, float* lds_unused) {
     const upk_igraph_t& G = R.G;
     const int* fl = UPK_FLAG_LIST(G);
     const int n_flagged = fl[0];
     const int NN = R.n_node;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_wave = blockDim.x >> 6;
-    for (int fi = blockIdx.y; fi < n_flagged; fi += gridDim.y) {
+    for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         const int s = fl[1 + fi];
         const int* slot_of = R.slot_of + (size_t)s * NN * NN;
         // (a word is a chain of three dependent loads -- word, node of the partner, slot of the node pair -- and a row is rarely longer
         //  than one trip: four rows per wavefront at a time, so that every lane has four chains in flight: 0.55 -> 0.31 ms per step at 4096 systems)
         constexpr int RB = 4;
-        for (int row0 = (blockIdx.x * n_wave + wave) * RB; row0 < G.n1; row0 += gridDim.x * n_wave * RB) {
+        for (int row0 = (B.bx * n_wave + wave) * RB; row0 < G.n1; row0 += B.gx * n_wave * RB) {
             int cnt[RB], a[RB], cmax = 0;
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
@@ -274,7 +284,9 @@ __global__ void k_rotamer_nbr_slots(upk_rotamer_t R) {
         }
     }
 }
+__global__ void k_rotamer_nbr_slots(upk_rotamer_t R)  { d_rotamer_nbr_slots(R, BX_REAL, nullptr); }
 extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    if (batch_add(L, BK_NBR_SLOTS, (R->G.n1 + 63) / 64, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;      // (16 wavefronts x 4 rows)
     UPK_FLUSH(L);
     int blocks = (R->G.n1 + 15) / 16;          // 4 wavefronts x 4 rows
     hipLaunchKernelGGL(k_rotamer_nbr_slots, dim3(blocks, UPK_FLAG_GRID(L->n_system)), dim3(256), 0, ST(L), *R);
