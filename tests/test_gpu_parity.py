@@ -605,6 +605,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '0'},      # one-workgroup BP of 1024 lanes streaming every pair matrix
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '1'},      # 512 lanes, two 6x6 trips of pair matrices pinned in registers (large batches)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '2'},      # the other register layout of the resident matrices
+    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '3'},      # 512 lanes, one slot of every class pinned per lane (small batches)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes

@@ -284,13 +284,17 @@ void DerivEngine::finalize() {
             auto fused = [&](size_t i) { auto* c = nodes[i].computation.get(); return backward ? c->fused_backward : c->fused_forward; };
             int lvl = 0;
             for (size_t n_done = 0; n_done < N;) {
-                bool progress = true;
-                while (progress) {
-                    progress = false;
-                    for (size_t i = 0; i < N; ++i) if (fused(i) && ready(i)) {
-                        schedule.push_back(Step{(int)i, backward}); done[i] = 1; ++n_done; progress = true;
+                // (round by round: the fused steps that are ready NOW do not depend on each other -- their ops run without barriers
+                //  between them, on different wavefronts of the system's workgroup -- then the ones they unlock, ...)
+                for (;;) {
+                    std::vector<size_t> round;
+                    for (size_t i = 0; i < N; ++i) if (fused(i) && ready(i)) round.push_back(i);
+                    if (round.empty()) break;
+                    for (size_t i : round) {
+                        schedule.push_back(Step{(int)i, backward}); done[i] = 1; ++n_done;
                         (backward ? nodes[i].deriv_exec_level : nodes[i].germ_exec_level) = lvl;
                     }
+                    ++lvl;
                 }
                 ++lvl;
                 // then every other step that is ready: they do not depend on each other, so their kernels may share launches

@@ -40,7 +40,7 @@ static inline int launch_status() { return (int)hipGetLastError(); }
 #define FUSE_PAYLOAD 232
 #define FUSE_MAX_PENDING 224
 struct FusedOp { int kind, n, lds_bytes, flags; unsigned char payload[FUSE_PAYLOAD]; };   // flags bit 0: no barrier needed in front of this op
-struct FusedIds { int n; unsigned short id[FUSE_MAX_PENDING]; };
+struct FusedIds { int n; unsigned short id[FUSE_MAX_PENDING], rot[FUSE_MAX_PENDING]; };    // rot: first lane of the op's element loop
 // What an op reads and writes, so that the queue knows where a workgroup barrier is needed: ops that touch disjoint data run without one
 // (every wavefront walks the op list at its own pace, and the latencies of independent ops overlap).  A region is the per-system
 // slice [lo + s * stride, + len) of a device array (lo = NULL: an absent optional buffer); FUSE_ALL: everything; FUSE_LDS: the workgroup's LDS scratch.
@@ -1587,12 +1587,15 @@ extern "C" int upk_membrane(const upk_launch_t* L, const upk_membrane_t* M, upk_
 // ------------------------------------------------------------------------------------------------
 // The fused-op interpreter (see the top of this file) and its host-side queue.
 template <typename A> __device__ __forceinline__ const A& fop_args(const FusedOp& op) { return *(const A*)op.payload; }
-#define FOP_LOOP(i, n) for (int i = threadIdx.x; i < (n); i += blockDim.x)
+// element loops start at lane `rot` of the workgroup (a multiple of 64): consecutive ops without a barrier between them start on
+// different wavefronts, so that short independent ops (a few wavefronts each) run side by side instead of queueing on wavefront 0
+#define FOP_LOOP(i, n) for (int i = tid_r; i < (n); i += blockDim.x)
 // HEAVY: the instance that also holds the affine-alignment backward op, whose unrolled tables want ~200 registers per lane (every
 // other op fits 64); launches without that op take the light instance and its occupancy
 template <bool HEAVY>
-__device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, float* lds) {
+__device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, float* lds, const int rot) {
     const int n = op.n;
+    int tid_r = (int)threadIdx.x - rot; if (tid_r < 0) tid_r += blockDim.x;
     switch (op.kind) {       // (wave-uniform: op is the same record for the whole workgroup)
         case FOP_ZERO_MANY: c_zero_many(fop_args<ZeroManyArgs>(op), s); break;
         case FOP_REDUCE_SUM: c_reduce_sum(fop_args<ReduceSumArgs>(op), s, lds); break;
@@ -1642,19 +1645,21 @@ __device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, flo
 // one workgroup per system walks the ops of the launch in order
 // (T = the largest workgroup the instance may be launched with)
 template <bool HEAVY, int T>
-__global__ void __launch_bounds__(T) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids) {
+__global__ void __launch_bounds__(T) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x;
     for (int k = 0; k < ids.n; ++k) {
         const FusedOp& op = table[ids.id[k]];
         if (k && !(op.flags & 1)) __syncthreads();     // what the ops before wrote (global memory, this CU) is visible; LDS scratch is free again
-        run_fused_op<HEAVY>(op, s, lds);
+        if (trace && s == 0 && threadIdx.x == 0) trace[k] = wall_clock64();      // (diagnostics, UPSIDE_HIP_FUSE_TRACE: when wavefront 0 of system 0 reaches op k)
+        run_fused_op<HEAVY>(op, s, lds, ids.rot[k]);
     }
+    if (trace && s == 0 && threadIdx.x == 0) trace[ids.n] = wall_clock64();
 }
 template <bool HEAVY, int T>
 __global__ void __launch_bounds__(T) k_fused_one(FusedOp op) {       // an op on its own (no queue, or UPSIDE_HIP_FUSE=0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    run_fused_op<HEAVY>(op, blockIdx.x, lds);
+    run_fused_op<HEAVY>(op, blockIdx.x, lds, 0);
 }
 
 namespace {
@@ -1667,7 +1672,9 @@ struct FuseQueue {
     FusedIds pending; int pending_lds = 0; bool pending_heavy = false;
     std::vector<FuseRegion> live;                                 // regions touched since the last barrier of the pending list
     bool elide = true;                                            // UPSIDE_HIP_FUSE_BARRIERS=1: a barrier in front of every op
+    int next_rot = 0;                                             // lanes taken by the ops since the last barrier (see FOP_LOOP)
     long n_launch = 0, n_ops_run = 0;
+    long long* trace_dev = nullptr; double trace_us[FOP_N] = {0}; long trace_n[FOP_N] = {0};      // UPSIDE_HIP_FUSE_TRACE
 };
 unsigned long long fuse_hash(const FusedOp& op) {
     const unsigned char* b = (const unsigned char*)&op;
@@ -1706,6 +1713,7 @@ extern "C" void* upk_fuse_create(int n_system) {
     q->enabled = !(e && !atoi(e));
     q->pending.n = 0;
     { const char* b = getenv("UPSIDE_HIP_FUSE_BARRIERS"); q->elide = !(b && atoi(b)); }
+    if (getenv("UPSIDE_HIP_FUSE_TRACE")) (void)hipMalloc((void**)&q->trace_dev, sizeof(long long) * (FUSE_MAX_PENDING + 1));
     if (hipMalloc((void**)&q->table_dev, (size_t)q->cap * sizeof(FusedOp)) != hipSuccess) { delete q; return nullptr; }
     q->table.reserve(256);
     return q;
@@ -1714,6 +1722,15 @@ extern "C" int upk_fuse_table_size(const upk_launch_t* L) { return L->fuse ? (in
 extern "C" void upk_fuse_destroy(void* fuse) {
     FuseQueue* q = (FuseQueue*)fuse;
     if (!q) return;
+    if (q->trace_dev) {
+        static const char* names[FOP_N] = {"", "zero_many", "reduce_sum", "gather_contrib", "integration_stage", "thermostat", "affine_fwd", "affine_bwd", "rama_fwd", "rama_bwd", "infer_fwd",
+            "infer_bwd", "spring", "placement_fwd", "placement_bwd", "rama_map_pot", "weighted_pos_fwd", "weighted_pos_bwd", "nonlinear_coupling", "hbond_energy", "protein_hbond_finish",
+            "protein_hbond_bwd_pre", "protein_hbond_passthrough", "backbone_pairs"};
+        double tot = 0.; long steps = q->trace_n[FOP_ZERO_MANY] ? q->trace_n[FOP_ZERO_MANY] : 1;
+        for (int k = 1; k < FOP_N; ++k) if (q->trace_n[k]) { fprintf(stderr, "fused op %-28s %6.2f us per call  x %5.2f per pass = %7.2f us\n", names[k], q->trace_us[k] / q->trace_n[k], (double)q->trace_n[k] / steps, q->trace_us[k] / steps); tot += q->trace_us[k] / steps; }
+        fprintf(stderr, "fused ops per force pass: %.1f us\n", tot);
+        (void)hipFree(q->trace_dev);
+    }
     if (getenv("UPSIDE_HIP_FUSE_STATS")) fprintf(stderr, "fused ops: %ld launches, %ld ops, %zu distinct ops registered\n", q->n_launch, q->n_ops_run, q->table.size());
     if (q->table_dev) (void)hipFree(q->table_dev);
     delete q;
@@ -1726,9 +1743,15 @@ extern "C" int upk_fuse_flush(const upk_launch_t* L) {
     size_t lds = (size_t)q->pending_lds; if (lds < 64) lds = 64;      // (c_reduce_sum's partial sums)
     static const bool debug = getenv("UPSIDE_HIP_FUSE_DEBUG") != nullptr;
     if (debug) { fprintf(stderr, "fused launch (%s):", q->pending_heavy ? "heavy" : "light"); for (int k = 0; k < q->pending.n; ++k) fprintf(stderr, " %d%s", q->table[q->pending.id[k]].kind, (q->table[q->pending.id[k]].flags & 1) ? "" : "|"); fprintf(stderr, "\n"); }
-    fuse_launch<true>(q->pending_heavy, q->threads, q->n_system, lds, ST(L), (const FusedOp*)q->table_dev, q->pending);
+    { const int T = q->pending_heavy && q->threads > 512 ? 512 : q->threads; for (int k = 0; k < q->pending.n; ++k) q->pending.rot[k] %= T; }   // (the heavy instance runs 512 lanes)
+    fuse_launch<true>(q->pending_heavy, q->threads, q->n_system, lds, ST(L), (const FusedOp*)q->table_dev, q->pending, q->trace_dev);
+    if (q->trace_dev) {       // per-op times of wavefront 0 of system 0 (with barriers elided an op's time includes waiting for nothing: reach-to-reach)
+        long long t[FUSE_MAX_PENDING + 1];
+        if (hipStreamSynchronize(ST(L)) == hipSuccess && hipMemcpy(t, q->trace_dev, sizeof(long long) * (q->pending.n + 1), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < q->pending.n; ++k) { const int kind = q->table[q->pending.id[k]].kind; q->trace_us[kind] += (t[k + 1] - t[k]) * 0.01; q->trace_n[kind] += 1; }
+    }
     q->n_launch += 1; q->n_ops_run += q->pending.n;
-    q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false; q->live.clear();
+    q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false; q->live.clear(); q->next_rot = 0;
     return launch_status();
 }
 static bool fuse_overlap(const FuseRegion& a, const FuseRegion& b, int n_system) {
@@ -1754,7 +1777,7 @@ static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, si
         bool conflict = !q->elide;
         for (int i = 0; i < n_regs && !conflict; ++i)
             for (const FuseRegion& r : q->live) if (fuse_overlap(regs[i], r, q->n_system)) { conflict = true; break; }
-        if (conflict) q->live.clear(); else op.flags |= 1;
+        if (conflict) { q->live.clear(); q->next_rot = 0; } else op.flags |= 1;
         q->live.insert(q->live.end(), regs, regs + n_regs);
     }
     auto alone = [&]() {
@@ -1782,8 +1805,14 @@ static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, si
     if (kind == FOP_AFFINE_BWD) {
         // a large batch, or a system whose other ops want all 1024 lanes, runs the register-hungry op in a launch of its own: the ops
         // around it keep the light instance (its occupancy, its workgroup size)
-        if (q->n_system >= 256 || n > 64) { UPK_FLUSH(L); q->pending.id[q->pending.n++] = (unsigned short)id; q->pending_heavy = true; return upk_fuse_flush(L); }
+        if (q->n_system >= 256 || n > 64) { UPK_FLUSH(L); q->pending.rot[q->pending.n] = 0; q->pending.id[q->pending.n++] = (unsigned short)id; q->pending_heavy = true; return upk_fuse_flush(L); }
         q->pending_heavy = true;
+    }
+    {   // where this op's element loop starts: behind the lanes of the ops it may run beside (whole wavefronts; collective ops take them all)
+        const int T = q->pending_heavy && q->threads > 512 ? 512 : q->threads;
+        const int lanes = n > 0 ? (n + 63) & ~63 : T;
+        q->pending.rot[q->pending.n] = (unsigned short)(q->next_rot % T);
+        q->next_rot = (q->next_rot + (lanes < T ? lanes : T)) % T;
     }
     q->pending.id[q->pending.n++] = (unsigned short)id;
     if (lds_bytes > q->pending_lds) q->pending_lds = lds_bytes;

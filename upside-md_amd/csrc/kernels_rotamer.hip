@@ -1480,11 +1480,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         // (tried in round 3: the 3-state nodes in one round as a MIX -- 116 on four lanes, 24 on two: slower, the round waits for the
         //  two-lane nodes; ALL of them on two lanes is what won)
         const int e1n = R.n_node1, e3n = R.n_node1 + R.n_node3;
-        for (int part = 0; part < 2; ++part)
-        for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += part == 0 ? nt / BP_GROUP6 : nt / BP_GROUP3) {
-            const int grp = part == 0 ? BP_GROUP6 : BP_GROUP3, glx = tid & (grp - 1);
-            const int g = g0 + tid / grp;
-            const bool live = g < g_hi;
+        // one node: lanes glx = 0 .. grp-1 of its group (`live`: the group has a node)
+        auto node_update = [&](const int grp, const int glx, const int g, const bool live) {
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
@@ -1559,6 +1556,21 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                     }
                 }
             }
+        };
+        // A small system has lanes for all its nodes at once -- four per 6-state node, then two per 3-state node --: ONE round, one
+        // chain of dependent LDS accesses per sweep instead of two (the arithmetic of a node does not depend on which lanes hold it).
+        const int lanes6 = (NN - e3n) * BP_GROUP6, lanes3 = (e3n - e1n) * BP_GROUP3;
+        if (lanes6 + lanes3 <= nt) {
+            const bool six = tid < lanes6;
+            const int grp = six ? BP_GROUP6 : BP_GROUP3, t = six ? tid : tid - lanes6;
+            const int g = (six ? e3n : e1n) + t / grp;
+            node_update(grp, t & (grp - 1), g, six || t < lanes3);
+        } else
+        for (int part = 0; part < 2; ++part)
+        for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += part == 0 ? nt / BP_GROUP6 : nt / BP_GROUP3) {
+            const int grp = part == 0 ? BP_GROUP6 : BP_GROUP3;
+            const int g = g0 + tid / grp;
+            node_update(grp, tid & (grp - 1), g, g < g_hi);
         }
         __syncthreads();
         if (trace) tr_node += wall_clock64() - tr_b;
@@ -2076,7 +2088,10 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     if (resident_env == -2) { const char* e = getenv("UPSIDE_HIP_BP_RESIDENT"); resident_env = e ? atoi(e) : -1; }
     // (re-measured after the look-ahead loads of bp_edge_packed: 32 systems 0.381 vs 0.379 ms, 64: 0.411 vs 0.466, 96: 0.470 vs 0.510,
     //  128: 0.489 vs 0.527 -- the register layout from 1/8 system per CU on)
-    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 0);
+    // (round 4, small batches: 512 lanes with ONE slot of every class pinned per lane -- all of a 56-residue system, most of a
+    //  150-residue one -- instead of 1024 lanes streaming every matrix: 56 residues, 1 / 8 systems: 4.28 k / 29.1 k against 4.13 k / 27.9 k
+    //  system-steps/s; 150 residues, 8 systems: 13.4 k against 13.0 k)
+    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 3);
     const dim3 grid(1, L->n_system);
     static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
     if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
@@ -2085,7 +2100,11 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     const bool dense = compact && R->slot_row && R->row_start && (size_t)lds_msg_floats * sizeof(float) >= layout_scratch;
     // (every one-workgroup variant lays its inbox out the same way: the order in which a node multiplies its messages, and with
     //  it every bit of the result, is then the same whichever variant a batch size selects)
-    if ((resident == 0 || threads != BP_BLOCK) && !only_fallback && dense && threads == BP_BLOCK)
+    if (resident == 3 && !only_fallback && dense && threads == BP_BLOCK)      // 512 lanes, one slot of every class pinned per lane: all of a small system
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 1, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else if (resident == 4 && !only_fallback && dense && threads == BP_BLOCK)
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 2, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
+    else if ((resident == 0 || threads != BP_BLOCK) && !only_fallback && dense && threads == BP_BLOCK)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0, true>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
     else if (resident == 0 || threads != BP_BLOCK || only_fallback)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
