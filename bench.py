@@ -81,15 +81,15 @@ def check(c, rc, what):
         raise RuntimeError('%s failed: %s' % (what, c.upside_hip_last_error().decode()))
 
 
-def cpu_baseline(fixture, variant, budget_s=float(os.environ.get('UPSIDE_BENCH_CPU_BUDGET_S', '15'))):
+def cpu_baseline(fixture, variant, budget_s=float(os.environ.get('UPSIDE_BENCH_CPU_BUDGET_S', '15')), one_core=False, n_atom=900):
     """the unmodified reference (oracle/_ref, kind "reference") timed on this host's cores over a bounded
     sample; falls back to the C restatement (kind "port", 1 core) when the reference binary is absent."""
     exe = os.path.join(ROOT, 'oracle', '_ref', 'upside_' + variant)
     n_cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     if os.path.exists(exe):
-        n_sys = max(1, min(n_cores, 16))
-        # ~9 ms per step per core for this workload (BASELINE.md): size the sample for `budget_s`
-        steps = max(30, int(budget_s / 0.010))
+        n_sys = 1 if one_core else max(1, min(n_cores, 16))       # (a one-system workload is compared with ONE host core)
+        # ~9 ms per step per core for the 300-residue workload (BASELINE.md), roughly linear in the atoms: size the sample for `budget_s`
+        steps = max(30, int(budget_s / (0.010 * max(n_atom, 60) / 900.)))
         duration = steps * DT
         tmp = tempfile.mkdtemp(prefix='upside_cpu_')
         try:
@@ -309,6 +309,18 @@ def main():
         # every sweep
         dom = max(rows, key=lambda r: r[1])
         roofline = entry(dom)
+        if roofline.get('traffic') is not None:      # FETCH_SIZE counts wide (128-byte) requests at half their size on gfx950: raw ... all reads wide
+            wide = profiled(dom[0], args.workload, R, 'fetch_bytes_if_wide'); wr = profiled(dom[0], args.workload, R, 'write_bytes')
+            if wide is not None and wr is not None:
+                roofline['frac_range'] = [roofline['frac'], (wide + wr) / (roofline['avg_launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS]
+        # the whole step: counted HBM bytes of every kernel of a force pass (same PMC passes) / the measured step time
+        st = profiled('_step', args.workload, R, 'bytes_per_step')
+        if st is not None:
+            ms_step = elapsed / steps_done * 1e3
+            roofline['step'] = dict(bound='hbm', bytes_per_step=st, achieved=st / (ms_step * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                    frac=st / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, ms_per_step=ms_step,
+                                    frac_if_reads_wide=(profiled('_step', args.workload, R, 'bytes_per_step_if_wide') or 0.) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    share_of_bytes=profiled('_step', args.workload, R, 'share'), traffic_source=PROFILE_NOTE)
         # The interaction-graph kernel north_star names: the side-chain gradient pass.  It is bound by VALU issue, not by HBM
         # (DESIGN.md section 3), so its roofline is arithmetic: achieved = pair evaluations of the launch (counted by the
         # engine) x 350 flop per evaluation / the launch time measured here, against the 157.3 TFLOP/s of the
@@ -365,6 +377,25 @@ def main():
             single = 600 / (time.perf_counter() - ts)
             lib.calc.free_deriv_engine(ct.c_void_p(eng1))
 
+    # the strong-scaling workloads: what eight GPUs would deliver if each ran its eighth of the systems at the rate ONE GPU reaches
+    # with that many (measured here, plain MD) -- so that the first run on an 8-GPU node surprises nobody
+    projected = None
+    if rank == 0 and total_systems and world == 1 and total_systems % 8 == 0:
+        r8 = total_systems // 8
+        eng8 = c.upside_hip_construct(n_atom, fixture.encode(), r8, True)
+        if eng8:
+            p8 = np.ascontiguousarray(pos[:r8]); t8 = np.ascontiguousarray(temps[:r8])
+            check(c, c.upside_hip_set_pos(eng8, p8.ctypes.data), 'set_pos')
+            check(c, c.upside_hip_init_md(eng8, t8.ctypes.data, rep.system_seed(1000, 0), 5.0, DT, 1), 'init_md')
+            check(c, c.upside_hip_run_steps(eng8, 90), 'run_steps')
+            ts = time.perf_counter()
+            check(c, c.upside_hip_run_steps(eng8, 300), 'run_steps')
+            rate8 = r8 * 300 / (time.perf_counter() - ts)
+            lib.calc.free_deriv_engine(ct.c_void_p(eng8))
+            projected = dict(value=8 * rate8, unit='system-steps/s', systems_per_gpu=r8, one_gpu_rate_at_that_size=rate8,
+                             basis='8 x the rate of ONE GPU holding total / 8 systems, measured in this run (plain MD: exchange traffic and '
+                                   'straggling not included); NOT a measurement on 8 GPUs')
+
     _trace('single-system leg done')
     if rank == 0:
         if describe is None:
@@ -376,6 +407,8 @@ def main():
                    # the reference's own unit of simulated time (it defines no ns/day, README.md:173-177): steps/s x dt x 86400
                    sim_time_units_per_day_per_system=steps_done / elapsed * DT * 86400.,
                    single_system_steps_per_s=single)
+        if projected is not None:
+            cfg['projected_8gpu'] = projected
         if remd:
             cfg.update(exchange_every_steps=exchange_steps_saved, exchange_attempts_timed=timed_attempts, swap_sets=len(swap_sets),
                        exchange='RCCL: ncclAllGather of one fp32 per replica, device Metropolis, ncclSend/ncclRecv of straddling pairs')
@@ -385,7 +418,7 @@ def main():
                    higher_is_better=True, scaling='strong' if total_systems else 'weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=cfg, roofline=roofline)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (rank 0 has the host to itself)
-            res['cpu_baseline'] = cpu_baseline(fixture, variant)
+            res['cpu_baseline'] = cpu_baseline(fixture, variant, one_core=(R == 1), n_atom=int(n_atom))
         # (flushed at once: tearing down the RCCL communicator below has been seen to end the process without running Python's
         #  exit-time flush of a buffered stdout)
         sys.stdout.flush()

@@ -501,6 +501,11 @@ static S4 house(int n, S4* x) {   /* src/eig.cpp:56-73 */
     FORL {
         float sigma2 = 1e-20f;
         for (int i = 1; i < n; ++i) sigma2 += x[i].v[l] * x[i].v[l];
+        /* A vector that is zero to within 1e-9 (a residue lying EXACTLY in a coordinate plane of its reference frame: the first residue
+         * of an ideal chain built at the origin) needs no reflection.  The formulas below are not a reflection there -- the 1e-20 added
+         * to sigma2 dominates, beta comes out as 1 instead of 2 / |v|^2 and the transformed matrix loses an eigenvalue; the reference is
+         * spared by the rounding noise of its fused arithmetic (it returns the true eigenvector, as this branch does). */
+        if (x[0].v[l] * x[0].v[l] + sigma2 < 1e-18f) { for (int i = 1; i < n; ++i) x[i].v[l] = 0.f; beta.v[l] = 0.f; continue; }
         float mu = sqrtf(x[0].v[l] * x[0].v[l] + sigma2);
         float s = (0.f < x[0].v[l]) ? -sigma2 * rcpf(x[0].v[l] + mu) : x[0].v[l] - mu;
         beta.v[l] = 2.f * s * s * rcpf(sigma2 + s * s);

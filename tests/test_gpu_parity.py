@@ -585,6 +585,19 @@ def test_ensemble_exchange_matches_device_swap(hip):
     a.close(); b.close()
 
 
+@pytest.mark.gpu
+def test_ideal_chain_alignment_frames(hip):
+    """an ideal chain built at the origin (its first residue lies exactly in a coordinate plane of its reference frame: the all-zero
+    Householder vector of affine_alignment's eigensolver, see tests/test_oracle_pinning.py): frames and forces of the REFERENCE"""
+    name = 'trpcage20_7A'
+    g = dict(np.load(os.path.join(P.GOLD, name + '.ideal_chain.npz')))
+    up = P.pkg.Upside(P.fixture(name))
+    d = up.deriv(g['pos']); e = up.energy(g['pos']); a = up.get_output('affine_alignment')
+    up.close()
+    assert np.abs(np.abs((g['affine_alignment'][:, 3:] * a[:, 3:]).sum(axis=1)) - 1.).max() < 1e-5
+    assert abs(e - g['energy']) < 1e-4 * max(1., abs(g['energy'])) and P.rel_rms(g['deriv'], d) < 1e-4
+
+
 ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1'},          # one-workgroup belief propagation instead of the cluster solve
     {'UPSIDE_HIP_BP_CLUSTER': '3'},          # cluster too small for the pair matrices: on-device fallback flag

@@ -218,3 +218,17 @@ def test_oracle_md_is_deterministic_and_thermalised(oracle):
     kin = 0.5 * (res[0][1] ** 2).sum() / pos.shape[0]
     assert 0.4 < kin / (1.5 * 0.8) < 1.8       # avg_kinetic_energy/1.5kT ~ 1 (main.cpp:684-695), 60 atoms only
     assert np.isfinite(res[0][0]).all()
+
+
+def test_ideal_chain_alignment_frames():
+    """an ideal chain built at the origin: its first residue lies exactly in a coordinate plane of its reference frame, and the second
+    Householder vector of affine_alignment's 4x4 eigensolver is all zeros (eig.cpp:56-73 is not a reflection there; the reference is
+    spared by rounding noise).  The restatement takes the no-reflection branch and must land on the reference's frame and forces."""
+    name = 'trpcage20_7A'
+    g = dict(np.load(os.path.join(P.GOLD, name + '.ideal_chain.npz')))
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    e = orc.energy(g['pos']); d = orc.deriv(g['pos']); a = orc.get_output('affine_alignment')
+    orc.close()
+    q_ref, q = g['affine_alignment'][:, 3:], a[:, 3:]
+    assert np.abs(np.abs((q_ref * q).sum(axis=1)) - 1.).max() < 1e-5          # the same rotations (a quaternion and its negative are one rotation)
+    assert abs(e - g['energy']) < 1e-4 * max(1., abs(g['energy'])) and P.rel_rms(g['deriv'], d) < 1e-4

@@ -68,6 +68,13 @@ def main():
             entry[label]['valu_insts_per_launch'] = q[k][0]
             if label in pairs and pairs[label] > 0:
                 entry[label]['valu_insts_per_pair'] = q[k][0] / pairs[label]
+    # the whole step: every kernel's counted bytes x its launches per force pass (the belief-propagation solve runs once per pass),
+    # allocation-time fills and copies left out
+    n_pass = max([v['launches_sampled'] for k, v in entry.items() if k == 'bp:rotamer'] or [1])
+    per_step = {k: v['bytes_per_launch'] * v['launches_sampled'] / n_pass for k, v in entry.items() if not k.startswith('__amd_rocclr')}
+    wide_step = {k: (v['fetch_bytes_if_wide'] + v['write_bytes']) * v['launches_sampled'] / n_pass for k, v in entry.items() if not k.startswith('__amd_rocclr')}
+    entry['_step'] = dict(bytes_per_step=sum(per_step.values()), bytes_per_step_if_wide=sum(wide_step.values()), force_passes_sampled=n_pass,
+                          share={k: b / max(sum(per_step.values()), 1.) for k, b in sorted(per_step.items(), key=lambda kv: -kv[1])[:12]})
     entry['_kernel_sources_sha256'] = kernel_source_stamp()
     tab['%s/R%s' % (workload, replicas)] = entry
     json.dump(tab, open(out, 'w'), indent=1, sort_keys=True)

@@ -86,6 +86,20 @@ def add_param_derivs(name):
     print(name, dict((k, (v.shape, float(np.abs(v).max()))) for k, v in g.items() if k.startswith('param_deriv/')))
 
 
+def add_ideal_chain(name='trpcage20_7A'):
+    """golden vectors of the reference at an IDEAL chain (config.helix_chain: built at the origin, its first residue lies exactly in a
+    coordinate plane of its reference frame -- the case in which the 4x4 eigensolver of affine_alignment meets an all-zero
+    Householder vector, oracle/upside_oracle.c: house) for an existing fixture's force field -> tests/golden/<name>.ideal_chain.npz"""
+    variant = FIXTURES[name][1]
+    lib = pkg.UpsideLibrary(os.path.join(REF, 'libupside_%s.so' % variant))
+    up = pkg.Upside(os.path.join(GOLD, name + '.up'), library=lib)
+    pos = cfg.helix_chain(up.initial_pos.shape[0] // 3).astype('f4')
+    g = dict(pos=pos, energy=np.float32(up.energy(pos)), deriv=up.deriv(pos), affine_alignment=up.get_output('affine_alignment'))
+    up.close()
+    np.savez_compressed(os.path.join(GOLD, name + '.ideal_chain.npz'), **g)
+    print(name, 'ideal chain: energy', g['energy'], 'frame of residue 0', g['affine_alignment'][0])
+
+
 RESTRAINT_NODES = ['z_flat_bottom', 'tension', 'AFM', 'atom_pos_spring', 'contact', 'membrane_potential',
                    'linear_coupling_uniform_env', 'linear_coupling_with_inactivation_env', 'atom_pos_spring_on_slice',
                    'radial', 'hbond_sc_radial']
@@ -280,6 +294,9 @@ def make(name):
 if __name__ == '__main__':
     if sys.argv[1:2] == ['--edge-cases']:
         make_edge_cases()
+        sys.exit(0)
+    if sys.argv[1:2] == ['--ideal-chain']:
+        add_ideal_chain()
         sys.exit(0)
     if sys.argv[1:2] == ['--restraints']:            # the optional-node fixture (built on proteinG56_7A)
         make_restraints()

@@ -117,6 +117,149 @@ def synthetic_rama_maps(n_res, ref_map, seed, amplitude=1.0):
     return pots
 
 
+# ---------------------------------------------------------------------------------------------
+# Ramachandran library (py/upside_config.py:567-640, 692-734): neighbour-dependent maps of the coil and sheet libraries, mixed.
+# Library file (HDF5, the README's rama.dat): groups `coil` and `sheet`, each with
+#   attributes restype (n_restype names, among them ALL and -- coil only -- CPR) and dir (left, right),
+#   dimer_pot    [n_restype][2][n_restype][n_phi][n_psi]   -log probability of (phi, psi) of the central residue given its neighbour
+#   dimer_weight [n_restype][2][n_restype]                 occurrence weights
+def mixture_potential(weights, potentials):
+    """-log of the weighted mixture of the densities exp(-potentials[k]) (weights normalised over k); upside_config.py:567-581.
+    Computed as a log-sum-exp around the smallest term."""
+    potentials = np.asarray(potentials, dtype='f8'); weights = np.asarray(weights, dtype='f8')
+    assert len(weights) == len(potentials)
+    weights = weights / weights.sum(axis=0)
+    weights = weights.reshape(weights.shape + (1,) * (potentials.ndim - weights.ndim))
+    shifted = potentials - np.log(weights)
+    low = shifted.min(axis=0)
+    return low - np.log(np.exp(low - shifted).sum(axis=0))
+
+
+def rama_maps_and_weights(seq, group, mode='mixture', allow_cpr=True):
+    """per-residue maps (n_res, n_phi, n_psi) and weights (n_res,) of one library group (an h5lite group): every residue's map
+    given its left and right neighbours, combined by `mode` (upside_config.py:584-627); maps normalised so that exp(-map) sums to 1"""
+    if mode not in ('mixture', 'product'):
+        raise ValueError('combining rule must be mixture or product')
+    if len(seq) < 3:
+        raise ValueError('the Ramachandran library needs at least three residues')
+    as_str = lambda x: x.decode() if isinstance(x, bytes) else str(x)
+    restype = [as_str(x) for x in np.atleast_1d(group.get_attr('restype'))]
+    dirs = [as_str(x) for x in np.atleast_1d(group.get_attr('dir'))]
+    r_of = dict((x, i) for i, x in enumerate(restype)); d_of = dict((x, i) for i, x in enumerate(dirs))
+    pot = group.read('dimer_pot', 'f8'); wt = group.read('dimer_weight', 'f8')
+    # cis-proline is its own type only as the CENTRAL residue (and only where the library has it); as a neighbour it is PRO
+    centre = lambda r: r_of[r if (r != 'CPR' or allow_cpr) else 'PRO']
+    nbr = lambda r: r_of['PRO' if r == 'CPR' else r]
+    V = lambda c, d, n: pot[centre(c), d_of[d], nbr(n)]
+    W = lambda c, d, n: wt[centre(c), d_of[d], nbr(n)]
+    n = len(seq)
+    maps = np.zeros((n,) + pot.shape[-2:]); weights = np.zeros(n)
+    maps[0] = V(seq[0], 'right', seq[1]); weights[0] = W(seq[0], 'right', seq[1])
+    for i in range(1, n - 1):
+        l, c, r = seq[i - 1], seq[i], seq[i + 1]
+        if mode == 'product':
+            maps[i] = V(c, 'left', l) + V(c, 'right', r) - V(c, 'right', 'ALL')
+        else:
+            maps[i] = mixture_potential([W(c, 'left', l), W(c, 'right', r)], [V(c, 'left', l), V(c, 'right', r)])
+        weights[i] = 0.5 * (W(c, 'left', l) + W(c, 'right', r))
+    maps[-1] = V(seq[-1], 'left', seq[-2]); weights[-1] = W(seq[-1], 'left', seq[-2])
+    maps += np.log(np.exp(-maps).sum(axis=(-2, -1), keepdims=True))
+    return maps, weights
+
+
+def read_weighted_maps(seq, library_path, sheet_mixing=None, mode='mixture'):
+    """the coil maps of `seq`, or -- with a sheet mixing energy -- their mixture with the sheet maps, the sheet weights scaled by
+    exp(-sheet_mixing) (upside_config.py:630-639)"""
+    with h5lite.open_file(library_path) as lib:
+        coil, coil_w = rama_maps_and_weights(seq, lib.group('coil'), mode=mode)
+        if sheet_mixing is None:
+            return coil
+        sheet, sheet_w = rama_maps_and_weights(seq, lib.group('sheet'), allow_cpr=False)
+    return mixture_potential([coil_w, sheet_w * np.exp(-sheet_mixing)], [coil, sheet])
+
+
+def secstr_bias_maps(n_phi, n_psi):
+    """smooth indicator maps of the helical and the sheet basin on the library's grid (upside_config.py:706-713)"""
+    phi = np.linspace(-np.pi, np.pi, n_phi, endpoint=False)[:, None]
+    psi = np.linspace(-np.pi, np.pi, n_psi, endpoint=False)[None, :]
+    below = lambda a, b: 1. / (1. + np.exp(-(b - a) / (10. * deg)))          # smooth (a < b)
+    helix = below(phi, 0.) * below(-100. * deg, psi) * below(psi, 50. * deg)
+    sheet = below(phi, 0.) * (below(psi, -100. * deg) + below(50. * deg, psi))
+    return helix, sheet
+
+
+def library_rama_potential(seq, library_path, sheet_mixing=None, secstr_bias=(), mode='mixture'):
+    """rama_pot of the rama_map_pot node from a Ramachandran library (upside_config.py:692-734): the weighted maps, optional
+    per-residue basin biases [(residue, 'helix' | 'sheet', energy), ...], then each map's mean energy removed"""
+    maps = read_weighted_maps(seq, library_path, sheet_mixing, mode)
+    if len(secstr_bias):
+        helix, sheet = secstr_bias_maps(maps.shape[1], maps.shape[2])
+        for residue, kind, energy in secstr_bias:
+            if kind not in ('helix', 'sheet'):
+                raise ValueError('secstr in a secstr-bias table must be helix or sheet')
+            maps[int(residue)] += float(energy) * (helix if kind == 'helix' else sheet)
+    maps -= (maps * np.exp(-maps)).sum(axis=(-2, -1), keepdims=True)
+    return maps
+
+
+def read_secstr_bias(path):
+    """table with the header `residue secstr energy` (upside_config.py:715-725)"""
+    rows = [ln.split() for ln in open(path) if ln.strip()]
+    if rows[0] != 'residue secstr energy'.split():
+        raise ValueError('first line of a secstr-bias table must be "residue secstr energy"')
+    return [(int(r), k, float(e)) for r, k, e in rows[1:]]
+
+
+# ---------------------------------------------------------------------------------------------
+# fixed rotamers (py/upside_config.py --fix-rotamer, :884-935)
+def chi1_state(angles):
+    """0: [0, 120) degrees, 2: [-120, 0), 1: the rest (upside_config.py:885-889)"""
+    angles = np.asarray(angles, dtype='f8')
+    st = np.ones(angles.shape, dtype='i4')
+    st[(0. <= angles) & (angles < 120. * deg)] = 0
+    st[(-120. * deg <= angles) & (angles < 0.)] = 2
+    return st
+
+
+def fixed_rotamer_states(fasta, table, restype_order, restype_chi_state):
+    """residue -> rotamer state for the rows of a --fix-rotamer table [(residue, restype, chain, resnum, chi1, chi2), ...] (angles in
+    degrees, NaN = unknown): the library state of the residue type whose chi1 falls in the same third of the circle and whose chi2 is
+    closest (periodically); residue types with one state (GLY, ALA) take state 0; rows with an unknown angle that is needed are skipped.
+    restype_chi_state: the library's restype_and_chi_and_state table (restype number, chi1, chi2, state)."""
+    tab = np.asarray(restype_chi_state, dtype='f8')
+    lib_restype = tab[:, 0].astype('i4'); lib_chi1_state = chi1_state(tab[:, 1]); lib_chi2 = tab[:, 2]; lib_state = tab[:, 3].astype('i4')
+    num = dict((aa, i) for i, aa in enumerate(restype_order))
+    fix = {}
+    for residue, restype, chain, resnum, chi1, chi2 in table:
+        residue = int(residue)
+        if fasta[residue] != (restype if restype != 'CPR' else 'PRO'):
+            raise ValueError('fix-rotamer table does not match the sequence: residue %i is %s, the table says %s' % (residue, fasta[residue], restype))
+        chi1 = float(chi1) * deg; chi2 = float(chi2) * deg
+        if restype in ('GLY', 'ALA'):
+            fix[residue] = 0
+            continue
+        if np.isnan(chi1):
+            continue
+        ok = (lib_restype == num[fasta[residue]]) & (lib_chi1_state == chi1_state(np.array([chi1]))[0])
+        states, chi2s = lib_state[ok], lib_chi2[ok]
+        if len(states) == 1:
+            fix[residue] = int(states[0])
+            continue
+        if np.isnan(chi2):
+            continue
+        d = (chi2s - chi2) % (2. * np.pi)
+        d[d > np.pi] -= 2. * np.pi
+        fix[residue] = int(states[np.argmin(d)])       # (sic: the signed difference, as the reference selects it)
+    return fix
+
+
+def read_fix_rotamer(path):
+    rows = [ln.split() for ln in open(path) if ln.strip()]
+    if [x.lower() for x in rows[0]] != 'residue restype chain resnum chi1 chi2'.split():
+        raise ValueError('first line of a fix-rotamer table must be "residue restype chain resnum chi1 chi2"')
+    return rows[1:]
+
+
 def load_rama_reference(path):
     import pickle
     with open(path, 'rb') as f:
@@ -130,14 +273,21 @@ def _args(g, names):
 
 def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref, hbond_energy,
                  rama_seed=0, cavity_radius=0., rotamer_damping=0.4, bond_stiffness=48.,
-                 angle_stiffness=175., per_residue_rama=True, chain_first_residue=(), hbond_exclude_residues=()):
+                 angle_stiffness=175., per_residue_rama=True, chain_first_residue=(), hbond_exclude_residues=(),
+                 rama_library=None, rama_sheet_mixing_energy=None, secstr_bias=(), rama_combining_rule='mixture',
+                 fix_rotamer=(), loose_hbond_criteria=False):
     """fasta: array of 3-letter codes; init_pos (3*n_res,3); sidechain_lib / environment_lib: paths to
     the parameter HDF5 libraries; rama_ref: (72,72) reference-state probabilities.
     chain_first_residue: first residue of every chain but the first (py/upside_config.py --chain-break-from-file,
     :1413-1451): recorded as /input/chain_break/chain_first_residue, and the two residues at every junction join
     hbond_exclude_residues (no donor / acceptor site inferred from atoms of two chains).  The bonded terms across the
-    junctions are removed afterwards by break_chains(), as the reference does with py/ugly_hack_break_chain.py."""
-    fasta = np.asarray(fasta)
+    junctions are removed afterwards by break_chains(), as the reference does with py/ugly_hack_break_chain.py.
+    rama_library (+ rama_sheet_mixing_energy, secstr_bias, rama_combining_rule): the Ramachandran maps from a library file
+    (py/upside_config.py --rama-library ..., :692-734) instead of the synthetic maps; fasta may then name cis-prolines CPR.
+    fix_rotamer: rows of a --fix-rotamer table (read_fix_rotamer): those residues keep ONE rotamer state (:905-959).
+    loose_hbond_criteria: the permissive hydrogen-bond geometry of --loose-hbond-criteria (:317-321; not for simulation)."""
+    fasta_cpr = np.asarray(fasta)                                             # cis-prolines named CPR (Ramachandran library, dihedral springs)
+    fasta = np.array(['PRO' if s == 'CPR' else s for s in fasta_cpr])         # ... and PRO everywhere else (upside_config.py:1395-1405)
     n_res = len(fasta)
     n_atom = 3 * n_res
     assert init_pos.shape == (n_atom, 3)
@@ -148,6 +298,7 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
         rotamer_center_fixed = lib.read('rotamer_center_fixed', 'f8')
         rotamer_prob = lib.read('rotamer_prob', 'f8')
         start_stop = lib.read('rotamer_start_stop_bead', 'i8')
+        restype_chi_state = lib.read('restype_and_chi_and_state', 'f8') if len(fix_rotamer) else None
         pair_interaction = lib.read('pair_interaction', 'f8')
         coverage_interaction = lib.read('coverage_interaction', 'f8')
         hydrophobe_placement = lib.read('hydrophobe_placement', 'f8')
@@ -163,7 +314,7 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
 
     f = h5lite.open_file(path, 'w')
     inp = f.create_group('input')
-    inp.write('sequence', fasta)
+    inp.write('sequence', fasta_cpr)                     # (cis-prolines keep their CPR name here, upside_config.py:1374)
     inp.write('pos', init_pos.reshape(n_atom, 3, 1).astype('f4'))
     pot = inp.create_group('potential')
 
@@ -188,7 +339,7 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
     ids = np.arange(1, n_atom - 3, 3)
     ids = np.column_stack((ids, ids + 1, ids + 2, ids + 3))
     g.write('id', ids.astype('i4'))
-    g.write('equil_dist', np.where(fasta[1:] == 'CPR', 0. * deg, 180. * deg))
+    g.write('equil_dist', np.where(fasta_cpr[1:] == 'CPR', 0. * deg, 180. * deg))
     g.write('spring_const', 30.0 * np.ones(ids.shape[0]))
 
     # --- rotamer placement (fixed placement, dynamic 1-body) ---------------------------------
@@ -196,10 +347,16 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
     placement_energy = -np.log(rotamer_prob.transpose((2, 0, 1)))[..., None]
     rama_residue, affine_residue, layer_index, beadtype_seq, id_seq = [], [], [], [], []
     count_by_n_rot = dict()
+    fix = fixed_rotamer_states(fasta, fix_rotamer, restype_order, restype_chi_state) if len(fix_rotamer) else {}
     for rnum, aa in enumerate(fasta):
         start, stop, n_bead = [int(x) for x in start_stop[restype_num[aa]]]
         assert (stop - start) % n_bead == 0
         n_rot = (stop - start) // n_bead
+        if rnum in fix:                                   # a fixed residue keeps the beads of one state: a 1-state node
+            if not 0 <= fix[rnum] < n_rot:
+                raise ValueError('invalid fix rotamer state')
+            start, stop = start + n_bead * fix[rnum], start + n_bead * (fix[rnum] + 1)
+            n_rot = 1
         base_id = (count_by_n_rot.get(n_rot, 0) << n_bit_rotamer) + n_rot
         count_by_n_rot[n_rot] = count_by_n_rot.get(n_rot, 0) + 1
         rama_residue.extend([rnum] * (stop - start))
@@ -218,6 +375,7 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
     g.write('placement_data', placement_pos[..., :6])
     g.write('beadtype_seq', np.array(beadtype_seq))
     g.write('id_seq', np.array(id_seq, dtype='i4'))
+    g.write('fix_rotamer', np.array(sorted(fix.items()), dtype='i4').reshape(-1, 2))
 
     g = pot.create_group(pl_node_name); _args(g, ['affine_alignment', 'rama_coord'])
     g.write('rama_residue', np.array(rama_residue, dtype='i4'))
@@ -247,7 +405,9 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
     g.write('id1', donor_res)
     g.write('index2', np.arange(n_donor, n_donor + n_acceptor, dtype='i4'))
     g.write('type2', np.zeros(n_acceptor, dtype='i4')); g.write('id2', acc_res)
-    g.write('interaction_param', np.array([[[1.4, 1. / 0.10, 2.5, 1. / 0.125, 0.682, 1. / 0.05, 0., 0.]]]))
+    # inner barrier, inner scale, outer barrier, outer scale, wall_dp, inv_dp_width (upside_config.py:316-321)
+    g.write('interaction_param', np.array([[[0.5 if loose_hbond_criteria else 1.4, 1. / 0.10, 3.1 if loose_hbond_criteria else 2.5, 1. / 0.125,
+                                             0.182 if loose_hbond_criteria else 0.682, 1. / 0.05, 0., 0.]]]))
 
     g = pot.create_group('hbond_coverage'); _args(g, ['protein_hbond', sc_node_name])
     g.write('interaction_param', coverage_interaction)
@@ -313,7 +473,16 @@ def write_config(path, fasta, init_pos, sidechain_lib, environment_lib, rama_ref
 
     # --- Ramachandran maps ------------------------------------------------------------------
     g = pot.create_group('rama_map_pot'); _args(g, ['rama_coord'])
-    if per_residue_rama:
+    if rama_library:
+        seq = [str(x) for x in fasta_cpr]
+        rama_pot = library_rama_potential(seq, rama_library, rama_sheet_mixing_energy, secstr_bias, rama_combining_rule)
+        map_id = np.arange(n_res, dtype='i4')
+        if rama_sheet_mixing_energy is not None:      # the maps a little more / less sheet-like: finite differences in the mixing energy (:698-703)
+            eps = 1e-2
+            g.set_attr('sheet_eps', eps)
+            g.write('more_sheet_rama_pot', read_weighted_maps(seq, rama_library, rama_sheet_mixing_energy + eps).astype('f4'))
+            g.write('less_sheet_rama_pot', read_weighted_maps(seq, rama_library, rama_sheet_mixing_energy - eps).astype('f4'))
+    elif per_residue_rama:
         rama_pot = synthetic_rama_maps(n_res, rama_ref, rama_seed)
         map_id = np.arange(n_res, dtype='i4')
     else:

@@ -275,6 +275,8 @@ __device__ __forceinline__ bool group_any(bool p) {
 __device__ void house(int n, float* x, float& beta) {   // eig.cpp:56-73
     float sigma2 = 1e-20f;
     for (int i = 1; i < n; ++i) sigma2 += x[i] * x[i];
+    // a vector that is zero to within 1e-9 needs no reflection (and the formulas below are not one there: see oracle/upside_oracle.c: house)
+    if (x[0] * x[0] + sigma2 < 1e-18f) { for (int i = 1; i < n; ++i) x[i] = 0.f; beta = 0.f; return; }
     const float mu = sqrtf(x[0] * x[0] + sigma2);
     const float s = (0.f < x[0]) ? -sigma2 * rcp(x[0] + mu) : x[0] - mu;
     beta = 2.f * s * s * rcp(sigma2 + s * s);
@@ -1644,8 +1646,9 @@ __device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, flo
 }
 // one workgroup per system walks the ops of the launch in order
 // (T = the largest workgroup the instance may be launched with)
-template <bool HEAVY, int T>
-__global__ void __launch_bounds__(T) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids, long long* __restrict__ trace) {
+// (W: wavefronts per SIMD the register allocation aims at; 0 = whatever T allows)
+template <bool HEAVY, int T, int W = 0>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(W ? W : 1, W ? W : 8))) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x;
     for (int k = 0; k < ids.n; ++k) {
@@ -1697,7 +1700,12 @@ void fuse_launch(bool heavy, int threads, int n_system, size_t lds, hipStream_t 
     const dim3 b(threads);
     if constexpr (LIST) {
         if (heavy) { if (threads <= 256) hipLaunchKernelGGL((k_fused_list<true, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<true, 512>), g, b, lds, st, args...); }
-        else { if (threads <= 256) hipLaunchKernelGGL((k_fused_list<false, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<false, 1024>), g, b, lds, st, args...); }
+        else {
+            static int w8 = -1;      // UPSIDE_HIP_FUSE_W8=0: the 256-lane light instance without the 8-wavefronts-per-SIMD register cap (experiments)
+            if (w8 < 0) { const char* e = getenv("UPSIDE_HIP_FUSE_W8"); w8 = (e && !atoi(e)) ? 0 : 1; }
+            if (threads <= 256) { if (w8) hipLaunchKernelGGL((k_fused_list<false, 256, 8>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<false, 256>), g, b, lds, st, args...); }
+            else hipLaunchKernelGGL((k_fused_list<false, 1024>), g, b, lds, st, args...);
+        }
     } else {
         if (heavy) { if (threads <= 256) hipLaunchKernelGGL((k_fused_one<true, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_one<true, 512>), g, b, lds, st, args...); }
         else { if (threads <= 256) hipLaunchKernelGGL((k_fused_one<false, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_one<false, 1024>), g, b, lds, st, args...); }
