@@ -27,6 +27,7 @@ void upk_batch_destroy(void* batch);
 int upk_batch_begin(const upk_launch_t* L);
 void upk_batch_chain(const upk_launch_t* L, int chain);
 int upk_batch_run(const upk_launch_t* L);
+void upk_batch_fused_submitted(const upk_launch_t* L);   /* (called by the fused-op queue) */
 int upk_batch_end(const upk_launch_t* L);
 void* upk_fuse_create(int n_system);
 void upk_fuse_destroy(void* fuse);

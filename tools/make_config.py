@@ -5,8 +5,10 @@ of upside_config.py; needs the reference's parameter directory, so it runs where
     python tools/make_config.py --pdb 1abc.pdb --chains A --out 1abc.up [--param-dir /root/reference/parameters]
                                 [--cutoff 7|10] [--cavity-radius R] [--contacts table] [--z-flat-bottom table] ...
 
-The Ramachandran maps are the synthetic per-residue maps of config.synthetic_rama_maps around the shipped reference
-state (the README's rama.dat library is not part of the parameter directory here)."""
+The Ramachandran maps come from --rama-library (the README's rama.dat: neighbour-dependent coil / sheet maps, with
+--rama-sheet-mixing-energy, --rama-library-combining-rule, --secstr-bias as in py/upside_config.py) or, without one, are the
+synthetic per-residue maps of config.synthetic_rama_maps around the shipped reference state (rama.dat is not part of the
+parameter directory here).  --fix-rotamer, --hbond-exclude-residues and --loose-hbond-criteria as in py/upside_config.py."""
 import argparse
 import os
 import sys
@@ -36,6 +38,13 @@ def main():
     ap.add_argument('--join-chains', action='store_true', help='keep the chains of the PDB file bonded end to end (default: cut them, '
                     'py/upside_config.py --chain-break-from-file + py/ugly_hack_break_chain.py)')
     ap.add_argument('--rl-chains', nargs=2, type=int, default=None, help='numbers of receptor and ligand chains: two collective jump moves')
+    ap.add_argument('--rama-library', default='', help='Ramachandran library file (groups coil and sheet: dimer_pot, dimer_weight)')
+    ap.add_argument('--rama-library-combining-rule', default='mixture', choices=['mixture', 'product'])
+    ap.add_argument('--rama-sheet-mixing-energy', type=float, default=None, help='energy of the sheet library relative to the coil library')
+    ap.add_argument('--secstr-bias', default='', help='table "residue secstr energy" (secstr: helix | sheet)')
+    ap.add_argument('--fix-rotamer', default='', help='table "residue restype chain resnum chi1 chi2" (degrees): those residues keep one rotamer state')
+    ap.add_argument('--hbond-exclude-residues', default='', help='comma-separated residues without backbone H-bond sites (ranges a-b allowed)')
+    ap.add_argument('--loose-hbond-criteria', action='store_true', help='permissive H-bond geometry (static structures only)')
     a = ap.parse_args()
     pkg = load_package(); cfg = pkg.config
     if not a.pdb:
@@ -50,7 +59,14 @@ def main():
                             environment_lib=os.path.join(P, 'ff_1', 'environment.h5'),
                             rama_ref=cfg.load_rama_reference(os.path.join(P, 'common', 'rama_reference.pkl')),
                             hbond_energy=float(open(os.path.join(P, 'ff_1', 'hbond')).read()), cavity_radius=a.cavity_radius,
-                            chain_first_residue=() if a.join_chains else first)
+                            chain_first_residue=() if a.join_chains else first,
+                            rama_library=a.rama_library or None, rama_sheet_mixing_energy=a.rama_sheet_mixing_energy,
+                            rama_combining_rule=a.rama_library_combining_rule,
+                            secstr_bias=cfg.read_secstr_bias(a.secstr_bias) if a.secstr_bias else (),
+                            fix_rotamer=cfg.read_fix_rotamer(a.fix_rotamer) if a.fix_rotamer else (),
+                            hbond_exclude_residues=[r for seg in a.hbond_exclude_residues.split(',') if seg
+                                                    for r in (range(int(seg.split('-')[0]), int(seg.split('-')[-1]) + 1))],
+                            loose_hbond_criteria=a.loose_hbond_criteria)
     if first and not a.join_chains:      # upside_config.py --chain-break-from-file + ugly_hack_break_chain.py --chain-break-from-file
         removed = cfg.break_chains(a.out, rl_chains=a.rl_chains)
         print('chains start at residues %s: removed across the junctions %s; one jump move per %s' %

@@ -1748,6 +1748,7 @@ extern "C" long upk_fuse_launch_count(const upk_launch_t* L) { return L->fuse ? 
 extern "C" int upk_fuse_flush(const upk_launch_t* L) {
     FuseQueue* q = (FuseQueue*)L->fuse;
     if (!q || !q->pending.n) return 0;
+    if (L->batch) { const int r_ = upk_batch_run(L); if (r_) return r_; }      // items of an open merged launch precede the ops queued behind them
     size_t lds = (size_t)q->pending_lds; if (lds < 64) lds = 64;      // (c_reduce_sum's partial sums)
     static const bool debug = getenv("UPSIDE_HIP_FUSE_DEBUG") != nullptr;
     if (debug) { fprintf(stderr, "fused launch (%s):", q->pending_heavy ? "heavy" : "light"); for (int k = 0; k < q->pending.n; ++k) fprintf(stderr, " %d%s", q->table[q->pending.id[k]].kind, (q->table[q->pending.id[k]].flags & 1) ? "" : "|"); fprintf(stderr, "\n"); }
@@ -1778,7 +1779,7 @@ static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, si
     op.kind = kind; op.n = n; op.lds_bytes = lds_bytes; op.flags = 0;
     memcpy(op.payload, args, bytes);
     FuseQueue* q = (FuseQueue*)L->fuse;
-    if (L->batch) { const int r_ = upk_batch_run(L); if (r_) return r_; }      // an open merged launch (kernels_batch.h) runs first
+    if (L->batch) upk_batch_fused_submitted(L);      // (inside an open merged launch, kernels_batch.h: the batch's items so far run before this op does -- upk_fuse_flush)
     if (q && q->enabled) {
         if (q->pending.n == FUSE_MAX_PENDING) UPK_FLUSH(L);
         // barrier in front of this op?  only if it touches something an op since the last barrier touched, one of them writing
@@ -1793,8 +1794,8 @@ static int fuse_submit_raw(const upk_launch_t* L, int kind, const void* args, si
         fuse_launch<false>(kind == FOP_AFFINE_BWD, q ? q->threads : fuse_threads(L->n_system), L->n_system, lds, ST(L), op);
         return launch_status();
     };
-    if (!q) return alone();
-    if (!q->enabled) { UPK_FLUSH(L); return alone(); }
+    // (an op that launches now, not through the queue: what an open merged launch holds runs first)
+    if (!q || !q->enabled) { if (L->batch) { const int r_ = upk_batch_run(L); if (r_) return r_; } if (q) UPK_FLUSH(L); return alone(); }
     // look the op up; register it on first sight (blocking upload of one record: in-flight launches read older records only)
     const unsigned long long h = fuse_hash(op);
     int id = -1;

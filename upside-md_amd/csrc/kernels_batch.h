@@ -31,6 +31,7 @@ namespace {
 struct BatchItem { int kind, gx, gy, i0, i1; double d0; size_t lds; std::vector<unsigned char> args; };
 struct BatchState {
     bool open = false; int chain = 0;
+    std::vector<char> chain_fused;                  // chain c has submitted fused per-element ops that are still queued (program order: they precede its next item)
     std::vector<std::vector<BatchItem>> chains;     // chains[c] = the launches of chain c in order
     long n_merged = 0, n_items = 0;
 };
@@ -46,9 +47,12 @@ static bool batch_add(const upk_launch_t* L, int kind, int gx, int gy, size_t ld
     static long mask = -2;      // UPSIDE_HIP_BATCH_KINDS (experiments): bit k set = kernels of kind k may join merged launches
     if (mask == -2) { const char* e = getenv("UPSIDE_HIP_BATCH_KINDS"); mask = e ? strtol(e, nullptr, 0) : -1; }
     if (!((mask >> kind) & 1)) return false;
-    // program order inside a chain: fused per-element ops queued since the batch opened (they ran the batch's earlier items when they
-    // were submitted, kernels_basic.hip: fuse_submit_raw) go out before this item joins
-    if (upk_fuse_pending(L) && upk_fuse_flush(L)) return false;
+    // program order inside a chain: fused per-element ops THIS chain has queued since the batch opened go out before this item joins
+    // (upk_fuse_flush runs the batch's earlier items first); ops queued by other chains are independent of it and stay queued
+    if ((int)s->chain_fused.size() > s->chain && s->chain_fused[s->chain]) {
+        if (upk_fuse_flush(L)) return false;
+        std::fill(s->chain_fused.begin(), s->chain_fused.end(), 0);
+    }
     if (gx < 1 || gy < 1) return true;
     if ((int)s->chains.size() <= s->chain) s->chains.resize(s->chain + 1);
     BatchItem it; it.kind = kind; it.gx = gx; it.gy = gy; it.i0 = i0; it.i1 = i1; it.d0 = d0; it.lds = lds;
@@ -58,6 +62,14 @@ static bool batch_add(const upk_launch_t* L, int kind, int gx, int gy, size_t ld
     if (n1) memcpy(it.args.data() + o1, a1, n1);
     s->chains[s->chain].push_back(std::move(it));
     return true;
+}
+// a fused per-element op was queued (kernels_basic.hip: fuse_submit_raw): it follows the current chain's items so far -- which is kept by
+// running the batch in front of every flush of the fused queue (upk_fuse_flush) -- and precedes the chain's next item (batch_add)
+extern "C" void upk_batch_fused_submitted(const upk_launch_t* L) {
+    BatchState* s = batch_of(L);
+    if (!s || !s->open) return;
+    if ((int)s->chain_fused.size() <= s->chain) s->chain_fused.resize(s->chain + 1, 0);
+    s->chain_fused[s->chain] = 1;
 }
 // a launcher without a batch form: what the batch holds runs first
 #define UPK_BATCH_BREAK(L) do { const int r_ = upk_batch_run(L); if (r_) return r_; } while (0)

@@ -56,7 +56,7 @@ extern "C" int upk_batch_begin(const upk_launch_t* L) {
     BatchState* s = batch_of(L);
     if (!s) return 0;
     UPK_FLUSH(L);
-    s->open = true; s->chain = 0; s->chains.clear();
+    s->open = true; s->chain = 0; s->chains.clear(); s->chain_fused.clear();
     return 0;
 }
 extern "C" void upk_batch_chain(const upk_launch_t* L, int chain) { BatchState* s = batch_of(L); if (s) s->chain = chain; }
