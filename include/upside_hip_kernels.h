@@ -272,6 +272,7 @@ typedef struct {
     unsigned long long* grad_acc;        /* [S][n_bead][6] exact fixed-point (x 2^32) gradient accumulators of the gradient pass when a system is
                                             served by several workgroups or does not fit LDS; zero between evaluations */
     int one_bead_per_state;              /* every (residue, rotamer state) owns exactly one bead: each pair-matrix entry has a single writer */
+    int node_prob_in_solve;              /* the one-workgroup solve computes the node probabilities itself (upk_rotamer_node_prob is then a no-op): small batches */
     int p_prob;                          /* the pair-energy kernel stores exp(-E) (resting value 1) instead of E (resting value 0): the
                                             one-workgroup solve then has no exp pass.  Needs one_bead_per_state and bp_C <= 1 */
     const int *node_bead_start, *node_bead_list;   /* CSR (node*6+rot) -> beads of that rotamer state */

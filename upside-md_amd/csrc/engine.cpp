@@ -277,13 +277,16 @@ void DerivEngine::finalize() {
         n_batch_group = 0;
         auto sweep = [&](bool backward) {
             std::fill(done.begin(), done.end(), 0);
+            size_t n_pre = 0;
+            if (backward)      // a potential term has no backward step (it pushed its derivatives in the forward sweep): nobody waits for it
+                for (size_t i = 0; i < N; ++i) if (nodes[i].computation->potential_term) { done[i] = 1; ++n_pre; nodes[i].deriv_exec_level = 0; }
             auto ready = [&](size_t i) {
                 const auto& deps = backward ? nodes[i].children : nodes[i].parents;
                 return !done[i] && all_of(begin(deps), end(deps), [&](size_t d) { return done[d] != 0; });
             };
             auto fused = [&](size_t i) { auto* c = nodes[i].computation.get(); return backward ? c->fused_backward : c->fused_forward; };
             int lvl = 0;
-            for (size_t n_done = 0; n_done < N;) {
+            for (size_t n_done = n_pre; n_done < N;) {
                 // (round by round: the fused steps that are ready NOW do not depend on each other -- their ops run without barriers
                 //  between them, on different wavefronts of the system's workgroup -- then the ones they unlock, ...)
                 for (;;) {
@@ -308,8 +311,7 @@ void DerivEngine::finalize() {
                         for (size_t j : group) for (size_t pa : nodes[i].parents)
                             if (std::find(begin(nodes[j].parents), end(nodes[j].parents), pa) != end(nodes[j].parents)) clash = true;
                     if (clash) continue;
-                    group.push_back(i);
-                    if (!ctx.L.batch) break;
+                    group.push_back(i);      // (the same order with and without merged launches: the bits of a system's forces do not depend on the batch size)
                 }
                 const int gid = group.size() > 1 ? n_batch_group++ : -1;
                 for (size_t i : group) {
@@ -476,7 +478,7 @@ void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
         const Step& st = schedule[k];
         auto* c = nodes[st.node].computation.get();
         // merged launches: the steps of a group append to their own chains; the group's launches go out at its end
-        const int want_batch = ctx.profile ? -1 : st.batch;      // (profiling brackets single launches with events: no merged launches then)
+        const int want_batch = (ctx.profile || !ctx.L.batch) ? -1 : st.batch;      // (profiling brackets single launches with events: no merged launches then)
         if (want_batch != open_batch) {
             if (open_batch >= 0) upk_check(upk_batch_end(&ctx.L), "batch_end");
             open_batch = want_batch; chain = 0;

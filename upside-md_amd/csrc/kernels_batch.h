@@ -17,7 +17,7 @@
 #include <vector>
 
 enum { BK_CHECK = 1, BK_BUILD_ROT, BK_BUILD_COV, BK_BUILD_ENV, BK_BUILD_HB, BK_REFINE, BK_REFINE_SYM, BK_REFINE_SHORT, BK_ORDER,
-       BK_CLEAR_SLOTS, BK_BUILD_SLOTS, BK_NBR_SLOTS,
+       BK_CLEAR_SLOTS, BK_BUILD_SLOTS, BK_NBR_SLOTS, BK_SLOTS_BOTH,
        BK_ROWS_HB_FWD, BK_ROWS_HB_BWD, BK_ROWS_ENV_FWD, BK_COV_ROWS2, BK_COV_ROWS2_POLY, BK_ENV_BWD, BK_COV_BWD2, BK_COV_BWD2_POLY, BK_BWD_FINISH };
 static inline bool bk_is_pair(int kind) { return kind >= BK_ROWS_HB_FWD; }
 
@@ -30,7 +30,7 @@ static_assert(sizeof(BatchArgs) <= 4096, "the merged launch takes its arguments 
 namespace {
 struct BatchItem { int kind, gx, gy, i0, i1; double d0; size_t lds; std::vector<unsigned char> args; };
 struct BatchState {
-    bool open = false; int chain = 0;
+    bool open = false; int chain = 0; bool skip_nbr_slots = false;
     std::vector<char> chain_fused;                  // chain c has submitted fused per-element ops that are still queued (program order: they precede its next item)
     std::vector<std::vector<BatchItem>> chains;     // chains[c] = the launches of chain c in order
     long n_merged = 0, n_items = 0;

@@ -26,6 +26,12 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_batch(BatchArgs A) {
             case BK_CLEAR_SLOTS: d_rotamer_clear_slots(R, B, lds); break;
             case BK_BUILD_SLOTS: d_rotamer_build_slots(R, B, lds); break;
             case BK_NBR_SLOTS: d_rotamer_nbr_slots(R, B, lds); break;
+            case BK_SLOTS_BOTH: {      // numbering, then the stamping of the same systems by the same workgroup (what it reads it wrote itself)
+                d_rotamer_build_slots(R, B, lds);
+                __syncthreads();
+                const BX B1 = {0, 1, B.by, B.gy};
+                d_rotamer_nbr_slots(R, B1, lds);
+            } break;
             default: break;
         }
     } else {
@@ -56,7 +62,7 @@ extern "C" int upk_batch_begin(const upk_launch_t* L) {
     BatchState* s = batch_of(L);
     if (!s) return 0;
     UPK_FLUSH(L);
-    s->open = true; s->chain = 0; s->chains.clear(); s->chain_fused.clear();
+    s->open = true; s->chain = 0; s->chains.clear(); s->chain_fused.clear(); s->skip_nbr_slots = false;
     return 0;
 }
 extern "C" void upk_batch_chain(const upk_launch_t* L, int chain) { BatchState* s = batch_of(L); if (s) s->chain = chain; }

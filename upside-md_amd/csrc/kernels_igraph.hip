@@ -175,6 +175,13 @@ __device__ __forceinline__ void d_pairlist_check(const upk_igraph_t& G, const BX
             float4* c = (float4*)(side1 ? G.cache_pos1 + (size_t)s * G.n1 * 4 : G.cache_pos2 + (size_t)s * G.n2 * 4) + i;
             *c = make_float4(x[0], x[1], x[2], __int_as_float(side1 ? G.id1[i] : G.id2[i]));
         }
+        // side-chain graph: the node x node mark table of a system that rebuilds is cleared here (the list build marks it next;
+        // round 4: this was a launch of its own, upk_rotamer_clear_slots)
+        if (G.mark_table) {
+            uint4* m = (uint4*)(G.mark_table + (size_t)s * G.mark_stride);
+            const int n16 = (G.mark_n * G.mark_n + 15) / 16;
+            for (int i = threadIdx.x; i < n16; i += blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
+        }
     }
     if (threadIdx.x == 0) {
         G.rebuild_flag[s] = moved;

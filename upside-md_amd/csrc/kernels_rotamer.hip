@@ -61,6 +61,11 @@ __device__ __forceinline__ void d_rotamer_clear_slots(const upk_rotamer_t& R, co
 }
 __global__ void k_rotamer_clear_slots(upk_rotamer_t R)  { d_rotamer_clear_slots(R, BX_REAL, nullptr); }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    // (since round 4 upk_pairlist_check clears the table of a system it flags -- one launch less on the upkeep chain; this launcher stays for
+    //  callers that mark a table without that check: UPSIDE_HIP_CLEAR_SLOTS=1 brings the launch back)
+    static int separate = -1;
+    if (separate < 0) { const char* e = getenv("UPSIDE_HIP_CLEAR_SLOTS"); separate = (e && atoi(e)) ? 1 : 0; }
+    if (!separate) return 0;
     const int n16 = (R->n_node * R->n_node + 15) / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
     if (batch_add(L, BK_CLEAR_SLOTS, blocks, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;
@@ -240,6 +245,8 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     //  list words through a chain of dependent loads, the separate kernel spreads them over hundreds of workgroups)
     static int wgs = 0;   // UPSIDE_HIP_SLOT_WGS (experiments): workgroups looping over the flagged systems
     if (!wgs) { const char* e = getenv("UPSIDE_HIP_SLOT_WGS"); wgs = e ? atoi(e) : 1024; if (wgs < 1) wgs = 1024; }
+    // a small system's slot stamping (upk_rotamer_nbr_slots) rides behind the numbering in the same workgroup: one launch less on the upkeep chain
+    if (R->G.n1 <= 512 && batch_add(L, BK_SLOTS_BOTH, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) { batch_of(L)->skip_nbr_slots = true; return 0; }
     if (batch_add(L, BK_BUILD_SLOTS, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) return 0;
     UPK_FLUSH(L);
     hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < wgs ? L->n_system : wgs), dim3(BP_BLOCK), lds, ST(L), *R);
@@ -286,6 +293,7 @@ __device__ __forceinline__ void d_rotamer_nbr_slots(const upk_rotamer_t& R, cons
 }
 __global__ void k_rotamer_nbr_slots(upk_rotamer_t R)  { d_rotamer_nbr_slots(R, BX_REAL, nullptr); }
 extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
+    if (batch_of(L) && batch_of(L)->skip_nbr_slots) { batch_of(L)->skip_nbr_slots = false; return 0; }      // (done by the BK_SLOTS_BOTH item just queued)
     if (batch_add(L, BK_NBR_SLOTS, (R->G.n1 + 63) / 64, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;      // (16 wavefronts x 4 rows)
     UPK_FLUSH(L);
     int blocks = (R->G.n1 + 15) / 16;          // 4 wavefronts x 4 rows
@@ -295,12 +303,9 @@ extern "C" int upk_rotamer_nbr_slots(const upk_launch_t* L, const upk_rotamer_t*
 
 // ------------------------------------------------------------------------------------------------
 // 1-body energies -> node probabilities (rotamer.cpp:811-826, 239-256)
-__global__ void k_rotamer_node_prob(upk_rotamer_t R) {
+// one node's 1-body energies -> probabilities; pr[6] out
+__device__ __forceinline__ void rotamer_node_prob_one(const upk_rotamer_t& R, int s, int g, float* pr_out) {
     const int* __restrict__ nb_start = R.node_bead_start; const int* __restrict__ nb_list = R.node_bead_list;
-    const int s = blockIdx.y;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0 && R.bp_bar) R.bp_bar[s] = 0;             // cluster barrier counter of the solve that follows
-    if (g >= R.n_node) return;
     const int n_rot = R.node_nrot[g];
     float e[6];
     float off = 0.f;
@@ -316,10 +321,19 @@ __global__ void k_rotamer_node_prob(upk_rotamer_t R) {
         off = r == 0 ? e[0] : fminf(off, e[r]);
     }
     float* pr = R.node_prob + ((size_t)s * R.n_node + g) * 6;
-    for (int r = 0; r < 6; ++r) pr[r] = r < n_rot ? expf(off - e[r]) : 0.f;
+    for (int r = 0; r < 6; ++r) { const float v = r < n_rot ? expf(off - e[r]) : 0.f; pr[r] = v; pr_out[r] = v; }
     R.node_off[(size_t)s * R.n_node + g] = off;
 }
+__global__ void k_rotamer_node_prob(upk_rotamer_t R) {
+    const int s = blockIdx.y;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && R.bp_bar) R.bp_bar[s] = 0;             // cluster barrier counter of the solve that follows
+    if (g >= R.n_node) return;
+    float pr[6];
+    rotamer_node_prob_one(R, s, g, pr);
+}
 extern "C" int upk_rotamer_node_prob(const upk_launch_t* L, const upk_rotamer_t* R) {
+    if (R->node_prob_in_solve) return 0;     // (the one-workgroup solve computes them in its prologue)
     UPK_FLUSH(L);
     hipLaunchKernelGGL(k_rotamer_node_prob, dim3((R->n_node + 255) / 256, L->n_system), dim3(256), 0, ST(L), *R);
     return launch_status();
@@ -1257,6 +1271,9 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     else for (int i = tid; i <= NN; i += nt) bp_start[i] = R.bp_start[(size_t)s * (NN + 1) + i];
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
     if (tid < 3) n_act[tid] = 0;
+    if (R.node_prob_in_solve) {      // the 1-body pass of upk_rotamer_node_prob, one lane per node, at the head of the solve (a launch less)
+        for (int g = tid; g < NN; g += nt) { float pr[6]; rotamer_node_prob_one(R, s, g, pr); for (int r = 0; r < 6; ++r) prob[g * NS + r] = pr[r]; }
+    } else
     for (int i = tid; i < NN * 6; i += nt) prob[(i / 6) * NS + i % 6] = R.node_prob[(size_t)s * NN * 6 + i];
     __syncthreads();
 

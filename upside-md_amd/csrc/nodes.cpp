@@ -1372,6 +1372,8 @@ struct RotamerSidechain : public PotentialNode {
     // (= no interaction) between evaluations, which removes the solve's exp pass over every active matrix.  The cluster
     // solves and the accumulating (several beads per state) path keep energies resting at 0.
     void set_matrix_form() {
+        // (a small batch is a chain of launches: the 1-body pass rides in the prologue of the one-workgroup solve)
+        R.node_prob_in_solve = (R.bp_C <= 1 && ctx->n_system <= 16 && env_int("UPSIDE_HIP_NODE_PROB_IN_SOLVE", 1)) ? 1 : 0;
         R.p_prob = (R.bp_C <= 1 && one_bead_per_state && !env_int("UPSIDE_HIP_BP_ENERGY_TABLE", 0)) ? 1 : 0;
         rest_matrices();
     }
