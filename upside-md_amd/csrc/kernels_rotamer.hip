@@ -872,6 +872,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+// 16- / 8-byte sc1 loads: served by L2 past this CU's L1, so that what another workgroup published with sc1 stores is seen without an
+// L1 invalidate (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 loads may replace the acquire only when the producer stored sc1")
+__device__ __forceinline__ float4 ld_wt16(__amdgpu_buffer_rsrc_t r, int float_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ld_wt8(__amdgpu_buffer_rsrc_t r, int float_off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, float_off * 4, 0, 16);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
 __device__ __forceinline__ void st_wt16(__amdgpu_buffer_rsrc_t r, int float_off, float a, float b, float c, float d) {   // 16-byte sc1 store
     u32x4 v; v.x = __float_as_uint(a); v.y = __float_as_uint(b); v.z = __float_as_uint(c); v.w = __float_as_uint(d);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, 16);
@@ -1693,6 +1704,13 @@ struct BpcShared {            // cluster-visible state of one system
     float* en_part;           // [16] energy partial sums
     int* bar;                 // barrier counter (zeroed by upk_rotamer_node_prob)
 };
+// BPC_SC1_LOADS (round 4 experiment, measured and NOT taken): everything a workgroup reads from its partners after a barrier -- message
+// rows, node beliefs -- read with sc1 loads, so that the barrier needs no acquire fence (buffer_inv sc1, two per sweep).  One
+// 300-residue system, 6 workgroups: 520 us per step against 500 with the fence -- the L2-served 16- and 8-byte loads of the node
+// phase (a dozen rows per node, each a round trip past the L1) cost more than the two invalidates they replace.
+#ifndef BPC_SC1_LOADS
+#define BPC_SC1_LOADS 0
+#endif
 __device__ __forceinline__ void cluster_barrier(int* bar, int& phase, int C, int* error_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores have landed
     __syncthreads();
@@ -1705,7 +1723,9 @@ __device__ __forceinline__ void cluster_barrier(int* bar, int& phase, int C, int
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1 << 22)) { *error_flag = 7; break; }   // a partner never arrived: report instead of hanging the device
         }
+#if !BPC_SC1_LOADS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // one buffer_inv for the whole CU
+#endif
     }
     __syncthreads();
 }
@@ -1923,7 +1943,11 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     auto reload = [&](int half) {   // beliefs of every multi-state node from the exchange buffer into LDS
         for (int g = tid; g < NN; g += nt) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float2 b = make_float2(0.f, 0.f);
+#if BPC_SC1_LOADS
+            if (g >= e1) { a = ld_wt16(X.nbx_w, (half * NN + g) * 8); b = ld_wt8(X.nbx_w, (half * NN + g) * 8 + 4); }
+#else
             if (g >= e1) { const float* src = X.nbx + ((size_t)half * NN + g) * 8; a = *(const float4*)src; b = *(const float2*)(src + 4); }
+#endif
             nb[g * 6] = a.x; nb[g * 6 + 1] = a.y; nb[g * 6 + 2] = a.z; nb[g * 6 + 3] = a.w; nb[g * 6 + 4] = b.x; nb[g * 6 + 5] = b.y;
         }
         __syncthreads();
@@ -1961,9 +1985,14 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
                         const int k = kb + u * BPC_GROUP;
                         lo4[u] = make_float4(1.f, 1.f, 1.f, 1.f); hi2[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
+#if BPC_SC1_LOADS
+                            lo4[u] = ld_wt16(X.inbox_w, (base + k * q) * 4);
+                            if (n == 6) hi2[u] = ld_wt8(X.inbox_w, (base + k * q) * 4 + 4);
+#else
                             const float* m = X.inbox + (size_t)(base + k * q) * 4;
                             lo4[u] = *(const float4*)m;
                             if (n == 6) hi2[u] = *(const float2*)(m + 4);
+#endif
                         }
                     }
 #pragma unroll

@@ -478,7 +478,10 @@ struct IGraphHost {
     // longer.  Measured at 1024 x 300 residues, system-steps/s by scale: 1.8: 73 k, 1.4: 79 k, 1.0: 85.6 k, 0.8: 89.2 k,
     // 0.6: 91.2 k, 0.45: 90.6 k (256 systems: 78.0 / 82.4 / 82.2 k at 1.0 / 0.6 / 0.45); with the straight-line list
     // build 0.6: 92.3 k, 0.5: 93.8 k, 0.4: 93.4 k.
-    static float skin_scale() { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.5f); return v; }
+    // (round 4: a batch of a few systems is a chain of launches, not work -- a longer list is cheap there and every rebuild lengthens the
+    //  chain: 1.5 x the reference's margin up to 16 systems; 56 residues, 1 / 8 systems: 4.97 k / 34.4 k against 4.88 k / 32.8 k system-steps/s
+    //  at 0.5, one 300-residue system 2.09 k against 1.99 k; 64 systems: 57 k against 62 k)
+    float skin_scale() const { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.f); return v > 0.f ? v : (ctx->n_system <= 16 ? 1.5f : 0.5f); }
 
     IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
         memset(&G, 0, sizeof(G));
