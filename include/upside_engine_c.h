@@ -157,6 +157,9 @@ int upside_hip_comm_get_unique_id(char* id_out /* [128] */);
 int upside_hip_comm_init(DerivEngine* engine, int rank, int world, const char* id /* [128] */, const float* temperature_global);
 int upside_hip_comm_replica_swap(DerivEngine* engine, int n_pair, const int* pairs_global, uint32_t base_seed, uint64_t round,
                                  int first_set, int* accepted);
+/* collective: *first_differing_rank = the lowest rank whose value differs from rank 0's, or -1 when all agree (the command
+ * line uses it on the digest of /input/potential, so that a mixed launch ends on every rank together) */
+int upside_hip_comm_agree(DerivEngine* engine, unsigned long long value, int* first_differing_rank);
 int upside_hip_comm_free(DerivEngine* engine);
 
 /* diagnostics: flags[s] = 1 where system s rebuilt the cached pair list of `node_name` in the last force pass */

@@ -1471,12 +1471,28 @@ def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
     procs = [subprocess.Popen([exe] + margs + other, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
                                        UPSIDE_HIP_COMM_FILE=rendezvous + '2')) for r in range(2)]
+    outs = []
     try:
-        out1 = procs[1].communicate(timeout=300)[0].decode()
-        assert procs[1].returncode != 0 and 'different /input/potential' in out1, out1
+        for p in procs:                     # the check is a collective after the rendezvous: BOTH ranks end, neither waits
+            outs.append(p.communicate(timeout=300)[0].decode())
     finally:
-        for p in procs:                     # (rank 0 is left waiting for a peer that has refused to join)
+        for p in procs:
             if p.poll() is None:
                 p.kill()
-        if os.path.exists(rendezvous + '2'):
-            os.remove(rendezvous + '2')
+    for p, o in zip(procs, outs):
+        assert p.returncode not in (0, None) and p.returncode > 0 and 'rank 1 hold a different /input/potential' in o, o
+    assert not os.path.exists(rendezvous + '2')
+    # a record another launch left under the same name is not this launch's: rank 1 alone waits for its own and gives up
+    # (here: quickly, through the nonce of a launch that has no rank 0)
+    with open(rendezvous + '3', 'wb') as f:
+        f.write(b'\0' * 128 + (12345).to_bytes(8, 'little'))
+    p1 = subprocess.Popen([exe] + margs + other[:2] + other[:2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          env=dict(os.environ, RANK='1', WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
+                                   UPSIDE_HIP_COMM_FILE=rendezvous + '3', UPSIDE_HIP_COMM_WAIT_S='3'))
+    try:
+        o = p1.communicate(timeout=300)[0].decode()
+    finally:
+        if p1.poll() is None:
+            p1.kill()
+    os.remove(rendezvous + '3')
+    assert p1.returncode != 0 and 'no communicator id of this launch' in o, o

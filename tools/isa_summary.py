@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""Static instruction statistics of the pair kernels' inner loops (build container; needs hipcc): compiles the kernel files
-to gfx950 assembly and counts, inside the innermost loop of each named kernel, the VALU instructions, the packed ones
+"""Static instruction statistics of the pair kernels' inner loops (build container; needs hipcc): compiles the pair-kernel translation unit
+(kernels_graph.hip) to gfx950 assembly and counts, inside the innermost loop of each named kernel, the VALU instructions, the packed ones
 (v_pk_*) and the scalar fp32 arithmetic.  Writes profiles/isa_pk_share.json (read by bench.py) and a text table.
 
-usage: python tools/isa_summary.py [round tag, default r03]"""
+usage: python tools/isa_summary.py [round tag, default r04]"""
 import collections, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'upside-md_amd', 'csrc')
 KERNELS = {   # label -> (file, mangled-name prefix)
-    'k_rotamer_grad2<false> (side-chain gradient)': ('kernels_rotamer.hip', '_Z15k_rotamer_grad2ILb0EE'),
-    'k_cov_rows2<2,true> (coverage forward)': ('kernels_pair.hip', '_Z11k_cov_rows2ILi2ELb1EE'),
-    'k_cov_backward2<2,true> (coverage backward)': ('kernels_pair.hip', '_Z15k_cov_backward2ILi2ELb1EE'),
-    'k_rotamer_pair_energy<true,true> (side-chain energies, scalar form)': ('kernels_rotamer.hip', '_Z21k_rotamer_pair_energyILb1ELb1EE'),
-    'k_rotamer_grad<true> (round-2 scalar gradient, kept as UPSIDE_HIP_PAIR2=0)': ('kernels_rotamer.hip', '_Z14k_rotamer_gradILb1EE'),
+    'k_rotamer_grad2<false> (side-chain gradient)': ('kernels_graph.hip', '_Z15k_rotamer_grad2ILb0EE'),
+    'k_cov_rows2<2,true> (coverage forward)': ('kernels_graph.hip', '_Z11k_cov_rows2ILi2ELb1EE'),
+    'k_cov_backward2<2,true> (coverage backward)': ('kernels_graph.hip', '_Z15k_cov_backward2ILi2ELb1EE'),
+    'k_rotamer_pair_energy<true,true> (side-chain energies, scalar form)': ('kernels_graph.hip', '_Z21k_rotamer_pair_energyILb1ELb1EE'),
+    'k_rotamer_grad<true> (round-2 scalar gradient, kept as UPSIDE_HIP_PAIR2=0)': ('kernels_graph.hip', '_Z14k_rotamer_gradILb1EE'),
 }
 FP32_SCALAR = re.compile(r'^v_(add|sub|subrev|mul|fma|fmac|fmamk|fmaak|mac|mad)_f32')
 
@@ -43,7 +43,7 @@ def loop_stats(lines):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
     asm = {}
     out, table = {}, []
     for label, (fn, sym) in KERNELS.items():

@@ -52,6 +52,10 @@ for R in 1 8 64 512; do
   python3 bench.py --workload $w --replicas $R --steps $st --warmup 40 --no-cpu-baseline --no-single-system 2>/dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); print('$w', $R, round(d['value']))"
 done; done > "$OUT/other_configs.txt"
 # BASELINE configs[3] and [4] on one GPU (the multi-GPU lines need a node the builder cannot launch on)
+# BASELINE configs[1]: ONE protein G, with the reference timed on one host core in the same line; and the batch of 8
+for R in 1 8; do
+  python3 bench.py --workload proteinG56_7A --replicas $R --steps 400 --warmup 50 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_proteinG56_7A_R$R.json"
+done
 for w in remd64_proteinG56 ens512_syn150; do
   python3 bench.py --workload $w --steps 1665 --warmup 111 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > "$OUT/bench_$w.json"
 done

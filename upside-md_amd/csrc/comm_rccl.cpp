@@ -131,6 +131,27 @@ extern "C" int upside_hip_comm_init(DerivEngine* e, int rank, int world, const c
     API_CATCH
 }
 
+// Do all ranks hold the same 64-bit value (the launcher's digest of /input/potential)?  A collective: every rank learns the
+// answer, so a mismatch ends every rank together instead of leaving the others waiting in a later collective.
+extern "C" int upside_hip_comm_agree(DerivEngine* e, unsigned long long value, int* first_differing_rank) {
+    API_TRY
+    if (!e || !e->comm) throw string("no communicator");
+    ReplicaComm& c = *(ReplicaComm*)e->comm;
+    e->ctx.flush();
+    DevBuf<unsigned long long> mine, all;
+    mine.upload(vector<unsigned long long>(1, value)); all.alloc((size_t)c.world);
+    const ncclResult_t ag = rccl().AllGather(mine.p, all.p, sizeof(value), ncclChar, c.comm, e->ctx.stream);
+    if (ag != ncclSuccess) { c.broken = true; nccl_check(ag, "ncclAllGather"); }
+    vector<unsigned long long> got((size_t)c.world);
+    hip_check(hipMemcpyAsync(got.data(), all.p, got.size() * sizeof(value), hipMemcpyDeviceToHost, e->ctx.stream), "hipMemcpyAsync");
+    hip_check(hipStreamSynchronize(e->ctx.stream), "hipStreamSynchronize");
+    int bad = -1;
+    for (int r = c.world - 1; r >= 1; --r) if (got[r] != got[0]) bad = r;
+    if (first_differing_rank) *first_differing_rank = bad;
+    return 0;
+    API_CATCH
+}
+
 extern "C" int upside_hip_comm_free(DerivEngine* e) {
     if (e && e->comm) { e->sync(); e->comm_free(e->comm); e->comm = nullptr; }
     return 0;

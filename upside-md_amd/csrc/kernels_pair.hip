@@ -263,7 +263,8 @@ __device__ __forceinline__ void d_pair_backward(const upk_igraph_t& G, const Pai
     const int s = B.by;
     const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
     const PairLds L = pair_lds(lds, G, A.tab_floats);
-    unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
+    // (offset arithmetic on the LDS base, not an integer round trip of the pointer: the accumulators must stay ds_add_u64, not flat atomics)
+    unsigned long long* oacc = (unsigned long long*)lds + (((size_t)((float*)(L.counter + 1) - lds) + 1) >> 1);
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
@@ -453,7 +454,8 @@ __device__ __forceinline__ void d_cov_backward2(const upk_igraph_t& G, const Pai
     const int s = B.by;
     const int n_rows = RS == 1 ? G.n1 : G.n2, n_other = RS == 1 ? G.n2 : G.n1;
     const PairLds L = pair2_lds(lds, G, A.tab_floats);
-    unsigned long long* oacc = (unsigned long long*)(((size_t)(L.counter + 1) + 7) & ~(size_t)7);
+    // (offset arithmetic on the LDS base, not an integer round trip of the pointer: the accumulators must stay ds_add_u64, not flat atomics)
+    unsigned long long* oacc = (unsigned long long*)lds + (((size_t)((float*)(L.counter + 1) - lds) + 1) >> 1);
     float* site_sens = (float*)(oacc + (size_t)n_other * DO);            // [n1] (only when the sites carry a pair sensitivity)
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;

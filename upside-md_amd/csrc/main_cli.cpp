@@ -353,22 +353,30 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     if (!use_comm)      // (inside one process the swap sets address its own systems)
         for (auto& st : sets) for (int x : st) if (x >= n_system) throw string("invalid system");
     if (use_comm && !sets.empty()) {
-        // Rendezvous: rank 0 creates the communicator id and leaves it, with the digest of its potential, in a file every rank
-        // of the job can see.  The default name carries what tells one launch from another (the launcher's port, its process
-        // id, and torchrun's run id and restart count when present); rank 0 publishes with an exclusive create + rename after
-        // removing whatever an earlier crashed attempt left behind, and removes the file once every rank has joined.
+        // Rendezvous: rank 0 creates the communicator id and leaves it in a file every rank of the job can see, stamped with a
+        // nonce of THIS launch -- what every rank of one launch shares and another launch does not: the launcher's address and
+        // port, its process id, torchrun's run id and restart count (or UPSIDE_HIP_COMM_NONCE).  A rank that finds a record
+        // with another nonce (an earlier crashed attempt under the same file name) keeps waiting for this launch's.  Rank 0
+        // publishes with an exclusive create + rename and removes the file once every rank has joined.
+        string launch;
+        if (const char* x = getenv("UPSIDE_HIP_COMM_NONCE")) launch = x;
+        else {
+            for (const char* v : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) launch += string(getenv(v) ? getenv(v) : "") + "|";
+            launch += to_string((long)getppid());
+        }
+        unsigned long long nonce = 1469598103934665603ull;               // FNV-1a
+        for (unsigned char ch : launch) { nonce ^= ch; nonce *= 1099511628211ull; }
         string path;
         if (const char* f = getenv("UPSIDE_HIP_COMM_FILE")) path = f;
         else {
             path = string("/tmp/upside_hip_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + to_string((long)getppid());
             for (const char* v : {"TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) if (const char* x = getenv(v)) path += string("_") + x;
         }
-        struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long digest; long long stamp; } rec;
+        struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long nonce; } rec;
         memset(&rec, 0, sizeof(rec));
-        const long long started = (long long)time(nullptr);
         if (rank == 0) {
             if (upside_hip_comm_get_unique_id(rec.id)) throw string(upside_hip_last_error());
-            rec.digest = potential_digest; rec.stamp = started;
+            rec.nonce = nonce;
             remove(path.c_str());                                   // a stale record of an earlier attempt under this name
             const string tmp = path + ".tmp." + to_string((long)getpid());
             const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
@@ -377,20 +385,26 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             if (rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw string("cannot publish ") + path; }
         } else {
             bool got = false;
-            for (int tries = 0; tries < 1200 && !got; ++tries) {      // up to two minutes
+            const int wait_s = getenv("UPSIDE_HIP_COMM_WAIT_S") ? max(1, atoi(getenv("UPSIDE_HIP_COMM_WAIT_S"))) : 120;
+            for (int tries = 0; tries < wait_s * 10 && !got; ++tries) {
                 FILE* f = fopen(path.c_str(), "rb");
                 if (f) { got = fread(&rec, 1, sizeof(rec), f) == sizeof(rec); fclose(f); }
-                if (got && rec.stamp + 600 < started) got = false;    // written long before this process started: not this launch's
+                if (got && rec.nonce != nonce) got = false;           // another launch's record
                 if (!got) this_thread::sleep_for(chrono::milliseconds(100));
             }
-            if (!got) throw string("no communicator id at ") + path + " (is rank 0 running?)";
-            // every rank keeps its own files under ONE engine and the Metropolis kernel assumes one Hamiltonian for the whole
-            // ladder: the ranks' potentials must agree as the files of one rank must
-            if (rec.digest != potential_digest)
-                throw string("the configuration files of rank ") + to_string(rank) + " hold a different /input/potential than those of rank 0";
+            if (!got) throw string("no communicator id of this launch at ") + path + " (is rank 0 running?)";
         }
         if (upside_hip_comm_init(e, rank, world, rec.id, temps_global.data())) throw string(upside_hip_last_error());
         if (rank == 0) remove(path.c_str());                         // (ncclCommInitRank returns when every rank has joined)
+        // every rank keeps its own files under ONE engine and the Metropolis kernel assumes one Hamiltonian for the whole ladder:
+        // the ranks' potentials must agree as the files of one rank must.  Checked with the communicator, so that every rank
+        // learns of a mismatch and none is left waiting for a peer that has gone.
+        int differs = -1;
+        if (upside_hip_comm_agree(e, potential_digest, &differs)) throw string(upside_hip_last_error());
+        if (differs >= 0) {
+            upside_hip_comm_free(e);
+            throw string("the configuration files of rank ") + to_string(differs) + " hold a different /input/potential than those of rank 0";
+        }
     }
 
     vector<float> energy(n_system);
