@@ -78,8 +78,9 @@ def main():
     entry['_kernel_sources_sha256'] = kernel_source_stamp()
     tab['%s/R%s' % (workload, replicas)] = entry
     json.dump(tab, open(out, 'w'), indent=1, sort_keys=True)
-    for k, v in sorted(((k, v) for k, v in entry.items() if isinstance(v, dict)), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:
+    for k, v in sorted(((k, v) for k, v in entry.items() if isinstance(v, dict) and 'bytes_per_launch' in v), key=lambda kv: -kv[1]['bytes_per_launch'])[:12]:
         print('%-40s read %8.1f MB  write %8.1f MB' % (k, v['fetch_bytes'] / 1e6, v['write_bytes'] / 1e6))
+    print('whole step: %.2f GB counted (%.2f GB if every read is a wide one)' % (entry['_step']['bytes_per_step'] / 1e9, entry['_step']['bytes_per_step_if_wide'] / 1e9))
 
 
 if __name__ == '__main__':
