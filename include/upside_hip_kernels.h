@@ -302,7 +302,8 @@ typedef struct {
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */
     int bp_C, bp_resident;               /* workgroups per system; 1 = matrices resident in LDS (512 lanes), 0 = split solve over global memory */
-    int *bp_bar, *bp_fallback;           /* [S] barrier counter; [S] 1 = system did not fit, solved by the one-workgroup kernel */
+    int *bp_bar, *bp_fallback;           /* [S] barrier counter; [S] 1 = system did not fit or a cluster barrier gave up: solved by the one-workgroup kernel */
+    int bp_test_abort;                   /* tests (UPSIDE_HIP_BP_CLUSTER_TEST_ABORT): the last workgroup of every cluster leaves at once, barriers give up early */
     float *bp_nbx, *bp_dev, *bp_en_part; /* [S][2][n_node][8] exchanged node beliefs, [S][2][16] deviations, [S][16] energy partial sums */
 } upk_rotamer_t;
 

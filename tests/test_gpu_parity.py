@@ -602,11 +602,13 @@ ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1'},          # one-workgroup belief propagation instead of the cluster solve
     {'UPSIDE_HIP_BP_CLUSTER': '3'},          # cluster too small for the pair matrices: on-device fallback flag
     {'UPSIDE_HIP_BP_SPLIT': '3'},            # split cluster solve: 3 workgroups per system over global-memory matrices
+    {'UPSIDE_HIP_BP_CLUSTER': '6', 'UPSIDE_HIP_BP_CLUSTER_TEST_ABORT': '1'},   # a cluster workgroup never arrives: barriers give up, the one-workgroup solve re-solves
     {'UPSIDE_HIP_ASYNC_PREPARE': '0'},       # list upkeep inline on the main stream
     {'UPSIDE_HIP_IG_UNSTAGED': '1'},         # coverage graphs through the kernels for systems too large for LDS
     {'UPSIDE_HIP_IG_WGS': '4096'},           # many thin workgroups per pair kernel
     {'UPSIDE_HIP_ROT_UNSTAGED': '1'},        # rotamer pair kernels with bead rows in global memory (large systems)
-    {'UPSIDE_HIP_GRAPH': '1'},               # MD loop replayed from a captured hipGraph
+    {'UPSIDE_HIP_GRAPH': '1'},               # MD loop replayed from a captured hipGraph (the default up to 16 systems)
+    {'UPSIDE_HIP_GRAPH': '0'},               # ... and launched step by step
     {'UPSIDE_HIP_ROTAMER_ATOMIC': '1'},      # pair matrices accumulated with atomics (libraries with several beads per state)
     {'UPSIDE_HIP_PLB_UNSTAGED': '1'},        # list build reading the other side from global memory (very large systems)
     {'UPSIDE_HIP_SKIN_SCALE': '1.0'},        # the reference's cached-list margin

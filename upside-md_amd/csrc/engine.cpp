@@ -584,7 +584,11 @@ bool DerivEngine::capture_md_graph() {
     return true;
 }
 void DerivEngine::run_steps(int n_step) {
-    static const int use_graph = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : 0; }();   // opt-in: see DESIGN.md
+    // UPSIDE_HIP_GRAPH: six MD steps replayed from a captured hipGraph.  Default: up to 16 systems, where a step is a chain of ~17
+    // dependent launches and a graph node boundary is cheaper than an eager one (one / eight 56-residue systems: 193 / 223 against
+    // 201 / 233 us per step; one 300-residue system 465 against 474; 64 x 150 residues 716 against 689: off there)
+    static const int graph_env = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : -1; }();
+    const int use_graph = graph_env >= 0 ? graph_env : (ctx.n_system <= 16 ? 1 : 0);
     int left = n_step;
     while (left > 0) {
         const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;
@@ -687,7 +691,7 @@ void DerivEngine::check_device_errors() {
     auto f = ctx.error_flag.download();
     if (f[0]) {
         ctx.error_flag.fill_bytes(0);
-        if (f[0] == 7)   // kernels_rotamer.hip: cluster_barrier gave up waiting -- the cluster's workgroups were not all resident
+        if (f[0] == 7)   // kernels_rotamer.hip: the LAST cluster_barrier (behind the epilogue) gave up waiting; earlier ones hand the system to the one-workgroup solve
             throw string("belief propagation: a workgroup of a solve cluster never arrived (the cluster solve needs all its workgroups "
                          "co-resident; something else occupied the device): the forces of this step are not valid.  Set UPSIDE_HIP_BP_CLUSTER=1 "
                          "to use the one-workgroup solve");

@@ -103,13 +103,18 @@ __device__ __forceinline__ void c_reduce_sum(const ReduceSumArgs& A, int s, floa
 // every buffer holds n_system equal slices: a workgroup clears the slices of its system
 struct ZeroManyArgs { float* const* ptrs; const long* sizes; int n_buf, n_system; };
 __device__ __forceinline__ void c_zero_many(const ZeroManyArgs& A, int s) {
-    for (int b = 0; b < A.n_buf; ++b) {
-        const long per = A.sizes[b] / A.n_system;
+    // one buffer per WAVEFRONT at a time: a buffer costs a chain of dependent loads (size, pointer) before its first store, and a system's
+    // slice of a sensitivity array is a few KB -- walked buffer by buffer by the whole workgroup, a dozen buffers took 6 us of a
+    // 56-residue pass
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_wave = (int)(blockDim.x >> 6), lane = threadIdx.x & 63;
+    for (int b = wave; b < A.n_buf; b += n_wave) {
+        const long total = A.sizes[b];
+        const long per = total < (1L << 31) ? (long)((unsigned)total / (unsigned)A.n_system) : total / A.n_system;
         float* p = A.ptrs[b] + (size_t)s * per;
         if ((per & 3) == 0 && (((size_t)p) & 15) == 0) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (long i = threadIdx.x; i < (per >> 2); i += blockDim.x) ((float4*)p)[i] = z;
-        } else for (long i = threadIdx.x; i < per; i += blockDim.x) p[i] = 0.f;
+            for (long i = lane; i < (per >> 2); i += 64) ((float4*)p)[i] = z;
+        } else for (long i = lane; i < per; i += 64) p[i] = 0.f;
     }
 }
 extern "C" int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf) {

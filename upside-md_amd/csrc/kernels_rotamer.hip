@@ -1711,23 +1711,32 @@ struct BpcShared {            // cluster-visible state of one system
 #ifndef BPC_SC1_LOADS
 #define BPC_SC1_LOADS 0
 #endif
-__device__ __forceinline__ void cluster_barrier(int* bar, int& phase, int C, int* error_flag) {
+// Returns false when a partner never arrived (the cluster's workgroups were not all resident -- other kernels held CUs -- or a
+// partner has given up already).  `fallback` non-null: the system is handed to the one-workgroup solve that follows the cluster
+// launch in the stream (nothing the solve consumes has been modified yet: callers return at once); null (the last barrier, behind
+// the epilogue): reported as error 7.
+__device__ __forceinline__ bool cluster_barrier(int* bar, int& phase, int C, int* error_flag, int* fallback, int spin_limit) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores have landed
     __syncthreads();
     ++phase;
+    int gave_up = 0;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int target = phase * C;
         int spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) { *error_flag = 7; break; }   // a partner never arrived: report instead of hanging the device
+            if (++spins > spin_limit) {            // report / hand over instead of hanging the device
+                gave_up = 1;
+                if (fallback) __hip_atomic_store(fallback, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *error_flag = 7;
+                break;
+            }
         }
 #if !BPC_SC1_LOADS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // one buffer_inv for the whole CU
 #endif
     }
-    __syncthreads();
+    return __syncthreads_or(gave_up) == 0;
 }
 
 template <int NA, int NB> struct BpcSlot { int a, b, offa, offb, sl; bool live; float ma[NA], mb[NB]; };
@@ -1865,6 +1874,11 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     }
     if (!fits) { if (c == 0 && tid == 0) R.bp_fallback[s] = 1; return; }   // the single-workgroup kernel takes this system
     if (c == 0 && tid == 0) R.bp_fallback[s] = 0;
+    // a barrier that gives up writes 1 here (after this 0 in every order of events: a workgroup gives up only after its partners
+    // failed to arrive, and workgroup 0 itself gives up last if it is the late one)
+    int* fb = R.bp_fallback + s;
+    const int spin_limit = R.bp_test_abort ? (1 << 12) : (1 << 22);
+    if (R.bp_test_abort && c == C - 1) return;          // tests: a partner that never arrives
 
     float* nb = lds;                          // [NN][6] latest node beliefs (all nodes)
     float* prob = lds + NN * 6;               // [NN][6] own nodes only are valid: probabilities with 1-state partners folded
@@ -1939,7 +1953,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
             st_wt16(X.nbx_w, g * 8 + 4, p[4], p[5], 0.f, 0.f);
         }
     }
-    cluster_barrier(X.bar, phase, C, R.G.error_flag);
+    if (!cluster_barrier(X.bar, phase, C, R.G.error_flag, fb, spin_limit)) return;      // (handed to the one-workgroup solve)
     auto reload = [&](int half) {   // beliefs of every multi-state node from the exchange buffer into LDS
         for (int g = tid; g < NN; g += nt) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float2 b = make_float2(0.f, 0.f);
@@ -1967,7 +1981,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
             bp_edge_range_impl<3, 6, true>(Cx, lo[1], lo[1] + n_own[1], nb, tid, nt, X.inbox_w);
             bp_edge_range_impl<6, 6, true>(Cx, lo[2], lo[2] + n_own[2], nb, tid, nt, X.inbox_w);
         }
-        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        if (!cluster_barrier(X.bar, phase, C, R.G.error_flag, fb, spin_limit)) return;      // (handed to the one-workgroup solve)
         // ---- node phase over the own nodes
         float dev = 0.f;
         const int new_row0 = (cur ^ 1) * NN;
@@ -2042,7 +2056,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
             const float wg_dev = block_max(dev, scratch);
             if (tid == 0) st_agent(X.dev + (cur ^ 1) * 16 + c, wg_dev);
         }
-        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        if (!cluster_barrier(X.bar, phase, C, R.G.error_flag, fb, spin_limit)) return;      // (handed to the one-workgroup solve)
         cur ^= 1;
         reload(cur);
         if (sweep >= 0) {
@@ -2066,7 +2080,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
         for (int r = 0; r < 6; ++r) st_agent(out_nb + g * 6 + r, r < n ? nb[g * 6 + r] * rs : 0.f);
     }
     if (c == 0) for (int g = tid; g < e1; g += nt) { st_agent(out_nb + g * 6, 1.f); for (int r = 1; r < 6; ++r) st_agent(out_nb + g * 6 + r, 0.f); }
-    cluster_barrier(X.bar, phase, C, R.G.error_flag);
+    if (!cluster_barrier(X.bar, phase, C, R.G.error_flag, fb, spin_limit)) return;      // (handed to the one-workgroup solve)
     for (int i = tid; i < NN * 6; i += nt) nb[i] = ld_agent(out_nb + i);
     __syncthreads();
     float* marg = R.marg + (size_t)s * R.slot_cap * 36;
@@ -2108,7 +2122,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
         for (int i = lo_k + tid; i < hi_k; i += nt) { active_last[i] = active_w[i]; active_w[i] = 0; }
     }
     if (want_energy) {
-        cluster_barrier(X.bar, phase, C, R.G.error_flag);
+        (void)cluster_barrier(X.bar, phase, C, R.G.error_flag, nullptr, spin_limit);
         if (c == 0 && tid == 0) { float t = 0.f; for (int cc = 0; cc < C; ++cc) t += ld_agent(X.en_part + cc); R.energy[s] = t; }
     }
 }

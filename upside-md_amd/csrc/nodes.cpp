@@ -1369,6 +1369,7 @@ struct RotamerSidechain : public PotentialNode {
         if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", resident_limit)) C = 1;
         if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
+        R.bp_test_abort = env_int("UPSIDE_HIP_BP_CLUSTER_TEST_ABORT", 0);
         set_matrix_form();
     }
     // One-workgroup solve with single-writer matrices: the pair-energy kernel writes exp(-E) itself and the matrices rest at 1
