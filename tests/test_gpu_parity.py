@@ -615,7 +615,8 @@ ALT_PATHS = [
     {'UPSIDE_HIP_IG_POLY': '0'},             # coverage pair passes on the spline-coefficient table (tables too large for the polynomial form)
     {'UPSIDE_HIP_ROT_SORT_BEADS': '0'},      # side-chain beads in the configuration's own order (no renumbering by pair-matrix node)
     {'UPSIDE_HIP_ROT_POLY': '0'},            # side-chain energy pass on the spline-coefficient table (tables too large for the polynomial form)
-    {'UPSIDE_HIP_UPKEEP_STREAMS': '1'},      # one shared upkeep stream (the large-batch choice) for a small batch
+    {'UPSIDE_HIP_UPKEEP_STREAMS': '1', 'UPSIDE_HIP_BATCH': '0'},      # one shared upkeep stream instead of one per graph
+    {'UPSIDE_HIP_UPKEEP_STREAMS': '0', 'UPSIDE_HIP_BATCH': '0'},      # one upkeep stream per graph (the default above 16 systems) at one system
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '0'},      # one-workgroup BP of 1024 lanes streaming every pair matrix
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '1'},      # 512 lanes, two 6x6 trips of pair matrices pinned in registers (large batches)

@@ -412,11 +412,13 @@ void DerivEngine::finalize() {
         first.insert(first.end(), rest.begin(), rest.end());
         schedule.swap(first);
     }
-    // One upkeep stream per node (small batches: the rebuilds of different graphs run side by side), or ONE shared upkeep
-    // stream (large batches): the bandwidth-bound upkeep kernels then run in the order the main stream needs their results,
-    // beside the VALU-bound pair passes of the graphs whose lists are already done, instead of all at once in front of them.
+    // One upkeep stream per node (the rebuilds of different graphs run side by side), or ONE shared upkeep stream
+    // (UPSIDE_HIP_UPKEEP_STREAMS=1: the upkeep kernels then run in the order the main stream needs their results).  Round 3 shared
+    // the stream from 128 systems on (+1 % at 4096 then); since the per-element nodes are a dozen fused launches instead of forty
+    // small kernels that filled the gaps, one stream per graph wins at every size -- system-steps/s, shared vs per graph:
+    // 128 systems 86.6 vs 98.3 k, 256: 124.4 vs 138.8 k, 1024: 168.9 vs 177.0 k, 4096: 182.8 vs 188.7 k.
     const char* env_streams = getenv("UPSIDE_HIP_UPKEEP_STREAMS");
-    const bool shared_stream = env_streams ? atoi(env_streams) == 1 : ctx.n_system >= 128;
+    const bool shared_stream = env_streams ? atoi(env_streams) == 1 : false;
     hipStream_t shared = nullptr;
     std::vector<Step> hoisted;
     std::vector<int> n_dep_left(nodes.size(), -1);
