@@ -170,8 +170,9 @@ typedef struct {
                                           * grid.y instead of launching (and retiring) workgroups for every system. */
     int* error_flag;                     /* [1] set to non-zero on capacity overflow */
     /* optional hook used by the rotamer node: while a symmetric list is rebuilt, mark_table[s][node(i)][node(j)]
-       (mark_n x mark_n bytes, pre-cleared by upk_rotamer_clear_slots) is set to 1 for every cached pair */
+       (mark_n rows of mark_ld bytes, cleared by the rebuild test that flags the system) is set to 1 for every cached pair */
     unsigned char* mark_table; const int* mark_node; int mark_n, mark_stride;   /* mark_stride: bytes per system (multiple of 16) */
+    int mark_ld;                         /* bytes per row: mark_n rounded up to 64 (a row is whole 64-bit words of the packed bit matrix) */
     int mark_start3, mark_start6;        /* node of a bead id (rotamer.cpp:812-816): (id >> 8) + {0, mark_start3, mark_start6} by its state count */
     /* This step's in-range pairs ("hit lists", the refine of interaction_graph.h:201-257 done ONCE per step and side by
        upk_pairlist_refine): for every row of side 1 (hit1) / side 2 (hit2) the cached neighbours with d2 < cutoff2, in list
@@ -282,7 +283,7 @@ typedef struct {
     float *node_prob, *node_off, *nb_cur;               /* [S][n_node][6], off [S][n_node] */
     int slot_cap, adj_cap;
     int *n_slot, *slot_a, *slot_b, *slot_of, *slot_active;   /* [S], [S][cap], [S][cap], [S][n_node^2], [S][cap] */
-    unsigned char* mark;                 /* [S][n_node^2] residue pairs owning a cached bead pair (= G.mark_table) */
+    unsigned char* mark;                 /* [S][n_node][G.mark_ld] residue pairs owning a cached bead pair (= G.mark_table) */
     int *adj_cnt, *adj_slot;             /* [S][n_node], [S][n_node][adj_cap] */
     int *bp_start, *slot_off;            /* [S][n_node+1] inbox CSR of BP messages, [S][cap][2] inbox offsets of a slot */
     int *row_start, *slot_row;           /* the same inbox counted in ROWS (one per message): [S][n_node+2] first row of a node (entry n_node: end;

@@ -179,7 +179,7 @@ __device__ __forceinline__ void d_pairlist_check(const upk_igraph_t& G, const BX
         // round 4: this was a launch of its own, upk_rotamer_clear_slots)
         if (G.mark_table) {
             uint4* m = (uint4*)(G.mark_table + (size_t)s * G.mark_stride);
-            const int n16 = (G.mark_n * G.mark_n + 15) / 16;
+            const int n16 = G.mark_stride / 16;
             for (int i = threadIdx.x; i < n16; i += blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
         }
     }
@@ -283,7 +283,7 @@ __device__ __forceinline__ void d_pairlist_build(const upk_igraph_t& G, int bloc
                     const int key_prev = __builtin_amdgcn_update_dpp(-1, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                     if (up & (key_prev != key)) {
                         unsigned char* mt = G.mark_table + (size_t)s * G.mark_stride;
-                        mt[my_node * G.mark_n + key] = 1; mt[key * G.mark_n + my_node] = 1;
+                        mt[my_node * G.mark_ld + key] = 1; mt[key * G.mark_ld + my_node] = 1;
                     }
                 }
             }

@@ -53,7 +53,7 @@ __device__ __forceinline__ int slot_class(int na, int nb) {   // na <= nb
 __device__ __forceinline__ void d_rotamer_clear_slots(const upk_rotamer_t& R, const BX B, float* lds_unused) {
     const int* fl = UPK_FLAG_LIST(R.G);
     const int n_flagged = fl[0];
-    const int n16 = (R.n_node * R.n_node + 15) / 16;          // the table is padded to a multiple of 16 bytes
+    const int n16 = R.G.mark_stride / 16;
     for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         uint4* m = (uint4*)(R.mark + (size_t)fl[1 + fi] * R.G.mark_stride);
         for (int i = B.bx * blockDim.x + threadIdx.x; i < n16; i += B.gx * blockDim.x) m[i] = make_uint4(0, 0, 0, 0);
@@ -66,7 +66,7 @@ extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_
     static int separate = -1;
     if (separate < 0) { const char* e = getenv("UPSIDE_HIP_CLEAR_SLOTS"); separate = (e && atoi(e)) ? 1 : 0; }
     if (!separate) return 0;
-    const int n16 = (R->n_node * R->n_node + 15) / 16;
+    const int n16 = R->G.mark_stride / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
     if (batch_add(L, BK_CLEAR_SLOTS, blocks, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;
     UPK_FLUSH(L);
@@ -115,23 +115,31 @@ __device__ __forceinline__ void d_rotamer_build_slots(const upk_rotamer_t& R, co
         for (int c = 0; c * 64 < x && c < W; ++c) n += __popcll(bits[g * W + c] & below(x, c));
         return n;
     };
+    // B.gx workgroups share a system: each packs the marks and runs the scans (a few microseconds), and numbers the pairs of every
+    // B.gx-th node -- the numbering is a stream of scattered 4-byte stores (eight per pair) that one CU issues one address at a time
+    const int K = B.gx, kk = B.bx;
     for (int fi = B.by; fi < n_flagged; fi += B.gy) {
         const int s = fl[1 + fi];
         const unsigned char* mark = R.mark + (size_t)s * G.mark_stride;
         int* slot_of = R.slot_of + (size_t)s * NN * NN;
         __syncthreads();                                     // LDS of the previous system is no longer read
-        // ---- pack the marks: wave item = (row, word); 8 loads in flight per lane
-        for (int item0 = wave * 8; item0 < NN * W; item0 += n_wave * 8) {
-            unsigned char v[8];
+        // ---- pack the marks: a row is W * 64 bytes (G.mark_ld), so 16 bytes = 16 bits of ONE row word: every lane loads 16-byte
+        // pieces (all of its loads in flight at once) and stores 16 bits each.  (Round 3 read bytes, one 64-lane ballot per word and
+        // eight loads in flight per wavefront: 39 of the 97 us of a 300-node system.)
+        {
+            const uint4* m16 = (const uint4*)mark;
+            unsigned short* bits16 = (unsigned short*)bits;
+            const int n16 = NN * W * 4;
+            for (int i0 = tid; i0 < n16; i0 += 4 * (int)blockDim.x) {
+                uint4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int item = item0 + u, a = item / W, b = (item % W) * 64 + lane;
-                v[u] = (item < NN * W && b < NN) ? mark[(size_t)a * NN + b] : (unsigned char)0;
-            }
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * (int)blockDim.x; v[u] = i < n16 ? m16[i] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned long long m = __ballot(v[u] != 0);
-                if (lane == 0 && item0 + u < NN * W) bits[item0 + u] = m;
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * (int)blockDim.x;
+                    auto nib = [](unsigned x) { return (x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u); };   // bytes 0 / 1 -> 4 bits
+                    if (i < n16) bits16[i] = (unsigned short)(nib(v[u].x) | (nib(v[u].y) << 4) | (nib(v[u].z) << 8) | (nib(v[u].w) << 12));
+                }
             }
         }
         __syncthreads();
@@ -171,25 +179,27 @@ __device__ __forceinline__ void d_rotamer_build_slots(const upk_rotamer_t& R, co
             int acc = 0;
             for (int c = 0; c < N_CLASS; ++c) { cls_lds[c] = acc; acc += cnt[c]; }
             cls_lds[N_CLASS] = acc;
-            int* cs = R.class_start + (size_t)s * (N_CLASS + 1);
-            for (int c = 0; c <= N_CLASS; ++c) cs[c] = cls_lds[c] < R.slot_cap ? cls_lds[c] : R.slot_cap;
-            R.n_slot[s] = acc < R.slot_cap ? acc : R.slot_cap;
-            if (acc > R.slot_cap) *G.error_flag = 2;
+            if (kk == 0) {
+                int* cs = R.class_start + (size_t)s * (N_CLASS + 1);
+                for (int c = 0; c <= N_CLASS; ++c) cs[c] = cls_lds[c] < R.slot_cap ? cls_lds[c] : R.slot_cap;
+                R.n_slot[s] = acc < R.slot_cap ? acc : R.slot_cap;
+                if (acc > R.slot_cap) *G.error_flag = 2;
+            }
         }
         __syncthreads();
         int* bp_start = R.bp_start + (size_t)s * (NN + 1);
-        for (int g = tid; g <= NN; g += blockDim.x) bp_start[g] = bp_s[g];
+        if (kk == 0) for (int g = tid; g <= NN; g += blockDim.x) bp_start[g] = bp_s[g];
         // the same inbox as ROWS (one per message; a 6-state row is two quads): rows of the 3-state nodes in [0, rows3), rows of
         // the 6-state nodes from R6 = rows3 rounded up to 32 on -- so that every 32-row word of a per-solve activity mask holds
         // rows of ONE width (k_rotamer_bp<.., COMPACT>)
         const int rows3 = bp_s[e3 < NN ? e3 : NN], R6 = (rows3 + 31) & ~31;
         auto row_of = [&](int g) { return g < e3 ? bp_s[g] : R6 + ((bp_s[g] - rows3) >> 1); };   // first row of node g (g = NN: end)
-        if (R.row_start) {
+        if (R.row_start && kk == 0) {
             int* row_start = R.row_start + (size_t)s * (NN + 2);
             for (int g = tid; g <= NN; g += blockDim.x) row_start[g] = g < e1 ? 0 : row_of(g);
             if (tid == 0) row_start[NN + 1] = R6;
         }
-        if (a < NN) {
+        if (a < NN && kk == 0) {
             const int d = na > 1 ? deg1[a] : 0;
             R.adj_cnt[(size_t)s * NN + a] = d < R.adj_cap ? d : R.adj_cap;
             if (d > R.adj_cap) *G.error_flag = 3;
@@ -198,7 +208,7 @@ __device__ __forceinline__ void d_rotamer_build_slots(const upk_rotamer_t& R, co
         // popcounts of the two rows (messages TO node g sit at inbox quad bp_start[g] + rank among g's multi-state
         // partners x (1 quad = 4 floats for a 3-state g, 2 for a 6-state g); folded 1-state partners of g are listed
         // in ascending id)
-        if (a < NN) {
+        if (a < NN && a % K == kk) {
             int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
             int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
             int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
@@ -247,9 +257,13 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     if (!wgs) { const char* e = getenv("UPSIDE_HIP_SLOT_WGS"); wgs = e ? atoi(e) : 1024; if (wgs < 1) wgs = 1024; }
     // a small system's slot stamping (upk_rotamer_nbr_slots) rides behind the numbering in the same workgroup: one launch less on the upkeep chain
     if (R->G.n1 <= 512 && batch_add(L, BK_SLOTS_BOTH, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) { batch_of(L)->skip_nbr_slots = true; return 0; }
-    if (batch_add(L, BK_BUILD_SLOTS, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) return 0;
+    // workgroups per system (see the kernel): several while the device has CUs to spare, one when systems fill it
+    static int split = -1;    // UPSIDE_HIP_SLOT_SPLIT (experiments / tests)
+    if (split < 0) { const char* e = getenv("UPSIDE_HIP_SLOT_SPLIT"); split = e ? atoi(e) : 0; if (split < 0 || split > 16) split = 0; }
+    const int K = split ? split : ((L->n_system <= 256 && R->n_node > 64) ? 4 : 1);
+    if (batch_add(L, BK_BUILD_SLOTS, K, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) return 0;
     UPK_FLUSH(L);
-    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(1, L->n_system < wgs ? L->n_system : wgs), dim3(BP_BLOCK), lds, ST(L), *R);
+    hipLaunchKernelGGL(k_rotamer_build_slots, dim3(K, L->n_system < wgs ? L->n_system : wgs), dim3(BP_BLOCK), lds, ST(L), *R);
     return launch_status();
 }
 

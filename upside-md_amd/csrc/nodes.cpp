@@ -1259,7 +1259,8 @@ struct RotamerSidechain : public PotentialNode {
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
         row_start.alloc((size_t)S * (n_node + 2)); slot_row.alloc((size_t)S * R.slot_cap * 2);
-        ig.G.mark_stride = ((n_node * n_node + 15) / 16) * 16;
+        ig.G.mark_ld = ((n_node + 63) / 64) * 64;
+        ig.G.mark_stride = n_node * ig.G.mark_ld;
         mark.alloc((size_t)S * ig.G.mark_stride);
         ig.G.mark_table = mark.p; ig.G.mark_node = d_bead_node.p; ig.G.mark_n = n_node;
         ig.G.mark_start3 = n1; ig.G.mark_start6 = n1 + n3;
