@@ -62,6 +62,8 @@ def bind(lib):
     c.upside_hip_profile_dump.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int]
     c.upside_hip_igraph_bytes_per_system.restype = ct.c_double
     c.upside_hip_igraph_bytes_per_system.argtypes = [ct.c_void_p]
+    c.upside_hip_bp_min_bytes.restype = ct.c_double
+    c.upside_hip_bp_min_bytes.argtypes = [ct.c_void_p]
     c.upside_hip_last_error.restype = ct.c_char_p
     c.upside_hip_calibrate_valu.argtypes = [ct.c_void_p]
     c.upside_hip_comm_get_unique_id.argtypes = [ct.c_char_p]
@@ -309,6 +311,11 @@ def main():
         # every sweep
         dom = max(rows, key=lambda r: r[1])
         roofline = entry(dom)
+        if dom[0].startswith('bp:'):      # what the solve must move at least once (active matrices in, marginals out); counted traffic / this = re-read factor
+            mn = c.upside_hip_bp_min_bytes(eng)
+            if mn > 0:
+                roofline['min_bytes_per_launch'] = mn
+                if roofline.get('traffic'): roofline['traffic_over_min'] = roofline['traffic'] / mn
         if roofline.get('traffic') is not None:      # FETCH_SIZE counts wide (128-byte) requests at half their size on gfx950: raw ... all reads wide
             wide = profiled(dom[0], args.workload, R, 'fetch_bytes_if_wide'); wr = profiled(dom[0], args.workload, R, 'write_bytes')
             if wide is not None and wr is not None:

@@ -191,6 +191,8 @@ int upside_hip_profile_dump(DerivEngine* engine, char* buf, int buflen);
 int upside_hip_calibrate_valu(double* rates /* [2] */);
 /* algorithmic bytes of all interaction graphs for one force evaluation of one system */
 double upside_hip_igraph_bytes_per_system(DerivEngine* engine);
+/* bytes a belief-propagation launch must move at least once (active pair matrices in, marginals out, node rows), all systems, last solve */
+double upside_hip_bp_min_bytes(DerivEngine* engine);
 
 /* The per-interval polynomial image of one quadspline parameter row ([angular 1: ka][angular 2: ka][radial wide: k][radial narrow: k],
  * /root/reference/src/bead_interaction.h:30-84) that the LDS-staged pair passes read (layout: upside_hip_kernels.h, param_poly);

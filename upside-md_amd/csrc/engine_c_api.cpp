@@ -20,6 +20,7 @@ int engine_rotamer_iterations(DerivEngine& e, vector<int>& iters);
 int engine_rebuild_flags(DerivEngine& e, const string& node_name, vector<int>& flags);
 int engine_igraph_stats(DerivEngine& e, const string& node_name, double* out);
 double engine_bp_bytes(DerivEngine& e);
+double engine_bp_min_bytes(DerivEngine& e);
 double engine_igraph_bytes(DerivEngine& e);
 int upside_main_impl(int argc, const char* const* argv, int verbose);
 
@@ -565,6 +566,9 @@ extern "C" int upside_hip_profile_dump(DerivEngine* e, char* buf, int buflen) {
     memcpy(buf, out.c_str(), out.size() + 1);
     return 0;
     API_CATCH(1)
+}
+extern "C" double upside_hip_bp_min_bytes(DerivEngine* e) {
+    API_TRY return engine_bp_min_bytes(*e); API_CATCH(-1.)
 }
 extern "C" double upside_hip_igraph_bytes_per_system(DerivEngine* e) {
     API_TRY return engine_igraph_bytes(*e); API_CATCH(-1.)

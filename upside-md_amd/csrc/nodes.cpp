@@ -1575,6 +1575,28 @@ int engine_pairlist(DerivEngine& e, const string& node_name, int sys, vector<pai
 //   per sweep  4 * sum_t e_t * (P_t + 2 b_t) + 8 * sum_nodes w   with (P,b) = (12,8), (24,12), (48,16) floats for the
 //   3x3 / 3x6 / 6x6 residue pairs that are active this step (the reference's padded rows, rotamer.cpp:331-334) and
 //   w = 4 / 8 floats of belief per 3- / 6-state node; times the sweeps the solve took (+1 initial pass).
+// what a belief-propagation launch must move at least once: the matrices of the active residue pairs in, their marginals out
+// (same records), node probabilities in and beliefs out -- of the last solve, summed over the systems
+double engine_bp_min_bytes(DerivEngine& e) {
+    for (auto& n : e.nodes)
+        if (auto* r = dynamic_cast<RotamerSidechain*>(n.computation.get())) {
+            e.sync();
+            auto cs = r->class_start.download(); auto act = r->slot_active_last.download();
+            const int S = e.ctx.n_system, cap = r->R.slot_cap;
+            const double Pt[3] = {12, 24, 48};      // floats of a 3x3 / 3x6 / 6x6 matrix as stored ([row][slot][6]-records, engine_bp_bytes)
+            double total = 0.;
+            for (int s = 0; s < S; ++s) {
+                for (int c = 0; c < 3; ++c) {
+                    long e_t = 0;
+                    for (int sl = cs[(size_t)s * 6 + c]; sl < cs[(size_t)s * 6 + c + 1]; ++sl) e_t += act[(size_t)s * cap + sl] != 0;
+                    total += 2. * 4. * e_t * Pt[c];
+                }
+                total += 2. * 4. * 6. * r->R.n_node;
+            }
+            return total;
+        }
+    return 0.;
+}
 double engine_bp_bytes(DerivEngine& e) {
     for (auto& n : e.nodes)
         if (auto* r = dynamic_cast<RotamerSidechain*>(n.computation.get())) {
