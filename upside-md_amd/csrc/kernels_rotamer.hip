@@ -204,41 +204,53 @@ __device__ __forceinline__ void d_rotamer_build_slots(const upk_rotamer_t& R, co
             R.adj_cnt[(size_t)s * NN + a] = d < R.adj_cap ? d : R.adj_cap;
             if (d > R.adj_cap) *G.error_flag = 3;
         }
-        // ---- assign: node a numbers its pairs (a, b > a) in ascending b; everything a pair needs follows from
+        // ---- assign: the pairs (a, b > a) of node a are numbered in ascending b; everything a pair needs follows from
         // popcounts of the two rows (messages TO node g sit at inbox quad bp_start[g] + rank among g's multi-state
         // partners x (1 quad = 4 floats for a 3-state g, 2 for a 6-state g); folded 1-state partners of g are listed
-        // in ascending id)
-        if (a < NN && a % K == kk) {
+        // in ascending id).  One WAVEFRONT per (row a, word c) item, one lane per partner bit: a pair's numbers are popcounts, so
+        // the partners of a word are independent (round 3 walked them one lane per node: a chain of up to 60 trips of scattered stores)
+        {
             int* slot_a = R.slot_a + (size_t)s * R.slot_cap;
             int* slot_b = R.slot_b + (size_t)s * R.slot_cap;
             int* slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
-            const int cl_lo = slot_class(na, na), cl_hi = na == 1 ? CL1X : (na == 3 ? CL36 : CL66);
-            const int first = na == 1 ? 0 : (na == 3 ? e1 : e3);          // first row of a's class
-            const int base_lo = first < NN ? row_lo[first] : 0, base_hi = first < NN ? row_hi[first] : 0;
-            int p_lo = cls_lds[cl_lo] + row_lo[a] - base_lo, p_hi = cls_lds[cl_hi] + row_hi[a] - base_hi;
-            int k_multi = na > 1 ? rank_below(a, a) - deg1[a] : 0;        // multi-state partners of a below b so far
-            for (int c = a / 64; c < W; ++c) {
-                unsigned long long w = bits[a * W + c] & ~below(a + 1, c);
-                while (w) {
-                    const int b = c * 64 + __builtin_ctzll(w);
-                    w &= w - 1;
-                    const bool lo = b < cend;
-                    const int sl = lo ? p_lo++ : p_hi++;
-                    const int nb = nrot[b];
-                    if (sl < R.slot_cap) {
-                        slot_a[sl] = a; slot_b[sl] = b; slot_of[(size_t)a * NN + b] = sl; slot_of[(size_t)b * NN + a] = sl;
-                        if (na == 1 && nb > 1) {
-                            const int pos = rank_below(b, a);              // 1-state partners of b below a
-                            if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + b) * R.adj_cap + pos] = sl;
-                        } else if (na > 1) {
-                            const int kb = rank_below(b, a) - deg1[b];
-                            slot_off[sl * 2] = (bp_s[a] + k_multi * (na == 6 ? 2 : 1)) * 4;
-                            slot_off[sl * 2 + 1] = (bp_s[b] + kb * (nb == 6 ? 2 : 1)) * 4;
-                            if (R.slot_row) { int* sr = R.slot_row + (size_t)s * R.slot_cap * 2; sr[sl * 2] = row_of(a) + k_multi; sr[sl * 2 + 1] = row_of(b) + kb; }
-                        }
-                    } else { slot_of[(size_t)a * NN + b] = -1; slot_of[(size_t)b * NN + a] = -1; }
-                    if (na > 1) ++k_multi;
+            int* slot_row = R.slot_row ? R.slot_row + (size_t)s * R.slot_cap * 2 : nullptr;
+            const unsigned long long lane_below = (1ull << lane) - 1ull;
+            for (int item = kk * n_wave + wave; item < NN * W; item += K * n_wave) {
+                const int ra = item / W, c = item - ra * W;                       // (wave-uniform)
+                if (c < ra / 64) continue;
+                const unsigned long long w = bits[ra * W + c] & ~below(ra + 1, c);
+                if (!w) continue;
+                const int nra = nrot[ra];
+                const int rcend = nra == 1 ? e1 : (nra == 3 ? e3 : NN);          // end of the row node's own class
+                const int cl_lo = slot_class(nra, nra), cl_hi = nra == 1 ? CL1X : (nra == 3 ? CL36 : CL66);
+                const int first = nra == 1 ? 0 : (nra == 3 ? e1 : e3);           // first row of that class
+                const int base_lo = first < NN ? row_lo[first] : 0, base_hi = first < NN ? row_hi[first] : 0;
+                // partners of the row in the words before this one: above it in its own class / in a higher class; all of them below word c
+                int n_lo = 0, n_hi = 0, n_all = 0;
+                for (int c2 = 0; c2 < c; ++c2) {
+                    const unsigned long long w2 = bits[ra * W + c2];
+                    const unsigned long long up2 = w2 & ~below(ra + 1, c2);
+                    n_lo += __popcll(up2 & below(rcend, c2)); n_hi += __popcll(up2 & ~below(rcend, c2)); n_all += __popcll(w2);
                 }
+                if (!((w >> lane) & 1ull)) continue;
+                const int pb = c * 64 + lane;
+                const bool lo = pb < rcend;
+                const unsigned long long same = lo ? (w & below(rcend, c)) : (w & ~below(rcend, c));
+                const int sl = (lo ? cls_lds[cl_lo] + row_lo[ra] - base_lo + n_lo : cls_lds[cl_hi] + row_hi[ra] - base_hi + n_hi) + __popcll(same & lane_below);
+                const int npb = nrot[pb];
+                if (sl < R.slot_cap) {
+                    slot_a[sl] = ra; slot_b[sl] = pb; slot_of[(size_t)ra * NN + pb] = sl; slot_of[(size_t)pb * NN + ra] = sl;
+                    if (nra == 1 && npb > 1) {
+                        const int pos = rank_below(pb, ra);             // 1-state partners of b below a
+                        if (pos < R.adj_cap) R.adj_slot[((size_t)s * NN + pb) * R.adj_cap + pos] = sl;
+                    } else if (nra > 1) {
+                        const int k_multi = n_all + __popcll(bits[ra * W + c] & lane_below) - deg1[ra];   // multi-state partners of a below b
+                        const int kb = rank_below(pb, ra) - deg1[pb];
+                        slot_off[sl * 2] = (bp_s[ra] + k_multi * (nra == 6 ? 2 : 1)) * 4;
+                        slot_off[sl * 2 + 1] = (bp_s[pb] + kb * (npb == 6 ? 2 : 1)) * 4;
+                        if (slot_row) { slot_row[sl * 2] = row_of(ra) + k_multi; slot_row[sl * 2 + 1] = row_of(pb) + kb; }
+                    }
+                } else { slot_of[(size_t)ra * NN + pb] = -1; slot_of[(size_t)pb * NN + ra] = -1; }
             }
         }
     }
