@@ -958,6 +958,8 @@ def test_bench_contract(tmp_path):
         assert k in r, k
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert r['achieved'] > 0 and 'igraph' in r and r['igraph']['achieved'] > 0 and r['igraph']['unit'] == 'TFLOP/s'
+    if r.get('kernel', '').startswith('bp:'):        # the solve's floor: active pair matrices in, marginals out (below the model's per-sweep re-reads)
+        assert 0 < r['min_bytes_per_launch'] < r['algorithmic_bytes_per_launch']
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
