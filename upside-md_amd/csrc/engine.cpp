@@ -214,8 +214,15 @@ DerivEngine::DerivEngine(int n_atom, int n_system) {
     // merged launches (kernels_batch.h) for batches that are chains of dependent launches rather than work: measured on one MI355X,
     // system-steps/s with / without -- 56 residues: 1 system 3.79 k / 3.18 k, 8: 25.9 k / 23.1 k; 300 residues: 1 system 1.83 k / 1.69 k,
     // 64: 56 k / 62 k, 4096: 149 k / 184 k (there the upkeep kernels want their own launch shapes and the side streams).
-    // UPSIDE_HIP_BATCH=1 / 0 forces them on / off.
-    { const char* e = getenv("UPSIDE_HIP_BATCH"); const bool on = e ? atoi(e) != 0 : n_system <= 16; ctx.L.batch = on ? upk_batch_create() : nullptr; }
+    // UPSIDE_HIP_BATCH=1 / 0 forces them on / off.  Where they stop winning depends on the protein as much as on the count (a launch of a
+    // 20-residue system is latency at 64 systems still): with / without merged launches + graph replay, k system-steps/s --
+    //   20 residues: 64 systems 290 / 207, 128: 532 / 407, 256: 729 / 715, 512: 940 / 1111;  56 residues: 32: 127 / 97, 64: 227 / 184,
+    //   128: 407 / 357, 256: 571 / 612;  150 residues: 32: 56.5 / 51.1, 48: 79.1 / 74.0, 64: 81.5 / 85.8;  300 residues: 24: 31.7 / 31.2,
+    //   32: 35.6 / 35.0 (54.1 / 52.5 at the 7 A list), 64: 56.3 / 62.1
+    // -- up to 16 systems always, else while atoms x systems <= 24 000 and systems <= 160.
+    { const char* e = getenv("UPSIDE_HIP_BATCH");
+      const bool on = e ? atoi(e) != 0 : (n_system <= 16 || ((long)n_system * n_atom <= 24000 && n_system <= 160));
+      ctx.L.batch = on ? upk_batch_create() : nullptr; }
     ctx.error_flag.alloc(1);
     potential.assign(n_system, 0.f);
     Node n; n.name = "pos"; n.computation.reset(new Pos(&ctx, n_atom));
@@ -586,11 +593,11 @@ bool DerivEngine::capture_md_graph() {
     return true;
 }
 void DerivEngine::run_steps(int n_step) {
-    // UPSIDE_HIP_GRAPH: six MD steps replayed from a captured hipGraph.  Default: up to 16 systems, where a step is a chain of ~17
+    // UPSIDE_HIP_GRAPH: six MD steps replayed from a captured hipGraph.  Default: wherever launches are merged, where a step is a chain of ~17
     // dependent launches and a graph node boundary is cheaper than an eager one (one / eight 56-residue systems: 193 / 223 against
     // 201 / 233 us per step; one 300-residue system 465 against 474; 64 x 150 residues 716 against 689: off there)
     static const int graph_env = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : -1; }();
-    const int use_graph = graph_env >= 0 ? graph_env : (ctx.n_system <= 16 ? 1 : 0);
+    const int use_graph = graph_env >= 0 ? graph_env : (ctx.L.batch ? 1 : 0);        // (with the merged launches: one stream; a multi-stream capture replays slower than it launches)
     int left = n_step;
     while (left > 0) {
         const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;
