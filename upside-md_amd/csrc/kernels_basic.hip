@@ -1696,7 +1696,10 @@ int fuse_threads(int n_system) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("UPSIDE_HIP_FUSE_THREADS"); forced = e ? atoi(e) : 0; if (forced % 64 || forced > 1024) forced = 0; }
     if (forced) return forced;
-    return n_system >= 256 ? 256 : 1024;
+    // (256-lane workgroups fill a CU eight at a time: worth it once there are systems for all of them -- 512 lanes against 256, k
+    //  system-steps/s: 300 residues x 256 149 / 142, x 1024 178 / 175, x 2048 equal, x 4096 186 / 187; 56 residues x 256 664 / 613,
+    //  x 512 893 / 846, x 2048 1069 / 1099)
+    return n_system >= 2048 ? 256 : (n_system >= 256 ? 512 : 1024);
 }
 template <bool LIST, typename... Args>
 void fuse_launch(bool heavy, int threads, int n_system, size_t lds, hipStream_t st, Args... args) {

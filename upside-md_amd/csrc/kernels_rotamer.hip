@@ -2177,7 +2177,10 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     // (round 4, small batches: 512 lanes with ONE slot of every class pinned per lane -- all of a 56-residue system, most of a
     //  150-residue one -- instead of 1024 lanes streaming every matrix: 56 residues, 1 / 8 systems: 4.28 k / 29.1 k against 4.13 k / 27.9 k
     //  system-steps/s; 150 residues, 8 systems: 13.4 k against 13.0 k)
-    const int resident = resident_env >= 0 ? resident_env : (L->n_system >= device_cu_count() / 8 ? 1 : 3);
+    // (round 4, all batches: one slot of every class pinned beats two 6x6 slots wherever the classes are small, and ties on the benchmark
+    //  protein -- k system-steps/s, variant 3 / variant 1: 56 residues x 512 861 / 840, x 2048 1132 / 1099; 150 residues x 512 281 / 276,
+    //  x 2048 327 / 323; 300 residues / 7 A x 512 248 / 240; 300 residues / 10 A x 4096 188.1 / 187.8 (four interleaved runs each))
+    const int resident = resident_env >= 0 ? resident_env : 3;
     const dim3 grid(1, L->n_system);
     static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
     if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
