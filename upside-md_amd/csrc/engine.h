@@ -75,6 +75,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     // included, and replayed.  Invalidated by anything that changes a kernel argument.
     hipGraph_t md_graph = nullptr; hipGraphExec_t md_graph_exec = nullptr;
     bool md_graph_ready = false; int md_graph_parity = 0; uint64_t steps_done = 0, n_compute = 0;
+    DevBuf<float> swap_row;           // staging row of upside_hip_swap_between (exchange between engines of different potentials)
     std::vector<float> swap_energy;   // energies seen by the last replica-swap set, accepted pairs already traded (upside_hip_replica_swap_next)
     uint64_t swap_energy_round = ~0ull, swap_energy_compute = 0;   // the attempt they belong to: (round, force passes done when they were captured)
     bool graph_failed = false;   // capture was refused once: stay on plain launches

@@ -430,12 +430,17 @@ extern "C" int upside_hip_swap_between(DerivEngine* e1, int s1, DerivEngine* e2,
     if (e1->pos->n_elem != e2->pos->n_elem) throw string("the two systems differ in their number of atoms");
     if (e1 == e2 && s1 == s2) return 0;
     const size_t row = (size_t)e1->pos->n_elem * e1->pos->stride;
+    // Both engines have drained their streams (their pending work reads or writes the rows); the three copies go through e1's
+    // stream into a staging row the engine keeps (an allocation and three blocking copies per pair before: a rejected pair of a
+    // Hamiltonian exchange attempt comes through here twice), and e2 is made to wait for them by the final synchronisation.
     e1->sync(); e2->sync();
-    DevBuf<float> tmp; tmp.alloc(row);
+    if (e1->swap_row.n < row) e1->swap_row.alloc(row);
     float* a = e1->pos->output.p + (size_t)s1 * row; float* b = e2->pos->output.p + (size_t)s2 * row;
-    hip_check(hipMemcpy(tmp.p, a, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
-    hip_check(hipMemcpy(a, b, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
-    hip_check(hipMemcpy(b, tmp.p, row * sizeof(float), hipMemcpyDeviceToDevice), "D2D");
+    hipStream_t st = e1->ctx.stream;
+    hip_check(hipMemcpyAsync(e1->swap_row.p, a, row * sizeof(float), hipMemcpyDeviceToDevice, st), "D2D");
+    hip_check(hipMemcpyAsync(a, b, row * sizeof(float), hipMemcpyDeviceToDevice, st), "D2D");
+    hip_check(hipMemcpyAsync(b, e1->swap_row.p, row * sizeof(float), hipMemcpyDeviceToDevice, st), "D2D");
+    hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
     e1->swap_energy.clear(); e2->swap_energy.clear();
     return 0;
     API_CATCH(1)
