@@ -139,11 +139,20 @@ int upk_nonlinear_coupling(const upk_launch_t* L, upk_coord_t input, const int* 
                            float offset, float inv_dx, float* pot_terms);
 /* hbond_energy (src/hbond.cpp:430-444) */
 int upk_hbond_energy(const upk_launch_t* L, upk_coord_t protein_hbond, float E_protein, float* pot_terms);
-/* backbone_pairs (src/backbone_steric.cpp:81-145): brute force over residue pairs, gather form;
- * aff_contrib [res][6]; pot_terms [S][n_res] (each pair counted once) */
+/* backbone_pairs (src/backbone_steric.cpp:81-145): gather form over residue pairs; aff_contrib [res][6]; pot_terms [S][n_res]
+ * (each pair counted once).  cache (may be NULL: every residue scans all others each step, what the reference does): per-row lists
+ * of the residues within dist_cutoff + skin of the row's REFERENCE centre, rebuilt by the kernel when the two largest centre
+ * displacements add up to the skin; used by the multi-workgroup launch (n_res > 128).  The caller flips `parity` on every call. */
+typedef struct {
+    int* list;            /* [S][n_res][cap] */
+    int* cnt;             /* [S][n_res] */
+    float *ref0, *ref1;   /* [S][n_res][4] reference centres, double buffered (initialised far away: the first call builds) */
+    int cap, parity; float skin;
+    int* error_flag;      /* set to 1 when a row outgrows cap */
+} upk_backbone_list_t;
 int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
                        const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
-                       float* pot_terms);
+                       float* pot_terms, const upk_backbone_list_t* cache);
 
 /* ---- interaction graph (src/interaction_graph.h) ---------------------------------------------------- */
 enum { UPK_IT_ROTAMER = 0, UPK_IT_HBOND_COVERAGE = 1, UPK_IT_ENVIRONMENT = 2, UPK_IT_PROTEIN_HBOND = 3,

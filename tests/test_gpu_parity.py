@@ -632,6 +632,8 @@ ALT_PATHS = [
     {'UPSIDE_HIP_SCHEDULE': 'bfs'},          # the reference's level-by-level order of the sweep instead of the grouped one
     {'UPSIDE_HIP_FUSE_THREADS': '1024'},     # fused launches with 1024-lane workgroups (the instance that spills the alignment ops)
     {'UPSIDE_HIP_FUSE_THREADS': '128'},      # ... and with two wavefronts per system
+    {'UPSIDE_HIP_BACKBONE_LIST': '0'},       # backbone sterics scanning all residue pairs every step (no cached residue-pair lists)
+    {'UPSIDE_HIP_BACKBONE_SKIN': '0.5'},     # ... and with a short margin (rebuilds every other step)
     {'UPSIDE_HIP_SLOT_SPLIT': '1'},          # slot numbering by one workgroup per system (the large-batch choice)
     {'UPSIDE_HIP_SLOT_SPLIT': '3'},          # ... and by three
     {'UPSIDE_HIP_PAIR2': '0'},               # scalar (one partner per lane) forms of the side-chain gradient and coverage passes

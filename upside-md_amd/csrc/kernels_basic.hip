@@ -874,7 +874,9 @@ __device__ __forceinline__ void nonbonded_kernel(float& v, float& dv_over_r, flo
 }
 #define BBP_QUEUE 72      // per-wave queue of close residues (64 new + < 4 left over)
 struct BackbonePairsArgs { upk_coord_t aff; const int* residue; const int* id; const int* n_atom; const float* ref_pos; int n_res; float dist_cutoff;
-                           float* aff_contrib; long aff_stride; float* pot_terms; };
+                           float* aff_contrib; long aff_stride; float* pot_terms;
+                           // cached residue-pair lists (standalone launches; list == nullptr: every residue scans all others each step)
+                           int* list; int* cnt; const float4* refc_in; float4* refc_out; int cap; float skin; int* error_flag; };
 // collective op of the system's workgroup (any number of wavefronts); lds: (n_res * 17 + waves * BBP_QUEUE) floats
 // rows [row0, row1) of the system (the whole system as a fused op; a range of BBP_ROWS per workgroup in a launch of its own)
 #define BBP_ROWS 64
@@ -908,6 +910,49 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
     int* q = queues + wave * BBP_QUEUE;
     const int qi = lane >> 4, i1 = (lane >> 2) & 3, i2 = lane & 3;
     if (row1 > n_res) row1 = n_res;
+    // Cached lists (the reference keeps none: backbone_steric.cpp:81-145 scans all residue pairs; here the scan was 0.48 ms of a
+    // 4096-system step at the scalar issue ceiling): a row's partners within cutoff + skin of the REFERENCE centres, rebuilt when the two
+    // largest centre displacements add up to the skin (the rule of k_pairlist_check).  Every workgroup of a system takes the same decision
+    // from the same reference centres (refc_in, written by nobody in this launch) and hands the next step its rows' references
+    // (refc_out: double buffered by the caller).  A list is ascending, so the in-range partners reach the queue in the order of the
+    // all-pairs scan: the sums are the same bits with and without it.
+    const bool use_list = A.list != nullptr;
+    bool rebuild = false;
+    if (use_list) {
+        __shared__ float bb_top[2][16];
+        __shared__ int bb_moved;
+        const float4* rin = A.refc_in + (size_t)s * n_res;
+        float d1 = 0.f, d2 = 0.f;
+        for (int nr = threadIdx.x; nr < n_res; nr += blockDim.x) {
+            const float4 r = rin[nr];
+            const float dx = ctr[nr * 3] - r.x, dy = ctr[nr * 3 + 1] - r.y, dz = ctr[nr * 3 + 2] - r.z;
+            const float dd = dx * dx + dy * dy + dz * dz;
+            d2 = fmaxf(d2, fminf(d1, dd)); d1 = fmaxf(d1, dd);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o1 = __shfl_xor(d1, off, 64), o2 = __shfl_xor(d2, off, 64);
+            const float n1 = fmaxf(d1, o1), n2 = fmaxf(fminf(d1, o1), fmaxf(d2, o2));
+            d1 = n1; d2 = n2;
+        }
+        if (lane == 0) { bb_top[0][wave] = d1; bb_top[1][wave] = d2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < n_wave; ++w) {
+                const float o1 = bb_top[0][w], o2 = bb_top[1][w];
+                const float n1 = fmaxf(a, o1), n2 = fmaxf(fminf(a, o1), fmaxf(b, o2));
+                a = n1; b = n2;
+            }
+            bb_moved = (sqrtf(a) + sqrtf(b) > 0.999f * A.skin) ? 1 : 0;      // (first step: the references sit at 1e10)
+        }
+        __syncthreads();
+        rebuild = bb_moved != 0;
+        float4* rout = A.refc_out + (size_t)s * n_res;
+        for (int nr = row0 + threadIdx.x; nr < row1; nr += blockDim.x)
+            rout[nr] = rebuild ? make_float4(ctr[nr * 3], ctr[nr * 3 + 1], ctr[nr * 3 + 2], 0.f) : rin[nr];
+    }
+    const float cutn = dist_cutoff + (use_list ? A.skin : 0.f), cutn2 = cutn * cutn;
     for (int nr1 = row0 + wave; nr1 < row1; nr1 += n_wave) {
         const f3 t1 = ld3(ctr + nr1 * 3);
         const int na1 = meta[nr1 * 2], id1 = meta[nr1 * 2 + 1];
@@ -932,14 +977,26 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
                 }
             }
         };
-        for (int c0 = 0; c0 < n_res; c0 += 64) {
-            const int nr2 = c0 + lane;
-            bool hit = false;
-            if (nr2 < n_res) {
+        int* row_list = use_list ? A.list + ((size_t)s * n_res + nr1) * A.cap : nullptr;
+        const int n_cand = (use_list && !rebuild) ? A.cnt[(size_t)s * n_res + nr1] : n_res;      // candidates: the cached partners, or everybody
+        int n_near = 0;
+        for (int c0 = 0; c0 < n_cand; c0 += 64) {
+            int nr2 = c0 + lane;
+            bool hit = false, near = false;
+            if (nr2 < n_cand) {
+                if (use_list && !rebuild) nr2 = row_list[nr2];
                 const int id2 = meta[nr2 * 2 + 1];
                 const f3 t2 = ld3(ctr + nr2 * 3);
-                hit = ((1 < id1 - id2) || (1 < id2 - id1)) &&                        // backbone_steric.cpp:32-35
-                      (dist2_exact(t1.x, t1.y, t1.z, t2.x, t2.y, t2.z) < cut2);
+                const float dd = dist2_exact(t1.x, t1.y, t1.z, t2.x, t2.y, t2.z);
+                const bool sep = (1 < id1 - id2) || (1 < id2 - id1);                 // backbone_steric.cpp:32-35
+                hit = sep && (dd < cut2);
+                near = sep && (dd < cutn2);
+            }
+            if (rebuild) {           // (wave-uniform) this row's cached list: everybody within cutoff + skin, ascending
+                const unsigned long long mn = __ballot(near);
+                const int pos = n_near + __popcll(mn & ((1ull << lane) - 1ull));
+                if (near && pos < A.cap) row_list[pos] = nr2;
+                n_near += __popcll(mn);
             }
             const unsigned long long m = __ballot(hit);
             if (hit) q[nq + __popcll(m & ((1ull << lane) - 1ull))] = nr2;
@@ -956,6 +1013,10 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (nq > 0) eval4(0, nq);
+        if (rebuild && lane == 0) {
+            A.cnt[(size_t)s * n_res + nr1] = n_near < A.cap ? n_near : A.cap;
+            if (n_near > A.cap) *A.error_flag = 1;
+        }
         const float t = wave_sum8(acc, lane);       // lane 8*c holds component c
         const int c = lane >> 3;
         if ((lane & 7) == 0) {
@@ -970,19 +1031,22 @@ __global__ void __launch_bounds__(1024) k_backbone_pairs(BackbonePairsArgs A) {
 }
 extern "C" int upk_backbone_pairs(const upk_launch_t* L, upk_coord_t aff, const int* residue, const int* id, const int* n_atom,
                                   const float* ref_pos, int n_res, float dist_cutoff, float* aff_contrib, long aff_stride,
-                                  float* pot_terms) {
+                                  float* pot_terms, const upk_backbone_list_t* cache) {
     const size_t lds = ((size_t)n_res * (12 + 3 + 2) + 16 * BBP_QUEUE) * sizeof(float);
     if (lds > 150 * 1024) return 9001;   // > ~2200 residues: needs the tiled variant
+    FARGS(BackbonePairsArgs, a); a.aff = cz(aff); a.residue = residue; a.id = id; a.n_atom = n_atom; a.ref_pos = ref_pos; a.n_res = n_res; a.dist_cutoff = dist_cutoff;
+    a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.pot_terms = pot_terms;
     // a system of more than a hundred residues gets several workgroups (each stages all centres, serves BBP_ROWS rows): as an op of the
     // fused list its N^2 / 2 centre tests would sit on the 16 wavefronts of one workgroup
     if (n_res > 2 * BBP_ROWS) {
         UPK_FLUSH(L);
-        FARGS(BackbonePairsArgs, b); b.aff = cz(aff); b.residue = residue; b.id = id; b.n_atom = n_atom; b.ref_pos = ref_pos; b.n_res = n_res; b.dist_cutoff = dist_cutoff;
-        b.aff_contrib = aff_contrib; b.aff_stride = aff_stride; b.pot_terms = pot_terms;
-        hipLaunchKernelGGL(k_backbone_pairs, dim3((n_res + BBP_ROWS - 1) / BBP_ROWS, L->n_system), dim3(1024), lds, ST(L), b);
+        if (cache && cache->list) {      // cached residue-pair lists (see the kernel); parity: which reference buffer this step reads
+            a.list = cache->list; a.cnt = cache->cnt; a.cap = cache->cap; a.skin = cache->skin; a.error_flag = cache->error_flag;
+            a.refc_in = (const float4*)(cache->parity ? cache->ref1 : cache->ref0); a.refc_out = (float4*)(cache->parity ? cache->ref0 : cache->ref1);
+        }
+        hipLaunchKernelGGL(k_backbone_pairs, dim3((n_res + BBP_ROWS - 1) / BBP_ROWS, L->n_system), dim3(1024), lds, ST(L), a);
         return launch_status();
     }
-    FARGS(BackbonePairsArgs, a); a.aff = cz(aff); a.residue = residue; a.id = id; a.n_atom = n_atom; a.ref_pos = ref_pos; a.n_res = n_res; a.dist_cutoff = dist_cutoff; a.aff_contrib = aff_contrib; a.aff_stride = aff_stride; a.pot_terms = pot_terms;
     return fuse_submit(L, FOP_BACKBONE_PAIRS, a, 0, {r_out(aff, false), r_slice(aff_contrib, (size_t)n_res * 24, (size_t)aff_stride * 4, true), r_buf(pot_terms, pot_terms ? (size_t)n_res * 4 : 0, true), r_lds()}, (int)lds);
 }
 

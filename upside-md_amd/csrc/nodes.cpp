@@ -351,6 +351,7 @@ RegisterNodeType<Builtin<RamaMapPot>, 1> rama_map_pot_node("rama_map_pot");
 struct BackbonePairs : public PotentialNode {
     int n_residue; CoordNode& alignment;
     DevBuf<int> id, n_atom; DevBuf<float> ref_pos; float dist_cutoff; int src;
+    DevBuf<int> bb_list, bb_cnt; DevBuf<float> bb_ref0, bb_ref1; upk_backbone_list_t cache;    // cached residue-pair lists (n_residue > 128)
     BackbonePairs(DeviceCtx* c, hid_t_compat grp, CoordNode& alignment_) : PotentialNode(c), alignment(alignment_) {
         check_elem_width(alignment, 7);
         auto ids = read<int>(H(grp), "id", 1);
@@ -369,11 +370,22 @@ struct BackbonePairs : public PotentialNode {
         src = alignment.scatter.add_source(n_residue, 1, 6, ids);
         alloc_terms(n_residue);
         fused_forward = fused_backward = true;
+        memset(&cache, 0, sizeof(cache));
+        if (n_residue > 128 && env_int("UPSIDE_HIP_BACKBONE_LIST", 1)) {
+            // residue centres move by ~0.15 A per step: a 3 A skin is rebuilt every ~10 steps and keeps ~45 partners per row at 300 residues
+            const size_t S = (size_t)ctx->n_system;
+            cache.cap = min(n_residue, env_int("UPSIDE_HIP_BACKBONE_LIST_CAP", 128)); cache.skin = env_float("UPSIDE_HIP_BACKBONE_SKIN", 3.f);
+            bb_list.alloc(S * n_residue * cache.cap); bb_cnt.alloc(S * n_residue);
+            vector<float> far(S * n_residue * 4, 1e10f);
+            bb_ref0.upload(far); bb_ref1.upload(far);
+            cache.list = bb_list.p; cache.cnt = bb_cnt.p; cache.ref0 = bb_ref0.p; cache.ref1 = bb_ref1.p; cache.error_flag = ctx->error_flag.p;
+        }
     }
     void compute_value(ComputeMode mode) override {
         upk_check(upk_backbone_pairs(&ctx->L, alignment.coord(), id.p, id.p, n_atom.p, ref_pos.p, n_residue, dist_cutoff,
                                      alignment.scatter.source_ptr(src), alignment.scatter.arena_size,
-                                     mode == PotentialAndDerivMode ? pot_terms.p : nullptr), "backbone_pairs");
+                                     mode == PotentialAndDerivMode ? pot_terms.p : nullptr, cache.list ? &cache : nullptr), "backbone_pairs");
+        cache.parity ^= 1;
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
