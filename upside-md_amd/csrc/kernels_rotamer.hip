@@ -1274,6 +1274,7 @@ template <int BLOCK, int K66, int K36, int K33, bool COMPACT = false>
 __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    if (only_fallback && threadIdx.x == 0 && R.bp_bar) R.bp_bar[s] = 0;      // the cluster barrier counter of this system, for the next solve (this launch follows every cluster launch in the stream)
     if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
     const int NN = R.n_node;
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
@@ -1957,6 +1958,8 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
             }
     }
     // fold the edges to 1-state partners into the probabilities of the own nodes (rotamer.cpp:378-385)
+    if (R.node_prob_in_solve && c == 0)      // (the 1-state nodes' 1-body terms: read back by this workgroup's energy sum)
+        for (int g = tid; g < e1; g += nt) { float p1[6]; rotamer_node_prob_one(R, s, g, p1); }
     {
         const float* P = R.P + (size_t)s * R.slot_cap * 36;
         const int* active = R.slot_active + (size_t)s * R.slot_cap;
@@ -1965,8 +1968,11 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
         for (int g = g_lo + tid; g < g_hi; g += nt) {
             const int n = R.node_nrot[g], na = adj_cnt[g];
             float p[6];
+            if (R.node_prob_in_solve) rotamer_node_prob_one(R, s, g, p);     // (1-body energies -> probabilities of the own nodes: no launch of their own)
+            else {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) p[r] = R.node_prob[((size_t)s * NN + g) * 6 + r];
+                for (int r = 0; r < 6; ++r) p[r] = R.node_prob[((size_t)s * NN + g) * 6 + r];
+            }
             for (int k = 0; k < na; ++k) {
                 const int sl = adj_slot[g * R.adj_cap + k];
                 if (!active[sl]) continue;

@@ -1390,7 +1390,7 @@ struct RotamerSidechain : public PotentialNode {
     // solves and the accumulating (several beads per state) path keep energies resting at 0.
     void set_matrix_form() {
         // (a small batch is a chain of launches: the 1-body pass rides in the prologue of the one-workgroup solve)
-        R.node_prob_in_solve = (R.bp_C <= 1 && (ctx->n_system <= 16 || ctx->L.batch) && env_int("UPSIDE_HIP_NODE_PROB_IN_SOLVE", 1)) ? 1 : 0;   // (a launch less where launches are what a step waits for)
+        R.node_prob_in_solve = ((ctx->n_system <= 16 || ctx->L.batch) && env_int("UPSIDE_HIP_NODE_PROB_IN_SOLVE", 1)) ? 1 : 0;   // (a launch less where launches are what a step waits for; the cluster solve does the same for its own nodes)
         R.p_prob = (R.bp_C <= 1 && one_bead_per_state && !env_int("UPSIDE_HIP_BP_ENERGY_TABLE", 0)) ? 1 : 0;
         rest_matrices();
     }
