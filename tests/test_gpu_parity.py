@@ -671,15 +671,17 @@ def test_alternate_code_paths_agree(tmp_path):
 
 
 def test_large_batch_solver_on_every_fixture():
-    """the belief-propagation variant of large batches (512 lanes, active slots packed, pair matrices pinned in
-    registers) is chosen by batch size; forced here for the small parity cases -- every fixture incl. the degenerate
-    sequences (empty slot classes), named values, truncated solves -- by re-running those tests in a child pytest"""
+    """what a LARGE batch runs is chosen by batch size (one-workgroup belief propagation, list upkeep on one side stream per graph, every
+    kernel a launch of its own, no graph replay); forced here for the small parity cases -- every fixture incl. the degenerate
+    sequences (empty slot classes), named values, truncated solves -- by re-running those tests in a child pytest: once with the
+    solve variant of round 4 (one slot of every class pinned), once with round 3's (two 6x6 slots pinned)"""
     import subprocess
-    env = dict(os.environ, UPSIDE_HIP_BP_RESIDENT='1', UPSIDE_HIP_BP_CLUSTER='1')
-    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
-                          '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200).stdout.decode()
-    assert ' passed' in out and 'failed' not in out and 'error' not in out.lower(), out[-3000:]
+    for extra in ({}, {'UPSIDE_HIP_BP_RESIDENT': '1'}):
+        env = dict(os.environ, UPSIDE_HIP_BP_CLUSTER='1', UPSIDE_HIP_BATCH='0', UPSIDE_HIP_GRAPH='0', **extra)
+        out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                              '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200).stdout.decode()
+        assert ' passed' in out and 'failed' not in out and 'error' not in out.lower(), (extra, out[-3000:])
 
 
 def test_side_chain_node_limit_is_refused_with_a_message():
