@@ -82,6 +82,9 @@ int upside_hip_init_md_seeds(DerivEngine* engine, const float* temperature, cons
  * Ornstein-Uhlenbeck thermostat (thermostat.cpp:9-18) every thermostat_interval rounds; everything
  * stays on the device, the call returns after the stream has drained. */
 int upside_hip_run_md(DerivEngine* engine, int n_round);
+/* the weights of the three stages of a cycle (IntegratorType, /root/reference/src/deriv_engine.h:230, deriv_engine.cpp:173-180):
+ * 0 = Verlet (the default; what main.cpp:663 uses), 1 = Predescu et al. 2012.  Between cycles only. */
+int upside_hip_set_integrator(DerivEngine* engine, int type);
 /* change the thermostat temperature of every system between run_md calls (simulated annealing, main.cpp:436-442,658-660) */
 int upside_hip_set_temperature(DerivEngine* engine, const float* temperature);
 /* the same loop counted in MD steps (one force evaluation + one leapfrog stage each, the unit of the reference's

@@ -84,6 +84,7 @@ struct DeviceCtx {
     // run the queued per-element ops (upside_hip_kernels.h: upk_launch_t::fuse).  A node that enqueues its OWN work on `stream`
     // (kernels, copies, events) calls this first; the launchers of upside_hip_kernels.h do it themselves.
     void flush();
+    unsigned long long n_pass = 0;   // number of the force pass being enqueued (DerivEngine::compute), for nodes that double-buffer by step parity
 };
 
 // deferred derivative contributions gathered into a CoordNode's sens (see upk_gather_contrib)

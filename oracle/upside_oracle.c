@@ -2378,8 +2378,15 @@ static void thermostat_apply(Thermostat* t, float* mom, int n_atom) {   /* therm
     t->n_invocations++;
 }
 
+/* integrator_type: 0 = Verlet, 1 = Predescu (deriv_engine.h:230, deriv_engine.cpp:173-180) */
+int oracle_run_md_integrator(DerivEngine* e, float* pos, float* mom, int n_round, float dt, float temperature, uint32_t seed,
+                             float thermostat_timescale, int thermostat_interval_rounds, int integrator_type);
 int oracle_run_md(DerivEngine* e, float* pos, float* mom, int n_round, float dt, float temperature, uint32_t seed,
                   float thermostat_timescale, int thermostat_interval_rounds) {
+    return oracle_run_md_integrator(e, pos, mom, n_round, dt, temperature, seed, thermostat_timescale, thermostat_interval_rounds, 0);
+}
+int oracle_run_md_integrator(DerivEngine* e, float* pos, float* mom, int n_round, float dt, float temperature, uint32_t seed,
+                             float thermostat_timescale, int thermostat_interval_rounds, int integrator_type) {
     int n_atom = e->n_atom;
     Node* p = &e->nodes[0];
     for (int na = 0; na < n_atom; ++na) for (int d = 0; d < 3; ++d) { VA(p->output, d, na) = pos[na * 3 + d]; mom[na * 3 + d] = 0.f; }
@@ -2391,9 +2398,10 @@ int oracle_run_md(DerivEngine* e, float* pos, float* mom, int n_round, float dt,
     t.delta_t = thermostat_interval_rounds * 3 * dt; thermostat_update(&t);
     for (int round = 0; round < n_round; ++round) {   /* main.cpp:621-666 */
         if (!(round % thermostat_interval_rounds)) thermostat_apply(&t, mom, n_atom);
-        for (int stage = 0; stage < 3; ++stage) {   /* deriv_engine.cpp:172-192 with Verlet weights {1,1,1} */
+        for (int stage = 0; stage < 3; ++stage) {   /* deriv_engine.cpp:172-192: Verlet weights {1,1,1}, or Predescu et al. 2012 */
             engine_compute(e, DerivMode);
-            float a = 1.f / 6.f, b = 1.f / 3.f;
+            float a = integrator_type == 1 ? (float)0.108991425403425322 : (float)(1. / 6.);   /* deriv_engine.cpp:176-177: double constants narrowed */
+            float b = integrator_type == 1 ? (float)0.290485609075128726 : (float)(1. / 3.);
             float mom_update[3] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
             float pos_update[3] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
             float vel_factor = dt * mom_update[stage], pos_factor = dt * pos_update[stage];

@@ -65,6 +65,9 @@ int oracle_rotamer_iterations(DerivEngine* engine);
  * thermostat applied every thermostat_interval rounds.  pos (n_atom,3) in/out; mom (n_atom,3) out. */
 int oracle_run_md(DerivEngine* engine, float* pos, float* mom, int n_round, float dt, float temperature,
                   uint32_t seed, float thermostat_timescale, int thermostat_interval_rounds);
+/* ... with the integrator chosen: 0 = Verlet, 1 = Predescu (deriv_engine.h:230, deriv_engine.cpp:173-180) */
+int oracle_run_md_integrator(DerivEngine* engine, float* pos, float* mom, int n_round, float dt, float temperature,
+                             uint32_t seed, float thermostat_timescale, int thermostat_interval_rounds, int integrator_type);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,44 @@
+"""bench.py's launcher contract without a GPU: `python bench.py --gpus N` with no launcher in the environment starts its N ranks
+itself (a child torch.distributed.run, rendezvous on 127.0.0.1), rank 0 prints ONE JSON line, the exit code is relayed, and a
+WORLD_SIZE that contradicts --gpus is refused.  The unit of work is the host-only `_stub` workload over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID'):
+        env.pop(k, None)
+    return env
+
+
+def test_self_launch_two_ranks_prints_one_line():
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '5', '--warmup', '2', '--workload', '_stub'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=_clean_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().split('\n') if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['warmup'] == 2 and d['scaling'] == 'weak'
+    # whole-job value: the units of BOTH ranks over the slower rank's time
+    assert abs(d['value'] - 2 * 64 * 5 / (d['ms_per_step'] * 5e-3)) < 1e-6 * d['value']
+
+
+def test_single_rank_stub_and_exit_code_relay():
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', '_stub'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_clean_env())
+    assert r.returncode == 0 and json.loads(r.stdout.decode().strip())['n_gpus'] == 1
+    # a launcher whose world contradicts --gpus is refused loudly, by every rank
+    env = dict(_clean_env(), RANK='0', LOCAL_RANK='0', WORLD_SIZE='4', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', '_stub'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and b'WORLD_SIZE=4' in r.stderr and not r.stdout.strip()
+    # a rank's failure is the parent's exit code
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', '_stub', '--steps', '2', '--warmup', '1'], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, env=dict(_clean_env(), UPSIDE_BENCH_STUB_FAIL='1'))
+    assert r.returncode != 0

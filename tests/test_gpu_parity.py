@@ -346,6 +346,37 @@ def test_thermostat_and_integrator_match_oracle(hip):
     c.free_deriv_engine(ct.c_void_p(eng))
 
 
+def test_predescu_integrator_matches_oracle(hip):
+    """IntegratorType Predescu (deriv_engine.h:230, the stage weights of deriv_engine.cpp:173-180) through upside_hip_set_integrator:
+    a six-step (two-cycle) trajectory equals the oracle's loop with the same constants and differs from the Verlet trajectory."""
+    name = 'trpcage20_7A'
+    c = hip.calc
+    c.upside_hip_set_integrator.argtypes = [ct.c_void_p, ct.c_int]
+    orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+    orc.calc.oracle_run_md_integrator.restype = ct.c_int
+    orc.calc.oracle_run_md_integrator.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_float, ct.c_float, ct.c_uint32,
+                                                  ct.c_float, ct.c_int, ct.c_int]
+    pos0 = orc.initial_pos.copy(); n_atom = pos0.shape[0]
+    T, seed, dt, n_round = 0.8, 4321, 0.009, 2
+    out = {}
+    for kind in (0, 1):
+        eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), 1, True)
+        x = pos0[None].astype('f4').copy(); temps = np.array([T], 'f4')
+        assert c.upside_hip_set_pos(eng, x.ctypes.data) == 0
+        assert c.upside_hip_init_md(eng, temps.ctypes.data, seed, 5.0, dt, 1) == 0
+        assert c.upside_hip_set_integrator(ct.c_void_p(eng), 7) != 0            # refused with a message
+        assert c.upside_hip_set_integrator(ct.c_void_p(eng), kind) == 0
+        assert c.upside_hip_run_md(eng, n_round) == 0
+        pos_h = np.zeros((1, n_atom, 3), 'f4'); mom_h = np.zeros((1, n_atom, 3), 'f4')
+        c.upside_hip_get_pos(eng, pos_h.ctypes.data); c.upside_hip_get_mom(eng, mom_h.ctypes.data)
+        c.free_deriv_engine(ct.c_void_p(eng))
+        p = pos0.copy(); m = np.zeros_like(p)
+        assert orc.calc.oracle_run_md_integrator(orc.engine, p.ctypes.data, m.ctypes.data, n_round, dt, T, seed, 5.0, 1, kind) == 0
+        assert P.rel_rms(p, pos_h[0]) < 1e-6 and P.rel_rms(m, mom_h[0]) < 1e-4, (kind, P.rel_rms(p, pos_h[0]), P.rel_rms(m, mom_h[0]))
+        out[kind] = pos_h[0].copy()
+    assert P.rel_rms(out[0], out[1]) > 1e-5          # the two integrators do take different steps
+
+
 def test_cached_pairlist_path_after_md(hip):
     """after MD steps (cached Verlet lists, some rebuilds) the device's in-range pair lists and forces still equal
     the oracle's evaluated at the device's current coordinates"""
@@ -967,9 +998,37 @@ def test_bench_contract(tmp_path):
     if r.get('kernel', '').startswith('bp:'):        # the solve's floor: active pair matrices in, marginals out (below the model's per-sweep re-reads)
         assert 0 < r['min_bytes_per_launch'] < r['algorithmic_bytes_per_launch']
     c = d['cpu_baseline']
-    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+    for k in ('value', 'unit', 'cores', 'host_cores_total', 'kind', 'sample'):
         assert k in c, k
-    assert c['kind'] in ('reference', 'port') and c['value'] > 0
+    assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['host_cores_total'] >= c['cores']
+    pc = d['parity_check']          # the timed engine itself against the oracle, behind the timed region
+    assert pc['ok'] is True and pc['n'] == 3 and pc['max_rel_rms'] <= 1e-5 and pc['deriv_vs_one_system_engine'] <= 1e-6, pc
+    ig = r['igraph']
+    assert ig['bound'] == 'valu' and ig['target_frac'] == 0.5 and 0.3 < ig['hbm_frac_at_fp32_peak'] < 1.0, ig
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2 --workload remd64_proteinG56` with NO launcher in the environment: bench.py starts its two ranks
+    itself (child torch.distributed.run), each builds its half of the 64-temperature ladder and they exchange through
+    upside_hip_comm_* -- on this one-GPU box over tests/plugin/libshmccl.so (UPSIDE_HIP_COMM_LIB) with both ranks on device 0 and
+    gloo for the barrier (RCCL cannot put two ranks on one device; a real node sets neither variable).  One JSON line, n_gpus 2,
+    strong scaling, exchange attempts inside the timed region."""
+    import json
+    import subprocess
+    shm = os.path.join(P.ROOT, 'tests', 'plugin', 'libshmccl.so')
+    env = dict(os.environ, UPSIDE_HIP_COMM_LIB=shm, UPSIDE_BENCH_ONE_DEVICE='1', UPSIDE_BENCH_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(P.ROOT, 'bench.py'), '--gpus', '2', '--steps', '1200', '--warmup', '30',
+                        '--workload', 'remd64_proteinG56', '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().split('\n') if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 1200 and d['scaling'] == 'strong' and d['config']['replicas_per_gpu'] == 32
+    assert d['config']['exchange_attempts_timed'] >= 2 and d['value'] > 0
+    assert d['parity_check']['ok'] is True, d['parity_check']
 
 
 def test_long_md_is_thermalised_and_stable(hip):
@@ -1493,19 +1552,30 @@ def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
             if p.poll() is None:
                 p.kill()
     for p, o in zip(procs, outs):
-        assert p.returncode not in (0, None) and p.returncode > 0 and 'rank 1 hold a different /input/potential' in o, o
+        assert p.returncode not in (0, None) and p.returncode > 0 and 'ranks 0 and 1 hold different /input/potential' in o, o
     assert not os.path.exists(rendezvous + '2')
     # a record another launch left under the same name is not this launch's: rank 1 alone waits for its own and gives up
     # (here: quickly, through the nonce of a launch that has no rank 0)
-    with open(rendezvous + '3', 'wb') as f:
-        f.write(b'\0' * 128 + (12345).to_bytes(8, 'little'))
-    p1 = subprocess.Popen([exe] + margs + other[:2] + other[:2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                          env=dict(os.environ, RANK='1', WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
-                                   UPSIDE_HIP_COMM_FILE=rendezvous + '3', UPSIDE_HIP_COMM_WAIT_S='3'))
-    try:
-        o = p1.communicate(timeout=300)[0].decode()
-    finally:
-        if p1.poll() is None:
-            p1.kill()
-    os.remove(rendezvous + '3')
-    assert p1.returncode != 0 and 'no communicator id of this launch' in o, o
+    def fnv(text):
+        h = 1469598103934665603
+        for ch in text.encode():
+            h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    import time as _time
+    # (a) another launch's nonce; (b) THIS launch line's nonce on a record written long before this attempt started (what a crashed
+    # earlier attempt from the same shell leaves behind: same nonce, same file name)
+    for record in (b'\0' * 128 + (12345).to_bytes(8, 'little') + int(_time.time()).to_bytes(8, 'little'),
+                   b'\0' * 128 + fnv('same-launch-line').to_bytes(8, 'little') + int(_time.time() - 1000).to_bytes(8, 'little')):
+        with open(rendezvous + '3', 'wb') as f:
+            f.write(record)
+        p1 = subprocess.Popen([exe] + margs + other[:2] + other[:2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, RANK='1', WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
+                                       UPSIDE_HIP_COMM_FILE=rendezvous + '3', UPSIDE_HIP_COMM_WAIT_S='3',
+                                       UPSIDE_HIP_COMM_NONCE='same-launch-line'))
+        try:
+            o = p1.communicate(timeout=300)[0].decode()
+        finally:
+            if p1.poll() is None:
+                p1.kill()
+        os.remove(rendezvous + '3')
+        assert p1.returncode != 0 and 'no communicator id of this launch' in o, o

@@ -44,8 +44,16 @@ Rccl& rccl() {
     if (const char* over = getenv("UPSIDE_HIP_COMM_LIB")) {
         r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) throw string("cannot load UPSIDE_HIP_COMM_LIB=") + over + ": " + dlerror();
-    } else
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    } else {
+        // a librccl that is ALREADY mapped into the process wins (torch ships its own next to libtorch_hip.so and has loaded it by the
+        // time bench.py gets here): two RCCL instances in one process would each run their own bootstrap and proxy threads
+        for (const char* name : {"librccl.so.1", "librccl.so"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (r.lib) break; }
+        if (!r.lib) {      // (RTLD_NOLOAD matches by soname; a copy loaded under a private path is found through the global scope)
+            void* self = dlopen(nullptr, RTLD_NOW);
+            if (self && dlsym(self, "ncclCommInitRank") && dlsym(self, "ncclGroupEnd")) r.lib = self;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if (r.lib) break; r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); }
+    }
     if (!r.lib) throw string("cannot load librccl.so: ") + dlerror();
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) throw string("librccl.so lacks ") + n; return p; };
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");

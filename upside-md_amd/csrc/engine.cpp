@@ -473,6 +473,7 @@ void DerivEngine::print_schedule() {
 
 void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
     ++n_compute;
+    ctx.n_pass = n_compute;      // (nodes that double-buffer by step parity read it: always in step with what a graph capture rolled back)
     // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
     // node's sens before that node's own forward step
     upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
@@ -538,7 +539,9 @@ void DerivEngine::fetch_potentials() {
 }
 
 void DerivEngine::integration_stage(int stage, float dt_, float max_force) {
-    const float a = 1.f / 6.f, b = 1.f / 3.f;   // Verlet
+    // deriv_engine.cpp:176-177 (integrator from Predescu et al., 2012: double constants narrowed to float there as here)
+    const float a = integrator_type == 1 ? (float)0.108991425403425322 : (float)(1. / 6.);
+    const float b = integrator_type == 1 ? (float)0.290485609075128726 : (float)(1. / 3.);
     const float mom_update[] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
     const float pos_update[] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
     compute(DerivMode, true);       // the tail of the backward sweep, the leapfrog update and the head of the next force pass share a launch
@@ -706,6 +709,9 @@ void DerivEngine::check_device_errors() {
                          "to use the one-workgroup solve");
         if (f[0] == 8)   // kernels_rotamer.hip: RotGradOp2::flush
             throw string("side-chain gradient: a bead's gradient is not finite (NaN or overflow in the pair pass): the forces of this step are not valid");
+        if (f[0] == 4)   // kernels_basic.hip: c_backbone_pairs
+            throw string("backbone sterics: a residue has more neighbours within cutoff + skin than its cached row holds: raise "
+                         "UPSIDE_HIP_BACKBONE_LIST_CAP (default 128) or set UPSIDE_HIP_BACKBONE_LIST=0");
         throw string("device capacity overflow (code ") + to_string(f[0]) +
             "): raise UPSIDE_HIP_NBR_CAP / UPSIDE_HIP_SLOT_FACTOR (1 = neighbour list, 2 = residue-pair slots, 3 = node adjacency)";
     }

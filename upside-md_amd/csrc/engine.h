@@ -37,6 +37,7 @@ struct DerivEngine {   // deriv_engine.h:145-237
     DevBuf<uint32_t> seed; DevBuf<float> mom_scale, noise_scale;
     std::vector<float> temperature; std::vector<uint32_t> seeds;
     float thermostat_timescale = 5.f, dt = 0.009f; int thermostat_interval = 1;
+    int integrator_type = 0;        // IntegratorType of deriv_engine.h:230: 0 = Verlet, 1 = Predescu
     uint64_t n_invocations = 0, round_num = 0;      // host mirrors; the thermostat reads the device copy below
     DevBuf<unsigned long long> n_invocations_dev;   // [S] (equal entries: each system's workgroup advances its own)
     void set_invocations(uint64_t n);

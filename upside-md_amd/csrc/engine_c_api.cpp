@@ -288,6 +288,16 @@ extern "C" int upside_hip_init_md_seeds(DerivEngine* e, const float* temperature
     return 0;
     API_CATCH(1)
 }
+extern "C" int upside_hip_set_integrator(DerivEngine* e, int type) {
+    API_TRY
+    if (type != 0 && type != 1) throw string("integrator type must be 0 (Verlet) or 1 (Predescu)");
+    if (e->stage_num != 0) throw string("an integration cycle is in progress");
+    e->sync();
+    if (type != e->integrator_type) e->invalidate_graph();      // (the stage weights are launch arguments of the recorded steps)
+    e->integrator_type = type;
+    return 0;
+    API_CATCH(1)
+}
 extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
     API_TRY
     if (e->stage_num != 0) throw string("an integration cycle is in progress (upside_hip_run_steps left it unfinished)");

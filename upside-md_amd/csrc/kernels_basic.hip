@@ -1015,7 +1015,7 @@ __device__ __forceinline__ void c_backbone_pairs(const BackbonePairsArgs& A, con
         if (nq > 0) eval4(0, nq);
         if (rebuild && lane == 0) {
             A.cnt[(size_t)s * n_res + nr1] = n_near < A.cap ? n_near : A.cap;
-            if (n_near > A.cap) *A.error_flag = 1;
+            if (n_near > A.cap) *A.error_flag = 4;      // (its own code: engine.cpp names UPSIDE_HIP_BACKBONE_LIST_CAP)
         }
         const float t = wave_sum8(acc, lane);       // lane 8*c holds component c
         const int c = lane >> 3;

@@ -619,6 +619,16 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     return launch_status();
 }
 
+// the finish pass of a backward item that DID join a merged launch but could not join itself (kind masked out, or the queue flush inside
+// batch_add failed): what the batch holds runs first, then the conversion is launched on its own -- never dropped
+static int finish_alone(const upk_launch_t* L, const upk_igraph_t* G, int n_other, int other_side, double unit) {
+    const int r = upk_batch_run(L);
+    if (r) return r;
+    UPK_FLUSH(L);
+    hipLaunchKernelGGL(k_pair_backward_finish, dim3((n_other * 8 + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, other_side, unit);
+    return launch_status();
+}
+
 extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
                                    const float* sens2, long sens_sys_stride, int sens_stride) {
     if (row_side != 1 && row_side != 2) return 9007;
@@ -648,7 +658,8 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
             pair2_geometry(L->n_system, n_rows, bps, threads);
             if (!G->gacc) bps = 1;
             if (row_side == 2 && batch_add(L, table2 == 2 ? BK_COV_BWD2_POLY : BK_COV_BWD2, bps, L->n_system, lds2, G, sizeof(*G), &A, sizeof(A))) {
-                if (bps > 1) batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / (double)(1 << P2_FIX_BITS));
+                if (bps > 1 && !batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / (double)(1 << P2_FIX_BITS)))
+                    return finish_alone(L, G, n_other, 3 - row_side, 1.0 / (double)(1 << P2_FIX_BITS));
                 return 0;
             }
             UPK_FLUSH(L);
@@ -662,7 +673,8 @@ extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G,
     pair_geometry(L->n_system, n_rows, bps, threads);
     if (!G->gacc) bps = 1;
     if (G->itype == UPK_IT_ENVIRONMENT && row_side == 1 && batch_add(L, BK_ENV_BWD, bps, L->n_system, lds, G, sizeof(*G), &A, sizeof(A))) {
-        if (bps > 1) batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / 4294967296.0);
+        if (bps > 1 && !batch_add(L, BK_BWD_FINISH, (n_other * 8 + 1023) / 1024, L->n_system, 0, G, sizeof(*G), nullptr, 0, 3 - row_side, 0, 1.0 / 4294967296.0))
+            return finish_alone(L, G, n_other, 3 - row_side, 1.0 / 4294967296.0);
         return 0;
     }
     UPK_FLUSH(L);

@@ -1274,8 +1274,14 @@ template <int BLOCK, int K66, int K36, int K33, bool COMPACT = false>
 __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_energy, int only_fallback, int lds_msg_floats) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    if (only_fallback && threadIdx.x == 0 && R.bp_bar) R.bp_bar[s] = 0;      // the cluster barrier counter of this system, for the next solve (this launch follows every cluster launch in the stream)
-    if (only_fallback && !R.bp_fallback[s]) return;      // solved by the cluster kernel
+    if (only_fallback) {
+        // this launch follows every cluster launch in the stream: it resets the cluster's barrier counter AND its hand-over word for the
+        // next solve (the cluster kernel itself only ever SETS the word: a late workgroup can then never erase its partners' verdict)
+        const int handed_over = R.bp_fallback[s];
+        __syncthreads();
+        if (threadIdx.x == 0) { if (R.bp_bar) R.bp_bar[s] = 0; R.bp_fallback[s] = 0; }
+        if (!handed_over) return;      // solved by the cluster kernel
+    }
     const int NN = R.n_node;
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
     constexpr int NS = BP_NODE_STRIDE;   // floats per node in the LDS belief arrays: 8, so that a node's states are one b128 (+ one b64) access
@@ -1758,7 +1764,10 @@ __device__ __forceinline__ bool cluster_barrier(int* bar, int& phase, int C, int
                 if (fallback) __hip_atomic_store(fallback, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *error_flag = 7;
                 break;
             }
+            if (fallback && !(spins & 255) && __hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = 1; break; }   // a partner gave up
         }
+        // the counter alone can let a late workgroup through (partners that have left did arrive at this barrier before they gave up at a later one)
+        if (fallback && !gave_up && __hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = 1;
 #if !BPC_SC1_LOADS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // one buffer_inv for the whole CU
 #endif
@@ -1900,9 +1909,9 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
         if (nd > p_cap) fits = false;
     }
     if (!fits) { if (c == 0 && tid == 0) R.bp_fallback[s] = 1; return; }   // the single-workgroup kernel takes this system
-    if (c == 0 && tid == 0) R.bp_fallback[s] = 0;
-    // a barrier that gives up writes 1 here (after this 0 in every order of events: a workgroup gives up only after its partners
-    // failed to arrive, and workgroup 0 itself gives up last if it is the late one)
+    // a barrier that gives up writes 1 here; the word is 0 on entry (cleared by the one-workgroup launch that follows every cluster
+    // launch), is only ever set by this kernel, and every barrier also reads it: a workgroup that arrives after its partners have
+    // given up leaves at its first barrier instead of running phases on data nobody produced
     int* fb = R.bp_fallback + s;
     const int spin_limit = R.bp_test_abort ? (1 << 12) : (1 << 22);
     if (R.bp_test_abort && c == C - 1) return;          // tests: a partner that never arrives

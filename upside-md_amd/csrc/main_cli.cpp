@@ -178,6 +178,7 @@ static vector<string> split_string(const string& src, const string& sep) {
 }
 
 int upside_main_impl(int argc, const char* const* argv, int verbose) {
+    const time_t process_start = time(nullptr);      // (of this run: the rendezvous below ignores records older than it)
     double duration = -1., frame_interval = -1., time_step = 0.009, thermostat_timescale = 5., thermostat_interval = -1., replica_interval = 0., mc_interval = 0.;
     string temperature_str = "1.0";
     unsigned long seed = 42;
@@ -359,10 +360,17 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // with another nonce (an earlier crashed attempt under the same file name) keeps waiting for this launch's.  Rank 0
         // publishes with an exclusive create + rename and removes the file once every rank has joined.
         string launch;
-        if (const char* x = getenv("UPSIDE_HIP_COMM_NONCE")) launch = x;
+        bool job_wide = false;      // the nonce is made of variables every rank of the job shares, on whatever node it runs
+        if (const char* x = getenv("UPSIDE_HIP_COMM_NONCE")) { launch = x; job_wide = true; }
         else {
-            for (const char* v : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) launch += string(getenv(v) ? getenv(v) : "") + "|";
-            launch += to_string((long)getppid());
+            for (const char* v : {"MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) {
+                if (getenv(v)) job_wide = true;
+                launch += string(getenv(v) ? getenv(v) : "") + "|";
+            }
+            launch += to_string(world) + "|";
+            // the launcher's pid is the same for the ranks of ONE node only: it stands in for the job-wide variables where a launcher
+            // exports none (plain RANK / WORLD_SIZE from a shell), never beside them (a multi-node job shares the file, not the agent)
+            if (!job_wide) launch += to_string((long)getppid());
         }
         unsigned long long nonce = 1469598103934665603ull;               // FNV-1a
         for (unsigned char ch : launch) { nonce ^= ch; nonce *= 1099511628211ull; }
@@ -372,12 +380,16 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             path = string("/tmp/upside_hip_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + to_string((long)getppid());
             for (const char* v : {"TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"}) if (const char* x = getenv(v)) path += string("_") + x;
         }
-        struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long nonce; } rec;
+        // Two attempts started one after the other from the same shell share nonce and file name: the record also carries the wall-clock
+        // second it was written, and a rank takes only records written after (its own start - UPSIDE_HIP_COMM_SKEW_S, default 20 s:
+        // how far apart the ranks of one launch may start) -- what a crashed earlier attempt left behind is older than that.
+        struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long nonce; long long stamp; } rec;
         memset(&rec, 0, sizeof(rec));
+        const long long skew_s = getenv("UPSIDE_HIP_COMM_SKEW_S") ? max(0, atoi(getenv("UPSIDE_HIP_COMM_SKEW_S"))) : 20;
         if (rank == 0) {
-            if (upside_hip_comm_get_unique_id(rec.id)) throw string(upside_hip_last_error());
-            rec.nonce = nonce;
             remove(path.c_str());                                   // a stale record of an earlier attempt under this name
+            if (upside_hip_comm_get_unique_id(rec.id)) throw string(upside_hip_last_error());
+            rec.nonce = nonce; rec.stamp = (long long)time(nullptr);
             const string tmp = path + ".tmp." + to_string((long)getpid());
             const int fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
             if (fd < 0 || write(fd, &rec, sizeof(rec)) != (ssize_t)sizeof(rec)) { if (fd >= 0) close(fd); throw string("cannot write ") + tmp; }
@@ -390,9 +402,11 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                 FILE* f = fopen(path.c_str(), "rb");
                 if (f) { got = fread(&rec, 1, sizeof(rec), f) == sizeof(rec); fclose(f); }
                 if (got && rec.nonce != nonce) got = false;           // another launch's record
+                if (got && rec.stamp < (long long)process_start - skew_s) got = false;      // an earlier attempt of the same launch line
                 if (!got) this_thread::sleep_for(chrono::milliseconds(100));
             }
-            if (!got) throw string("no communicator id of this launch at ") + path + " (is rank 0 running?)";
+            if (!got) throw string("no communicator id of this launch at ") + path + " (is rank 0 running?  a multi-node job needs UPSIDE_HIP_COMM_FILE on a "
+                                   "shared file system and either a launcher that exports MASTER_ADDR / MASTER_PORT or UPSIDE_HIP_COMM_NONCE)";
         }
         if (upside_hip_comm_init(e, rank, world, rec.id, temps_global.data())) throw string(upside_hip_last_error());
         if (rank == 0) remove(path.c_str());                         // (ncclCommInitRank returns when every rank has joined)
@@ -403,7 +417,8 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         if (upside_hip_comm_agree(e, potential_digest, &differs)) throw string(upside_hip_last_error());
         if (differs >= 0) {
             upside_hip_comm_free(e);
-            throw string("the configuration files of rank ") + to_string(differs) + " hold a different /input/potential than those of rank 0";
+            // (which of the two has the wrong files the digests cannot tell: with more than two ranks the odd one out is usually it)
+            throw string("the configuration files of ranks 0 and ") + to_string(differs) + " hold different /input/potential groups";
         }
     }
 

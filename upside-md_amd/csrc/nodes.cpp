@@ -382,10 +382,12 @@ struct BackbonePairs : public PotentialNode {
         }
     }
     void compute_value(ComputeMode mode) override {
+        // the reference centres of the cached list are double buffered by the parity of the force pass (the engine's counter: a graph
+        // capture that is rolled back rolls this back with it; a host toggle of its own would be left flipped)
+        cache.parity = (int)(ctx->n_pass & 1);
         upk_check(upk_backbone_pairs(&ctx->L, alignment.coord(), id.p, id.p, n_atom.p, ref_pos.p, n_residue, dist_cutoff,
                                      alignment.scatter.source_ptr(src), alignment.scatter.arena_size,
                                      mode == PotentialAndDerivMode ? pot_terms.p : nullptr, cache.list ? &cache : nullptr), "backbone_pairs");
-        cache.parity ^= 1;
         if (mode == PotentialAndDerivMode) reduce_terms();
     }
 };
