@@ -89,9 +89,11 @@ def cpu_baseline(fixture, variant, budget_s=float(os.environ.get('UPSIDE_BENCH_C
     exe = os.path.join(ROOT, 'oracle', '_ref', 'upside_' + variant)
     n_cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     if os.path.exists(exe):
-        # one thread per system as the reference parallelises (main.cpp:618); every core this process may use, up to 64 (a one-system
+        # one thread per system as the reference parallelises (main.cpp:618); one thread per system, at most UPSIDE_BENCH_CPU_THREADS (a one-system
         # workload is compared with ONE host core).  `cores` = threads used, `host_cores_total` = what the host offers this process
-        n_sys = 1 if one_core else max(1, min(n_cores, int(os.environ.get('UPSIDE_BENCH_CPU_THREADS', '64'))))
+        # (16 threads by default: measured on a 256-core GPU host, 64 threads deliver LESS in total -- 2.8 k against 4.1 k system-steps/s --
+        #  and take 37 s instead of 7 s of wall time)
+        n_sys = 1 if one_core else max(1, min(n_cores, int(os.environ.get('UPSIDE_BENCH_CPU_THREADS', '16'))))
         # ~9 ms per step per core for the 300-residue workload, roughly linear in the atoms: size the sample for `budget_s`
         steps = max(30, int(budget_s / (0.010 * max(n_atom, 60) / 900.)))
         duration = steps * DT
@@ -187,16 +189,19 @@ def parity_check(pkg, c, eng, fixture, R, n_atom, n_check=4):
     for k in pick:
         x = np.ascontiguousarray(pos[k])
         e_ref = float(orc.energy(x)); d_ref = orc.deriv(x)
+        # a total energy is a sum of large terms of both signs: its error is measured against the sum of the |per-node potentials|
+        # (the gate of tests/test_gpu_parity.py), not against the total
+        e_scale = max(1., sum(abs(float(orc.get_output(nm)[0, 0])) for nm in P.POTENTIAL_NODES))
         d_one = one.deriv(x)
         worst['deriv_vs_oracle'] = max(worst['deriv_vs_oracle'], P.rel_rms(d_ref, deriv[k]))
-        worst['energy_vs_oracle'] = max(worst['energy_vs_oracle'], abs(float(energy[k]) - e_ref) / max(1., abs(e_ref)))
+        worst['energy_vs_oracle'] = max(worst['energy_vs_oracle'], abs(float(energy[k]) - e_ref) / e_scale)
         worst['deriv_vs_one_system_engine'] = max(worst['deriv_vs_one_system_engine'], P.rel_rms(d_one, deriv[k]))
         worst['one_system_engine_vs_oracle'] = max(worst['one_system_engine_vs_oracle'], P.rel_rms(d_ref, d_one))
     finite = bool(np.isfinite(deriv).all() and np.isfinite(energy).all())
     mx = max(worst['deriv_vs_oracle'], worst['energy_vs_oracle'])
     return dict(max_rel_rms=mx, n=len(pick), tol=PARITY_TOL, ok=bool(finite and mx <= PARITY_TOL), replicas=pick,
                 all_replicas_finite=finite, systems_in_engine=R, **worst,
-                what='forces (relative RMS) and total energy of %d random replicas of the TIMED engine at their current positions vs '
+                what='forces (relative RMS) and total energy (relative to the sum of |node potentials|) of %d random replicas of the TIMED engine at their current positions vs '
                      'oracle/upside_oracle.c; also vs a fresh one-system engine' % len(pick))
 
 
