@@ -1485,6 +1485,44 @@ def test_ens512_syn150(hip):
     c.free_deriv_engine(ct.c_void_p(eng))
 
 
+def test_benchmark_engine_2048_systems_matches_oracle(hip):
+    """The configuration the headline is measured in -- >= 2048 systems of syn300_10A in ONE engine, which selects the large-batch
+    code paths by itself (256-lane fused lists with the 8-waves cap, no merged launches, upkeep on side streams, the one-workgroup
+    solve; bench.py's default is 4096 of them) -- against the oracle: every system starts from its own structure, 15 MD steps put the
+    cached-list path and a few rebuilds behind them, then six systems drawn at random must agree with the CPU oracle at their
+    current positions within 1e-5 (forces: relative RMS; energy: relative to the sum of |node potentials|) and with a fresh
+    one-system engine (another solve variant: 1e-6), and every system of the batch must be finite."""
+    name, S = 'syn300_10A', 2048
+    c = hip.calc
+    g = P.golden(name)
+    n_atom = g['pos'].shape[0]
+    rng = np.random.RandomState(2048)
+    pos = np.ascontiguousarray((g['pos'][None] + rng.normal(0., 0.05, (S, n_atom, 3))).astype('f4'))
+    eng = c.upside_hip_construct(n_atom, P.fixture(name).encode(), S, True)
+    assert eng, c.upside_hip_last_error()
+    try:
+        assert c.upside_hip_set_pos(eng, pos.ctypes.data) == 0
+        temps = np.full(S, 0.8, 'f4')
+        assert c.upside_hip_init_md(eng, temps.ctypes.data, 77, 5.0, 0.009, 1) == 0
+        assert c.upside_hip_run_md(eng, 5) == 0, c.upside_hip_last_error()
+        assert c.upside_hip_get_pos(eng, pos.ctypes.data) == 0
+        en = np.zeros(S, 'f4'); der = np.zeros((S, n_atom, 3), 'f4')
+        assert c.upside_hip_compute(eng, en.ctypes.data, der.ctypes.data) == 0, c.upside_hip_last_error()
+        assert np.isfinite(en).all() and np.isfinite(der).all() and np.isfinite(pos).all()
+        orc = P.pkg.Upside(P.fixture(name), library=P.oracle_library())
+        single = P.pkg.Upside(P.fixture(name), library=hip)
+        for s in rng.choice(S, 6, replace=False):
+            ref_e = orc.energy(pos[s]); ref_d = orc.deriv(pos[s])
+            scale = sum(abs(orc.get_output(nm)[0, 0]) for nm in P.POTENTIAL_NODES)
+            assert P.rel_rms(ref_d, der[s]) < RTOL, (s, P.rel_rms(ref_d, der[s]))
+            assert abs(ref_e - en[s]) < RTOL * scale, (s, ref_e, en[s], scale)
+            d1 = single.deriv(pos[s])
+            assert P.rel_rms(d1, der[s]) < 1e-6, (s, P.rel_rms(d1, der[s]))
+        single.close(); orc.close()
+    finally:
+        c.free_deriv_engine(ct.c_void_p(eng))
+
+
 def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
     """The cross-rank half of csrc/comm_rccl.cpp and the multi-rank branch of `upside_main` (main.cpp:227-275, 616-672 for a
     ladder spread over processes), executed for real: TWO processes on this one GPU, each with RANK / WORLD_SIZE in its

@@ -5,7 +5,7 @@ ARGS="$1"; shift
 for setting in "$@"; do
   echo "== $setting"
   s="$setting"; [ "$s" = "-" ] && s=""
-  env $s python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-single-system $ARGS 2>gpurun_out/ab_env.err | python3 -c "
+  env $s python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-single-system --no-parity-check $ARGS 2>gpurun_out/ab_env.err | python3 -c "
 import sys,json
 L=[l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')]
 if not L: print('   FAILED'); sys.exit()

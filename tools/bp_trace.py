@@ -38,4 +38,5 @@ print("per sweep: edge %.2f us  node %.2f us" % (t[3] * 0.01 / (t[5] + 1), t[4] 
 
 sub = ["setup", "layout+pack", "msg init", "fold+nb init", "resident load", "resident marginals", "packed marginals", "energy+beliefs out"]
 print("stamps since kernel start (us): " + ", ".join("%s %.1f" % (n_, v * 0.01) for n_, v in zip(sub, t[16:24])))
+print("node phase of wavefront 0, per sweep: rows + products %.2f us, combine %.2f us, finish %.2f us (rest of the node phase: waiting at the barrier)" % tuple(t[24 + i] * 0.01 / (t[5] + 1) for i in range(3)))
 print("loop end at %.1f us, kernel end at %.1f us" % ((t[0] + t[1]) * 0.01, (t[0] + t[1] + t[2]) * 0.01))

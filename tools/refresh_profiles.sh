@@ -16,7 +16,7 @@ if want pmc; then
 [ -s "$OUT/bench_R4096.json" ] || python3 bench.py --steps 100 --warmup 30 --no-cpu-baseline 2>"$OUT/bench_R4096.err" | grep '^{' | tail -1 > "$OUT/bench_R4096.json"
 # (the one-replica latency leg is left out of the profiled command: its launches of the same kernels would dilute the
 #  per-launch averages of the counters)
-CMD="python3 bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-single-system"
+CMD="python3 bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-single-system --no-parity-check"
 for t in trace fetch write sq; do rm -rf "$OUT/$t"; done
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
@@ -49,7 +49,7 @@ if want configs; then
 for w in trpcage20_7A proteinG56_7A syn150_10A syn300_7A syn300_10A; do
 for R in 1 8 64 512; do
   st=300; [ $R -ge 64 ] && st=150
-  python3 bench.py --workload $w --replicas $R --steps $st --warmup 40 --no-cpu-baseline --no-single-system 2>/dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); print('$w', $R, round(d['value']))"
+  python3 bench.py --workload $w --replicas $R --steps $st --warmup 40 --no-cpu-baseline --no-single-system --no-parity-check 2>/dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); print('$w', $R, round(d['value']))"
 done; done > "$OUT/other_configs.txt"
 # BASELINE configs[3] and [4] on one GPU (the multi-GPU lines need a node the builder cannot launch on)
 # BASELINE configs[1]: ONE protein G, with the reference timed on one host core in the same line; and the batch of 8

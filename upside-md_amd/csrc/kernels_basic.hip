@@ -1829,7 +1829,15 @@ extern "C" int upk_fuse_flush(const upk_launch_t* L) {
     if (q->trace_dev) {       // per-op times of wavefront 0 of system 0 (with barriers elided an op's time includes waiting for nothing: reach-to-reach)
         long long t[FUSE_MAX_PENDING + 1];
         if (hipStreamSynchronize(ST(L)) == hipSuccess && hipMemcpy(t, q->trace_dev, sizeof(long long) * (q->pending.n + 1), hipMemcpyDeviceToHost) == hipSuccess)
+        {
             for (int k = 0; k < q->pending.n; ++k) { const int kind = q->table[q->pending.id[k]].kind; q->trace_us[kind] += (t[k + 1] - t[k]) * 0.01; q->trace_n[kind] += 1; }
+            static const int level = atoi(getenv("UPSIDE_HIP_FUSE_TRACE"));
+            if (level >= 2 && q->n_launch >= 1000 && q->n_launch < 1012) {      // (a dozen launches of a warmed-up run: "kind@us since the list's start", | = barrier in front)
+                fprintf(stderr, "fused list %ld (%s):", q->n_launch, q->pending_heavy ? "heavy" : "light");
+                for (int k = 0; k < q->pending.n; ++k) fprintf(stderr, " %s%d@%.1f", (q->table[q->pending.id[k]].flags & 1) ? "" : "| ", q->table[q->pending.id[k]].kind, (t[k] - t[0]) * 0.01);
+                fprintf(stderr, " end@%.1f\n", (t[q->pending.n] - t[0]) * 0.01);
+            }
+        }
     }
     q->n_launch += 1; q->n_ops_run += q->pending.n;
     q->pending.n = 0; q->pending_lds = 0; q->pending_heavy = false; q->live.clear(); q->next_rot = 0;

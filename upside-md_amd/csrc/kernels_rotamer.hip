@@ -958,6 +958,13 @@ struct BpCtx {
     //  that fits LDS as a whole -- plain ds_read / ds_write there --, the branch taken once per solve: 6.01 against 5.98 ms, no gain)
     __device__ __forceinline__ float* msg(int off) const { return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
+// ALL: the whole inbox of this solve sits in LDS (decided per solve, once the dense layout is known): message rows are then plain LDS
+// accesses (ds_read / ds_write) instead of the flat ones a two-address-space pointer costs -- measured with every row in LDS,
+// 150 residues: edge phase 4.99 -> 3.72 us, node phase 4.40 -> 3.70 us per sweep (one system 2.40 -> 2.62 k steps/s, 512 systems
+// 277 -> 296 k); 300 residues / 7 A x 512: 261 -> 272 k.  The solve below is instantiated for both.
+template <bool ALL> struct BpCtxT : BpCtx {
+    __device__ __forceinline__ float* msg(int off) const { if (ALL) return inbox_lds + off; return off < lds_floats ? inbox_lds + off : inbox + off; }
+};
 
 // One message row, wide: a row to a 3-state node is 4 floats at a 16-byte boundary (one b128 access, the 4th word unused), a
 // row to a 6-state node 6 or 8 floats at an 8-byte boundary (three b64 accesses) -- in both inbox layouts.  (Dword accesses
@@ -983,8 +990,8 @@ template <int N, int NS> __device__ __forceinline__ void bp_load_nb(const float*
         for (int i = 0; i < N; ++i) v[i] = p[i];
     }
 }
-template <int NA, int NB, bool WT, int NS = 6>   // WT: messages leave through 16-byte write-through stores (cluster solve)
-__device__ __forceinline__ void bp_edge_slot(const BpCtx& C, int oa, int ob, int a, int b, const float (&P)[NA * NB], const float* __restrict__ nb_old,
+template <int NA, int NB, bool WT, int NS = 6, typename CTX = BpCtx>   // WT: messages leave through 16-byte write-through stores (cluster solve)
+__device__ __forceinline__ void bp_edge_slot(const CTX& C, int oa, int ob, int a, int b, const float (&P)[NA * NB], const float* __restrict__ nb_old,
                                              __amdgpu_buffer_rsrc_t inbox_w) {
     float* pa = C.msg(oa);
     float* pb = C.msg(ob);
@@ -1038,8 +1045,8 @@ __device__ __forceinline__ void bp_load_matrix(const BpCtx& C, int sl, float (&P
         else P[i * NB + 2] = ((const float*)r)[2];
     }
 }
-template <int NA, int NB, bool WT, int NS = 6>
-__device__ __forceinline__ void bp_edge_range_impl(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
+template <int NA, int NB, bool WT, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ void bp_edge_range_impl(const CTX& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt,
                                                    __amdgpu_buffer_rsrc_t inbox_w) {
     // (measured and rejected: fetching the next slot's flag and message offsets one trip ahead.  In the 6x6 instance it
     // spills 58 VGPRs (sweep 34.5 -> 47.7 us at 1024 systems); in the 3x3 / 3x6 instances alone it costs 1 % of the
@@ -1079,8 +1086,8 @@ __device__ __forceinline__ void bp_pack_active(const BpCtx& C, int4* __restrict_
         __syncthreads();
     }
 }
-template <int NA, int NB, int NS = 6>
-__device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int end, const float* __restrict__ nb_old, int tid, int nt,
+template <int NA, int NB, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ void bp_edge_packed(const CTX& C, int first, int end, const float* __restrict__ nb_old, int tid, int nt,
                                                __amdgpu_buffer_rsrc_t rs) {
 #ifndef BP_REC_AHEAD
 #define BP_REC_AHEAD 1
@@ -1122,8 +1129,8 @@ __device__ __forceinline__ void bp_edge_packed(const BpCtx& C, int first, int en
         if (BP_REC_AHEAD) r = rn; else if (idx + nt < end) r = C.rec[idx + nt];
     }
 }
-template <int NA, int NB, int NS = 6>
-__device__ __forceinline__ void bp_edge_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
+template <int NA, int NB, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ void bp_edge_range(const CTX& C, int lo, int hi, const float* __restrict__ nb_old, int tid, int nt) {
     bp_edge_range_impl<NA, NB, false, NS>(C, lo, hi, nb_old, tid, nt, make_rsrc(C.inbox, 0u));
 }
 // energies -> probabilities, in place, for slots [lo, hi) of one class (rotamer.cpp:835)
@@ -1142,8 +1149,8 @@ __device__ __forceinline__ void exp_class(float* P, int cap, int lo, int hi, int
 }
 
 // pair marginals and (optionally) their Bethe free-energy terms (rotamer.cpp:405-451)
-template <int NA, int NB, int NS = 6>
-__device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa, int ob, int a, int b, const float (&P)[NA * NB],
+template <int NA, int NB, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ float bp_marginal_slot(const CTX& C, int sl, int oa, int ob, int a, int b, const float (&P)[NA * NB],
                                                   const float* __restrict__ nbm, bool want_energy) {
     float en = 0.f;
     float ma[NA], mb[NB];
@@ -1170,8 +1177,8 @@ __device__ __forceinline__ float bp_marginal_slot(const BpCtx& C, int sl, int oa
         }
     return en;
 }
-template <int NA, int NB, int NS = 6>
-__device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int hi, const float* __restrict__ nbm, int tid, int nt,
+template <int NA, int NB, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ float bp_marginal_range(const CTX& C, int lo, int hi, const float* __restrict__ nbm, int tid, int nt,
                                                    bool want_energy) {
     float en = 0.f;
     for (int sl = lo + tid; sl < hi; sl += nt) {
@@ -1183,8 +1190,8 @@ __device__ __forceinline__ float bp_marginal_range(const BpCtx& C, int lo, int h
     return en;
 }
 
-template <int NA, int NB, int NS = 6>
-__device__ __forceinline__ float bp_marginal_packed(const BpCtx& C, int first, int end, const float* __restrict__ nbm, int tid, int nt, bool want_energy) {
+template <int NA, int NB, int NS = 6, typename CTX = BpCtx>
+__device__ __forceinline__ float bp_marginal_packed(const CTX& C, int first, int end, const float* __restrict__ nbm, int tid, int nt, bool want_energy) {
     float en = 0.f;
     int idx = first + tid;                                         // (the next trip's record is fetched one trip ahead, as in bp_edge_packed)
     int4 r = idx < end ? C.rec[idx] : make_int4(0, 0, 0, 0);
@@ -1230,6 +1237,9 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
 #ifndef BP_NODE_ROWS_512
 #define BP_NODE_ROWS_512 4
 #endif
+#ifndef BP_WIDE_NODE_GROUPS
+#define BP_WIDE_NODE_GROUPS 1
+#endif
 
 // Pair matrices pinned in registers for the whole solve.  The edge phase is bandwidth bound (at 1024 systems every CU
 // streams ~0.6 MB per sweep, half of it exp(-E) matrices that never change during the solve), and the register file
@@ -1253,12 +1263,12 @@ struct BpResident {
             }
         }
     }
-    template <int NS> __device__ __forceinline__ void edge(const BpCtx& C, const float* __restrict__ nb_old, __amdgpu_buffer_rsrc_t rs) const {
+    template <int NS, typename CTX> __device__ __forceinline__ void edge(const CTX& C, const float* __restrict__ nb_old, __amdgpu_buffer_rsrc_t rs) const {
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (ab[k] >= 0) bp_edge_slot<NA, NB, false, NS>(C, oa[k], ob[k], ab[k] & 0xffff, ab[k] >> 16, P[k], nb_old, rs);
     }
-    template <int NS> __device__ __forceinline__ float marginal(const BpCtx& C, const float* __restrict__ nbm, bool want_energy) const {
+    template <int NS, typename CTX> __device__ __forceinline__ float marginal(const CTX& C, const float* __restrict__ nbm, bool want_energy) const {
         float en = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -1293,7 +1303,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     int* cls = bp_start + NN + 1;                // [N_CLASS+1]
     int* n_act = cls + N_CLASS + 1;              // [3] active slots of the 3x3 / 3x6 / 6x6 classes
     const int n_slot = R.n_slot[s];
-    long long tr_t0 = 0, tr_edge = 0, tr_node = 0, tr_pro = 0, tr_loop = 0;
+    long long tr_t0 = 0, tr_edge = 0, tr_node = 0, tr_pro = 0, tr_loop = 0, tr_n1 = 0, tr_n2 = 0, tr_n3 = 0, tr_nm = 0;
     const bool trace = R.bp_trace != nullptr && tid == 0;
     if (trace) tr_t0 = wall_clock64();
     long long* TX = R.bp_trace ? R.bp_trace + (size_t)s * 32 + 16 : nullptr;     // sub-phase stamps since the kernel's start (diagnostics)
@@ -1307,7 +1317,9 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     C.P = R.P + (size_t)s * R.slot_cap * 36;
     C.inbox = R.msg_cur + (size_t)s * R.slot_cap * 16;
     C.marg = R.marg + (size_t)s * R.slot_cap * 36;
-    C.inbox_lds = (float*)(((size_t)(cls + N_CLASS + 5) + 15) & ~(size_t)15);   // [lds_msg_floats], 16-byte aligned
+    // [lds_msg_floats], 16-byte aligned; kept as an OFFSET from the kernel's LDS symbol (no integer round trip), so that the address
+    // space stays visible to the compiler
+    C.inbox_lds = lds + ((((int)((float*)(cls + N_CLASS + 5) - lds)) + 3) & ~3);
     const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
     const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
     for (int i = tid; i < NN; i += nt) nrot[i] = R.node_nrot[i];
@@ -1462,6 +1474,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     }
     __syncthreads();       // (bp_start holds float offsets now; the scratch of the compact layout is dead)
     BP_STAMP(1);
+    // the rest of the solve, instantiated twice: for an inbox that sits in LDS as a whole (BpCtxT<true>) and for one with a tail in
+    // global memory; which one runs is decided here, once per solve (uniform over the workgroup)
+    const BpCtx& C_base = C;
+    auto solve = [&](auto all_lds_tag) __attribute__((always_inline)) {
+    BpCtxT<decltype(all_lds_tag)::value> C; static_cast<BpCtx&>(C) = C_base;
     for (int i = tid; i < inbox_floats; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
     BP_STAMP(2);
@@ -1542,7 +1559,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         //  two-lane nodes; ALL of them on two lanes is what won)
         const int e1n = R.n_node1, e3n = R.n_node1 + R.n_node3;
         // one node: lanes glx = 0 .. grp-1 of its group (`live`: the group has a node)
-        auto node_update = [&](const int grp, const int glx, const int g, const bool live) {
+        auto node_update = [&](const int grp, const int glx, const int g, const bool live, const int wd) {
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
@@ -1584,10 +1601,31 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 }
             }
             static_assert(BP_GROUP == 4, "the combine below is the lane^2, lane^1 butterfly of a quad");
+            if (trace) { const long long t = wall_clock64(); tr_n1 += t - tr_nm; tr_nm = t; }      // (diagnostics: rows in, per-lane products done)
+#if BP_WIDE_NODE_GROUPS
+            // groups of 16 / 8 lanes (small systems, one round): two more combine stages in front of the quad's, L <-> 15-L and
+            // L <-> 7-L of the DPP row (every lane of a group ends with the same bits: each stage multiplies a symmetric pair)
+            if (wd >= 4) {       // (`wd` is uniform over the workgroup: no lane sits out a DPP step; which lanes multiply is a per-lane select)
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_ROW_MIRROR>(bb[r]); bb[r] *= grp >= 16 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+            }
+            if (wd >= 2) {
+                float mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_HALF_MIRROR>(bb[r]); bb[r] *= grp >= 8 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
+                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+            }
+#endif
             {
                 float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR2>(bb[r]); bb[r] *= grp == 4 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }   // (a pair has no lane^2 partner)
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR2>(bb[r]); bb[r] *= grp >= 4 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }   // (a pair has no lane^2 partner)
                 const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
@@ -1600,6 +1638,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
 #pragma unroll
                 for (int r = 0; r < 6; ++r) bb[r] *= rm;
             }
+            if (trace) { const long long t = wall_clock64(); tr_n2 += t - tr_nm; tr_nm = t; }      // (combine done)
             if (live) {
                 // b = prob * product, then standardize (rotamer.cpp:258-273); lane glx of the node finishes states glx, glx + grp, ...
                 float v[6], mx = 0.f;
@@ -1620,19 +1659,28 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         };
         // A small system has lanes for all its nodes at once -- four per 6-state node, then two per 3-state node --: ONE round, one
         // chain of dependent LDS accesses per sweep instead of two (the arithmetic of a node does not depend on which lanes hold it).
+        if (trace) tr_nm = wall_clock64();
         const int lanes6 = (NN - e3n) * BP_GROUP6, lanes3 = (e3n - e1n) * BP_GROUP3;
+#if BP_WIDE_NODE_GROUPS
+        // ... and where the lanes are there, four or two times as many per node: a node's inbox is then ONE batch of row loads per lane
+        // instead of two to four dependent ones (a 56-residue protein has ~50 multi-state nodes for 512 lanes)
+        const int wide = (lanes6 + lanes3) * 4 <= nt ? 4 : ((lanes6 + lanes3) * 2 <= nt ? 2 : 1);
+#else
+        constexpr int wide = 1;
+#endif
         if (lanes6 + lanes3 <= nt) {
-            const bool six = tid < lanes6;
-            const int grp = six ? BP_GROUP6 : BP_GROUP3, t = six ? tid : tid - lanes6;
+            const bool six = tid < lanes6 * wide;
+            const int grp = (six ? BP_GROUP6 : BP_GROUP3) * wide, t = six ? tid : tid - lanes6 * wide;
             const int g = (six ? e3n : e1n) + t / grp;
-            node_update(grp, t & (grp - 1), g, six || t < lanes3);
+            node_update(grp, t & (grp - 1), g, six || t < lanes3 * wide, wide);
         } else
         for (int part = 0; part < 2; ++part)
         for (int g0 = part == 0 ? e3n : e1n, g_hi = part == 0 ? NN : e3n; g0 < g_hi; g0 += part == 0 ? nt / BP_GROUP6 : nt / BP_GROUP3) {
             const int grp = part == 0 ? BP_GROUP6 : BP_GROUP3;
             const int g = g0 + tid / grp;
-            node_update(grp, tid & (grp - 1), g, g < g_hi);
+            node_update(grp, tid & (grp - 1), g, g < g_hi, 1);
         }
+        if (trace) { const long long t = wall_clock64(); tr_n3 += t - tr_nm; tr_nm = t; }          // (beliefs written; what is left of tr_node is the barrier)
         __syncthreads();
         if (trace) tr_node += wall_clock64() - tr_b;
         if (sweep >= 0) {
@@ -1711,9 +1759,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     if (trace) {
         long long* T = R.bp_trace + (size_t)s * 32;
         T[0] = tr_pro - tr_t0; T[1] = tr_loop - tr_pro; T[2] = wall_clock64() - tr_loop; T[3] = tr_edge; T[4] = tr_node;
+        T[24] = tr_n1; T[25] = tr_n2; T[26] = tr_n3;
         T[5] = iter; T[6] = n_slot; T[7] = COMPACT ? C.lds_floats : bp_start[NN];
         for (int c = 0; c <= N_CLASS; ++c) T[8 + c] = cls[c];
+        T[27] = decltype(all_lds_tag)::value ? 1 : 0;
     }
+    };      // solve
+    if (COMPACT && C.lds_floats >= inbox_floats) solve(std::true_type{}); else solve(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
