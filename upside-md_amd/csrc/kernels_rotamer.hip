@@ -956,25 +956,31 @@ struct BpCtx {
     float* inbox_lds = nullptr; int lds_floats = 0;
     // (a pointer selected between two address spaces: FLAT accesses.  Round 3 instantiated the rest of the solve a second time for an inbox
     //  that fits LDS as a whole -- plain ds_read / ds_write there --, the branch taken once per solve: 6.01 against 5.98 ms, no gain)
+    static constexpr int W3 = 4;       // floats per message row to a 3-state node
     __device__ __forceinline__ float* msg(int off) const { return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
 // ALL: the whole inbox of this solve sits in LDS (decided per solve, once the dense layout is known): message rows are then plain LDS
 // accesses (ds_read / ds_write) instead of the flat ones a two-address-space pointer costs -- measured with every row in LDS,
 // 150 residues: edge phase 4.99 -> 3.72 us, node phase 4.40 -> 3.70 us per sweep (one system 2.40 -> 2.62 k steps/s, 512 systems
 // 277 -> 296 k); 300 residues / 7 A x 512: 261 -> 272 k.  The solve below is instantiated for both.
-template <bool ALL> struct BpCtxT : BpCtx {
+// W3_: 3 = rows to 3-state nodes hold 3 floats instead of 4 (two LDS instructions per row instead of one b128, 11 KB less for the
+// benchmark protein): taken only when that is what makes the inbox fit (then ALL is set as well).
+template <bool ALL, int W3_ = 4> struct BpCtxT : BpCtx {
+    static constexpr int W3 = W3_;
     __device__ __forceinline__ float* msg(int off) const { if (ALL) return inbox_lds + off; return off < lds_floats ? inbox_lds + off : inbox + off; }
 };
 
 // One message row, wide: a row to a 3-state node is 4 floats at a 16-byte boundary (one b128 access, the 4th word unused), a
 // row to a 6-state node 6 or 8 floats at an 8-byte boundary (three b64 accesses) -- in both inbox layouts.  (Dword accesses
 // cost an LDS instruction each: the dense inbox of 3 / 6 dwords per row kept the LDS index unit busy 52 % of the solve.)
-template <int N> __device__ __forceinline__ void bp_load_row(const float* p, float* v) {
-    if (N == 3) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; }
+template <int N, int W3 = 4> __device__ __forceinline__ void bp_load_row(const float* p, float* v) {
+    if (N == 3 && W3 == 3) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; }       // (12-byte rows: dword aligned only)
+    else if (N == 3) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; }
     else { const float2 a = ((const float2*)p)[0], b = ((const float2*)p)[1], c = ((const float2*)p)[2]; v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; }
 }
-template <int N> __device__ __forceinline__ void bp_store_row(float* p, const float* v) {
-    if (N == 3) *(float4*)p = make_float4(v[0], v[1], v[2], 1.f);
+template <int N, int W3 = 4> __device__ __forceinline__ void bp_store_row(float* p, const float* v) {
+    if (N == 3 && W3 == 3) { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; }
+    else if (N == 3) *(float4*)p = make_float4(v[0], v[1], v[2], 1.f);
     else { ((float2*)p)[0] = make_float2(v[0], v[1]); ((float2*)p)[1] = make_float2(v[2], v[3]); ((float2*)p)[2] = make_float2(v[4], v[5]); }
 }
 // edge phase over one class range: new messages from the old beliefs (update_beliefs, rotamer.cpp:468-499 and the
@@ -996,7 +1002,7 @@ __device__ __forceinline__ void bp_edge_slot(const CTX& C, int oa, int ob, int a
     float* pa = C.msg(oa);
     float* pb = C.msg(ob);
     float ma[NA], mb[NB];
-    bp_load_row<NA>(pa, ma); bp_load_row<NB>(pb, mb);
+    bp_load_row<NA, CTX::W3>(pa, ma); bp_load_row<NB, CTX::W3>(pb, mb);
     float va[NA], vb[NB];
     bp_load_nb<NA, NS>(nb_old + a * NS, va); bp_load_nb<NB, NS>(nb_old + b * NS, vb);
 #pragma unroll
@@ -1031,7 +1037,7 @@ __device__ __forceinline__ void bp_edge_slot(const CTX& C, int oa, int ob, int a
         for (int i = 0; i < NA; ++i) ta[i] *= ra;
 #pragma unroll
         for (int j = 0; j < NB; ++j) tb[j] *= rb;
-        bp_store_row<NA>(pa, ta); bp_store_row<NB>(pb, tb);
+        bp_store_row<NA, CTX::W3>(pa, ta); bp_store_row<NB, CTX::W3>(pb, tb);
     }
 }
 // the NA x NB entries of one slot, row-major, from the [36][cap] table
@@ -1154,7 +1160,7 @@ __device__ __forceinline__ float bp_marginal_slot(const CTX& C, int sl, int oa, 
                                                   const float* __restrict__ nbm, bool want_energy) {
     float en = 0.f;
     float ma[NA], mb[NB];
-    bp_load_row<NA>(C.msg(oa), ma); bp_load_row<NB>(C.msg(ob), mb);
+    bp_load_row<NA, CTX::W3>(C.msg(oa), ma); bp_load_row<NB, CTX::W3>(C.msg(ob), mb);
     // the unnormalised marginals are formed twice (sum, then store) rather than kept: 36 fewer live registers next
     // to the resident matrices, and the products round identically both times
     float bc1[NA], bc2[NB], sum = 0.f;
@@ -1234,6 +1240,7 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
 #ifndef BP_NODE_STRIDE
 #define BP_NODE_STRIDE 6      // (8 = one b128 + one b64 per node row: measured equal, and 6 leaves 7 KB more of the LDS to the inbox)
 #endif
+#define BP_NODE_ARRAYS 2      // node arrays of BP_NODE_STRIDE floats in the one-workgroup solve's LDS: probabilities, beliefs
 #ifndef BP_NODE_ROWS_512
 #define BP_NODE_ROWS_512 4
 #endif
@@ -1295,10 +1302,13 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     const int NN = R.n_node;
     float* prob = lds;                 // [NN][6]  node probabilities with the 1-state partners folded in
     constexpr int NS = BP_NODE_STRIDE;   // floats per node in the LDS belief arrays: 8, so that a node's states are one b128 (+ one b64) access
+    // ONE belief array: the edge phase reads any node's belief, the node phase reads and rewrites a node's belief with the lanes that
+    // own the node, and a workgroup barrier separates the phases -- the reference's old / current pair (rotamer.cpp:1040-1044) updated in
+    // place.  (Round 5: the second array's 7 KB go to the message inbox.)
     float* nb0 = lds + NN * NS;        // [NN][NS]
-    float* nb1 = lds + NN * 2 * NS;    // [NN][NS]
-    float* scratch = lds + NN * 3 * NS;   // [32]
-    int* nrot = (int*)(lds + NN * 3 * NS + 32);  // [NN]   state counts
+    float* nb1 = nb0;
+    float* scratch = lds + NN * BP_NODE_ARRAYS * NS;   // [32]
+    int* nrot = (int*)(lds + NN * BP_NODE_ARRAYS * NS + 32);  // [NN]   state counts
     int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
     int* cls = bp_start + NN + 1;                // [N_CLASS+1]
     int* n_act = cls + N_CLASS + 1;              // [3] active slots of the 3x3 / 3x6 / 6x6 classes
@@ -1346,6 +1356,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // (the streaming variant serves small, latency-bound batches: packing costs it more than the sweeps get back)
     constexpr bool PACK = K66 + K36 + K33 > 0 || COMPACT;      // (the compact inbox is laid out by the packing pass)
     int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
+    int w3 = 4;                            // floats per row to a 3-state node (dense layout: 4, or 3 when only that makes the inbox fit the LDS)
     if (COMPACT) {
         // Which rows carry a message in this solve: an activity bit per cached row (LDS, in the region the messages will take),
         // a prefix sum over its 32-row words (every word holds rows of one width: build_slots pads the 3-state block to 32), and
@@ -1410,21 +1421,28 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             chunk_base[tid] = before;
         }
         {
+            // active rows to 3-state nodes (T3) and to 6-state nodes (T6): two scans over row counts, then the row width of the 3-state
+            // block is chosen -- 4 floats if the inbox then fits the LDS (or does not fit either way), else 3 if that makes it fit --
+            // and the 6-state block starts at an even float (8-byte accesses)
             const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
-            int sum = 0;
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) sum += __popc(rmask[w]) * (w * 32 < R6 ? 4 : 6); }
-            int total;
-            int run = block_excl_scan(sum, (int*)scratch, &total);
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { wbase[w] = run; run += __popc(rmask[w]) * (w * 32 < R6 ? 4 : 6); } }
-            if (tid == 0) wbase[n_words] = total;
-            inbox_floats = total;
+            int c3 = 0, c6 = 0;
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { const int c = __popc(rmask[w]); if (w * 32 < R6) c3 += c; else c6 += c; } }
+            int T3, T6;
+            int x3 = block_excl_scan(c3, (int*)scratch, &T3);
+            int x6 = block_excl_scan(c6, (int*)scratch, &T6);
+            w3 = (4 * T3 + 6 * T6 > lds_msg_floats && 3 * T3 + (T3 & 1) + 6 * T6 <= lds_msg_floats) ? 3 : 4;
+            const int base6 = w3 * T3 + (w3 == 3 ? (T3 & 1) : 0);
+            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) {
+                const int c = __popc(rmask[w]);
+                if (w * 32 < R6) { wbase[w] = w3 * x3; x3 += c; } else { wbase[w] = base6 + 6 * x6; x6 += c; } } }
+            inbox_floats = base6 + 6 * T6; inbox_floats3 = base6;
+            if (tid == 0) wbase[n_words] = inbox_floats;
         }
         __syncthreads();
-        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? 4 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
+        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? w3 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
         int my_start[(1024 + BLOCK - 1) / BLOCK + 1];          // first message float of the nodes this lane copies (NN <= 1024)
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; my_start[k] = g <= NN ? dense(bp_start[g]) : 0; }
-        inbox_floats3 = dense(R6);
         int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
         C.rec = rec;
         if (fast_pack) {
@@ -1467,9 +1485,9 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // the head of the inbox stays in LDS as far as it reaches: the rows to the 3-state nodes come first, then the rows to the
     // 6-state nodes (the boundary never cuts a row)
     {
-        constexpr int W3 = 4, W6 = COMPACT ? 6 : 8;
+        constexpr int W6 = COMPACT ? 6 : 8;
         int n = lds_msg_floats < inbox_floats ? lds_msg_floats : inbox_floats;
-        if (n > inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / W3) * W3;
+        if (n > inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / w3) * w3;
         C.lds_floats = n;
     }
     __syncthreads();       // (bp_start holds float offsets now; the scratch of the compact layout is dead)
@@ -1477,8 +1495,10 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // the rest of the solve, instantiated twice: for an inbox that sits in LDS as a whole (BpCtxT<true>) and for one with a tail in
     // global memory; which one runs is decided here, once per solve (uniform over the workgroup)
     const BpCtx& C_base = C;
-    auto solve = [&](auto all_lds_tag) __attribute__((always_inline)) {
-    BpCtxT<decltype(all_lds_tag)::value> C; static_cast<BpCtx&>(C) = C_base;
+    auto solve = [&](auto all_lds_tag) __attribute__((always_inline)) {      // tag: 0 = inbox with a tail in global memory, 1 = all in LDS, 2 = all in LDS with 3-float rows
+    constexpr int SOLVE_KIND = decltype(all_lds_tag)::value;
+    BpCtxT<SOLVE_KIND != 0, SOLVE_KIND == 2 ? 3 : 4> C; static_cast<BpCtx&>(C) = C_base;
+    constexpr int CW3 = SOLVE_KIND == 2 ? 3 : 4;
     for (int i = tid; i < inbox_floats; i += nt) *C.msg(i) = 1.f;
     __syncthreads();
     BP_STAMP(2);
@@ -1511,7 +1531,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         for (int r = 0; r < 6; ++r) if (r < n) prob[g * NS + r] = pr[r];
     }
     __syncthreads();
-    for (int i = tid; i < NN * NS; i += nt) { const float v = (i % NS) < 6 ? prob[i] : 0.f; nb0[i] = v; nb1[i] = v; }   // old node belief = prob (rotamer.cpp:1009-1013)
+    for (int i = tid; i < NN * NS; i += nt) nb0[i] = (i % NS) < 6 ? prob[i] : 0.f;   // old node belief = prob (rotamer.cpp:1009-1013)
     __syncthreads();
     BP_STAMP(3);
     BpResident<3, 3, K33> r33; BpResident<3, 6, K36> r36; BpResident<6, 6, K66> r66;
@@ -1563,7 +1583,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             const int n = live ? nrot[g] : 0;
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
-                const int q = COMPACT ? (n == 6 ? 6 : 4) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
+                const int q = COMPACT ? (n == 6 ? 6 : CW3) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
                 // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
                 // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
                 constexpr int ROWS = BP_NODE_ROWS_512;      // (one value for every variant: the renormalisation points of the product follow it)
@@ -1577,6 +1597,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                             if (COMPACT) {       // dense rows: 4 floats (16-byte aligned) to a 3-state node, 6 floats (8-byte aligned) to a 6-state node
                                 const float* m = C.msg(base + k * q);
                                 if (n == 6) { const float2 a = ((const float2*)m)[0], b = ((const float2*)m)[1]; m0[u] = make_float4(a.x, a.y, b.x, b.y); m1[u] = ((const float2*)m)[2]; }
+                                else if (CW3 == 3) m0[u] = make_float4(m[0], m[1], m[2], 1.f);
                                 else m0[u] = *(const float4*)m;
                             } else {
                                 const float* m = C.msg((base + k * q) * 4);
@@ -1690,7 +1711,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
                 if (!(maxdev > R.tol && iter < R.max_iter)) break;     // rotamer.cpp:1038
             }
         }
-        float* t = nb_old; nb_old = nb_cur; nb_cur = t;                // rotamer.cpp:1040-1044
+        // (rotamer.cpp:1040-1044 swaps its old / current arrays here: one array, updated in place by the node phase)
     }
     if (tid == 0) { R.iters[s] = iter; if (iter >= R.max_iter - R.chunk - 1) R.n_bad[s] += 1; }
     if (trace) tr_loop = wall_clock64();
@@ -1762,10 +1783,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
         T[24] = tr_n1; T[25] = tr_n2; T[26] = tr_n3;
         T[5] = iter; T[6] = n_slot; T[7] = COMPACT ? C.lds_floats : bp_start[NN];
         for (int c = 0; c <= N_CLASS; ++c) T[8 + c] = cls[c];
-        T[27] = decltype(all_lds_tag)::value ? 1 : 0;
+        T[27] = SOLVE_KIND;
     }
     };      // solve
-    if (COMPACT && C.lds_floats >= inbox_floats) solve(std::true_type{}); else solve(std::false_type{});
+    if (COMPACT && C.lds_floats >= inbox_floats) { if (w3 == 3) solve(std::integral_constant<int, 2>{}); else solve(std::integral_constant<int, 1>{}); }
+    else solve(std::integral_constant<int, 0>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2276,7 +2298,7 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
     UPK_FLUSH(L);
-    const size_t lds_base = ((size_t)R->n_node * (3 * BP_NODE_STRIDE + 2) + 64 + 8) * sizeof(float);
+    const size_t lds_base = ((size_t)R->n_node * (BP_NODE_ARRAYS * BP_NODE_STRIDE + 2) + 64 + 8) * sizeof(float);
     if (lds_base > 155 * 1024) return 9004;
     // LDS left over holds the messages to the 3-state nodes (at most all of the inbox: 16 floats per slot)
     static int lds_msg_kb = -1;   // UPSIDE_HIP_BP_LDS_MSG_KB (experiments): 0 keeps every message in global memory
