@@ -1225,6 +1225,14 @@ __device__ __forceinline__ void retire_flags(int lo, int hi, int* __restrict__ a
     for (int sl = lo + tid; sl < hi; sl += nt) { active_last[sl] = active_w[sl]; active_w[sl] = 0; }
 }
 
+// the running message product of a node (states 0..n-1 of bb) scaled by a power of two so that its largest entry lies in [0.5, 1): exact
+__device__ __forceinline__ void bp_rescale_pow2(float (&bb)[6], int n) {
+    float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
+    if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
+    const int e = -__builtin_amdgcn_frexp_expf(mx);          // (0 for an all-zero product)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) bb[r] = __builtin_amdgcn_ldexpf(bb[r], e);
+}
 #define BP_GROUP 4   // lanes cooperating on one node in the node phase (upper bound: the combine is the butterfly of a quad)
 // ... on a 6-state / a 3-state node.  The 140 3-state nodes of the benchmark protein need two rounds at four lanes each (128 + 12) and
 // one at two; measured at 4096 systems, solve in ms by (6-state, 3-state) lanes: (4,4) 6.36, (4,2) 6.14, (4,1) 6.66, (2,2) 7.28, (2,1) 6.92
@@ -1307,7 +1315,9 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     // place.  (Round 5: the second array's 7 KB go to the message inbox.)
     float* nb0 = lds + NN * NS;        // [NN][NS]
     float* nb1 = nb0;
-    float* scratch = lds + NN * BP_NODE_ARRAYS * NS;   // [32]
+    float* scratch = lds + NN * BP_NODE_ARRAYS * NS;   // [32]: [0, 17) the reductions and scans, [24, 32) a message row of ones (node phase)
+    const float* ones = scratch + 24;
+    if (tid < 8) scratch[24 + tid] = 1.f;
     int* nrot = (int*)(lds + NN * BP_NODE_ARRAYS * NS + 32);  // [NN]   state counts
     int* bp_start = nrot + NN;                   // [NN+1] inbox CSR
     int* cls = bp_start + NN + 1;                // [N_CLASS+1]
@@ -1584,41 +1594,33 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             float bb[6] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
             if (live && sweep >= 0) {
                 const int q = COMPACT ? (n == 6 ? 6 : CW3) : (n == 6 ? 2 : 1), base = bp_start[g], deg = (bp_start[g + 1] - base) / q;
-                // ROWS rows per trip are fetched before the first multiply (same operation order as one at a time); the
-                // 512-lane variant has the registers for eight, and a third fewer dependent trips per node
-                constexpr int ROWS = BP_NODE_ROWS_512;      // (one value for every variant: the renormalisation points of the product follow it)
+                // ROWS rows per trip are fetched before the first multiply.  A lane past the end of its node's rows reads the row of ones
+                // kept behind the scan scratch (an exact factor 1: no per-component selects, no bounds branch in the multiply loop), and the
+                // running product is rescaled ONCE per trip by a power of two (v_frexp_exp / v_ldexp: exact, so where the rescaling happens
+                // changes no bit of the result -- round 4 divided by the maximum every second row, 15 of its 27 instructions per two rows)
+                constexpr int ROWS = BP_NODE_ROWS_512;
                 for (int k0 = glx; k0 < deg; k0 += ROWS * grp) {
                     float4 m0[ROWS]; float2 m1[ROWS];
 #pragma unroll
                     for (int u = 0; u < ROWS; ++u) {
                         const int k = k0 + u * grp;
-                        m0[u] = make_float4(1.f, 1.f, 1.f, 1.f); m1[u] = make_float2(1.f, 1.f);
-                        if (k < deg) {
-                            if (COMPACT) {       // dense rows: 4 floats (16-byte aligned) to a 3-state node, 6 floats (8-byte aligned) to a 6-state node
-                                const float* m = C.msg(base + k * q);
-                                if (n == 6) { const float2 a = ((const float2*)m)[0], b = ((const float2*)m)[1]; m0[u] = make_float4(a.x, a.y, b.x, b.y); m1[u] = ((const float2*)m)[2]; }
-                                else if (CW3 == 3) m0[u] = make_float4(m[0], m[1], m[2], 1.f);
-                                else m0[u] = *(const float4*)m;
-                            } else {
-                                const float* m = C.msg((base + k * q) * 4);
-                                m0[u] = *(const float4*)m;
-                                if (n == 6) m1[u] = *(const float2*)(m + 4);
-                            }
+                        if (COMPACT) {       // dense rows: 4 (or 3) floats to a 3-state node, 6 floats (8-byte aligned) to a 6-state node
+                            const float* m = k < deg ? C.msg(base + k * q) : ones;
+                            if (n == 6) { const float2 a = ((const float2*)m)[0], b = ((const float2*)m)[1]; m0[u] = make_float4(a.x, a.y, b.x, b.y); m1[u] = ((const float2*)m)[2]; }
+                            else if (CW3 == 3) { m0[u] = make_float4(m[0], m[1], m[2], 1.f); m1[u] = make_float2(1.f, 1.f); }
+                            else { m0[u] = *(const float4*)m; m1[u] = make_float2(1.f, 1.f); }
+                        } else {
+                            const float* m = k < deg ? C.msg((base + k * q) * 4) : ones;
+                            m0[u] = *(const float4*)m; m1[u] = make_float2(1.f, 1.f);
+                            if (n == 6) m1[u] = *(const float2*)(m + 4);
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < ROWS; ++u) {
-                        if (k0 + u * grp >= deg) break;
                         bb[0] *= m0[u].x; bb[1] *= m0[u].y; bb[2] *= m0[u].z;
                         if (n == 6) { bb[3] *= m0[u].w; bb[4] *= m1[u].x; bb[5] *= m1[u].y; }
-                        if (u & 1) {                    // keep the running product O(1) (rotamer.cpp:489-493 re-normalises too)
-                            float mx = fmaxf(fmaxf(bb[0], bb[1]), bb[2]);
-                            if (n == 6) mx = fmaxf(fmaxf(mx, bb[3]), fmaxf(bb[4], bb[5]));
-                            const float rm = fast_rcp(mx);
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) bb[r] *= rm;
-                        }
                     }
+                    bp_rescale_pow2(bb, n);
                 }
             }
             static_assert(BP_GROUP == 4, "the combine below is the lane^2, lane^1 butterfly of a quad");
@@ -1627,37 +1629,25 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
             // groups of 16 / 8 lanes (small systems, one round): two more combine stages in front of the quad's, L <-> 15-L and
             // L <-> 7-L of the DPP row (every lane of a group ends with the same bits: each stage multiplies a symmetric pair)
             if (wd >= 4) {       // (`wd` is uniform over the workgroup: no lane sits out a DPP step; which lanes multiply is a per-lane select)
-                float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_ROW_MIRROR>(bb[r]); bb[r] *= grp >= 16 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
-                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_ROW_MIRROR>(bb[r]); bb[r] *= grp >= 16 ? o : 1.f; }
+                bp_rescale_pow2(bb, n);
             }
             if (wd >= 2) {
-                float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_HALF_MIRROR>(bb[r]); bb[r] *= grp >= 8 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
-                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_HALF_MIRROR>(bb[r]); bb[r] *= grp >= 8 ? o : 1.f; }
+                bp_rescale_pow2(bb, n);
             }
 #endif
             {
-                float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR2>(bb[r]); bb[r] *= grp >= 4 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }   // (a pair has no lane^2 partner)
-                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR2>(bb[r]); bb[r] *= grp >= 4 ? o : 1.f; }   // (a pair has no lane^2 partner)
+                bp_rescale_pow2(bb, n);
             }
             {
-                float mx = 0.f;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR1>(bb[r]); bb[r] *= grp >= 2 ? o : 1.f; mx = fmaxf(mx, r < n ? bb[r] : 0.f); }
-                const float rm = mx > 0.f ? fast_rcp(mx) : 1.f;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) bb[r] *= rm;
+                for (int r = 0; r < 6; ++r) { const float o = dpp_mov<UP_DPP_XOR1>(bb[r]); bb[r] *= grp >= 2 ? o : 1.f; }
+                bp_rescale_pow2(bb, n);
             }
             if (trace) { const long long t = wall_clock64(); tr_n2 += t - tr_nm; tr_nm = t; }      // (combine done)
             if (live) {
