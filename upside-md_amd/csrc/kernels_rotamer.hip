@@ -1986,7 +1986,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     int* nrot = (int*)(lds + NN * 12 + 32);   // [NN]
     int* bp_start = nrot + NN;                // [NN+1]
     float* Pl0 = (float*)(bp_start + NN + 1 + 3);
-    Pl0 = (float*)(((size_t)Pl0 + 15) & ~(size_t)15);
+    Pl0 = lds + ((((int)(Pl0 - lds)) + 3) & ~3);      // 16-byte aligned, as an OFFSET from the LDS symbol: an integer round trip of the pointer turns every read of the resident matrices into a flat access
     float* Pl1 = Pl0 + n_own[0] * 9;
     float* Pl2 = Pl1 + n_own[1] * 18;
     (void)need;
