@@ -47,9 +47,6 @@ int upk_scale(const upk_launch_t* L, float* x, int n, float factor);   /* x[i] *
 /* zero n_buf device buffers (float counts in sizes[], 16-byte aligned) in one launch:
  * the per-node "zero sensitivity" of deriv_engine.cpp:147-151 for the whole graph */
 int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf);
-/* ... with the buffers also named on the host (host_ptrs[b], host_sizes[b] = the device arrays' contents): as an op of a fused list it is
- * then ordered against the ops that touch THOSE buffers only, instead of against everything */
-int upk_zero_many_named(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf, float* const* host_ptrs, const long* host_sizes);
 /* deterministic gather of deferred derivative contributions into a node's sens:
  * sens[s][t][c] += sum_{e in csr[t]} arena[s][entry[e] + c], c < width  (replaces the scatter-adds of
  * e.g. src/bonds.cpp:315-316, src/placement.cpp:304-305, src/eig.cpp:467)                               */
@@ -80,9 +77,8 @@ int upk_mc_accept(const upk_launch_t* L, upk_coord_t pos, const float* pos_copy,
                   int accept_draw, int* stats);   /* accept_draw: index of the generator's draw used for the test */
 
 /* ---- integrator / thermostat (src/deriv_engine.cpp:11-48, src/thermostat.cpp:9-18, src/random.h) ---- */
-/* clear_sens: the stage also zeroes pos.sens behind its read (the next force pass then need not) */
 int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
-                          float max_force, int clear_sens);
+                          float max_force);
 /* n_invocations[S] lives on the device, one (equal) entry per system -- all systems are thermalised at the same rounds --:
  * the op reads its system's entry and then advances it, so a captured MD graph replays correctly; mom is [S][n_atom][4] */
 int upk_thermostat(const upk_launch_t* L, float* mom, int n_atom, const uint32_t* seed, unsigned long long* n_invocations,

@@ -649,10 +649,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_UPKEEP_STREAMS': '1', 'UPSIDE_HIP_BATCH': '0'},      # one shared upkeep stream instead of one per graph
     {'UPSIDE_HIP_UPKEEP_STREAMS': '0', 'UPSIDE_HIP_BATCH': '0'},      # one upkeep stream per graph (the default above 16 systems) at one system
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
-    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '0'},      # one-workgroup BP of 1024 lanes streaming every pair matrix
-    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '1'},      # 512 lanes, two 6x6 trips of pair matrices pinned in registers (large batches)
-    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '2'},      # the other register layout of the resident matrices
-    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_RESIDENT': '3'},      # 512 lanes, one slot of every class pinned per lane (small batches)
+    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_COMPACT': '0'},       # one-workgroup BP of 1024 lanes streaming every pair matrix over the cached inbox layout
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes
@@ -674,10 +671,12 @@ ALT_PATHS = [
 ]
 
 
-def test_alternate_code_paths_agree(tmp_path):
-    """every selectable code path gives the golden forces and the same short MD trajectory as the default path"""
+@pytest.mark.parametrize('name', ['syn150_10A', 'syn300_10A'])
+def test_alternate_code_paths_agree(tmp_path, name):
+    """every selectable code path gives the golden forces and the same short MD trajectory as the default path -- on the 150-residue fixture
+    and on the benchmark protein (whose belief-propagation inbox, pair tables and staged elements sit at the LDS limits the smaller one is
+    far from)"""
     import subprocess
-    name = 'syn150_10A'
     g = P.golden(name)
 
     def run(env_extra, tag):
@@ -705,9 +704,9 @@ def test_large_batch_solver_on_every_fixture():
     """what a LARGE batch runs is chosen by batch size (one-workgroup belief propagation, list upkeep on one side stream per graph, every
     kernel a launch of its own, no graph replay); forced here for the small parity cases -- every fixture incl. the degenerate
     sequences (empty slot classes), named values, truncated solves -- by re-running those tests in a child pytest: once with the
-    solve variant of round 4 (one slot of every class pinned), once with round 3's (two 6x6 slots pinned)"""
+    pinned-matrix solve over the dense inbox, once with the streaming solve over the cached inbox layout (the two compiled solves)"""
     import subprocess
-    for extra in ({}, {'UPSIDE_HIP_BP_RESIDENT': '1'}):
+    for extra in ({}, {'UPSIDE_HIP_BP_COMPACT': '0'}):
         env = dict(os.environ, UPSIDE_HIP_BP_CLUSTER='1', UPSIDE_HIP_BATCH='0', UPSIDE_HIP_GRAPH='0', **extra)
         out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
                               '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,

@@ -352,7 +352,7 @@ void DerivEngine::finalize() {
     // one launch clears every sensitivity buffer at the start of a force pass
     {
         vector<float*> ptrs; vector<long> sizes;
-        for (auto& n : nodes) {      // (nodes[0] is pos: entry 0 of the list, see engine.h)
+        for (auto& n : nodes) {
             if (n.computation->potential_term) continue;
             auto* cn = static_cast<CoordNode*>(n.computation.get());
             if (!cn->sens.n) continue;
@@ -360,7 +360,6 @@ void DerivEngine::finalize() {
         }
         n_zero = (int)ptrs.size();
         zero_ptrs.upload(ptrs); zero_sizes.upload(sizes);
-        zero_ptrs_host = ptrs; zero_sizes_host = sizes;
     }
     // hoist prepare() of the nodes that have one to just after the forward step of the last parent it reads, on a
     // side stream
@@ -477,11 +476,7 @@ void DerivEngine::compute(ComputeMode mode, bool keep_pending) {
     ctx.n_pass = n_compute;      // (nodes that double-buffer by step parity read it: always in step with what a graph capture rolled back)
     // zero sensitivity for later derivative writing (deriv_engine.cpp:147-151), all nodes at once: nothing writes a
     // node's sens before that node's own forward step
-    {   // (behind a leapfrog stage pos.sens is clean already: the op then does not touch what the stage reads or writes and shares its phase of the fused list)
-        const int skip = (pos_sens_clean && n_zero > 1 && zero_ptrs_host[0] == pos->sens.p) ? 1 : 0;
-        upk_check(upk_zero_many_named(&ctx.L, zero_ptrs.p + skip, zero_sizes.p + skip, n_zero - skip, zero_ptrs_host.data() + skip, zero_sizes_host.data() + skip), "zero_many");
-        pos_sens_clean = false;
-    }
+    upk_check(upk_zero_many(&ctx.L, zero_ptrs.p, zero_sizes.p, n_zero), "zero_many");
     auto on_stream = [&](hipStream_t st, const std::function<void()>& f) {     // (the fused-op queue is empty on entry; what f queues runs on st)
         hipStream_t main_stream = ctx.stream;
         ctx.stream = st; ctx.L.stream = (void*)st;
@@ -550,8 +545,7 @@ void DerivEngine::integration_stage(int stage, float dt_, float max_force) {
     const float mom_update[] = {1.5f - 3.f * a, 1.5f - 3.f * a, 6.f * a};
     const float pos_update[] = {3.f * b, 3.0f - 6.f * b, 3.f * b};
     compute(DerivMode, true);       // the tail of the backward sweep, the leapfrog update and the head of the next force pass share a launch
-    upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force, 1), "integration_stage");
-    pos_sens_clean = true;
+    upk_check(upk_integration_stage(&ctx.L, mom.p, pos->coord(), dt_ * mom_update[stage], dt_ * pos_update[stage], max_force), "integration_stage");
 }
 void DerivEngine::integration_cycle(float dt_, float max_force) {
     for (int stage = 0; stage < 3; ++stage) integration_stage(stage, dt_, max_force);

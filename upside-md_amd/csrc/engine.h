@@ -49,10 +49,6 @@ struct DerivEngine {   // deriv_engine.h:145-237
     std::map<int, Side> side;                  // node index -> side stream of its prepare() (empty when disabled)
     int last_prepare_step = -1;                // index in `schedule` of the last prepare step
     DevBuf<float*> zero_ptrs; DevBuf<long> zero_sizes; int n_zero = 0;   // every CoordNode's sens, cleared by one launch per force pass
-    // the same list on the host (the fused queue orders the clearing op against the ops that touch these buffers only); entry 0 is pos.sens,
-    // which the leapfrog stage clears itself behind its read: the force pass that follows a stage starts at entry 1
-    std::vector<float*> zero_ptrs_host; std::vector<long> zero_sizes_host;
-    bool pos_sens_clean = false;
 
     DerivEngine(int n_atom, int n_system);
     ~DerivEngine();

@@ -122,13 +122,6 @@ extern "C" int upk_zero_many(const upk_launch_t* L, float* const* ptrs, const lo
     FARGS(ZeroManyArgs, a); a.ptrs = ptrs; a.sizes = sizes; a.n_buf = n_buf; a.n_system = L->n_system;
     return fuse_submit(L, FOP_ZERO_MANY, a, 0, {r_all()});
 }
-extern "C" int upk_zero_many_named(const upk_launch_t* L, float* const* ptrs, const long* sizes, int n_buf, float* const* host_ptrs, const long* host_sizes) {
-    if (n_buf <= 0) return 0;
-    FARGS(ZeroManyArgs, a); a.ptrs = ptrs; a.sizes = sizes; a.n_buf = n_buf; a.n_system = L->n_system;
-    std::vector<FuseRegion> regs;
-    for (int b = 0; b < n_buf; ++b) regs.push_back(r_buf(host_ptrs[b], (size_t)(host_sizes[b] / L->n_system) * sizeof(float), true));
-    return fuse_submit_raw(L, FOP_ZERO_MANY, &a, sizeof(a), 0, 0, regs.data(), (int)regs.size());
-}
 extern "C" int upk_reduce_sum(const upk_launch_t* L, const float* in, int n, float* out, int accumulate) {
     FARGS(ReduceSumArgs, a); a.in = in; a.n = n; a.out = out; a.accumulate = accumulate;
     return fuse_submit(L, FOP_REDUCE_SUM, a, 0, {r_buf(in, (size_t)n * 4, false), r_buf(out, 4, true), r_lds()});
@@ -180,15 +173,13 @@ extern "C" int upk_gather_contrib(const upk_launch_t* L, const float* arena, lon
 
 // ------------------------------------------------------------------------------------------------
 // integrator (deriv_engine.cpp:11-35), thermostat (thermostat.cpp:9-18), recenter (deriv_engine.cpp:37-48)
-struct IntegrationStageArgs { float* mom; upk_coord_t pos; float vel_factor, pos_factor, max_force; int clear_sens; };
-__device__ __forceinline__ void b_integration_stage(const int na, const int s, float* __restrict__ mom, upk_coord_t pos, float vel_factor, float pos_factor, float max_force,
-                                                    const int clear_sens) {
+struct IntegrationStageArgs { float* mom; upk_coord_t pos; float vel_factor, pos_factor, max_force; };
+__device__ __forceinline__ void b_integration_stage(const int na, const int s, float* __restrict__ mom, upk_coord_t pos, float vel_factor, float pos_factor, float max_force) {
     if (na >= pos.n_elem) return;
-    float* d_ = C_SENS(pos, s) + (size_t)na * pos.stride;
+    const float* d_ = C_SENS(pos, s) + (size_t)na * pos.stride;
     float* x = C_OUT(pos, s) + (size_t)na * pos.stride;
     float* m = mom + ((size_t)s * pos.n_elem + na) * 4;
     f3 d = ld3(d_);
-    if (clear_sens) { d_[0] = 0.f; d_[1] = 0.f; d_[2] = 0.f; }      // (padding words of the row are never written by anybody)
     if (max_force != 0.f) {
         const float f_mag = sqrtf(mag2(d)) + 1e-6f;
         const float scale = atanf(f_mag * ((0.5f * UP_PI_F) / max_force)) * (max_force / f_mag * (2.f / UP_PI_F));
@@ -199,9 +190,9 @@ __device__ __forceinline__ void b_integration_stage(const int na, const int s, f
     x[0] += pos_factor * p.x; x[1] += pos_factor * p.y; x[2] += pos_factor * p.z;
 }
 extern "C" int upk_integration_stage(const upk_launch_t* L, float* mom, upk_coord_t pos, float vel_factor, float pos_factor,
-                                     float max_force, int clear_sens) {
-    FARGS(IntegrationStageArgs, a); a.mom = mom; a.pos = cz(pos); a.vel_factor = vel_factor; a.pos_factor = pos_factor; a.max_force = max_force; a.clear_sens = clear_sens;
-    return fuse_submit(L, FOP_INTEGRATION_STAGE, a, pos.n_elem, {r_buf(mom, (size_t)pos.n_elem * 16, true), r_sens(pos, clear_sens != 0), r_out(pos, true)});
+                                     float max_force) {
+    FARGS(IntegrationStageArgs, a); a.mom = mom; a.pos = cz(pos); a.vel_factor = vel_factor; a.pos_factor = pos_factor; a.max_force = max_force;
+    return fuse_submit(L, FOP_INTEGRATION_STAGE, a, pos.n_elem, {r_buf(mom, (size_t)pos.n_elem * 16, true), r_sens(pos, false), r_out(pos, true)});
 }
 
 struct ThermostatArgs { float* mom; int n_atom; const uint32_t* seed; unsigned long long* n_inv; const float* mom_scale; const float* noise_scale; };
@@ -1688,7 +1679,7 @@ __device__ __forceinline__ void run_fused_op(const FusedOp& op, const int s, flo
         case FOP_GATHER_CONTRIB: { const auto& a = fop_args<GatherContribArgs>(op);
             FOP_LOOP(i, n) b_gather_contrib(i, s, a.arena, a.arena_stride, a.csr_start, a.csr_entry, a.target, a.width, a.comp_offset); } break;
         case FOP_INTEGRATION_STAGE: { const auto& a = fop_args<IntegrationStageArgs>(op);
-            FOP_LOOP(i, n) b_integration_stage(i, s, a.mom, a.pos, a.vel_factor, a.pos_factor, a.max_force, a.clear_sens); } break;
+            FOP_LOOP(i, n) b_integration_stage(i, s, a.mom, a.pos, a.vel_factor, a.pos_factor, a.max_force); } break;
         case FOP_AFFINE_FWD: { const auto& a = fop_args<AffineFwdArgs>(op);      // n is a multiple of 64: whole wavefronts reach the ballots
             FOP_LOOP(i, n) b_affine_fwd(i, s, a.pos, a.atoms, a.ref_geom, a.n_res, a.out, a.eig); } break;
         case FOP_AFFINE_BWD: if constexpr (HEAVY) { const auto& a = fop_args<AffineBwdArgs>(op);
@@ -1733,8 +1724,11 @@ template <bool HEAVY, int T, int W = 0>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(W ? W : 1, W ? W : 8))) k_fused_list(const FusedOp* __restrict__ table, FusedIds ids, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x;
-    // (Round 5, measured and removed: requesting the records of all ops of the list through the scalar cache at the start -- one protein G
-    //  5.52 -> 5.46 k steps/s; an op's own argument loads are not what its phase waits for)
+    // (Round 5, measured and removed: (i) requesting the records of all ops of the list through the scalar cache at the start -- one protein G
+    //  5.52 -> 5.46 k steps/s: an op's own argument loads are not what its phase waits for; (ii) the sensitivity-clearing op ordered against the
+    //  buffers it names only, with the leapfrog stage clearing pos.sens itself, one phase fewer per step -- no measurable change, and a recorded
+    //  MD graph then depends on what ran before it: a frame's energy evaluation between two replays left forces in pos.sens that the
+    //  replayed first pass no longer cleared (the 10 k-step protein-G run came out 5 % too hot).)
     for (int k = 0; k < ids.n; ++k) {
         const FusedOp& op = table[ids.id[k]];
         if (k && !(op.flags & 1)) __syncthreads();     // what the ops before wrote (global memory, this CU) is visible; LDS scratch is free again
@@ -1788,9 +1782,7 @@ void fuse_launch(bool heavy, int threads, int n_system, size_t lds, hipStream_t 
     if constexpr (LIST) {
         if (heavy) { if (threads <= 256) hipLaunchKernelGGL((k_fused_list<true, 256>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<true, 512>), g, b, lds, st, args...); }
         else {
-            static int w8 = -1;      // UPSIDE_HIP_FUSE_W8=0: the 256-lane light instance without the 8-wavefronts-per-SIMD register cap (experiments)
-            if (w8 < 0) { const char* e = getenv("UPSIDE_HIP_FUSE_W8"); w8 = (e && !atoi(e)) ? 0 : 1; }
-            if (threads <= 256) { if (w8) hipLaunchKernelGGL((k_fused_list<false, 256, 8>), g, b, lds, st, args...); else hipLaunchKernelGGL((k_fused_list<false, 256>), g, b, lds, st, args...); }
+            if (threads <= 256) hipLaunchKernelGGL((k_fused_list<false, 256, 8>), g, b, lds, st, args...);
             else hipLaunchKernelGGL((k_fused_list<false, 1024>), g, b, lds, st, args...);
         }
     } else {

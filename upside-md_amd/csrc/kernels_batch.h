@@ -44,9 +44,6 @@ static bool batch_add(const upk_launch_t* L, int kind, int gx, int gy, size_t ld
                       int i0 = 0, int i1 = 0, double d0 = 0.) {
     BatchState* s = batch_of(L);
     if (!s || !s->open) return false;
-    static long mask = -2;      // UPSIDE_HIP_BATCH_KINDS (experiments): bit k set = kernels of kind k may join merged launches
-    if (mask == -2) { const char* e = getenv("UPSIDE_HIP_BATCH_KINDS"); mask = e ? strtol(e, nullptr, 0) : -1; }
-    if (!((mask >> kind) & 1)) return false;
     // program order inside a chain: fused per-element ops THIS chain has queued since the batch opened go out before this item joins
     // (upk_fuse_flush runs the batch's earlier items first); ops queued by other chains are independent of it and stay queued
     if ((int)s->chain_fused.size() > s->chain && s->chain_fused[s->chain]) {

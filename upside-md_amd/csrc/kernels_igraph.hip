@@ -490,10 +490,8 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
     int rows_per_wg = L->n_system >= upk_device_cu_count() ? PLR_ROWS : (L->n_system >= 16 ? 64 : 16);
     {   // a side of a few hundred rows (environment graph: 300): smaller workgroups, or one of its two would walk 256 rows as 32
-        // dependent row pairs per wavefront while the other has 44 (0.30 -> 0.24 ms; UPSIDE_HIP_PLR_ROWS_SMALL: experiments, 0 = off)
-        static int small_rows = -1;
-        if (small_rows < 0) { const char* e = getenv("UPSIDE_HIP_PLR_ROWS_SMALL"); small_rows = e ? atoi(e) : 128; }
-        if (small_rows > 0 && n_rows <= 512 && rows_per_wg > small_rows) rows_per_wg = small_rows;
+        // dependent row pairs per wavefront while the other has 44 (0.30 -> 0.24 ms)
+        if (n_rows <= 512 && rows_per_wg > 128) rows_per_wg = 128;
     }
     {   // merged launch: 1024-lane workgroups, four times the wavefronts -- four times the rows, so that a wavefront keeps its run of row pairs
         const int rows_b = rows_per_wg * 4;

@@ -594,11 +594,9 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
     }
     pair_geometry(L->n_system, n_rows, bps, threads);
     // (a few hundred rows of two or three pairs: the pass is the latency of staging the system, which several small workgroups
-    //  per CU overlap: 1024 lanes 0.29 + 0.23 ms, 512: 0.25 + 0.18, 256: 0.23 + 0.17, 128: 0.29 + 0.20 -- UPSIDE_HIP_HB_THREADS, experiments; the environment graph, 300 rows of ~40 pairs, is best left at 1024)
+    //  per CU overlap: 1024 lanes 0.29 + 0.23 ms, 512: 0.25 + 0.18, 256: 0.23 + 0.17, 128: 0.29 + 0.20; the environment graph, 300 rows of ~40 pairs, is best left at 1024)
     if (G->itype == UPK_IT_PROTEIN_HBOND && bps == 1) {
-        static int hb_threads = 0;
-        if (!hb_threads) { const char* e = getenv("UPSIDE_HIP_HB_THREADS"); hb_threads = e ? atoi(e) : 256; if (hb_threads < 64 || hb_threads > 1024) hb_threads = 256; }
-        threads = hb_threads;
+        threads = 256;
     }
     {   // merged launch (kernels_batch.h): the instances the README force field uses
         const int bk = (G->itype == UPK_IT_PROTEIN_HBOND && side == 3 && mode == 0) ? BK_ROWS_HB_FWD : (G->itype == UPK_IT_PROTEIN_HBOND && side == 3 && mode == 2) ? BK_ROWS_HB_BWD

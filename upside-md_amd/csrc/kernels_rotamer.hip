@@ -61,11 +61,7 @@ __device__ __forceinline__ void d_rotamer_clear_slots(const upk_rotamer_t& R, co
 }
 __global__ void k_rotamer_clear_slots(upk_rotamer_t R)  { d_rotamer_clear_slots(R, BX_REAL, nullptr); }
 extern "C" int upk_rotamer_clear_slots(const upk_launch_t* L, const upk_rotamer_t* R) {
-    // (since round 4 upk_pairlist_check clears the table of a system it flags -- one launch less on the upkeep chain; this launcher stays for
-    //  callers that mark a table without that check: UPSIDE_HIP_CLEAR_SLOTS=1 brings the launch back)
-    static int separate = -1;
-    if (separate < 0) { const char* e = getenv("UPSIDE_HIP_CLEAR_SLOTS"); separate = (e && atoi(e)) ? 1 : 0; }
-    if (!separate) return 0;
+    // (upk_pairlist_check clears the table of a system it flags; this launcher is for callers that mark a table without that test)
     const int n16 = R->G.mark_stride / 16;
     int blocks = (n16 + 1023) / 1024; if (blocks > 64) blocks = 64;
     if (batch_add(L, BK_CLEAR_SLOTS, blocks, UPK_FLAG_GRID(L->n_system), 0, R, sizeof(*R))) return 0;
@@ -265,8 +261,7 @@ extern "C" int upk_rotamer_build_slots(const upk_launch_t* L, const upk_rotamer_
     // (tried in round 3: stamping the slots into the list words inside this kernel from the popcounts of the bit matrix, without
     //  the node x node table -- 1.33 ms per step against 0.53 + 0.59 for the two kernels: one workgroup per system walks its 66 k
     //  list words through a chain of dependent loads, the separate kernel spreads them over hundreds of workgroups)
-    static int wgs = 0;   // UPSIDE_HIP_SLOT_WGS (experiments): workgroups looping over the flagged systems
-    if (!wgs) { const char* e = getenv("UPSIDE_HIP_SLOT_WGS"); wgs = e ? atoi(e) : 1024; if (wgs < 1) wgs = 1024; }
+    const int wgs = 1024;   // workgroups looping over the flagged systems
     // a small system's slot stamping (upk_rotamer_nbr_slots) rides behind the numbering in the same workgroup: one launch less on the upkeep chain
     if (R->G.n1 <= 512 && batch_add(L, BK_SLOTS_BOTH, 1, L->n_system < wgs ? L->n_system : wgs, lds, R, sizeof(*R))) { batch_of(L)->skip_nbr_slots = true; return 0; }
     // workgroups per system (see the kernel): several while the device has CUs to spare, one when systems fill it
@@ -1801,13 +1796,8 @@ struct BpcShared {            // cluster-visible state of one system
     float* en_part;           // [16] energy partial sums
     int* bar;                 // barrier counter (zeroed by upk_rotamer_node_prob)
 };
-// BPC_SC1_LOADS (round 4 experiment, measured and NOT taken): everything a workgroup reads from its partners after a barrier -- message
-// rows, node beliefs -- read with sc1 loads, so that the barrier needs no acquire fence (buffer_inv sc1, two per sweep).  One
-// 300-residue system, 6 workgroups: 520 us per step against 500 with the fence -- the L2-served 16- and 8-byte loads of the node
-// phase (a dozen rows per node, each a round trip past the L1) cost more than the two invalidates they replace.
-#ifndef BPC_SC1_LOADS
-#define BPC_SC1_LOADS 0
-#endif
+// (Round 4, measured and not taken: everything a workgroup reads from its partners after a barrier read with sc1 loads, so that the barrier
+//  needs no acquire fence -- one 300-residue system, 6 workgroups: 520 us per step against 500 with the fence.)
 // Returns false when a partner never arrived (the cluster's workgroups were not all resident -- other kernels held CUs -- or a
 // partner has given up already).  `fallback` non-null: the system is handed to the one-workgroup solve that follows the cluster
 // launch in the stream (nothing the solve consumes has been modified yet: callers return at once); null (the last barrier, behind
@@ -1832,9 +1822,7 @@ __device__ __forceinline__ bool cluster_barrier(int* bar, int& phase, int C, int
         }
         // the counter alone can let a late workgroup through (partners that have left did arrive at this barrier before they gave up at a later one)
         if (fallback && !gave_up && __hip_atomic_load(fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) gave_up = 1;
-#if !BPC_SC1_LOADS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // one buffer_inv for the whole CU
-#endif
     }
     return __syncthreads_or(gave_up) == 0;
 }
@@ -2062,11 +2050,7 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
     auto reload = [&](int half) {   // beliefs of every multi-state node from the exchange buffer into LDS
         for (int g = tid; g < NN; g += nt) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float2 b = make_float2(0.f, 0.f);
-#if BPC_SC1_LOADS
-            if (g >= e1) { a = ld_wt16(X.nbx_w, (half * NN + g) * 8); b = ld_wt8(X.nbx_w, (half * NN + g) * 8 + 4); }
-#else
             if (g >= e1) { const float* src = X.nbx + ((size_t)half * NN + g) * 8; a = *(const float4*)src; b = *(const float2*)(src + 4); }
-#endif
             nb[g * 6] = a.x; nb[g * 6 + 1] = a.y; nb[g * 6 + 2] = a.z; nb[g * 6 + 3] = a.w; nb[g * 6 + 4] = b.x; nb[g * 6 + 5] = b.y;
         }
         __syncthreads();
@@ -2104,14 +2088,9 @@ __global__ void __launch_bounds__(BPC_BLOCK) k_rotamer_bp_cluster(upk_rotamer_t 
                         const int k = kb + u * BPC_GROUP;
                         lo4[u] = make_float4(1.f, 1.f, 1.f, 1.f); hi2[u] = make_float2(1.f, 1.f);
                         if (k < deg) {
-#if BPC_SC1_LOADS
-                            lo4[u] = ld_wt16(X.inbox_w, (base + k * q) * 4);
-                            if (n == 6) hi2[u] = ld_wt8(X.inbox_w, (base + k * q) * 4 + 4);
-#else
                             const float* m = X.inbox + (size_t)(base + k * q) * 4;
                             lo4[u] = *(const float4*)m;
                             if (n == 6) hi2[u] = *(const float2*)(m + 4);
-#endif
                         }
                     }
 #pragma unroll
@@ -2244,47 +2223,21 @@ extern "C" int upk_rotamer_bp_cluster_capacity(const upk_rotamer_t* R) {   // fl
     return (int)(156 * 1024 / sizeof(float)) - fixed;
 }
 // one-workgroup solve: BP_BLOCK lanes streaming every matrix, or BP_BLOCK / 2 lanes with the first trips of each class pinned in registers
-static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy, int only_fallback, size_t lds, int lds_msg_floats, int threads) {
-    // UPSIDE_HIP_BP_RESIDENT: 0 = always stream every matrix, 1 / 2 = always a register layout; unset: by batch size.  With
-    // few systems per CU the solve is latency bound and the wider workgroup wins (64 systems on 256 CUs: 48.1 k vs 46.0 k
-    // system-steps/s); the pinned matrices and packed slots draw level at 3/8 system per CU (96: 51.6 k vs 51.4 k) and
-    // win from there on (128: 73.3 vs 72.7 k, 192: 77.6 vs 75.9 k, 256: 96 vs 93 k, 1024: 108 vs 103 k)
-    static int resident_env = -2;
-    if (resident_env == -2) { const char* e = getenv("UPSIDE_HIP_BP_RESIDENT"); resident_env = e ? atoi(e) : -1; }
-    // (re-measured after the look-ahead loads of bp_edge_packed: 32 systems 0.381 vs 0.379 ms, 64: 0.411 vs 0.466, 96: 0.470 vs 0.510,
-    //  128: 0.489 vs 0.527 -- the register layout from 1/8 system per CU on)
-    // (round 4, small batches: 512 lanes with ONE slot of every class pinned per lane -- all of a 56-residue system, most of a
-    //  150-residue one -- instead of 1024 lanes streaming every matrix: 56 residues, 1 / 8 systems: 4.28 k / 29.1 k against 4.13 k / 27.9 k
-    //  system-steps/s; 150 residues, 8 systems: 13.4 k against 13.0 k)
-    // (round 4, all batches: one slot of every class pinned beats two 6x6 slots wherever the classes are small, and ties on the benchmark
-    //  protein -- k system-steps/s, variant 3 / variant 1: 56 residues x 512 861 / 840, x 2048 1132 / 1099; 150 residues x 512 281 / 276,
-    //  x 2048 327 / 323; 300 residues / 7 A x 512 248 / 240; 300 residues / 10 A x 4096 188.1 / 187.8 (four interleaved runs each))
-    const int resident = resident_env >= 0 ? resident_env : 3;
+static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy, int only_fallback, size_t lds, int lds_msg_floats) {
+    // TWO compiled solves.  (i) 512 lanes x 256 registers, the dense per-solve inbox, one slot of every class pinned in registers per lane:
+    // every batch size (round 4 measured it against two pinned 6x6 slots, a 1024-lane streaming form and larger pinned sets across proteins
+    // and batch sizes; the losers are gone: `git log` has them).  (ii) 1024 lanes streaming every matrix over the CACHED inbox layout: the
+    // hand-over solve behind a cluster launch, systems whose layout scratch does not fit, UPSIDE_HIP_BP_COMPACT=0 (tests).
     const dim3 grid(1, L->n_system);
-    static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (A/B and tests)
+    static int compact = -1;  // UPSIDE_HIP_BP_COMPACT=0: the cached inbox layout (tests)
     if (compact < 0) { const char* e = getenv("UPSIDE_HIP_BP_COMPACT"); compact = (e && !atoi(e)) ? 0 : 1; }
     // (the layout pass borrows the LDS inbox for an activity bit per cached row and a prefix per 32 rows: at most two rows per slot)
     const size_t layout_scratch = (((size_t)2 * R->slot_cap + 64) / 32 * 2 + 2) * sizeof(int);
     const bool dense = compact && R->slot_row && R->row_start && (size_t)lds_msg_floats * sizeof(float) >= layout_scratch;
-    // (every one-workgroup variant lays its inbox out the same way: the order in which a node multiplies its messages, and with
-    //  it every bit of the result, is then the same whichever variant a batch size selects)
-    if (resident == 3 && !only_fallback && dense && threads == BP_BLOCK)      // 512 lanes, one slot of every class pinned per lane: all of a small system
+    if (!only_fallback && dense)
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 1, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else if (resident == 4 && !only_fallback && dense && threads == BP_BLOCK)
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 2, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else if ((resident == 0 || threads != BP_BLOCK) && !only_fallback && dense && threads == BP_BLOCK)
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0, true>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else if (resident == 0 || threads != BP_BLOCK || only_fallback)
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(threads), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    // (tried in round 3: 256 lanes x 2 workgroups per CU, so that the barrier stalls of one solve are filled by the other -- 10.9 ms
-    //  per launch against 6.6: half of each inbox no longer fits LDS and a lane walks twice the streamed 3x3 slots)
-    else if (resident == 2)   // one 6x6 and two 3x6 trips: the same bytes saved, measured 1 % slower
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 2, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else {                    // two 6x6 trips (78 registers per lane; a third 3x6 trip spills)
-        if (dense)
-            hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-        else hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 2, 0, 0>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    }
+    else
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
     UPK_FLUSH(L);
@@ -2294,12 +2247,8 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
     static int lds_msg_kb = -1;   // UPSIDE_HIP_BP_LDS_MSG_KB (experiments): 0 keeps every message in global memory
     if (lds_msg_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_MSG_KB"); lds_msg_kb = e ? atoi(e) : 160; }
     size_t msg_bytes = (size_t)lds_msg_kb * 1024;
-    // LDS of the one-workgroup solve, beliefs + inbox: all 160 KB of the CU (the kernel has no static LDS) -- 140 instead of 126 KB of the
-    // benchmark protein's 151 KB dense inbox, fewer message rows in global memory for a sweep to wait for (solve at 4096 systems:
-    // 140 KB 6.16 ms, 150 KB 6.04, 156-160 KB 5.98).  UPSIDE_HIP_BP_LDS_CAP_KB: experiments.
-    static int lds_cap_kb = -1;
-    if (lds_cap_kb < 0) { const char* e = getenv("UPSIDE_HIP_BP_LDS_CAP_KB"); lds_cap_kb = e ? atoi(e) : 160; if (lds_cap_kb < 32 || lds_cap_kb > 160) lds_cap_kb = 160; }
-    if (lds_base + msg_bytes > (size_t)lds_cap_kb * 1024) msg_bytes = lds_base >= (size_t)lds_cap_kb * 1024 ? 0 : (size_t)lds_cap_kb * 1024 - lds_base;
+    // LDS of the one-workgroup solve, beliefs + inbox: all 160 KB of the CU (the kernel has no static LDS)
+    if (lds_base + msg_bytes > (size_t)160 * 1024) msg_bytes = lds_base >= (size_t)160 * 1024 ? 0 : (size_t)160 * 1024 - lds_base;
     if (msg_bytes > (size_t)R->slot_cap * 64) msg_bytes = (size_t)R->slot_cap * 64;
     msg_bytes &= ~(size_t)15;
     const int lds_msg_floats = (int)(msg_bytes / sizeof(float));
@@ -2318,12 +2267,10 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
                 if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
                 else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BPC_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
-            bp_launch(L, R, want_energy, 1, lds_base, 0, BP_BLOCK);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
+            bp_launch(L, R, want_energy, 1, lds_base, 0);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
             return launch_status();
         }
     }
-    static int bp_threads = 0;   // UPSIDE_HIP_BP_THREADS (experiments): lanes per one-workgroup solve
-    if (!bp_threads) { const char* e = getenv("UPSIDE_HIP_BP_THREADS"); bp_threads = e ? atoi(e) : BP_BLOCK; if (bp_threads < 64 || bp_threads > BP_BLOCK) bp_threads = BP_BLOCK; }
-    bp_launch(L, R, want_energy, 0, lds, lds_msg_floats, bp_threads);
+    bp_launch(L, R, want_energy, 0, lds, lds_msg_floats);
     return launch_status();
 }

@@ -631,12 +631,12 @@ struct IGraphHost {
     }
     // this step's in-range pairs + the row order of the pair passes (G_: the graph, possibly with a substituted source node)
     // (The row order only balances the work of the pair passes -- their results do not depend on it -- and hit counts drift
-    //  slowly: it is recomputed every ORDER_EVERY-th step instead of every step; the first steps always, so that the order
+    //  slowly: it is recomputed every 4th step instead of every step; the first steps always, so that the order
     //  never predates the first list.)
     long n_refine = 0;
     void refine(const upk_igraph_t& G_, int sides = 3) {
         if (!G_.hit1 && !G_.hit2) return;
-        static const int order_every = max(1, env_int("UPSIDE_HIP_ORDER_EVERY", 4));
+        static const int order_every = 4;
         const bool reorder = n_refine < 2 || n_refine % order_every == 0;
         ++n_refine;
         for (int side = 1; side <= (G_.symmetric ? 1 : 2); ++side) {
@@ -1337,7 +1337,6 @@ struct RotamerSidechain : public PotentialNode {
         ig.begin_step();
         R.G = ig.G;
         upk_check(upk_pairlist_check(&ctx->L, &ig.G), "pairlist_check");
-        upk_check(upk_rotamer_clear_slots(&ctx->L, &R), "rotamer_clear_slots");
         upk_check(upk_pairlist_build(&ctx->L, &ig.G), "pairlist_build");
         upk_check(upk_rotamer_build_slots(&ctx->L, &R), "rotamer_build_slots");
         upk_check(upk_rotamer_nbr_slots(&ctx->L, &R), "rotamer_nbr_slots");
@@ -1380,8 +1379,8 @@ struct RotamerSidechain : public PotentialNode {
         if (per_launch >= 8) per_launch &= ~7;
         // (round 2, after the one-workgroup solve got its look-ahead loads: 32 systems 0.37 vs 0.38 ms, 40: 0.41 vs 0.39, 48 (two launches):
         //  0.61 vs 0.39 -- the cluster up to 4/5 of one launch)
-        const int resident_limit = C >= env_int("UPSIDE_HIP_BP_CLUSTER_MIN_C", 6) ? per_launch * 4 / 5 : 0;
-        if (want <= 1 && ctx->n_system > env_int("UPSIDE_HIP_BP_CLUSTER_MAX_SYSTEMS", resident_limit)) C = 1;
+        const int resident_limit = C >= 6 ? per_launch * 4 / 5 : 0;
+        if (want <= 1 && ctx->n_system > resident_limit) C = 1;
         if (env_int("UPSIDE_HIP_BP_SPLIT", 0) > 1) { C = env_int("UPSIDE_HIP_BP_SPLIT", 0); R.bp_resident = 0; }   // experiments / tests
         R.bp_C = C < 1 ? 1 : C;
         R.bp_test_abort = env_int("UPSIDE_HIP_BP_CLUSTER_TEST_ABORT", 0);
