@@ -340,15 +340,15 @@ extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_
 // 64 cached neighbours per trip and appends the survivors' list words to the row's hit list in list order (ballot +
 // popcount prefix).  Latency bound by design -- it runs on the upkeep streams next to the VALU-bound pair passes -- so a
 // wavefront fetches the positions and list lengths of ALL its rows with one load each and keeps the first list words of
-// PLR_AHEAD rows in flight.
+// the next PLR_DEPTH row pairs in flight.
 #ifndef PLR_BLOCK
 #define PLR_BLOCK 256
 #endif
 #ifndef PLR_ROWS
 #define PLR_ROWS 256
 #endif
-#ifndef PLR_AHEAD
-#define PLR_AHEAD 4
+#ifndef PLR_DEPTH
+#define PLR_DEPTH 2
 #endif
 // squared distances of two pairs at once, every operation rounded separately (no contraction): the same bits as dist2_exact,
 // from v_pk_add_f32 / v_pk_mul_f32 (3 + 3 + 2 packed instructions for the two candidates of a lane)
@@ -397,22 +397,29 @@ __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int sid
     const int my_cnt = have ? cnt_arr[r0 + lane] : 0;
     int my_n = 0, my_lo = 0;                                      // results of row r0 + lane
     auto bcast = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-    // the first 64 list words of the next row pair are fetched while this pair is tested
-    int nA = dead, nB = dead;
-    { const int cA = __builtin_amdgcn_readlane(my_cnt, 0), cB = r0 + 1 < r1 ? __builtin_amdgcn_readlane(my_cnt, 1) : 0;
-      if (lane < cA) nA = nbr_base[(size_t)r0 * cap + lane];
-      if (lane < cB) nB = nbr_base[(size_t)(r0 + 1) * cap + lane]; }
+    // The first 64 list words of the next PLR_DEPTH row pairs are in flight while this pair is tested: a wavefront's share of the memory
+    // system is what it keeps in flight, and one pair (two 256-byte rows) per wavefront left the refine at 2.4 TB/s of list traffic
+    // with neither the vector unit nor the LDS half busy (round 5: two pairs ahead).
+    auto fetch_pair = [&](int ra, int& a, int& b) {      // words [0, 64) of rows ra, ra + 1 (dead past the rows or their ends)
+        a = dead; b = dead;
+        if (ra < r1) {
+            const int la = ra - r0;
+            const int cA = __builtin_amdgcn_readlane(my_cnt, la & 63), cB = ra + 1 < r1 ? __builtin_amdgcn_readlane(my_cnt, (la + 1) & 63) : 0;
+            if (lane < cA) a = nbr_base[(size_t)ra * cap + lane];
+            if (lane < cB) b = nbr_base[(size_t)(ra + 1) * cap + lane];
+        }
+    };
+    int qA[PLR_DEPTH], qB[PLR_DEPTH];
+#pragma unroll
+    for (int d = 0; d < PLR_DEPTH; ++d) fetch_pair(r0 + 2 * d, qA[d], qB[d]);
     for (int ra = r0; ra < r1; ra += 2) {
         const int la = ra - r0, lb = la + 1;
         const bool hasB = ra + 1 < r1;
         const int cntA = __builtin_amdgcn_readlane(my_cnt, la), cntB = hasB ? __builtin_amdgcn_readlane(my_cnt, lb & 63) : 0;
-        int wA = nA, wB = nB;
-        nA = dead; nB = dead;
-        if (ra + 2 < r1) {
-            const int cA = __builtin_amdgcn_readlane(my_cnt, (la + 2) & 63), cB = ra + 3 < r1 ? __builtin_amdgcn_readlane(my_cnt, (la + 3) & 63) : 0;
-            if (lane < cA) nA = nbr_base[(size_t)(ra + 2) * cap + lane];
-            if (lane < cB) nB = nbr_base[(size_t)(ra + 3) * cap + lane];
-        }
+        int wA = qA[0], wB = qB[0];
+#pragma unroll
+        for (int d = 0; d + 1 < PLR_DEPTH; ++d) { qA[d] = qA[d + 1]; qB[d] = qB[d + 1]; }
+        fetch_pair(ra + 2 * PLR_DEPTH, qA[PLR_DEPTH - 1], qB[PLR_DEPTH - 1]);
         plr_v2 xx, xy, xz;
         xx.x = bcast(my_x.x, la); xy.x = bcast(my_x.y, la); xz.x = bcast(my_x.z, la);
         xx.y = bcast(my_x.x, lb & 63); xy.y = bcast(my_x.y, lb & 63); xz.y = bcast(my_x.z, lb & 63);
