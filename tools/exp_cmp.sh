@@ -1,5 +1,5 @@
 #!/bin/bash
-# Compare the library variants of upside-md_amd/csrc/exp/*.so (tools/exp_kg.sh, tools/exp_build.sh) inside ONE gpurun call, over several
+# Compare the library variants of upside-md_amd/csrc/exp/*.so (tools/exp_kg.sh) inside ONE gpurun call, over several
 # workloads: tools/exp_cmp.sh "proteinG56_7A:1 syn300_10A:1 syn300_10A:4096" [rounds]   (value = system-steps/s; the bench's own parity
 # check of the timed engine rides along)
 L=upside-md_amd/csrc

@@ -1,6 +1,6 @@
 #!/bin/bash
 # variant of the library that differs in kernels_graph.o only (pair / list / belief-propagation kernels):
-#   tools/exp_kg.sh <tag> [flags...]  ->  upside-md_amd/csrc/exp/<tag>.so     (compare on the box with tools/exp_libs.sh)
+#   tools/exp_kg.sh <tag> [flags...]  ->  upside-md_amd/csrc/exp/<tag>.so     (compare on the box with tools/exp_cmp.sh)
 set -e
 L=upside-md_amd/csrc
 tag=$1; shift
