@@ -400,6 +400,11 @@ RegisterNodeType<Builtin<BackbonePairs>, 1> backbone_pairs_node("backbone_pairs"
 // The cubic B-spline over the window c0..c3 is  a + b y + c y^2 + d y^3  with the coefficients below; computed in double.
 // Radial intervals 0 and k-2 are the clamped constants of spline.h:275-310.
 static int quadspline_poly_width(int ka, int k) { return 8 * (ka - 3) + 8 * (k - 1); }
+// Row STRIDE of a polynomial table in LDS: the width, plus one 16-byte piece of padding whenever the width is an even number of pieces.
+// A lane reads the SAME piece position of its pair's row (the angular interval, the radial interval); the 10 A tables are 128 floats
+// wide = two whole 256-byte bank rows, so every type pair's rows started in the same bank slot and the 64 gathers of an instruction fell
+// into the four or five slots of the intervals in use.  With an odd number of pieces per row, type pair t starts in slot t mod 16.
+static int quadspline_poly_stride(int ka, int k) { const int w = quadspline_poly_width(ka, k); return ((w / 4) % 2 == 0) ? w + 4 : w; }
 static void quadspline_poly_row(const float* p, int ka, int k, float* out) {
     auto cubic = [](const float* c, float* o) {
         const double c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
@@ -594,8 +599,8 @@ struct IGraphHost {
     // the polynomial image of the table for the LDS-staged pair passes (hbond_coverage); follows every set_param
     void pack_param_poly() {
         if (G.itype != UPK_IT_HBOND_COVERAGE) return;
-        G.n_poly = quadspline_poly_width(G.n_knot_angular, G.n_knot);
-        vector<float> poly((size_t)G.n_type1 * G.n_type2 * G.n_poly);
+        G.n_poly = quadspline_poly_stride(G.n_knot_angular, G.n_knot);
+        vector<float> poly((size_t)G.n_type1 * G.n_type2 * G.n_poly, 0.f);
         for (int t = 0; t < G.n_type1 * G.n_type2; ++t)
             quadspline_poly_row(&param[(size_t)t * G.n_param], G.n_knot_angular, G.n_knot, &poly[(size_t)t * G.n_poly]);
         if (d_param_poly.n != poly.size()) { d_param_poly.upload(poly); G.param_poly = d_param_poly.p; }
@@ -1297,8 +1302,8 @@ struct RotamerSidechain : public PotentialNode {
             tri.insert(tri.end(), ig.param.begin() + (size_t)(lo * nt + hi) * np, ig.param.begin() + (size_t)(lo * nt + hi + 1) * np);
         param_tri.upload(tri); R.param_tri = param_tri.p;
         // ... and as per-interval polynomials for the energy pass (quadspline_poly_row)
-        const int npoly = quadspline_poly_width(ig.G.n_knot_angular, ig.G.n_knot);
-        vector<float> poly((size_t)nt * (nt + 1) / 2 * npoly);
+        const int npoly = quadspline_poly_stride(ig.G.n_knot_angular, ig.G.n_knot);
+        vector<float> poly((size_t)nt * (nt + 1) / 2 * npoly, 0.f);
         for (size_t r = 0; r < (size_t)nt * (nt + 1) / 2; ++r) quadspline_poly_row(&tri[r * np], ig.G.n_knot_angular, ig.G.n_knot, &poly[r * npoly]);
         param_tri_poly.upload(poly); R.param_tri_poly = param_tri_poly.p; R.n_poly = npoly;
     }
