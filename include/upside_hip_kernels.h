@@ -204,6 +204,8 @@ typedef struct {
        NULL: they read `param`. */
     const float* param_poly; int n_poly;
     int sens_overlap;                    /* node1 and node2 are one node AND some element is listed on both sides (set by the host) */
+    int word16;                          /* 1: the words of nbr1/nbr2/hit1/hit2 are 16 bits wide (bare element indices; every graph but the rotamer's:
+                                            n1, n2 <= 65534), rows cap1 / cap2 such words apart in the first half of the arrays; 0: 32-bit words */
 } upk_igraph_t;
 #define UPK_ROT_J_BITS 13                /* rotamer list word = bead | slot << 13: <= 8191 beads (bead index n1 is the refine kernel's sentinel), < 2^19 - 1 slots */
 #define UPK_ROT_SLOT_NONE 0x7FFFF        /* slot field of a cached bead pair whose residue pair got no slot (capacity overflow) */

@@ -335,6 +335,16 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// List words.  A cached or hit list holds one word per pair: the partner's element index, 16 bits wide (the refine moves one word
+// per cached pair per step and is bound by those bytes), except in the rotamer graph, whose words also carry the residue-pair
+// slot (bead | slot << UPK_ROT_J_BITS, 32 bits).  The arrays are allocated as 32-bit words either way; a 16-bit graph uses the
+// first half, rows `cap` words apart.  upk_igraph_t::word16 says which (set by the host: itype != UPK_IT_ROTAMER).
+template <int IT> struct list_word { typedef unsigned short type; };
+template <> struct list_word<UPK_IT_ROTAMER> { typedef int type; };
+__device__ __forceinline__ int list_word_at(const int* lists, size_t idx, int word16) {
+    return word16 ? (int)((const unsigned short*)lists)[idx] : lists[idx];
+}
+
 // per-row hit range staged in LDS: first | end << 16 (list positions; the launchers check that capacities fit 16 bits), and
 // the sorted row order
 __device__ __forceinline__ void stage_ranges(int* lds_range, unsigned short* lds_ord, const int* __restrict__ hcnt, const int* __restrict__ hlo,
@@ -353,15 +363,16 @@ __device__ __forceinline__ void stage_ranges(int* lds_range, unsigned short* lds
 //   flush(row)      -- reduce over the group and write the row's results (also for rows without hits)
 // All control flow is wave-uniform except the predication of lanes past the end of their row.
 // (LANES: lanes per row group -- 8 by default; graphs whose rows hold two or three pairs take 2, so that a trip is not 3/4 idle lanes)
-template <typename Op, int LANES = PG_LANES>
+// (W: the graph's list word type -- list_word<IT> below; `hit` and `cap` count words of that type)
+template <typename Op, int LANES = PG_LANES, typename W = int>
 __device__ __forceinline__ void group_batch_loop(Op& op, int n_rows, const unsigned short* ord, const int* range,
-                                                 const int* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step) {
+                                                 const W* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step) {
     const int lane = threadIdx.x & 63, gl = lane & (LANES - 1), g = lane / LANES;
     const int n_batch = (n_rows + (UP_WAVE / LANES) - 1) / (UP_WAVE / LANES);
     auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
     // one batch = (row, list range, first chunk of list words) per group; the NEXT batch's is fetched while the current one
     // is processed, so a batch switch waits neither for the claim nor for the first global loads
-    struct Batch { int row, n_mine; const int* hrow; int w[PG_CHUNK]; bool valid; };
+    struct Batch { int row, n_mine; const W* hrow; int w[PG_CHUNK]; bool valid; };
     auto fetch = [&](int i, Batch& B) -> bool {                   // returns false past the last batch (wave-uniform)
         const int b = batch_first + i * batch_step;
         if (b >= n_batch) return false;

@@ -19,8 +19,8 @@ __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_batch(BatchArgs A) {
             case BK_BUILD_COV: d_pairlist_build<true, UPK_IT_HBOND_COVERAGE>(G, h.i0, h.i1, B, lds); break;
             case BK_BUILD_ENV: d_pairlist_build<true, UPK_IT_ENVIRONMENT>(G, h.i0, h.i1, B, lds); break;
             case BK_BUILD_HB: d_pairlist_build<true, UPK_IT_PROTEIN_HBOND>(G, h.i0, h.i1, B, lds); break;
-            case BK_REFINE: d_pairlist_refine<false>(G, h.i0, h.i1, B, lds); break;
-            case BK_REFINE_SYM: d_pairlist_refine<true>(G, h.i0, h.i1, B, lds); break;
+            case BK_REFINE: d_pairlist_refine<false, unsigned short>(G, h.i0, h.i1, B, lds); break;
+            case BK_REFINE_SYM: d_pairlist_refine<true, int>(G, h.i0, h.i1, B, lds); break;
             case BK_REFINE_SHORT: d_pairlist_refine_short(G, h.i0, B, lds); break;
             case BK_ORDER: d_pairlist_order(G, h.i0, B, lds); break;
             case BK_CLEAR_SLOTS: d_rotamer_clear_slots(R, B, lds); break;

@@ -256,7 +256,8 @@ __device__ __forceinline__ void d_pairlist_build(const upk_igraph_t& G, int bloc
             const float4 x = x_next;
             { const int in = i + n_wave; if (r + n_wave < rows_per_wg && in < n_my) x_next = mine[in]; }
             const int my_id = __float_as_int(x.w);
-            int* nbr = (side1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
+            typedef typename list_word<IT>::type W;      // (igraph_device.h: 16-bit partner indices, 32-bit words in the rotamer graph)
+            W* nbr = (side1 ? (W*)G.nbr1 + (size_t)s * G.n1 * G.cap1 : (W*)G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)i * cap;
             int count = 0;
             const int my_node = SYM ? plb_node_of(G, my_id) : 0;
             // (tried in round 3: 128 candidates per trip, two per lane with packed distances -- 1.40 instead of 1.08 ms for the coverage
@@ -274,7 +275,7 @@ __device__ __forceinline__ void d_pairlist_build(const upk_igraph_t& G, int bloc
                 const unsigned long long b = __ballot(hit);
                 if (!b) continue;                                  // (wave-uniform: most trips of a row find nobody within reach)
                 const int pos = count + __popcll(b & ((1ull << lane) - 1ull));
-                if (hit & (pos < cap)) nbr[pos] = j;
+                if (hit & (pos < cap)) nbr[pos] = (W)j;
                 count += __popcll(b);
                 if (SYM && G.mark_table) {   // residue pairs owning a cached bead pair (rotamer slots); benign race.  Beads of one
                                              // residue are adjacent: only the first hit lane of each residue run stores
@@ -363,7 +364,7 @@ __device__ __forceinline__ plr_v2 dist2_exact2(plr_v2 ax, plr_v2 ay, plr_v2 az, 
 // TWO rows per wavefront trip (rows 2a and 2a+1 of the wavefront's run: one candidate of each per lane), so that the distance
 // arithmetic issues packed and the per-trip bookkeeping (loop control, ballots, list-length broadcasts) is shared: the kernel
 // is bound by instruction issue, not by the 4 bytes it reads per cached pair.
-template <bool SYM>
+template <bool SYM, typename W>
 __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int side, int rows_per_wg, const BX B, float* plr_lds) {
         float4* oth = (float4*)plr_lds;
     const int s = B.by;
@@ -380,9 +381,9 @@ __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int sid
     // (lanes past the end of their row carry the word n_other, which names the far-away sentinel behind the staged elements: such a
     //  lane fails the distance test by itself and the trip needs no validity masks)
     const int dead = n_other;
-    const int* nbr_base = (rows1 ? G.nbr1 : G.nbr2) + (size_t)s * n_rows * cap;
+    const W* nbr_base = (const W*)(rows1 ? G.nbr1 : G.nbr2) + (size_t)s * n_rows * cap;
     const int* cnt_arr = (rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows;
-    int* hit_base = (rows1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap;
+    W* hit_base = (W*)(rows1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap;
     int* hcnt = (rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows;
     int* hlo = (SYM && G.hlo1) ? G.hlo1 + (size_t)s * n_rows : nullptr;
     const float cut2 = G.cutoff * G.cutoff;
@@ -423,8 +424,8 @@ __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int sid
         plr_v2 xx, xy, xz;
         xx.x = bcast(my_x.x, la); xy.x = bcast(my_x.y, la); xz.x = bcast(my_x.z, la);
         xx.y = bcast(my_x.x, lb & 63); xy.y = bcast(my_x.y, lb & 63); xz.y = bcast(my_x.z, lb & 63);
-        const int* nbrA = nbr_base + (size_t)ra * cap; const int* nbrB = nbrA + cap;
-        int* outA = hit_base + (size_t)ra * cap; int* outB = outA + cap;
+        const W* nbrA = nbr_base + (size_t)ra * cap; const W* nbrB = nbrA + cap;
+        W* outA = hit_base + (size_t)ra * cap; W* outB = outA + cap;
         int na = 0, nb = 0, loa = 0, lob = 0;
         const int cmax = cntA > cntB ? cntA : cntB;
         for (int k0 = 0; k0 < cmax; k0 += 64) {
@@ -437,8 +438,8 @@ __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int sid
             const bool hitA = d2.x < cut2, hitB = d2.y < cut2;
             const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA), mB = __builtin_amdgcn_ballot_w64(hitB);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (hitA) outA[na + __popcll(mA & below)] = wA;
-            if (hitB) outB[nb + __popcll(mB & below)] = wB;
+            if (hitA) outA[na + __popcll(mA & below)] = (W)wA;
+            if (hitB) outB[nb + __popcll(mB & below)] = (W)wB;
             na += __popcll(mA); nb += __popcll(mB);
             if (SYM) { loa += __popcll(__builtin_amdgcn_ballot_w64(hitA && jA < ra)); lob += __popcll(__builtin_amdgcn_ballot_w64(hitB && jB < ra + 1)); }
         }
@@ -447,10 +448,10 @@ __device__ __forceinline__ void d_pairlist_refine(const upk_igraph_t& G, int sid
     }
     if (have) { hcnt[r0 + lane] = my_n; if (SYM && hlo) hlo[r0 + lane] = my_lo; }
 }
-template <bool SYM>
+template <bool SYM, typename W>
 __global__ void __launch_bounds__(PLR_BLOCK) k_pairlist_refine(upk_igraph_t G, int side, int rows_per_wg)  {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn_[];
-    d_pairlist_refine<SYM>(G, side, rows_per_wg, BX_REAL, lds_dyn_);
+    d_pairlist_refine<SYM, W>(G, side, rows_per_wg, BX_REAL, lds_dyn_);
 }
 // Rows of a handful of cached neighbours (backbone hydrogen bonds: three per donor or acceptor): one LANE per row walks its list --
 // the row-pair machinery above costs a fixed ~100 instructions and a dependent chain per pair of rows, 0.19 ms per launch for
@@ -463,8 +464,9 @@ __device__ __forceinline__ void d_pairlist_refine_short(const upk_igraph_t& G, i
     const int cap = rows1 ? G.cap1 : G.cap2;
     const float4* src = (const float4*)((rows1 ? G.cur_pos2 : G.cur_pos1) + (size_t)s * n_other * 4);
     const float4 x = ((const float4*)((rows1 ? G.cur_pos1 : G.cur_pos2) + (size_t)s * n_rows * 4))[row];
-    const int* nbr = (rows1 ? G.nbr1 : G.nbr2) + ((size_t)s * n_rows + row) * cap;
-    int* hit = (rows1 ? G.hit1 : G.hit2) + ((size_t)s * n_rows + row) * cap;
+    typedef list_word<UPK_IT_PROTEIN_HBOND>::type W;
+    const W* nbr = (const W*)(rows1 ? G.nbr1 : G.nbr2) + ((size_t)s * n_rows + row) * cap;
+    W* hit = (W*)(rows1 ? G.hit1 : G.hit2) + ((size_t)s * n_rows + row) * cap;
     const int cnt = ((rows1 ? G.cnt1 : G.cnt2) + (size_t)s * n_rows)[row];
     const float cut2 = G.cutoff * G.cutoff;
     const int jmask = G.nbr_j_bits ? (1 << G.nbr_j_bits) - 1 : 0x7fffffff;
@@ -477,7 +479,7 @@ __device__ __forceinline__ void d_pairlist_refine_short(const upk_igraph_t& G, i
         for (int u = 0; u < 4; ++u) y[u] = src[w[u] & jmask];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (k0 + u < cnt && dist2_exact(x.x, x.y, x.z, y[u].x, y[u].y, y[u].z) < cut2) hit[n++] = w[u];
+            if (k0 + u < cnt && dist2_exact(x.x, x.y, x.z, y[u].x, y[u].y, y[u].z) < cut2) hit[n++] = (W)w[u];
     }
     ((rows1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows)[row] = n;
 }
@@ -492,6 +494,7 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
         hipLaunchKernelGGL(k_pairlist_refine_short, dim3((n_rows + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side);
         return launch_status();
     }
+    if ((G->symmetric != 0) == (G->word16 != 0)) return 9007;   // the two list forms there are: the rotamer graph's (symmetric, 32-bit words) and everyone else's
     const size_t lds = (size_t)((n_other > 0 ? n_other : 0) + 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one
@@ -506,8 +509,9 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
     }
     UPK_FLUSH(L);
     const dim3 grid((n_rows + rows_per_wg - 1) / rows_per_wg, L->n_system);
-    if (G->symmetric) hipLaunchKernelGGL(k_pairlist_refine<true>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
-    else hipLaunchKernelGGL(k_pairlist_refine<false>, grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
+    if (G->symmetric) hipLaunchKernelGGL((k_pairlist_refine<true, int>), grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
+    else hipLaunchKernelGGL((k_pairlist_refine<false, unsigned short>), grid, dim3(PLR_BLOCK), lds, ST(L), *G, side, rows_per_wg);
+
     return launch_status();
 }
 
@@ -572,7 +576,8 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
     const float cut2 = G.cutoff * G.cutoff;
     for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * ROWS_PER_BLOCK) {
         const int cap = side == 1 ? G.cap1 : G.cap2;
-        const int* nbr = (side == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)row * cap;
+        const int* lists = side == 1 ? G.nbr1 : G.nbr2;
+        const size_t row_at = ((size_t)s * n_rows + row) * cap;         // (in list words: list_word_at)
         const int cnt = (side == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[row];
         float xr[8];
         if (side == 1) load_elem(xr, G.node1, s, G.loc1[row], G.dim1); else load_elem(xr, G.node2, s, G.loc2[row], G.dim2);
@@ -581,7 +586,7 @@ __global__ void k_igraph_rowsum(upk_igraph_t G, int side, float* __restrict__ ou
 #pragma unroll
         for (int c = 0; c < 8; ++c) og[c] = 0.f;
         for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
+            const int j = list_word_at(lists, row_at + k, G.word16);
             float xo[8], d1[8], d2[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) { d1[c] = 0.f; d2[c] = 0.f; }
@@ -627,7 +632,8 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
     const float* S2 = sens2 ? sens2 + (size_t)s * sens_sys_stride : nullptr;
     for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * ROWS_PER_BLOCK) {
         const int cap = side == 1 ? G.cap1 : G.cap2;
-        const int* nbr = (side == 1 ? G.nbr1 + (size_t)s * G.n1 * G.cap1 : G.nbr2 + (size_t)s * G.n2 * G.cap2) + (size_t)row * cap;
+        const int* lists = side == 1 ? G.nbr1 : G.nbr2;
+        const size_t row_at = ((size_t)s * n_rows + row) * cap;         // (in list words: list_word_at)
         const int cnt = (side == 1 ? G.cnt1 + (size_t)s * G.n1 : G.cnt2 + (size_t)s * G.n2)[row];
         float xr[8];
         if (side == 1) load_elem(xr, G.node1, s, G.loc1[row], G.dim1); else load_elem(xr, G.node2, s, G.loc2[row], G.dim2);
@@ -640,7 +646,7 @@ __global__ void k_igraph_grad(upk_igraph_t G, int side, int sens_mode, const flo
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
         for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
+            const int j = list_word_at(lists, row_at + k, G.word16);
             float xo[8], d1[8], d2[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) { d1[c] = 0.f; d2[c] = 0.f; }
@@ -684,12 +690,13 @@ __global__ void k_igraph_inrange(upk_igraph_t G, unsigned char* __restrict__ fla
     const int lane = threadIdx.x & 63;
     const float cut2 = G.cutoff * G.cutoff;
     for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * ROWS_PER_BLOCK) {
-        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
+        const size_t row_at = ((size_t)s * G.n1 + row) * G.cap1;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
         const float* x = C_OUT(G.node1, s) + (size_t)G.loc1[row] * G.node1.stride;
         unsigned char* f = flags + ((size_t)s * G.n1 + row) * G.cap1;
         for (int k = lane; k < cnt; k += 64) {
-            const int j = G.nbr_j_bits ? (nbr[k] & ((1 << G.nbr_j_bits) - 1)) : nbr[k];
+            const int w = list_word_at(G.nbr1, row_at + k, G.word16);
+            const int j = G.nbr_j_bits ? (w & ((1 << G.nbr_j_bits) - 1)) : w;
             const float* y = C_OUT(G.node2, s) + (size_t)G.loc2[j] * G.node2.stride;
             f[k] = dist2_exact(x[0], x[1], x[2], y[0], y[1], y[2]) < cut2 ? 1 : 0;
         }
@@ -713,13 +720,13 @@ __global__ void k_igraph_param_deriv(upk_igraph_t G, int s, int sens_mode, const
     const float* S2 = sens2 ? sens2 + (size_t)s * sens_sys_stride : nullptr;
     const QuadShape Q = quad_shape(G);
     for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < G.n1; row += gridDim.x * ROWS_PER_BLOCK) {
-        const int* nbr = G.nbr1 + ((size_t)s * G.n1 + row) * G.cap1;
+        const size_t row_at = ((size_t)s * G.n1 + row) * G.cap1;
         const int cnt = G.cnt1[(size_t)s * G.n1 + row];
         float xr[8];
         load_elem(xr, G.node1, s, G.loc1[row], G.dim1);
         const int t1 = G.type1[row];
         for (int k = lane; k < cnt; k += 64) {
-            const int j = nbr[k];
+            const int j = list_word_at(G.nbr1, row_at + k, G.word16);
             float xo[8];
             load_elem(xo, G.node2, s, G.loc2[j], G.dim2);
             if (!(dist2_exact(xr[0], xr[1], xr[2], xo[0], xo[1], xo[2]) < cut2)) continue;

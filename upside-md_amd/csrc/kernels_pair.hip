@@ -11,6 +11,8 @@
 #include <cstring>
 
 using namespace up;
+// list words of the graphs served here (every graph but the rotamer's, which has its own passes in kernels_rotamer.hip): igraph_device.h
+typedef unsigned short PW;
 
 #define ST(L) ((hipStream_t)(L)->stream)
 #ifndef UPK_LAUNCH_STATUS_DEFINED
@@ -175,7 +177,7 @@ __device__ __forceinline__ void d_pair_rows(const upk_igraph_t& G, const PairArg
         stage_ranges(L.range, L.ord, G.hcnt1 + (size_t)s * G.n1, nullptr, G.ord1 + (size_t)s * G.n1, G.n1);
         __syncthreads();
         RowOp<IT, 1, MODE, POLY, LANES> op(G, L, A, s);
-        group_batch_loop<RowOp<IT, 1, MODE, POLY, LANES>, LANES>(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, B.bx, B.gx);
+        group_batch_loop<RowOp<IT, 1, MODE, POLY, LANES>, LANES>(op, G.n1, L.ord, L.range, (const PW*)G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, B.bx, B.gx);
     }
     if (SIDES & 2) {
         if (SIDES == 3) __syncthreads();
@@ -183,7 +185,7 @@ __device__ __forceinline__ void d_pair_rows(const upk_igraph_t& G, const PairArg
         stage_ranges(L.range, L.ord, G.hcnt2 + (size_t)s * G.n2, nullptr, G.ord2 + (size_t)s * G.n2, G.n2);
         __syncthreads();
         RowOp<IT, 2, MODE, POLY, LANES> op(G, L, A, s);
-        group_batch_loop<RowOp<IT, 2, MODE, POLY, LANES>, LANES>(op, G.n2, L.ord, L.range, G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, B.bx, B.gx);
+        group_batch_loop<RowOp<IT, 2, MODE, POLY, LANES>, LANES>(op, G.n2, L.ord, L.range, (const PW*)G.hit2 + (size_t)s * G.n2 * G.cap2, G.cap2, L.counter, B.bx, B.gx);
     }
 }
 template <int IT, int SIDES, int MODE, bool POLY>
@@ -278,7 +280,7 @@ __device__ __forceinline__ void d_pair_backward(const upk_igraph_t& G, const Pai
     {
         BackwardOp<IT, RS, POLY> op(G, L, oacc, A.sens_mode, s);
         const int cap = RS == 1 ? G.cap1 : G.cap2;
-        group_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx);
+        group_batch_loop(op, n_rows, L.ord, L.range, (const PW*)(RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx);
     }
     __syncthreads();
     const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;
@@ -373,7 +375,7 @@ __device__ __forceinline__ void d_cov_rows2(const upk_igraph_t& G, const PairArg
     stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
     __syncthreads();
     CovRowOp2<RS, POLY> op(G, L, A, s);
-    group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, RS == 1 ? G.n2 : G.n1);
+    group2_batch_loop(op, n_rows, L.ord, L.range, (const PW*)(RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, RS == 1 ? G.n2 : G.n1);
 }
 template <int RS, bool POLY>
 __global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_cov_rows2(upk_igraph_t G, PairArgs A)  {
@@ -471,7 +473,7 @@ __device__ __forceinline__ void d_cov_backward2(const upk_igraph_t& G, const Pai
         CovBackwardOp2<RS, POLY> op(G, L, oacc, A.sens_mode, s);
         op.site_sens = site_sens;
         const int cap = RS == 1 ? G.cap1 : G.cap2;
-        group2_batch_loop(op, n_rows, L.ord, L.range, (RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, n_other);
+        group2_batch_loop(op, n_rows, L.ord, L.range, (const PW*)(RS == 1 ? G.hit1 : G.hit2) + (size_t)s * n_rows * cap, cap, L.counter, B.bx, B.gx, n_other);
     }
     __syncthreads();
     const upk_coord_t& onode = RS == 1 ? G.node2 : G.node1;

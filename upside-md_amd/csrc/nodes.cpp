@@ -560,11 +560,15 @@ struct IGraphHost {
         const int S = c->n_system;
         d_loc1.upload(loc1); d_type1.upload(type1); d_id1.upload(id1);
         d_param.upload(param);
-        nbr1.alloc((size_t)S * G.n1 * G.cap1); cnt1.alloc((size_t)S * G.n1);
+        // list words: 16-bit element indices (two per allocated int), except the rotamer graph's bead | slot << 13 (igraph_device.h)
+        G.word16 = itype != UPK_IT_ROTAMER;
+        if (G.word16 && max(G.n1, G.n2) > 65534) throw string("pair lists hold 16-bit element indices (one value is the sentinel): at most 65534 elements per side");
+        auto list_ints = [&](size_t words) { return G.word16 ? (words + 1) / 2 : words; };
+        nbr1.alloc(list_ints((size_t)S * G.n1 * G.cap1)); cnt1.alloc((size_t)S * G.n1);
         cache_pos1.upload(vector<float>((size_t)S * G.n1 * 4, 1e10f));   // forces the first rebuild (interaction_graph.h:194-198)
         if (!G.symmetric) {
             d_loc2.upload(loc2); d_type2.upload(type2); d_id2.upload(id2);
-            nbr2.alloc((size_t)S * G.n2 * G.cap2); cnt2.alloc((size_t)S * G.n2);
+            nbr2.alloc(list_ints((size_t)S * G.n2 * G.cap2)); cnt2.alloc((size_t)S * G.n2);
             cache_pos2.upload(vector<float>((size_t)S * G.n2 * 4, 1e10f));
         }
         rebuild_flag.alloc(S);
@@ -574,9 +578,9 @@ struct IGraphHost {
         if (!G.symmetric) cur_pos2.alloc((size_t)S * G.n2 * 4);
         if (itype != UPK_IT_RADIAL && itype != UPK_IT_HBOND_SC_RADIAL) {   // (the radial potentials walk the cached lists themselves)
             // (+4 words: the packed pair passes fetch a lane's two list words together, the second may lie one past the last row's end)
-            hit1.alloc((size_t)S * G.n1 * G.cap1 + 4); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
+            hit1.alloc(list_ints((size_t)S * G.n1 * G.cap1 + 4)); hcnt1.alloc((size_t)S * G.n1); ord1.alloc((size_t)S * G.n1);
             if (G.symmetric) { /* (each pair once: the lists hold the partners above the row only) */ }
-            else { hit2.alloc((size_t)S * G.n2 * G.cap2 + 4); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
+            else { hit2.alloc(list_ints((size_t)S * G.n2 * G.cap2 + 4)); hcnt2.alloc((size_t)S * G.n2); ord2.alloc((size_t)S * G.n2); }
         }
         if (!G.symmetric && S < 256) { gacc.alloc((size_t)S * max(G.n1, G.n2) * 8); G.gacc = gacc.p; }   // (from 256 systems on a system has one workgroup)
         G.hit1 = hit1.p; G.hit2 = hit2.p; G.hcnt1 = hcnt1.p; G.hcnt2 = hcnt2.p; G.hlo1 = hlo1.p;
@@ -692,7 +696,8 @@ struct IGraphHost {
         for (int i = 0; i < G.n1; ++i)
             for (int k = 0; k < ct[(size_t)sys * G.n1 + i]; ++k) {
                 size_t idx = ((size_t)sys * G.n1 + i) * G.cap1 + k;
-                int j = G.nbr_j_bits ? (nb[idx] & ((1 << G.nbr_j_bits) - 1)) : nb[idx];
+                const int w = G.word16 ? (int)((const unsigned short*)nb.data())[idx] : nb[idx];
+                int j = G.nbr_j_bits ? (w & ((1 << G.nbr_j_bits) - 1)) : w;
                 if (!f[idx]) continue;
                 if (G.symmetric && j <= i) continue;
                 if (orig_of.empty()) out.emplace_back(i, j);

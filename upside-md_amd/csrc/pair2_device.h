@@ -233,13 +233,13 @@ __device__ __forceinline__ float group_sum4(float v) { return group_sum_n<P2_LAN
 //   begin(row)                       -- load the row element, reset the row accumulators
 //   body(row, wA, wB, liveA, liveB)  -- two hit-list words per lane; a dead half carries `dead_word` (the sentinel element)
 //   flush(row)                       -- reduce over the group and write the row's results (also for rows without hits)
-template <typename Op>
+template <typename Op, typename W>
 __device__ __forceinline__ void group2_batch_loop(Op& op, int n_rows, const unsigned short* ord, const int* range,
-                                                  const int* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step, int dead_word) {
+                                                  const W* __restrict__ hit, int cap, int* counter, int batch_first, int batch_step, int dead_word) {
     const int lane = threadIdx.x & 63, gl = lane & (P2_LANES - 1), g = lane / P2_LANES;
     const int n_batch = (n_rows + P2_ROWS - 1) / P2_ROWS;
     auto claim = [&]() { int v = 0; if (lane == 0) v = atomicAdd(counter, 1); return __builtin_amdgcn_readfirstlane(v); };
-    struct Batch { int row, n_mine; const int* hrow; int wa[P2_CHUNK], wb[P2_CHUNK]; bool valid; };
+    struct Batch { int row, n_mine; const W* hrow; int wa[P2_CHUNK], wb[P2_CHUNK]; bool valid; };
     auto load2 = [&](const Batch& B, int t, int& a, int& b) {        // this lane's two words of trip t: positions l and l + 4 of the trip's 8
         const int k = t * 2 * P2_LANES;
         a = k < B.n_mine ? B.hrow[k] : dead_word;
