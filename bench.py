@@ -161,6 +161,27 @@ def profiled(kernel_label, workload, replicas, field):
         return None
 
 
+def profiled_per_system(kernel_label, workload, replicas, field):
+    """(value, source replica count): as profiled(), from the table's entry of the SAME workload at another batch size, scaled per
+    system -- only between batches of at least 256 systems, where the same kernel variants run (one workgroup per system, the
+    dense solve) and a system's bytes do not depend on how many systems share the launch; (None, None) otherwise."""
+    if replicas < 256:
+        return None, None
+    try:
+        with open(os.path.join(ROOT, PROFILE_TABLE)) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for key in tab:
+        w, _, r0 = key.rpartition('/R')
+        if w != workload or not r0.isdigit() or int(r0) < 256 or int(r0) == replicas:
+            continue
+        v = profiled(kernel_label, workload, int(r0), field)
+        if v is not None:
+            return v * replicas / int(r0), int(r0)
+    return None, None
+
+
 WORKLOADS = {   # name -> (fixture, description, total systems or None (= --replicas per GPU, weak scaling))
     'remd64_proteinG56': ('proteinG56_7A', '64-temperature replica exchange of the 56-residue protein (BASELINE.json configs[3]): geometric '
                           'ladder T=0.50..1.00 in contiguous blocks per GPU, exchange attempt every 5 time units (185 rounds) with two '
@@ -307,6 +328,7 @@ def main():
     variant = '10A' if fix_name.endswith('10A') else '7A'
     pos0 = pkg.config.read_pos(fixture)
     n_atom = pos0.shape[0]
+    free_before = torch.cuda.mem_get_info()[0]
     eng = c.upside_hip_construct(n_atom, fixture.encode(), R, True)
     if not eng:
         raise RuntimeError('engine construction failed: %s' % c.upside_hip_last_error().decode())
@@ -363,6 +385,7 @@ def main():
     _trace('engine ready, warm-up')
     run_steps(args.warmup)
     barrier()
+    engine_bytes = free_before - torch.cuda.mem_get_info()[0]      # everything the engine holds for its R systems (lists sized on the first pass included)
     _trace('timed region')
     attempts0 = state['attempts']
     t0 = time.perf_counter()
@@ -409,6 +432,19 @@ def main():
                 d['frac'] = d['frac_counter']
             elif _TABLE_STATE.get('stale'):
                 d['traffic_source'] = 'profiles/hbm_traffic.json is STALE: the kernel sources changed after its PMC passes (rerun tools/refresh_profiles.sh pmc)'
+            else:
+                # no counter pass of this batch size: the per-system bytes of the profiled batch (same kernel variants from 256 systems on)
+                est, r0 = profiled_per_system(r[0], args.workload, R, 'bytes_per_launch')
+                if est is not None:
+                    d['traffic'] = est
+                    d['traffic_source'] = ('per-system HBM bytes of the %d-system PMC passes (%s) x %d systems: the same kernel variant, '
+                                           'not counted at this batch size' % (r0, PROFILE_TABLE, R))
+                    d['achieved_model'] = d['achieved']
+                    d['achieved'] = est / (avg_ms * 1e-3) / 1e9
+                    d['frac'] = d['frac_counter'] = d['achieved'] / HBM_PEAK_GBS
+                else:
+                    d['frac_note'] = ('model bytes only (SURVEY 8d counts every sweep\'s re-read of the pair matrices; the solve keeps them in '
+                                      'registers / LDS / L2, so the model rate may exceed the HBM peak); counters exist for the default command only')
             return d
         # the dominant kernel of the step (most time): belief propagation, which streams the pair matrices and messages
         # every sweep
@@ -525,7 +561,8 @@ def main():
         cfg = dict(workload=describe, replicas_per_gpu=R, n_atom=int(n_atom), per_system_steps_per_s=steps_done / elapsed,
                    # the reference's own unit of simulated time (it defines no ns/day, README.md:173-177): steps/s x dt x 86400
                    sim_time_units_per_day_per_system=steps_done / elapsed * DT * 86400.,
-                   single_system_steps_per_s=single)
+                   single_system_steps_per_s=single,
+                   engine_hbm_gib=engine_bytes / 2.**30, engine_hbm_mib_per_system=engine_bytes / 2.**20 / R)
         if remd:
             cfg.update(exchange_every_steps=exchange_steps_saved, exchange_attempts_timed=timed_attempts, swap_sets=len(swap_sets),
                        exchange='RCCL: ncclAllGather of one fp32 per replica, device Metropolis, ncclSend/ncclRecv of straddling pairs')

@@ -18,7 +18,8 @@ import sys,json
 try:
     d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
     pc=d.get('parity_check') or {}
-    print('%d(%.0e%s)' % (round(d['value']), pc.get('max_rel_rms', -1), '' if pc.get('ok', True) else ' PARITY-FAIL'))
+    rf=d.get('roofline') or {}
+    print('%d(%.0e%s %s=%.3fms)' % (round(d['value']), pc.get('max_rel_rms', -1), '' if pc.get('ok', True) else ' PARITY-FAIL', rf.get('kernel','?'), rf.get('avg_launch_ms', 0)))
 except Exception as e:
     print('FAILED')")
     line="$line  $w/R$r=$v"

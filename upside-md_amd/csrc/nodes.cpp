@@ -500,7 +500,9 @@ struct IGraphHost {
     // (round 4: a batch of a few systems is a chain of launches, not work -- a longer list is cheap there and every rebuild lengthens the
     //  chain: 1.5 x the reference's margin up to 16 systems; 56 residues, 1 / 8 systems: 4.97 k / 34.4 k against 4.88 k / 32.8 k system-steps/s
     //  at 0.5, one 300-residue system 2.09 k against 1.99 k; 64 systems: 57 k against 62 k)
-    float skin_scale() const { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.f); return v > 0.f ? v : (ctx->n_system <= 16 ? 1.5f : 0.5f); }
+    // (round 5: with 16-bit list words and the cheaper refine a longer list costs less: 4096 systems 215.4 k at 0.75 against 212.7 k at 0.5, four
+    //  alternating runs each on one box; 1024 and 256 systems no difference, 64 systems 0.5 still ahead by 0.6 %)
+    float skin_scale() const { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.f); return v > 0.f ? v : (ctx->n_system <= 16 ? 1.5f : (ctx->n_system <= 256 ? 0.5f : 0.75f)); }
 
     IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
         memset(&G, 0, sizeof(G));
