@@ -273,6 +273,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--settle', type=int, default=100,
+                    help='MD steps run while the workload is set up, before the warm-up: the replicas start from one structure (plus noise), so their '
+                         'pair lists are all built on step 0 and fall due together for the first few dozen steps -- a start-up burst, not the '
+                         'steady state the metric is about (20 timed steps after 5 / 65 / 125 untimed ones: 209 / 215 / 216 k system-steps/s at 4096 replicas)')
     ap.add_argument('--replicas', type=int, default=int(os.environ.get('UPSIDE_BENCH_REPLICAS', '4096')),
                     help='independent replicas resident per GPU')
     ap.add_argument('--workload', default='syn300_10A')
@@ -382,7 +386,9 @@ def main():
     def barrier():
         rep.barrier(dist, torch.cuda.synchronize)
 
-    _trace('engine ready, warm-up')
+    _trace('engine ready, settling')
+    run_steps(args.settle)           # set-up, reported as config.settle_steps: de-phases the replicas' list rebuilds (see --settle)
+    _trace('warm-up')
     run_steps(args.warmup)
     barrier()
     engine_bytes = free_before - torch.cuda.mem_get_info()[0]      # everything the engine holds for its R systems (lists sized on the first pass included)
@@ -562,7 +568,8 @@ def main():
                    # the reference's own unit of simulated time (it defines no ns/day, README.md:173-177): steps/s x dt x 86400
                    sim_time_units_per_day_per_system=steps_done / elapsed * DT * 86400.,
                    single_system_steps_per_s=single,
-                   engine_hbm_gib=engine_bytes / 2.**30, engine_hbm_mib_per_system=engine_bytes / 2.**20 / R)
+                   engine_hbm_gib=engine_bytes / 2.**30, engine_hbm_mib_per_system=engine_bytes / 2.**20 / R,
+                   settle_steps=args.settle)
         if remd:
             cfg.update(exchange_every_steps=exchange_steps_saved, exchange_attempts_timed=timed_attempts, swap_sets=len(swap_sets),
                        exchange='RCCL: ncclAllGather of one fp32 per replica, device Metropolis, ncclSend/ncclRecv of straddling pairs')
