@@ -42,3 +42,26 @@ def test_single_rank_stub_and_exit_code_relay():
     r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--workload', '_stub', '--steps', '2', '--warmup', '1'], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300, env=dict(_clean_env(), UPSIDE_BENCH_STUB_FAIL='1'))
     assert r.returncode != 0
+
+
+def test_counter_traffic_is_scaled_per_system_between_large_batches_only(tmp_path, monkeypatch):
+    """roofline.traffic of a batch size without its own PMC pass: the per-system bytes of the profiled batch (same kernel variants
+    from 256 systems on), never for small batches, never from a table measured on other kernel sources."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', BENCH)
+    b = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    spec.loader.exec_module(b)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hbm_traffic
+    table = {'syn300_10A/R4096': {'_kernel_sources_sha256': hbm_traffic.kernel_source_stamp(), 'bp:rotamer': {'bytes_per_launch': 4096e6}}}
+    (tmp_path / 'profiles').mkdir()
+    (tmp_path / 'profiles' / 'hbm_traffic.json').write_text(json.dumps(table))
+    monkeypatch.setattr(b, 'ROOT', str(tmp_path))
+    assert b.profiled('bp:rotamer', 'syn300_10A', 4096, 'bytes_per_launch') == 4096e6
+    assert b.profiled_per_system('bp:rotamer', 'syn300_10A', 1024, 'bytes_per_launch') == (1024e6, 4096)
+    assert b.profiled_per_system('bp:rotamer', 'syn300_10A', 64, 'bytes_per_launch') == (None, None)       # cluster solves: other kernels
+    assert b.profiled_per_system('bp:rotamer', 'syn150_10A', 512, 'bytes_per_launch') == (None, None)      # another workload
+    table['syn300_10A/R4096']['_kernel_sources_sha256'] = 'stale'
+    (tmp_path / 'profiles' / 'hbm_traffic.json').write_text(json.dumps(table))
+    assert b.profiled_per_system('bp:rotamer', 'syn300_10A', 1024, 'bytes_per_launch') == (None, None)
