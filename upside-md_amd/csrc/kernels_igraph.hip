@@ -191,13 +191,22 @@ __device__ __forceinline__ void d_pairlist_check(const upk_igraph_t& G, const BX
     }
 }
 __global__ void k_pairlist_check(upk_igraph_t G)  { d_pairlist_check(G, BX_REAL, nullptr); }
+// Workgroup size of the list-upkeep kernels (rebuild test, list build) when they are launched on their own.  A batch that fills the
+// device runs them on side streams next to the pair passes of the main stream, whose 1024-lane workgroups hold ~100 registers per lane
+// and 55-106 KB of LDS: what a CU has left beside one of those is 4 wavefront slots and ~96 registers per SIMD -- room for workgroups of
+// 256 lanes at <= 40 registers, none for one of 1024.  With 256 lanes the vector-bound list build and the memory-bound rebuild test run
+// BESIDE the LDS-bound pair passes instead of taking turns with them at workgroup granularity (4096 systems: 214.8 -> 218.2 k system-steps/s,
+// three alternating runs; the build alone +0.8 %; the slot-numbering kernel at 320 lanes as well: no further change; 1024 systems +0.9 %,
+// 512 x 150 residues +0.4 %, 256 systems -1.4 %: from two systems per CU on).  Smaller batches keep the large workgroups: there a
+// system's latency is what a step waits for.
+static inline int upkeep_block(int n_system, int large) { return n_system >= 2 * upk_device_cu_count() ? 256 : large; }
 extern "C" int upk_pairlist_check(const upk_launch_t* L, const upk_igraph_t* G) {
     if (batch_add(L, BK_CHECK, 1, L->n_system, 0, G, sizeof(*G))) return 0;
     UPK_FLUSH(L);
     // (latency bound -- every element is a chain load position -> load reference -> store packed copy: as many lanes as the
     //  system has elements, up to a full workgroup, so that a lane walks one or two elements instead of seven)
     const int n_tot = G->symmetric ? G->n1 : G->n1 + G->n2;
-    const int threads = n_tot <= 256 ? 256 : (n_tot <= 512 ? 512 : 1024);
+    const int threads = upkeep_block(L->n_system, n_tot <= 256 ? 256 : (n_tot <= 512 ? 512 : 1024));
     hipLaunchKernelGGL(k_pairlist_check, dim3(1, L->n_system), dim3(threads), 0, ST(L), *G);
     return launch_status();
 }
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_pairlist_build(upk_igraph_t G, int blo
 template <int IT>
 static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, size_t lds, bool staged, int blocks1) {
     const int rows = plb_rows(L->n_system);
-    if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(1024), lds, ST(L), *G, blocks1, rows);
+    if (staged) hipLaunchKernelGGL((k_pairlist_build<true, IT>), grid, dim3(upkeep_block(L->n_system, 1024)), lds, ST(L), *G, blocks1, rows);
     else hipLaunchKernelGGL((k_pairlist_build<false, IT>), grid, dim3(1024), 0, ST(L), *G, blocks1, rows);
 }
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) { return upk_pairlist_build_sides(L, G, 3); }
