@@ -283,6 +283,12 @@ def test_empty_and_degenerate_requests(hip):
     assert up.calc.get_output(1, buf.ctypes.data, up.engine, b'rotamer') == 0           # potential node -> (1,1)
     with pytest.raises((RuntimeError, OSError)):
         P.pkg.Upside('/nonexistent/file.up')
+    # MD steps before upside_hip_init_md: an error with a message, not a kernel launched on momenta that were never allocated
+    up.calc.upside_hip_run_steps.argtypes = [ct.c_void_p, ct.c_int]
+    assert up.calc.upside_hip_run_steps(up.engine, 3) == 1
+    up.calc.upside_hip_last_error.restype = ct.c_char_p
+    assert b'upside_hip_init_md' in up.calc.upside_hip_last_error()
+    up.energy(up.initial_pos)                     # the engine is still usable
     up.close()
 
 

@@ -1,4 +1,4 @@
-"""Print the phase clocks of the belief-propagation kernel (needs a GPU). Usage: python tools/bp_trace.py [fixture] [n_system]"""
+"""Print the phase clocks of the belief-propagation kernel (needs a GPU). Usage: python tools/bp_trace.py [fixture] [n_system] [md]   (md, with n_system > 1: the clocks of an MD step instead of an energy evaluation)"""
 import os, sys
 os.environ["UPSIDE_HIP_BP_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +28,14 @@ else:
     allpos = np.ascontiguousarray(np.tile(pos[None], (S, 1, 1)))
     c.upside_hip_set_pos(eng, allpos.ctypes.data)
     en = np.zeros(S, np.float32)
-    for _ in range(3): c.upside_hip_compute(eng, en.ctypes.data, None)
+    if len(sys.argv) > 3 and sys.argv[3] == "md":      # the clocks of an MD step (forces only: the marginal loops skip the energy terms)
+        c.upside_hip_run_steps.argtypes = [ct.c_void_p, ct.c_int]
+        c.upside_hip_init_md.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint32, ct.c_float, ct.c_float, ct.c_int]
+        temps = np.full(S, 0.8, np.float32)
+        assert c.upside_hip_init_md(eng, temps.ctypes.data, 7, 5.0, 0.009, 1) == 0
+        assert c.upside_hip_run_steps(eng, 7) == 0
+    else:
+        for _ in range(3): c.upside_hip_compute(eng, en.ctypes.data, None)
     t = np.zeros(32, np.float32)
     c.get_value_by_name(32, t.ctypes.data, eng, b"rotamer", b"bp_trace")
 names = ["prologue", "loop", "epilogue", "edge_phase", "node_phase"]

@@ -308,6 +308,7 @@ extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
 }
 extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
     API_TRY
+    if ((int)e->noise_scale.n != e->ctx.n_system) throw string("upside_hip_run_steps needs upside_hip_init_md first (momenta, thermostat seeds and scales are set there)");
     e->run_steps(n_step);
     e->check_device_errors();
     return 0;
