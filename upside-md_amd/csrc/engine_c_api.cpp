@@ -298,8 +298,12 @@ extern "C" int upside_hip_set_integrator(DerivEngine* e, int type) {
     return 0;
     API_CATCH(1)
 }
+static void require_md(DerivEngine* e, const char* who) {
+    if ((int)e->noise_scale.n != e->ctx.n_system) throw string(who) + " needs upside_hip_init_md first (the thermostat's seeds and scales are set there)";
+}
 extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
     API_TRY
+    require_md(e, "upside_hip_run_md");
     if (e->stage_num != 0) throw string("an integration cycle is in progress (upside_hip_run_steps left it unfinished)");
     e->run_steps(3 * n_round);                             // main.cpp:657-663
     e->check_device_errors();
@@ -308,7 +312,7 @@ extern "C" int upside_hip_run_md(DerivEngine* e, int n_round) {
 }
 extern "C" int upside_hip_run_steps(DerivEngine* e, int n_step) {
     API_TRY
-    if ((int)e->noise_scale.n != e->ctx.n_system) throw string("upside_hip_run_steps needs upside_hip_init_md first (momenta, thermostat seeds and scales are set there)");
+    require_md(e, "upside_hip_run_steps");
     e->run_steps(n_step);
     e->check_device_errors();
     return 0;
@@ -364,6 +368,7 @@ static int replica_swap_impl(DerivEngine* e, int n_pair, const int* pairs, uint3
         e->swap_energy = e->potential;
         e->swap_energy_round = round; e->swap_energy_compute = e->n_compute;
     }
+    if ((int)e->temperature.size() != S) throw string("replica exchange needs the systems' temperatures: call upside_hip_init_md first");
     vector<float> beta(S);
     for (int s = 0; s < S; ++s) beta[s] = 1.f / e->temperature[s];
     DevBuf<float> d_en, d_beta; d_en.upload(e->swap_energy); d_beta.upload(beta);
