@@ -502,8 +502,15 @@ struct IGraphHost {
     //  at 0.5, one 300-residue system 2.09 k against 1.99 k; 64 systems: 57 k against 62 k)
     // (round 5: with 16-bit list words and the cheaper refine a longer list costs less: 4096 systems 215.4 k at 0.75 against 212.7 k at 0.5, four
     //  alternating runs each on one box; 1024 and 256 systems no difference, 64 systems 0.5 still ahead by 0.6 %)
-    float skin_scale() const { static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.f); return v > 0.f ? v : (ctx->n_system <= 16 ? 1.5f : (ctx->n_system <= 256 ? 0.5f : 0.75f)); }
-
+    // (the side-chain graph keeps 0.5 there: its cached residue pairs are the solve's slots, and the slot matrices of pairs that are cached
+    //  but out of range lie between the active ones -- solve 4.98 -> 5.26 ms, pair energies 1.23 -> 1.35 ms at 0.75; with it at 0.5 and the
+    //  others at 0.75: 217.1 against 214.6 k on one box, 220.6 against 219.8 k on another)
+    float skin_scale() const {
+        static const float v = env_float("UPSIDE_HIP_SKIN_SCALE", 0.f);
+        if (v > 0.f) return v;
+        if (ctx->n_system <= 16) return 1.5f;
+        return (ctx->n_system <= 256 || G.itype == UPK_IT_ROTAMER) ? 0.5f : 0.75f;
+    }
     IGraphHost(DeviceCtx* c, hid_t grp, int itype, CoordNode* n1, CoordNode* n2) : ctx(c), node1(n1), node2(n2 ? n2 : n1) {
         memset(&G, 0, sizeof(G));
         G.itype = itype; G.symmetric = itype == UPK_IT_ROTAMER || itype == UPK_IT_RADIAL;
