@@ -360,6 +360,7 @@ extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_
 #ifndef PLR_DEPTH
 #define PLR_DEPTH 2
 #endif
+static_assert(PLR_ROWS <= 64 * (PLR_BLOCK / 64), "a wavefront of the refine keeps the positions and list lengths of its rows one per lane: at most 64 rows per wavefront");
 // squared distances of two pairs at once, every operation rounded separately (no contraction): the same bits as dist2_exact,
 // from v_pk_add_f32 / v_pk_mul_f32 (3 + 3 + 2 packed instructions for the two candidates of a lane)
 typedef float plr_v2 __attribute__((ext_vector_type(2)));
