@@ -65,3 +65,17 @@ def test_counter_traffic_is_scaled_per_system_between_large_batches_only(tmp_pat
     table['syn300_10A/R4096']['_kernel_sources_sha256'] = 'stale'
     (tmp_path / 'profiles' / 'hbm_traffic.json').write_text(json.dumps(table))
     assert b.profiled_per_system('bp:rotamer', 'syn300_10A', 1024, 'bytes_per_launch') == (None, None)
+
+
+def test_committed_counter_table_was_measured_on_these_kernel_sources():
+    """profiles/hbm_traffic.json (roofline.traffic of the default bench line) carries the sha256 of the kernel sources its PMC passes ran
+    on; bench.py drops the counters when they differ.  A kernel edit without `tools/refresh_profiles.sh pmc` shows up here, not in the
+    driver's bench line."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hbm_traffic
+    with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
+        table = json.load(f)
+    assert table, 'empty counter table'
+    for key, entry in table.items():
+        assert entry.get('_kernel_sources_sha256') == hbm_traffic.kernel_source_stamp(), \
+            '%s: counters collected on other kernel sources (rerun tools/refresh_profiles.sh pmc on the GPU box and publish)' % key
