@@ -29,6 +29,18 @@ def test_self_launch_two_ranks_prints_one_line():
     assert abs(d['value'] - 2 * 64 * 5 / (d['ms_per_step'] * 5e-3)) < 1e-6 * d['value']
 
 
+def test_self_launch_eight_ranks():
+    """the shape the driver's scaling run has (N = 8 ranks of one node), over gloo with the host-only unit of work"""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--steps', '4', '--warmup', '1', '--workload', '_stub'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=_clean_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().split('\n') if ln.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['steps'] == 4 and d['scaling'] == 'weak'
+    assert abs(d['value'] - 8 * 64 * 4 / (d['ms_per_step'] * 4e-3)) < 1e-6 * d['value']
+
+
 def test_single_rank_stub_and_exit_code_relay():
     r = subprocess.run([sys.executable, BENCH, '--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', '_stub'],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_clean_env())

@@ -1021,7 +1021,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu(tmp_path):
     import json
     import subprocess
     shm = os.path.join(P.ROOT, 'tests', 'plugin', 'libshmccl.so')
-    env = dict(os.environ, UPSIDE_HIP_COMM_LIB=shm, UPSIDE_BENCH_ONE_DEVICE='1', UPSIDE_BENCH_DIST_BACKEND='gloo')
+    env = dict(os.environ, UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_TESTING='1', UPSIDE_BENCH_ONE_DEVICE='1', UPSIDE_BENCH_DIST_BACKEND='gloo')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(P.ROOT, 'bench.py'), '--gpus', '2', '--steps', '1200', '--warmup', '30',
@@ -1554,7 +1554,7 @@ def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
     rendezvous = str(tmp_path / 'comm_id')
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_COMM_FILE=rendezvous)
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_TESTING='1', UPSIDE_HIP_COMM_FILE=rendezvous)
         env.pop('UPSIDE_HIP_COMM', None)
         procs.append(subprocess.Popen([exe] + rargs + two, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
     logs = []
@@ -1584,7 +1584,7 @@ def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
     margs = ['--duration', '0.27', '--frame-interval', '0.27', '--temperature', '0.8,0.82,0.84,0.86', '--seed', '3',
              '--replica-interval', '0.135', '--swap-set', '0-1,2-3', '--swap-set', '1-2', '--disable-recentering']
     procs = [subprocess.Popen([exe] + margs + other, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_TESTING='1',
                                        UPSIDE_HIP_COMM_FILE=rendezvous + '2')) for r in range(2)]
     outs = []
     try:
@@ -1612,7 +1612,7 @@ def test_two_ranks_exchange_across_the_rank_boundary(hip, tmp_path):
         with open(rendezvous + '3', 'wb') as f:
             f.write(record)
         p1 = subprocess.Popen([exe] + margs + other[:2] + other[:2], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              env=dict(os.environ, RANK='1', WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm,
+                              env=dict(os.environ, RANK='1', WORLD_SIZE='2', LOCAL_RANK='0', UPSIDE_HIP_COMM_LIB=shm, UPSIDE_HIP_TESTING='1',
                                        UPSIDE_HIP_COMM_FILE=rendezvous + '3', UPSIDE_HIP_COMM_WAIT_S='3',
                                        UPSIDE_HIP_COMM_NONCE='same-launch-line'))
         try:

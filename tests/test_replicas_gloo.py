@@ -151,7 +151,7 @@ class _FakeEnsemble(object):
         self.pos[[i, j]] = self.pos[[j, i]]
 
 
-def _exchange_worker(rank, world, port, out_dir):
+def _exchange_worker(rank, world, port, out_dir, per_rank=4, n_round=6):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     sys.path.insert(0, ROOT)
@@ -160,7 +160,7 @@ def _exchange_worker(rank, world, port, out_dir):
     rep = pkg.replicas
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        per_rank, n_atom = 4, 6
+        n_atom = 6
         n = per_rank * world
         rs = np.random.RandomState(11)
         all_pos = rs.randn(n, n_atom, 3).astype('f4')
@@ -169,11 +169,13 @@ def _exchange_worker(rank, world, port, out_dir):
         ens = _FakeEnsemble(all_pos[lo:hi])
         ens2 = _FakeEnsemble(all_pos[lo:hi])                 # one energy evaluation per attempt, energies traded between sets
         ref = _FakeEnsemble(all_pos)                         # the same run in one process
-        for round_num in range(6):
+        n_cross = 0
+        for round_num in range(n_round):
             draw = draw_ref = draw2 = 0
             energy = rep.all_gather_f32(dist, ens2.energies())
-            for pairs in rep.neighbour_swap_sets(n):         # set 1 has the cross-rank pair (3,4)
+            for pairs in rep.neighbour_swap_sets(n):         # the second set has the cross-rank pairs (per_rank - 1, per_rank), ...
                 acc, draw = rep.exchange_swap_set(dist, ens, pairs, beta, 5, round_num, draw)
+                n_cross += sum(1 for (a, b), ok in zip(pairs, acc) if ok and a // per_rank != b // per_rank)
                 acc_ref, draw_ref = rep.exchange_swap_set(None, ref, pairs, beta, 5, round_num, draw_ref)
                 acc2, draw2 = rep.exchange_swap_set(dist, ens2, pairs, beta, 5, round_num, draw2, energy_global=energy)
                 energy = rep.swap_energies(energy, pairs, acc2)
@@ -185,6 +187,8 @@ def _exchange_worker(rank, world, port, out_dir):
         moved = not np.array_equal(ref.pos, all_pos)
         with open(os.path.join(out_dir, 'x%d' % rank), 'w') as f:
             f.write('%d' % moved)
+        with open(os.path.join(out_dir, 'c%d' % rank), 'w') as f:
+            f.write('%d' % n_cross)
     finally:
         dist.destroy_process_group()
 
@@ -193,3 +197,20 @@ def test_two_rank_replica_exchange(tmp_path):
     world = 2
     mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert [open(os.path.join(str(tmp_path), 'x%d' % r)).read() for r in range(world)] == ['1', '1']
+
+
+def test_eight_rank_remd64_plan_equals_single_process(tmp_path):
+    """BASELINE configs[3] as it is placed on an 8-GPU node: 64 temperatures, 8 per rank, so the second swap set of
+    every attempt has 7 pairs that straddle a rank boundary.  Eight gloo ranks must reproduce the single-process exchange frame for
+    frame -- verdicts, generator position, coordinates after every set, and the traded energies of the one-evaluation form -- and
+    accepted cross-rank swaps must actually occur."""
+    world, per_rank = 8, 8
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), per_rank, 8), nprocs=world, join=True)
+    assert [open(os.path.join(str(tmp_path), 'x%d' % r)).read() for r in range(world)] == ['1'] * world
+    crossed = [int(open(os.path.join(str(tmp_path), 'c%d' % r)).read()) for r in range(world)]
+    assert len(set(crossed)) == 1 and crossed[0] > 0, crossed      # every rank saw the same accepted cross-rank swaps, and there were some
+    from __graft_entry__ import load_package
+    rep = load_package().replicas
+    sets = rep.neighbour_swap_sets(world * per_rank)
+    assert sum(1 for a, b in sets[0] if a // per_rank != b // per_rank) == 0
+    assert sum(1 for a, b in sets[1] if a // per_rank != b // per_rank) == world - 1

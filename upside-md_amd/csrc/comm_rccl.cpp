@@ -16,6 +16,8 @@
 #include "engine.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,8 +42,16 @@ Rccl& rccl() {
     static Rccl r;
     if (r.lib) return r;
     // UPSIDE_HIP_COMM_LIB names another library with the same nine entry points (tests: tests/plugin/libshmccl.so runs
-    // two ranks on one GPU, which RCCL cannot)
-    if (const char* over = getenv("UPSIDE_HIP_COMM_LIB")) {
+    // two ranks on one GPU, which RCCL cannot).  A TEST seam: honoured only together with UPSIDE_HIP_TESTING=1, so that a stray
+    // variable in a production environment cannot make the library load arbitrary code in RCCL's place.
+    const char* over = getenv("UPSIDE_HIP_COMM_LIB");
+    const char* testing = getenv("UPSIDE_HIP_TESTING");
+    if (over && !(testing && atoi(testing) == 1)) {
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "upside_hip: UPSIDE_HIP_COMM_LIB is ignored without UPSIDE_HIP_TESTING=1 (using RCCL)\n"); }
+        over = nullptr;
+    }
+    if (over) {
         r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) throw string("cannot load UPSIDE_HIP_COMM_LIB=") + over + ": " + dlerror();
     } else {

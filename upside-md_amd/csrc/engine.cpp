@@ -19,7 +19,21 @@ void hip_check(hipError_t e, const char* what) {
 }
 void upk_check(int code, const char* what) {
     if (code == 0) return;
-    if (code >= 9000) throw string("kernel launcher ") + what + " rejected its arguments (code " + to_string(code) + ")";
+    if (code >= 9000) {
+        const char* why = "";
+        switch (code) {      // (the codes of the launchers in kernels_*.hip)
+            case 9003: why = ": more than 1024 rotamer nodes"; break;
+            case 9004: case 9005: case 9006: why = ": the system does not fit the 160 KB of LDS this kernel stages it in"; break;
+            case 9007: case 9008: why = ": side / mode / interaction type outside what the launcher implements"; break;
+            case 9009: why = ": more than 65535 rows (row ids are 16 bits wide)"; break;
+            case 9010: why = ": the graph's pair lists were allocated with another word width than its kernels read (upk_igraph_t::word16: 16-bit element "
+                             "indices for every graph but the rotamer's, <= 65534 elements per side)"; break;
+            case 9011: why = ": the hit-list refine exists for the side-chain graph (symmetric, 32-bit words) and for two-sided graphs with 16-bit words; "
+                             "a symmetric radial graph walks its cached lists and has no hit lists"; break;
+            default: break;
+        }
+        throw string("kernel launcher ") + what + " rejected its arguments (code " + to_string(code) + ")" + why;
+    }
     throw string("HIP launch failure in ") + what + ": " + hipGetErrorString((hipError_t)code);
 }
 
@@ -709,6 +723,9 @@ void DerivEngine::check_device_errors() {
                          "to use the one-workgroup solve");
         if (f[0] == 8)   // kernels_rotamer.hip: RotGradOp2::flush
             throw string("side-chain gradient: a bead's gradient is not finite (NaN or overflow in the pair pass): the forces of this step are not valid");
+        if (f[0] == 9)   // kernels_rotamer.hip: k_rotamer_bp, layout of the message inbox
+            throw string("belief propagation: 3-float message rows were laid out for a solve that does not hold its inbox in LDS (internal error): "
+                         "the forces of this step are not valid");
         if (f[0] == 4)   // kernels_basic.hip: c_backbone_pairs
             throw string("backbone sterics: a residue has more neighbours within cutoff + skin than its cached row holds: raise "
                          "UPSIDE_HIP_BACKBONE_LIST_CAP (default 128) or set UPSIDE_HIP_BACKBONE_LIST=0");

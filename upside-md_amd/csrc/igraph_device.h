@@ -341,6 +341,9 @@ __device__ __forceinline__ float group_sum(float v) {
 // first half, rows `cap` words apart.  upk_igraph_t::word16 says which (set by the host: itype != UPK_IT_ROTAMER).
 template <int IT> struct list_word { typedef unsigned short type; };
 template <> struct list_word<UPK_IT_ROTAMER> { typedef int type; };
+// host side: the word width the device templates will read (list_word<IT>) against what the host allocated (upk_igraph_t::word16): a mismatch
+// would reinterpret the lists silently -- the launchers of the build, refine and pair kernels refuse it (code 9010)
+static inline bool list_words_match(const upk_igraph_t* G) { return (G->word16 != 0) == (G->itype != UPK_IT_ROTAMER); }
 __device__ __forceinline__ int list_word_at(const int* lists, size_t idx, int word16) {
     return word16 ? (int)((const unsigned short*)lists)[idx] : lists[idx];
 }

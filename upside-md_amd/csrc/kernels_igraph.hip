@@ -317,6 +317,7 @@ static void plb_launch(const upk_launch_t* L, const upk_igraph_t* G, dim3 grid, 
 }
 extern "C" int upk_pairlist_build(const upk_launch_t* L, const upk_igraph_t* G) { return upk_pairlist_build_sides(L, G, 3); }
 extern "C" int upk_pairlist_build_sides(const upk_launch_t* L, const upk_igraph_t* G, int sides) {
+    if (!list_words_match(G)) return 9010;
     const int rows = plb_rows(L->n_system);
     const int blocks1 = (sides & 1) ? (G->n1 + rows - 1) / rows : 0;
     const int blocks2 = (G->symmetric || !(sides & 2)) ? 0 : (G->n2 + rows - 1) / rows;
@@ -504,7 +505,8 @@ extern "C" int upk_pairlist_refine(const upk_launch_t* L, const upk_igraph_t* G,
         hipLaunchKernelGGL(k_pairlist_refine_short, dim3((n_rows + 255) / 256, L->n_system), dim3(256), 0, ST(L), *G, side);
         return launch_status();
     }
-    if ((G->symmetric != 0) == (G->word16 != 0)) return 9007;   // the two list forms there are: the rotamer graph's (symmetric, 32-bit words) and everyone else's
+    if (!list_words_match(G)) return 9010;
+    if ((G->symmetric != 0) == (G->word16 != 0)) return 9011;   // the two list forms there are: the rotamer graph's (symmetric, 32-bit words) and everyone else's
     const size_t lds = (size_t)((n_other > 0 ? n_other : 0) + 1) * 16;
     if (lds > 150 * 1024) return 9006;   // (callers fall back to the list-walking kernels long before this)
     // every workgroup stages the other side again: few fat workgroups for a large batch, many small ones for a small one

@@ -564,6 +564,7 @@ extern "C" int upk_igraph_rows(const upk_launch_t* L, const upk_igraph_t* G, int
                                int out_stride, int out_comp, int out_row0, int out_row0_2, float* own_grad, int sens_mode,
                                const float* sens1, const float* sens2, long sens_sys_stride, int sens_stride) {
     if (side < 1 || side > 3 || mode < 0 || mode > 2 || (mode == 1 && (!own_grad || side == 3))) return 9007;
+    if (!list_words_match(G)) return 9010;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.out = out; A.out_sys_stride = out_sys_stride; A.out_stride = out_stride; A.out_comp = out_comp;
     A.out_row0 = side == 2 ? 0 : out_row0; A.out_row0_2 = side == 2 ? out_row0 : out_row0_2;
@@ -632,6 +633,7 @@ static int finish_alone(const upk_launch_t* L, const upk_igraph_t* G, int n_othe
 extern "C" int upk_igraph_backward(const upk_launch_t* L, const upk_igraph_t* G, int row_side, int sens_mode, const float* sens1,
                                    const float* sens2, long sens_sys_stride, int sens_stride) {
     if (row_side != 1 && row_side != 2) return 9007;
+    if (!list_words_match(G)) return 9010;
     PairArgs A; memset(&A, 0, sizeof(A));
     A.sens_mode = sens_mode; A.sens1 = sens1; A.sens2 = sens2; A.sens_sys_stride = sens_sys_stride; A.sens_stride = sens_stride;
     const int n_rows = row_side == 1 ? G->n1 : G->n2, n_other = row_side == 1 ? G->n2 : G->n1;

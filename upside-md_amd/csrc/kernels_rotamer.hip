@@ -658,6 +658,7 @@ static int rot_geometry(const upk_launch_t* L, const upk_rotamer_t* R, bool want
     return staged;
 }
 extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_t* R) {
+    if (!list_words_match(&R->G)) return 9010;
     UPK_FLUSH(L);
     int tab_floats; size_t lds; dim3 grid, block;
     static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
@@ -793,6 +794,7 @@ __global__ void k_rotamer_grad_finish(upk_rotamer_t R, double unit) {   // unit:
 }
 
 extern "C" int upk_rotamer_grad(const upk_launch_t* L, const upk_rotamer_t* R) {
+    if (!list_words_match(&R->G)) return 9010;
     UPK_FLUSH(L);
     int tab_floats; size_t lds; dim3 grid, block;
     const double unit32 = 1.0 / 4294967296.0, unit22 = 1.0 / (double)(1 << P2_FIX_BITS);
@@ -1492,8 +1494,11 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     {
         constexpr int W6 = COMPACT ? 6 : 8;
         int n = lds_msg_floats < inbox_floats ? lds_msg_floats : inbox_floats;
-        if (n > inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / w3) * w3;
+        // (n == inbox_floats3 keeps the padding float behind an odd number of 3-float rows: with no row to a 6-state node the truncation
+        //  to whole rows would otherwise leave lds_floats one short of the inbox and send 3-float rows into the 4-float solve)
+        if (n >= inbox_floats3) n = inbox_floats3 + ((n - inbox_floats3) / W6) * W6; else n = (n / w3) * w3;
         C.lds_floats = n;
+        if (COMPACT && w3 == 3 && n < inbox_floats && tid == 0) *R.G.error_flag = 9;   // (cannot happen: 3-float rows are chosen only when the inbox then fits LDS)
     }
     __syncthreads();       // (bp_start holds float offsets now; the scratch of the compact layout is dead)
     BP_STAMP(1);

@@ -385,7 +385,10 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         // how far apart the ranks of one launch may start) -- what a crashed earlier attempt left behind is older than that.
         struct Record { char id[UPSIDE_HIP_COMM_ID_BYTES]; unsigned long long nonce; long long stamp; } rec;
         memset(&rec, 0, sizeof(rec));
-        const long long skew_s = getenv("UPSIDE_HIP_COMM_SKEW_S") ? max(0, atoi(getenv("UPSIDE_HIP_COMM_SKEW_S"))) : 20;
+        // (default = the wait window below: a rank that starts late -- a staggered multi-node launch -- or whose node clock lags still accepts
+        //  rank 0's record for as long as rank 0 waits for it)
+        const int wait_s = getenv("UPSIDE_HIP_COMM_WAIT_S") ? max(1, atoi(getenv("UPSIDE_HIP_COMM_WAIT_S"))) : 120;
+        const long long skew_s = getenv("UPSIDE_HIP_COMM_SKEW_S") ? max(0, atoi(getenv("UPSIDE_HIP_COMM_SKEW_S"))) : wait_s;
         if (rank == 0) {
             remove(path.c_str());                                   // a stale record of an earlier attempt under this name
             if (upside_hip_comm_get_unique_id(rec.id)) throw string(upside_hip_last_error());
@@ -397,7 +400,6 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             if (rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw string("cannot publish ") + path; }
         } else {
             bool got = false;
-            const int wait_s = getenv("UPSIDE_HIP_COMM_WAIT_S") ? max(1, atoi(getenv("UPSIDE_HIP_COMM_WAIT_S"))) : 120;
             for (int tries = 0; tries < wait_s * 10 && !got; ++tries) {
                 FILE* f = fopen(path.c_str(), "rb");
                 if (f) { got = fread(&rec, 1, sizeof(rec), f) == sizeof(rec); fclose(f); }
@@ -406,7 +408,9 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
                 if (!got) this_thread::sleep_for(chrono::milliseconds(100));
             }
             if (!got) throw string("no communicator id of this launch at ") + path + " (is rank 0 running?  a multi-node job needs UPSIDE_HIP_COMM_FILE on a "
-                                   "shared file system and either a launcher that exports MASTER_ADDR / MASTER_PORT or UPSIDE_HIP_COMM_NONCE)";
+                                   "shared file system and either a launcher that exports MASTER_ADDR / MASTER_PORT or UPSIDE_HIP_COMM_NONCE; a record older than this "
+                                   "rank's start by more than UPSIDE_HIP_COMM_SKEW_S = " + to_string(skew_s) + " s -- late start or clock skew between nodes -- is ignored; "
+                                   "waited UPSIDE_HIP_COMM_WAIT_S = " + to_string(wait_s) + " s)";
         }
         if (upside_hip_comm_init(e, rank, world, rec.id, temps_global.data())) throw string(upside_hip_last_error());
         if (rank == 0) remove(path.c_str());                         // (ncclCommInitRank returns when every rank has joined)
