@@ -37,7 +37,10 @@ FIXTURES = {
     'syn300_7A': (300, '7A', 'ff_1/sidechain.h5', 22.0, 14, False),
 }
 
-WELL_CONDITIONED = {'syn150_10A'}      # fixtures chosen among the relaxed frames of the compaction run (see make())
+# fixtures chosen among the relaxed frames of the compaction run (see make()): round 3 did it for syn150_10A, round 6 for the two whose
+# forces the reference reproduced between its own builds only to 1.1e-5 / 1.4e-5 (tests/golden/reference_noise_floor.json)
+WELL_CONDITIONED = {'syn150_10A', 'proteinG56_7A', 'syn300_7A'}
+FLOOR_WANTED = 4e-6     # reference -O1 against reference -O3 -ffast-math, relative RMS of the forces
 
 NODES = ['rama_coord', 'affine_alignment', 'infer_H_O', 'placement_fixed_point_vector_only',
          'placement_fixed_point_vector_only_CB', 'placement_fixed_point_vector_scalar', 'placement_scalar',
@@ -228,7 +231,7 @@ def make(name):
                 floor = float(np.sqrt(((d[0] - d[1]) ** 2).sum() / (d[0] ** 2).sum()))
                 cand.append((k, rg(x), floor))
             os.remove(probe)
-            good = [c for c in cand if c[2] < 4e-6] or [min(cand, key=lambda c: c[2])]
+            good = [c for c in cand if c[2] < FLOOR_WANTED] or [min(cand, key=lambda c: c[2])]
             k, r, fl = max(good, key=lambda c: c[1])
             print('%s: frame %d of %d (t = %g): Rg %.2f, reference-vs-reference force deviation %.1e; %d of %d relaxed frames below 4e-6, median %.1e'
                   % (name, k, len(frames), 2. * k, r, fl, len([c for c in cand if c[2] < 4e-6]), len(cand), float(np.median([c[2] for c in cand]))))
@@ -266,12 +269,30 @@ def make(name):
         em = up.get_value_by_name((n_node, n_node, 6, 6), 'rotamer', 'edge_marginal_in_graph_order')
         g['rotamer/node_marginal'] = np.stack([em[i, i].diagonal() for i in range(n_node)])
     g.update(param_derivs(up, out))
-    # a second, perturbed evaluation through the cached pair list (no rebuild)
-    rs = np.random.RandomState(seed + 100)
-    x2 = (x + 0.05 * rs.normal(size=x.shape)).astype('f4')
+    # a second, perturbed evaluation through the cached pair list (no rebuild).  The perturbation is the first of the seeds
+    # seed + 100, seed + 101, ... on which the reference agrees with itself (its -O1 build, tools/build_ref_O1.sh) within FLOOR_WANTED:
+    # 0.05 A of noise on every atom can push a steric wall or a clamped spline end into a spot where fp32 evaluation orders differ by 1e-5
+    o1_path = '/tmp/refO1_%s/libupside_O1.so' % variant
+    up1 = pkg.Upside(out, library=pkg.UpsideLibrary(o1_path)) if os.path.exists(o1_path) else None
+    best = None
+    for k in range(12):
+        rs = np.random.RandomState(seed + 100 + k)
+        x2 = (x + 0.05 * rs.normal(size=x.shape)).astype('f4')
+        up.energy(x)                                   # (the cached list is built at the first structure every time)
+        e2 = np.float32(up.energy(x2)); d2 = up.deriv(x2)
+        if up1 is None:
+            best = (0., k, x2, e2, d2); break
+        up1.energy(x); up1.energy(x2); d1 = up1.deriv(x2)
+        floor = float(np.sqrt(((d2 - d1) ** 2).sum() / (d2 ** 2).sum()))
+        if best is None or floor < best[0]: best = (floor, k, x2, e2, d2)
+        if floor < FLOOR_WANTED: break
+    floor, k, x2, e2, d2 = best
+    print('   second structure: perturbation seed %d + %d, reference-vs-reference force deviation %.1e' % (seed + 100, k, floor))
     g['pos2'] = x2
-    g['energy2'] = np.float32(up.energy(x2))
-    g['deriv2'] = up.deriv(x2)
+    g['pos2_seed'] = np.int32(seed + 100 + k)
+    g['energy2'] = e2
+    g['deriv2'] = d2
+    if up1 is not None: up1.close()
     up.close()
 
     # pair list (rotamer graph), both passes

@@ -317,11 +317,12 @@ __device__ __forceinline__ PairLds pair2_lds(float* lds, const upk_igraph_t& G, 
     return L;
 }
 // value of two hbond_coverage pairs (hbond.cpp:261-276) and, if WANT_D, the derivatives: d1[0..7) w.r.t. the sites, d2[0..6) w.r.t. the beads
+// (o1 / o2: the elements' shares of the table row's offset in floats, staged in place of their types -- site: type1 * n_type2 * row length,
+//  bead: type2 * row length, d_cov_rows2 / d_cov_backward2)
 template <bool WANT_D, bool POLY>
-__device__ __forceinline__ v2 coverage_pair2(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int t1A, int t1B, int t2A, int t2B,
+__device__ __forceinline__ v2 coverage_pair2(const upk_igraph_t& G, const QuadShape& Q, const float* tab, int o1A, int o1B, int o2A, int o2B,
                                              const v2* x1, v2 hb1, const v2* x2, v2* d1, v2* d2) {
-    const int n = POLY ? G.n_poly : G.n_param;
-    const float* pA = tab + (t1A * G.n_type2 + t2A) * n; const float* pB = tab + (t1B * G.n_type2 + t2B) * n;
+    const float* pA = tab + (o1A + o2A); const float* pB = tab + (o1B + o2B);
     const int o2 = POLY ? 4 * (Q.ka - 3) : Q.ka;
     v2 dd[3], g1[3], g2[3];
     const v2 coverage = quadspline_pair2<WANT_D, POLY>(Q, pA, pB, x1, x2, dd, g1, g2, 0, o2, 0, o2);
@@ -368,8 +369,9 @@ __device__ __forceinline__ void d_cov_rows2(const upk_igraph_t& G, const PairArg
         const int s = B.by;
     const PairLds L = pair2_lds(lds, G, A.tab_floats);
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
-    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0));
-    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, nullptr, 0, 0.f, __int_as_float(0));
+    const int row_len = POLY ? G.n_poly : G.n_param;
+    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0), G.n_type2 * row_len);
+    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, nullptr, 0, 0.f, __int_as_float(0), row_len);
     if (threadIdx.x == 0) *L.counter = 0;
     const int n_rows = RS == 1 ? G.n1 : G.n2, cap = RS == 1 ? G.cap1 : G.cap2;
     stage_ranges(L.range, L.ord, (RS == 1 ? G.hcnt1 : G.hcnt2) + (size_t)s * n_rows, nullptr, (RS == 1 ? G.ord1 : G.ord2) + (size_t)s * n_rows, n_rows);
@@ -462,8 +464,9 @@ __device__ __forceinline__ void d_cov_backward2(const upk_igraph_t& G, const Pai
     const float* S1 = A.sens1 ? A.sens1 + (size_t)s * A.sens_sys_stride : nullptr;
     const float* S2 = A.sens2 ? A.sens2 + (size_t)s * A.sens_sys_stride : nullptr;
     stage_table(L.tab, POLY ? G.param_poly : G.param, A.tab_floats);
-    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0));
-    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, S2, A.sens_stride, 0.f, __int_as_float(0));
+    const int row_len = POLY ? G.n_poly : G.n_param;
+    stage_rows_planes(L.c1, G.node1, s, G.loc1, G.n1, G.dim1, G.type1, nullptr, nullptr, 0, 0.f, __int_as_float(0), G.n_type2 * row_len);
+    stage_rows_planes(L.c2, G.node2, s, G.loc2, G.n2, G.dim2, G.type2, nullptr, S2, A.sens_stride, 0.f, __int_as_float(0), row_len);
     if (S1) for (int t = threadIdx.x; t < G.n1; t += blockDim.x) site_sens[t] = S1[(size_t)t * A.sens_stride];
     for (int t = threadIdx.x; t < n_other * DO; t += blockDim.x) oacc[t] = 0ull;
     if (threadIdx.x == 0) *L.counter = 0;

@@ -57,9 +57,11 @@ __device__ __forceinline__ void lds_add_fixed22(unsigned long long* p, float v) 
 // A ds_read_b128 is served in lane groups of 16, one 16-byte slot of the 256-byte bank row per lane: with 32-byte rows the
 // first halves of all rows share the 8 even slots (>= 2-way conflicts for any 16 partners), with 16-byte planes row j sits in
 // slot j mod 16 and the consecutive partners a row group reads are conflict free.
+// meta1_mul: the staged word is meta1[i] * meta1_mul (the coverage passes stage an element's share of its table row's OFFSET instead of its
+// type: the row of a pair is then one addition, not a multiply-add and a multiply per pair)
 __device__ __forceinline__ void stage_rows_planes(float* lds, const upk_coord_t& node, int s, const int* __restrict__ loc, int n, int dim,
                                                   const int* __restrict__ meta1, const int* __restrict__ meta0,
-                                                  const float* __restrict__ sens, int sens_stride, float sentinel6, float sentinel7) {
+                                                  const float* __restrict__ sens, int sens_stride, float sentinel6, float sentinel7, int meta1_mul = 1) {
     const float* base = node.out + (size_t)s * node.n_elem * node.stride;
     const int np = n + 1;
     // one lane per ELEMENT: its row index and metadata in one round of loads, its row as one or two 16-byte loads, two 16-byte LDS stores.
@@ -71,7 +73,7 @@ __device__ __forceinline__ void stage_rows_planes(float* lds, const upk_coord_t&
             if (i == n) { v[0] = v[1] = v[2] = 1.0e4f; v[3] = 1.f; v[6] = sentinel6; v[7] = sentinel7; }
             else {
                 const int l = loc[i];
-                const int m1 = meta1 ? meta1[i] : 0, m0 = meta0 ? meta0[i] : 0;
+                const int m1 = meta1 ? meta1[i] * meta1_mul : 0, m0 = meta0 ? meta0[i] : 0;
                 const float sv = sens ? sens[(size_t)i * sens_stride] : 0.f;
                 const float4* row = (const float4*)(base + (size_t)l * node.stride);
                 const float4 r0 = row[0];
@@ -93,7 +95,7 @@ __device__ __forceinline__ void stage_rows_planes(float* lds, const upk_coord_t&
         float v = 0.f;
         if (i == n) v = c < 3 ? 1.0e4f : (c == 3 ? 1.f : (c == 6 ? sentinel6 : (c == 7 ? sentinel7 : 0.f)));
         else if (c < dim) v = base[(size_t)loc[i] * node.stride + c];
-        else if (c == 7 && meta1) v = __int_as_float(meta1[i]);
+        else if (c == 7 && meta1) v = __int_as_float(meta1[i] * meta1_mul);
         else if (c == 6 && sens) v = sens[(size_t)i * sens_stride];
         else if (c == 6 && meta0) v = __int_as_float(meta0[i]);
         lds[(c >> 2) * np * 4 + i * 4 + (c & 3)] = v;
@@ -116,6 +118,27 @@ __device__ __forceinline__ void cubic2(const float* cA, const float* cB, v2 y, v
 __device__ __forceinline__ v2 cubic2_value(const float* cA, const float* cB, v2 y) {
     const float4 a = *(const float4*)cA, b = *(const float4*)cB;
     return fma2(fma2(fma2(mk2(a.w, b.w), y, mk2(a.z, b.z)), y, mk2(a.y, b.y)), y, mk2(a.x, b.x));
+}
+// value of one cubic piece for ONE pair, plain Horner on the registers the 16-byte read filled: 3 FMAs and no packing move.  (A packed
+// evaluation of two pairs is 3 v_pk_fma_f32 plus the 6-7 moves that interleave the two pieces' coefficients into register pairs, and a
+// wave64 VALU instruction holds its SIMD for one quad-cycle whether it is packed or a move: the value-only passes evaluate per pair;
+// the passes with derivatives keep cubic2, whose five packed FMAs per two pairs outweigh the moves.)
+// (The FMAs are written as instructions: left as fmaf() calls, the SLP vectoriser pairs the Horner steps of the two pairs a lane evaluates
+//  back into v_pk_fma_f32 behind eight moves -- 246 instead of 230 vector instructions per trip of the coverage forward pass.)
+__device__ __forceinline__ float fma_one(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float cubic1_value(const float* c4, float y) {
+    const float4 c = *(const float4*)c4;
+    return fma_one(fma_one(fma_one(c.w, y, c.z), y, c.y), y, c.x);
+}
+// knot interval i and offset y in [0, 1) of a spline coordinate x clamped to [0, hi]: v_med3_f32, v_cvt_i32_f32 (truncation = floor for
+// x >= 0), v_fract_f32 -- three instructions where (int)x, max, min, (float)i and x - i are four and a half.  hi is the last
+// representable coordinate inside the last interval (angular splines: |cos| may pass 1 by an ulp, which the integer clamp answered by
+// extrapolating the end piece by that ulp; here the coordinate stops an ulp short of the last knot -- the cubic is continuous, the
+// difference is O(1e-7) of the slope) or anywhere inside the constant end piece (radial splines).
+__device__ __forceinline__ float spline_interval(float x, float hi, int& i) {
+    const float xc = __builtin_amdgcn_fmed3f(x, 0.f, hi);
+    i = (int)xc;
+    return __builtin_amdgcn_fractf(xc);
 }
 // the four basis polynomials of a uniform cubic B-spline and their slopes, for two pairs (igraph_device.h: bspline_basis)
 __device__ __forceinline__ void bspline_basis2(v2 y, v2 b[4], v2 d[4]) {
@@ -157,11 +180,13 @@ __device__ __forceinline__ v2 quadspline_pair2(const QuadShape& Q, const float* 
     if constexpr (POLY) {
         const v2 xa = fma2(cos1, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta));    // (cos1 + 1) inv_dtheta
         const v2 xb = fma2(-ncos2, bc2(Q.inv_dtheta), bc2(Q.inv_dtheta));
-        const int iaA = min(max((int)xa.x, 0), Q.ka - 4), iaB = min(max((int)xa.y, 0), Q.ka - 4);
-        const int ibA = min(max((int)xb.x, 0), Q.ka - 4), ibB = min(max((int)xb.y, 0), Q.ka - 4);
-        const int irA = min((int)dist_coord.x, Q.k - 2), irB = min((int)dist_coord.y, Q.k - 2);
-        const v2 ya = xa - mk2((float)iaA, (float)iaB), yb = xb - mk2((float)ibA, (float)ibB);
-        const v2 yr = dist_coord - mk2((float)irA, (float)irB);
+        // last coordinate inside the last angular interval (ka - 3 intervals), any coordinate inside the constant radial end piece k - 2
+        const float hi_a = __uint_as_float(__float_as_uint((float)(Q.ka - 3)) - 1u), hi_r = (float)(Q.k - 2) + 0.5f;
+        int iaA, iaB, ibA, ibB, irA, irB;
+        const float yaA = spline_interval(xa.x, hi_a, iaA), yaB = spline_interval(xa.y, hi_a, iaB);
+        const float ybA = spline_interval(xb.x, hi_a, ibA), ybB = spline_interval(xb.y, hi_a, ibB);
+        const float yrA = spline_interval(dist_coord.x, hi_r, irA), yrB = spline_interval(dist_coord.y, hi_r, irB);
+        const v2 ya = mk2(yaA, yaB), yb = mk2(ybA, ybB), yr = mk2(yrA, yrB);
         const float* rA = pA + 8 * (Q.ka - 3) + 8 * irA; const float* rB = pB + 8 * (Q.ka - 3) + 8 * irB;
         if (WANT_D) {
             cubic2(pA + off1A + 4 * iaA, pB + off1B + 4 * iaB, ya, a1, da1);
@@ -169,10 +194,11 @@ __device__ __forceinline__ v2 quadspline_pair2(const QuadShape& Q, const float* 
             cubic2(rA, rB, yr, wide, dwide);
             cubic2(rA + 4, rB + 4, yr, narrow, dnarrow);
         } else {
-            a1 = cubic2_value(pA + off1A + 4 * iaA, pB + off1B + 4 * iaB, ya);
-            a2 = cubic2_value(pA + off2A + 4 * ibA, pB + off2B + 4 * ibB, yb);
-            wide = cubic2_value(rA, rB, yr);
-            narrow = cubic2_value(rA + 4, rB + 4, yr);
+            // value only: each pair on its own registers (cubic1_value), the two results land in a register pair for free
+            a1 = mk2(cubic1_value(pA + off1A + 4 * iaA, ya.x), cubic1_value(pB + off1B + 4 * iaB, ya.y));
+            a2 = mk2(cubic1_value(pA + off2A + 4 * ibA, yb.x), cubic1_value(pB + off2B + 4 * ibB, yb.y));
+            wide = mk2(cubic1_value(rA, yr.x), cubic1_value(rB, yr.y));
+            narrow = mk2(cubic1_value(rA + 4, yr.x), cubic1_value(rB + 4, yr.y));
         }
     } else {
         v2 b[4], db[4];
