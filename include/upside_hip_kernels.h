@@ -310,6 +310,9 @@ typedef struct {
     int* n_bad;                          /* [S] solves that ran into max_iter (rotamer.cpp:784-785), counted on the device */
     int* bp_rec;                         /* [S][slot_cap][4] scratch of the one-workgroup solve: per class, the slots active this step
                                             packed as {offset a, offset b, node a | node b << 16, slot} */
+    int* bp_layout;                      /* [S][n_node + 8] the dense inbox layout of the last solve when k_rotamer_bp_layout computes it in front of the
+                                            one-workgroup solve (first float of every node, active slots per class, inbox sizes, row width); NULL:
+                                            the solve lays its inbox out itself (small batches) */
     long long* bp_trace;                 /* [S][32] 100 MHz phase clocks of the last solve ([16..24): sub-phase stamps), or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */

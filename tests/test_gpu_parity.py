@@ -652,8 +652,6 @@ ALT_PATHS = [
     {'UPSIDE_HIP_IG_POLY': '0'},             # coverage pair passes on the spline-coefficient table (tables too large for the polynomial form)
     {'UPSIDE_HIP_ROT_SORT_BEADS': '0'},      # side-chain beads in the configuration's own order (no renumbering by pair-matrix node)
     {'UPSIDE_HIP_ROT_POLY': '0'},            # side-chain energy pass on the spline-coefficient table (tables too large for the polynomial form)
-    {'UPSIDE_HIP_UPKEEP_STREAMS': '1', 'UPSIDE_HIP_BATCH': '0'},      # one shared upkeep stream instead of one per graph
-    {'UPSIDE_HIP_UPKEEP_STREAMS': '0', 'UPSIDE_HIP_BATCH': '0'},      # one upkeep stream per graph (the default above 16 systems) at one system
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_COMPACT': '0'},       # one-workgroup BP of 1024 lanes streaming every pair matrix over the cached inbox layout
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
@@ -673,7 +671,6 @@ ALT_PATHS = [
     {'UPSIDE_HIP_SLOT_SPLIT': '1'},          # slot numbering by one workgroup per system (the large-batch choice)
     {'UPSIDE_HIP_SLOT_SPLIT': '3'},          # ... and by three
     {'UPSIDE_HIP_PAIR2': '0'},               # scalar (one partner per lane) forms of the side-chain gradient and coverage passes
-    {'UPSIDE_HIP_PAIR2_ENERGY': '1'},        # packed form of the side-chain energy pass
 ]
 
 
@@ -799,6 +796,36 @@ def _read_output(path):
     with h5lite.open_file(path) as f:
         out = f.group('output')
         return {k: out.read(k) for k in out.keys()}, out.get_attr('invocation') if out.has_attr('invocation') else None
+
+
+def test_upside_main_potential_deriv_agreement_matches_reference(tmp_path):
+    """--potential-deriv-agreement (the reference's finite-difference self-check, /root/reference/src/main.cpp:279-315, 368-372, 506-513):
+    the executable prints every potential term of the initial structure and the relative RMS deviation of the analytic derivative from
+    central differences of the total potential; same terms and (to the noise of an fp32 difference quotient) the same figure as the
+    unmodified reference executable on the same file"""
+    import re
+    import shutil
+    import subprocess
+    ref_exe = os.path.join(P.ROOT, 'oracle', '_ref', 'upside_7A')
+    exe = os.path.join(P.ROOT, 'upside-md_amd', 'csrc', 'upside_hip')
+    if not os.path.exists(ref_exe) or not os.path.exists(exe):
+        pytest.skip('executables not built')
+    a = str(tmp_path / 'ref.up'); b = str(tmp_path / 'hip.up')
+    shutil.copyfile(P.fixture('trpcage20_7A'), a); shutil.copyfile(P.fixture('trpcage20_7A'), b)
+    args = ['--duration', '0.05', '--frame-interval', '0.05', '--temperature', '0.8', '--seed', '1', '--potential-deriv-agreement']
+    out = {}
+    for tag, cmd in (('ref', [ref_exe] + args + [a]), ('hip', [exe] + args + [b])):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        txt = r.stdout.decode()
+        err = float(re.search(r'overall potential relative error:\s+([0-9.eE+-]+)', txt).group(1))
+        block = txt.split('Initial potential:')[1].split('overall potential')[0]
+        terms = dict((m.group(1), float(m.group(2))) for m in re.finditer(r'^(\w+):\s+(-?[0-9.]+)\s*$', block, re.M))
+        out[tag] = (err, terms)
+    assert set(out['ref'][1]) == set(out['hip'][1]) and len(out['ref'][1]) >= 9, (out['ref'][1], out['hip'][1])
+    for k, v in out['ref'][1].items():
+        assert abs(out['hip'][1][k] - v) <= 2e-3 + 1e-4 * abs(v), (k, v, out['hip'][1][k])
+    assert out['hip'][0] < 2e-3 and abs(out['hip'][0] - out['ref'][0]) < 5e-4, (out['hip'][0], out['ref'][0])
 
 
 def test_upside_main_output_matches_reference(hip, tmp_path):
@@ -998,8 +1025,11 @@ def test_bench_contract(tmp_path):
     r = d['roofline']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['achieved'] > 0 and 'igraph' in r and r['igraph']['achieved'] > 0 and r['igraph']['unit'] == 'TFLOP/s'
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s'
+    # (a fraction is printed only when it is one: a model rate above the HBM peak -- bytes served on chip -- is withheld, never shown as > 1)
+    assert r['frac'] is None or (0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12), r
+    assert 'frac_range' not in r and (r.get('frac_model') is None or r['frac_model'] <= 1.0)
+    assert 'igraph' in r and r['igraph']['unit'] == 'GB/s' and r['igraph']['valu']['achieved'] > 0 and r['igraph']['valu']['unit'] == 'TFLOP/s'
     if r.get('kernel', '').startswith('bp:'):        # the solve's floor: active pair matrices in, marginals out (below the model's per-sweep re-reads)
         assert 0 < r['min_bytes_per_launch'] < r['algorithmic_bytes_per_launch']
     c = d['cpu_baseline']
@@ -1008,8 +1038,9 @@ def test_bench_contract(tmp_path):
     assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['host_cores_total'] >= c['cores']
     pc = d['parity_check']          # the timed engine itself against the oracle, behind the timed region
     assert pc['ok'] is True and pc['n'] == 3 and pc['max_rel_rms'] <= 1e-5 and pc['deriv_vs_one_system_engine'] <= 1e-6, pc
-    ig = r['igraph']
-    assert ig['bound'] == 'valu' and ig['target_frac'] == 0.5 and 0.3 < ig['hbm_frac_at_fp32_peak'] < 1.0, ig
+    ig = r['igraph']          # north_star's criterion as stated (HBM fraction, target 0.5); the arithmetic view beside it
+    assert ig['bound'] == 'hbm' and ig['target_frac'] == 0.5 and 'HBM' in ig['target_of'] and (ig['frac'] is None or 0 < ig['frac'] <= 1.0), ig
+    assert ig['valu']['bound'] == 'valu' and 0.3 < ig['valu']['hbm_frac_at_fp32_peak'] < 1.0, ig
 
 
 def test_bench_self_launch_two_ranks_on_one_gpu(tmp_path):

@@ -216,7 +216,9 @@ void check_arguments_length(const ArgList& a, int n) {
 }
 
 // ---- DerivEngine -----------------------------------------------------------------------------------
+static void warn_removed_switches();
 DerivEngine::DerivEngine(int n_atom, int n_system) {
+    warn_removed_switches();
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev < 1) throw string("no HIP device available (this library has no CPU fallback)");
@@ -433,14 +435,9 @@ void DerivEngine::finalize() {
         first.insert(first.end(), rest.begin(), rest.end());
         schedule.swap(first);
     }
-    // One upkeep stream per node (the rebuilds of different graphs run side by side), or ONE shared upkeep stream
-    // (UPSIDE_HIP_UPKEEP_STREAMS=1: the upkeep kernels then run in the order the main stream needs their results).  Round 3 shared
-    // the stream from 128 systems on (+1 % at 4096 then); since the per-element nodes are a dozen fused launches instead of forty
-    // small kernels that filled the gaps, one stream per graph wins at every size -- system-steps/s, shared vs per graph:
-    // 128 systems 86.6 vs 98.3 k, 256: 124.4 vs 138.8 k, 1024: 168.9 vs 177.0 k, 4096: 182.8 vs 188.7 k.
-    const char* env_streams = getenv("UPSIDE_HIP_UPKEEP_STREAMS");
-    const bool shared_stream = env_streams ? atoi(env_streams) == 1 : false;
-    hipStream_t shared = nullptr;
+    // One upkeep stream per node: the rebuilds of different graphs run side by side.  (A single shared upkeep stream was an option until
+    // round 6 -- UPSIDE_HIP_UPKEEP_STREAMS=1 -- and lost at every batch size since the per-element nodes became a dozen fused launches:
+    // 128 systems 86.6 vs 98.3 k, 256: 124.4 vs 138.8 k, 1024: 168.9 vs 177.0 k, 4096: 182.8 vs 188.7 k system-steps/s.)
     std::vector<Step> hoisted;
     std::vector<int> n_dep_left(nodes.size(), -1);
     for (size_t i = 0; i < nodes.size(); ++i) if (nodes[i].computation->has_prepare()) n_dep_left[i] = (int)deps_of[i].size();
@@ -459,10 +456,7 @@ void DerivEngine::finalize() {
         for (size_t c : ready) {
             Step ps{(int)c, false}; ps.prepare = true; hoisted.push_back(ps);
             Side sd;
-            if (shared_stream) {
-                if (!shared) hip_check(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking), "hipStreamCreate");
-                sd.stream = shared; sd.owns_stream = side.empty();
-            } else hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking), "hipStreamCreate");
             hip_check(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming), "hipEventCreate");
             side[(int)c] = sd;
@@ -709,6 +703,16 @@ void DerivEngine::mc_step(uint64_t round) {   // MultipleMonteCarloSampler::exec
                                 seed.p, round, sampler == 0 ? 2 : 3, sampler == 0 ? 1 : 2, (sampler == 0 ? pivot.stats : jump.stats).p), "mc_accept");
         sync();
     }
+}
+// switches that earlier rounds read and this build does not: said once, so that an A/B script does not compare a variant with itself
+static void warn_removed_switches() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (const char* v : {"UPSIDE_HIP_BP_RESIDENT", "UPSIDE_HIP_BP_THREADS", "UPSIDE_HIP_BP_LDS_CAP_KB", "UPSIDE_HIP_FUSE_W8", "UPSIDE_HIP_BATCH_KINDS",
+                          "UPSIDE_HIP_HB_THREADS", "UPSIDE_HIP_PLR_ROWS_SMALL", "UPSIDE_HIP_SLOT_WGS", "UPSIDE_HIP_ORDER_EVERY", "UPSIDE_HIP_CLEAR_SLOTS",
+                          "UPSIDE_HIP_BP_CLUSTER_MIN_C", "UPSIDE_HIP_MAX_SYSTEMS", "UPSIDE_HIP_PAIR2_ENERGY", "UPSIDE_HIP_UPKEEP_STREAMS"})
+        if (getenv(v)) fprintf(stderr, "upside_hip: %s is set but no longer read by this build (removed experiment switch, see INTEGRATION.md section 6)\n", v);
 }
 void DerivEngine::sync() { ctx.flush(); hip_check(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize"); }
 

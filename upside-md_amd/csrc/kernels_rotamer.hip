@@ -460,54 +460,6 @@ __device__ __forceinline__ RotPairMeta rot_pair_meta(int w, const float* xo) {
     return m;
 }
 template <bool POLY>
-struct RotEnergyOp2 {
-    const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
-    float* P; int* active;
-    v2 x1[6]; int mr, a;
-    __device__ __forceinline__ RotEnergyOp2(const upk_rotamer_t& R_, const RotLds& L_, int s)
-        : R(R_), Q(quad_shape(R_.G)), L(L_), P(R_.P + (size_t)s * R_.slot_cap * 36), active(R_.slot_active + (size_t)s * R_.slot_cap) {}
-    __device__ __forceinline__ void begin(int row) {
-        float xr[8]; load_row8_planes(xr, L.rows, R.G.n1 + 1, row);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) x1[c] = bc2(xr[c]);
-        mr = __float_as_int(xr[6]); a = __float_as_int(xr[7]);
-    }
-    __device__ __forceinline__ void store(const RotPairMeta& m, float E) const {
-        if (m.sl == UPK_ROT_SLOT_NONE) return;              // (no slot: only after a capacity overflow, the error flag is set)
-        const int ra = (mr >> 8) & 0xF, rb = (m.mo >> 8) & 0xF;
-        float* pe = P + PIDX6(R.slot_cap, m.sl, a < m.b ? ra : rb, a < m.b ? rb : ra);
-        if (R.one_bead_per_state) *pe = R.p_prob ? expf(-E) : E;      // single writer per entry: plain store
-        else atomicAdd(pe, E);
-        active[m.sl] = 1;
-    }
-    __device__ __forceinline__ void body(int, int wA, int wB, bool liveA, bool liveB) {
-        float xa[8], xb[8];
-        load_row8_planes(xa, L.rows, R.G.n1 + 1, wA & ((1 << UPK_ROT_J_BITS) - 1));
-        load_row8_planes(xb, L.rows, R.G.n1 + 1, wB & ((1 << UPK_ROT_J_BITS) - 1));
-        const RotPairMeta mA = rot_pair_meta(wA, xa), mB = rot_pair_meta(wB, xb);
-        v2 x2[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) x2[c] = mk2(xa[c], xb[c]);
-        int o1A, o2A, o1B, o2B;
-        const float* pA = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mA.mo & 0xFF, o1A, o2A);   // row < partner: types [type(i1)][type(i2)], i1 < i2
-        const float* pB = rot_param_row<POLY>(R, L.tab, mr & 0xFF, mB.mo & 0xFF, o1B, o2B);
-        const v2 E = quadspline_pair2<false, POLY>(Q, pA, pB, x1, x2, nullptr, nullptr, nullptr, o1A, o2A, o1B, o2B);
-        if (liveA) store(mA, E.x);
-        if (liveB) store(mB, E.y);
-    }
-    __device__ __forceinline__ void flush(int) {}
-};
-template <bool POLY>
-__global__ void __launch_bounds__(1024) PG_KERNEL_ATTR k_rotamer_pair_energy2(upk_rotamer_t R, int tab_floats) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int s = blockIdx.y;
-    const upk_igraph_t& G = R.G;
-    const RotLds L = rot_stage<true, POLY, true>(R, lds, s, tab_floats, false);
-    RotEnergyOp2<POLY> op(R, L, s);
-    group2_batch_loop(op, G.n1, L.ord, L.range, G.hit1 + (size_t)s * G.n1 * G.cap1, G.cap1, L.counter, blockIdx.x, gridDim.x, G.n1);
-}
-
-template <bool POLY>
 struct RotGradOp2 {
     const upk_rotamer_t& R; const QuadShape Q; const RotLds& L;
     const float* marg; const float* nbm;
@@ -663,19 +615,8 @@ extern "C" int upk_rotamer_pair_energy(const upk_launch_t* L, const upk_rotamer_
     int tab_floats; size_t lds; dim3 grid, block;
     static int no_poly = -1;      // UPSIDE_HIP_ROT_POLY=0 keeps the energy pass on the spline-coefficient table (A/B and the large-table path)
     if (no_poly < 0) { const char* e = getenv("UPSIDE_HIP_ROT_POLY"); no_poly = (e && !atoi(e)) ? 1 : 0; }
-    // (the packed form of THIS pass is opt-in: it is bound by its scattered pair-matrix stores, and 16 rows x 4 partners per
-    //  store instruction touch 1.7x the cache lines of 8 rows x 8 partners: 1.26 ms scalar, 1.45 ms packed at 4096 systems)
-    static int packed_energy = -1;
-    if (packed_energy < 0) { const char* e = getenv("UPSIDE_HIP_PAIR2_ENERGY"); packed_energy = (e && atoi(e)) ? 1 : 0; }
-    if (rot_pair2_enabled() && packed_energy) {
-        for (int poly = no_poly ? 0 : 1; poly >= 0; --poly) {
-            if (poly && !R->param_tri_poly) continue;
-            if (rot_geometry(L, R, false, tab_floats, lds, grid, block, poly != 0, true) != 1) continue;
-            if (poly) hipLaunchKernelGGL(k_rotamer_pair_energy2<true>, grid, block, lds, ST(L), *R, tab_floats);
-            else hipLaunchKernelGGL(k_rotamer_pair_energy2<false>, grid, block, lds, ST(L), *R, tab_floats);
-            return launch_status();
-        }
-    }
+    // (the packed two-partners-per-lane form of THIS pass was built in round 3 and removed in round 6: the pass is bound by its scattered
+    //  pair-matrix stores, and 16 rows x 4 partners per store instruction touch 1.7x the cache lines of 8 rows x 8 partners: 1.45 against 1.26 ms)
     if (R->param_tri_poly && !no_poly && rot_geometry(L, R, false, tab_floats, lds, grid, block, true) == 1) {   // polynomial table + beads fit LDS
         hipLaunchKernelGGL((k_rotamer_pair_energy<true, true>), grid, block, lds, ST(L), *R, tab_floats);
         return launch_status();
@@ -1289,6 +1230,165 @@ struct BpResident {
     }
 };
 
+// The per-solve DENSE layout of the message inbox (COMPACT solves): which rows carry a message in this solve, where each active row sits,
+// and the packed records of the active slots.  In: bp_start = first ROW of every node (LDS), cls, the activity flags.  Out: bp_start =
+// first FLOAT of every node, n_act, C.rec / the records in R.bp_rec, and the sizes returned.  Runs inside the solve (small batches) or, from
+// 512 systems on, as k_rotamer_bp_layout in front of it: the layout is a chain of small dependent steps (flags -> row pairs -> bit
+// matrix -> two block scans -> records) that a workgroup owning a whole CU walks no faster than one of four sharing it -- 22 us of a
+// 303 us solve at one workgroup per CU, sixteen rounds per launch at 4096 systems.
+struct BpLayout { int inbox_floats, inbox_floats3, w3; };
+template <int BLOCK>
+__device__ __forceinline__ BpLayout bp_dense_layout(const upk_rotamer_t& R, const int s, BpCtx& C, const int NN, const int* cls, int* n_act, int* bp_start,
+                                                    float* scratch, float* nb0, const int lds_msg_floats, const int tid, const int nt) {
+    constexpr int NS = BP_NODE_STRIDE;
+    int inbox_floats, inbox_floats3, w3 = 4;
+    // Which rows carry a message in this solve: an activity bit per cached row (LDS, in the region the messages will take),
+    // a prefix sum over its 32-row words (every word holds rows of one width: build_slots pads the 3-state block to 32), and
+    // the dense position of row r is  wbase[r / 32] + width * popcount(bits of the word below r).
+    const int R6 = R.row_start[(size_t)s * (NN + 2) + NN + 1], n_rows = bp_start[NN], n_words = (n_rows + 31) >> 5;
+    unsigned* rmask = (unsigned*)C.inbox_lds;      // [n_words]
+    int* wbase = (int*)(rmask + n_words);          // [n_words + 1]
+    for (int i = tid; i < n_words; i += nt) rmask[i] = 0u;
+    __syncthreads();
+    // The slots are visited in the 64-slot chunks of the packing (chunk ch belongs to wavefront ch mod n_wave): ONE pass loads the
+    // activity flags -- four chunks' flags in flight per lane, then their row pairs --, counts each chunk, marks the rows and keeps
+    // the flags as a bit per visit; the records are written from those bits once the layout is known.  (The first form walked the
+    // slots three times, every visit a dependent global round trip: 36 -> 21 us of the solve's 430; all visits in flight at once,
+    // kept in registers for the record pass, measured no better: 24 us.)
+    constexpr int PK_MAXIT = 16, PK_UNR = 4;
+    const int pk_lane = tid & 63, pk_wave = tid >> 6, pk_nwave = nt >> 6;
+    const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
+    const int n_chunk = nc0 + nc1 + nc2, n_it = (n_chunk + pk_nwave - 1) / pk_nwave;
+    const bool fast_pack = n_it <= PK_MAXIT && 2 * n_chunk <= NN * NS;
+    int* chunk_cnt = (int*)nb0; int* chunk_base = chunk_cnt + n_chunk;     // (nb0 / nb1 are filled after the fold below)
+    auto chunk_of = [&](int it, int& ch, int& c, int& first, int& sl) -> bool {       // visit `it` of this wavefront; false past the last chunk
+        ch = pk_wave + it * pk_nwave;
+        c = ch < nc0 ? CL33 : (ch < nc0 + nc1 ? CL36 : CL66);
+        first = c == CL33 ? 0 : (c == CL36 ? nc0 : nc0 + nc1);
+        sl = cls[c] + (ch - first) * 64 + pk_lane;
+        return ch < n_chunk;
+    };
+    unsigned actbits = 0u;
+    if (fast_pack) {
+#pragma unroll
+        for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
+            if (it0 >= n_it) break;
+            int ch[PK_UNR], sl[PK_UNR], fl[PK_UNR]; bool ok[PK_UNR]; int2 rr[PK_UNR];
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) { int c, first; ok[u] = chunk_of(it0 + u, ch[u], c, first, sl[u]); ok[u] = ok[u] && sl[u] < cls[c + 1]; }
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) fl[u] = ok[u] ? C.active[sl[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) rr[u] = fl[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) {
+                const unsigned long long b = __ballot(fl[u] != 0);
+                if (pk_lane == 0 && ch[u] < n_chunk) chunk_cnt[ch[u]] = __popcll(b);
+                if (fl[u]) {
+                    actbits |= 1u << (it0 + u);
+                    atomicOr(&rmask[rr[u].x >> 5], 1u << (rr[u].x & 31)); atomicOr(&rmask[rr[u].y >> 5], 1u << (rr[u].y & 31));
+                }
+            }
+        }
+    } else {
+        for (int sl = cls[CL33] + tid; sl < cls[CL66 + 1]; sl += nt)
+            if (C.active[sl]) {
+                const int ra = C.slot_row[sl * 2], rb = C.slot_row[sl * 2 + 1];
+                atomicOr(&rmask[ra >> 5], 1u << (ra & 31)); atomicOr(&rmask[rb >> 5], 1u << (rb & 31));
+            }
+    }
+    __syncthreads();
+    if (fast_pack && tid < n_chunk) {          // records of the class in front of chunk tid
+        const int first = tid < nc0 ? 0 : (tid < nc0 + nc1 ? nc0 : nc0 + nc1);
+        int before = 0;
+        for (int k = first; k < tid; ++k) before += chunk_cnt[k];
+        chunk_base[tid] = before;
+    }
+    {
+        // active rows to 3-state nodes (T3) and to 6-state nodes (T6): two scans over row counts, then the row width of the 3-state
+        // block is chosen -- 4 floats if the inbox then fits the LDS (or does not fit either way), else 3 if that makes it fit --
+        // and the 6-state block starts at an even float (8-byte accesses)
+        const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
+        int c3 = 0, c6 = 0;
+        for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { const int c = __popc(rmask[w]); if (w * 32 < R6) c3 += c; else c6 += c; } }
+        int T3, T6;
+        int x3 = block_excl_scan(c3, (int*)scratch, &T3);
+        int x6 = block_excl_scan(c6, (int*)scratch, &T6);
+        w3 = (4 * T3 + 6 * T6 > lds_msg_floats && 3 * T3 + (T3 & 1) + 6 * T6 <= lds_msg_floats) ? 3 : 4;
+        const int base6 = w3 * T3 + (w3 == 3 ? (T3 & 1) : 0);
+        for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) {
+            const int c = __popc(rmask[w]);
+            if (w * 32 < R6) { wbase[w] = w3 * x3; x3 += c; } else { wbase[w] = base6 + 6 * x6; x6 += c; } } }
+        inbox_floats = base6 + 6 * T6; inbox_floats3 = base6;
+        if (tid == 0) wbase[n_words] = inbox_floats;
+    }
+    __syncthreads();
+    auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? w3 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
+    int my_start[(1024 + BLOCK - 1) / BLOCK + 1];          // first message float of the nodes this lane copies (NN <= 1024)
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; my_start[k] = g <= NN ? dense(bp_start[g]) : 0; }
+    int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
+    C.rec = rec;
+    if (fast_pack) {
+#pragma unroll
+        for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
+            if (it0 >= n_it) break;
+            int ch[PK_UNR], cc[PK_UNR], sl[PK_UNR], sa[PK_UNR], sb[PK_UNR]; bool act[PK_UNR]; int2 rr[PK_UNR];
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) { int first; chunk_of(it0 + u, ch[u], cc[u], first, sl[u]); act[u] = (actbits >> (it0 + u)) & 1u; }
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) {
+                rr[u] = act[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
+                sa[u] = act[u] ? C.slot_a[sl[u]] : 0; sb[u] = act[u] ? C.slot_b[sl[u]] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < PK_UNR; ++u) {
+                if (ch[u] >= n_chunk) continue;                              // (wave-uniform)
+                const unsigned long long b = __ballot(act[u]);
+                const int base = chunk_base[ch[u]];
+                if (act[u]) rec[cls[cc[u]] + base + __popcll(b & ((1ull << pk_lane) - 1ull))] = make_int4(dense(rr[u].x), dense(rr[u].y), sa[u] | (sb[u] << 16), sl[u]);
+                const int last = cc[u] == CL33 ? nc0 - 1 : (cc[u] == CL36 ? nc0 + nc1 - 1 : n_chunk - 1);
+                if (pk_lane == 0 && ch[u] == last) n_act[cc[u]] = base + __popcll(b);
+            }
+        }
+        __syncthreads();
+    } else
+        bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return dense(C.slot_row[sl * 2 + side]); });   // (ends with a barrier)
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; if (g <= NN) bp_start[g] = my_start[k]; }   // rows -> floats
+    return BpLayout{inbox_floats, inbox_floats3, w3};
+}
+// [S][bp_layout_stride(n_node)] ints: first float of every node [n_node + 1], active slots per class [3], inbox floats, floats of the rows
+// to 3-state nodes, row width of those rows
+__host__ __device__ static inline int bp_layout_stride(int n_node) { return n_node + 8; }
+__global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int lds_msg_floats, int* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, NN = R.n_node;
+    constexpr int NS = BP_NODE_STRIDE;
+    float* nb0 = lds;                                        // [NN * NS] scratch of the packing pass
+    float* scratch = lds + NN * NS;                          // [32]
+    int* bp_start = (int*)(scratch + 32);                    // [NN + 1]
+    int* cls = bp_start + NN + 1;                            // [N_CLASS + 1]
+    int* n_act = cls + N_CLASS + 1;                          // [3]
+    BpCtx C;
+    C.cap = R.slot_cap;
+    C.slot_a = R.slot_a + (size_t)s * R.slot_cap; C.slot_b = R.slot_b + (size_t)s * R.slot_cap;
+    C.active = R.slot_active + (size_t)s * R.slot_cap; C.slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
+    C.slot_row = R.slot_row + (size_t)s * R.slot_cap * 2;
+    C.P = nullptr; C.inbox = nullptr; C.marg = nullptr;
+    C.inbox_lds = lds + (((int)((float*)(n_act + 4) - lds) + 3) & ~3);      // row masks and word bases of the layout
+    for (int i = tid; i <= NN; i += nt) bp_start[i] = R.row_start[(size_t)s * (NN + 2) + i];
+    if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
+    if (tid < 3) n_act[tid] = 0;
+    __syncthreads();
+    const BpLayout ly = bp_dense_layout<512>(R, s, C, NN, cls, n_act, bp_start, scratch, nb0, lds_msg_floats, tid, nt);
+    __syncthreads();
+    int* o = out + (size_t)s * bp_layout_stride(NN);
+    for (int i = tid; i <= NN; i += nt) o[i] = bp_start[i];
+    if (tid < 3) o[NN + 1 + tid] = n_act[tid];
+    if (tid == 0) { o[NN + 4] = ly.inbox_floats; o[NN + 5] = ly.inbox_floats3; o[NN + 6] = ly.w3; }
+}
+
 // COMPACT: the message inbox is laid out per solve for the slots ACTIVE in this evaluation only, 4 / 6 floats per row instead of
 // the cached layout's 4 / 8 for every cached residue pair (a quarter of which has no bead pair in range on a given step): 151 KB
 // instead of 244 KB for the 300-residue benchmark protein, so that most of it stays in the LDS for all sweeps.
@@ -1365,120 +1465,17 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
     int w3 = 4;                            // floats per row to a 3-state node (dense layout: 4, or 3 when only that makes the inbox fit the LDS)
     if (COMPACT) {
-        // Which rows carry a message in this solve: an activity bit per cached row (LDS, in the region the messages will take),
-        // a prefix sum over its 32-row words (every word holds rows of one width: build_slots pads the 3-state block to 32), and
-        // the dense position of row r is  wbase[r / 32] + width * popcount(bits of the word below r).
-        const int R6 = R.row_start[(size_t)s * (NN + 2) + NN + 1], n_rows = bp_start[NN], n_words = (n_rows + 31) >> 5;
-        unsigned* rmask = (unsigned*)C.inbox_lds;      // [n_words]
-        int* wbase = (int*)(rmask + n_words);          // [n_words + 1]
-        for (int i = tid; i < n_words; i += nt) rmask[i] = 0u;
-        __syncthreads();
-        // The slots are visited in the 64-slot chunks of the packing (chunk ch belongs to wavefront ch mod n_wave): ONE pass loads the
-        // activity flags -- four chunks' flags in flight per lane, then their row pairs --, counts each chunk, marks the rows and keeps
-        // the flags as a bit per visit; the records are written from those bits once the layout is known.  (The first form walked the
-        // slots three times, every visit a dependent global round trip: 36 -> 21 us of the solve's 430; all visits in flight at once,
-        // kept in registers for the record pass, measured no better: 24 us.)
-        constexpr int PK_MAXIT = 16, PK_UNR = 4;
-        const int pk_lane = tid & 63, pk_wave = tid >> 6, pk_nwave = nt >> 6;
-        const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
-        const int n_chunk = nc0 + nc1 + nc2, n_it = (n_chunk + pk_nwave - 1) / pk_nwave;
-        const bool fast_pack = n_it <= PK_MAXIT && 2 * n_chunk <= NN * NS;
-        int* chunk_cnt = (int*)nb0; int* chunk_base = chunk_cnt + n_chunk;     // (nb0 / nb1 are filled after the fold below)
-        auto chunk_of = [&](int it, int& ch, int& c, int& first, int& sl) -> bool {       // visit `it` of this wavefront; false past the last chunk
-            ch = pk_wave + it * pk_nwave;
-            c = ch < nc0 ? CL33 : (ch < nc0 + nc1 ? CL36 : CL66);
-            first = c == CL33 ? 0 : (c == CL36 ? nc0 : nc0 + nc1);
-            sl = cls[c] + (ch - first) * 64 + pk_lane;
-            return ch < n_chunk;
-        };
-        unsigned actbits = 0u;
-        if (fast_pack) {
-#pragma unroll
-            for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
-                if (it0 >= n_it) break;
-                int ch[PK_UNR], sl[PK_UNR], fl[PK_UNR]; bool ok[PK_UNR]; int2 rr[PK_UNR];
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) { int c, first; ok[u] = chunk_of(it0 + u, ch[u], c, first, sl[u]); ok[u] = ok[u] && sl[u] < cls[c + 1]; }
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) fl[u] = ok[u] ? C.active[sl[u]] : 0;
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) rr[u] = fl[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) {
-                    const unsigned long long b = __ballot(fl[u] != 0);
-                    if (pk_lane == 0 && ch[u] < n_chunk) chunk_cnt[ch[u]] = __popcll(b);
-                    if (fl[u]) {
-                        actbits |= 1u << (it0 + u);
-                        atomicOr(&rmask[rr[u].x >> 5], 1u << (rr[u].x & 31)); atomicOr(&rmask[rr[u].y >> 5], 1u << (rr[u].y & 31));
-                    }
-                }
-            }
+        if (R.bp_layout) {          // laid out by k_rotamer_bp_layout in front of this launch
+            const int* LY = R.bp_layout + (size_t)s * bp_layout_stride(NN);
+            __syncthreads();        // (bp_start still holds the rows loaded above: nobody reads them)
+            for (int i = tid; i <= NN; i += nt) bp_start[i] = LY[i];
+            if (tid < 3) n_act[tid] = LY[NN + 1 + tid];
+            inbox_floats = LY[NN + 4]; inbox_floats3 = LY[NN + 5]; w3 = LY[NN + 6];
+            C.rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
         } else {
-            for (int sl = cls[CL33] + tid; sl < cls[CL66 + 1]; sl += nt)
-                if (C.active[sl]) {
-                    const int ra = C.slot_row[sl * 2], rb = C.slot_row[sl * 2 + 1];
-                    atomicOr(&rmask[ra >> 5], 1u << (ra & 31)); atomicOr(&rmask[rb >> 5], 1u << (rb & 31));
-                }
+            const BpLayout ly = bp_dense_layout<BLOCK>(R, s, C, NN, cls, n_act, bp_start, scratch, nb0, lds_msg_floats, tid, nt);
+            inbox_floats = ly.inbox_floats; inbox_floats3 = ly.inbox_floats3; w3 = ly.w3;
         }
-        __syncthreads();
-        if (fast_pack && tid < n_chunk) {          // records of the class in front of chunk tid
-            const int first = tid < nc0 ? 0 : (tid < nc0 + nc1 ? nc0 : nc0 + nc1);
-            int before = 0;
-            for (int k = first; k < tid; ++k) before += chunk_cnt[k];
-            chunk_base[tid] = before;
-        }
-        {
-            // active rows to 3-state nodes (T3) and to 6-state nodes (T6): two scans over row counts, then the row width of the 3-state
-            // block is chosen -- 4 floats if the inbox then fits the LDS (or does not fit either way), else 3 if that makes it fit --
-            // and the 6-state block starts at an even float (8-byte accesses)
-            const int wpl = (n_words + nt - 1) / nt, w0 = tid * wpl;       // words per lane, consecutive
-            int c3 = 0, c6 = 0;
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) { const int c = __popc(rmask[w]); if (w * 32 < R6) c3 += c; else c6 += c; } }
-            int T3, T6;
-            int x3 = block_excl_scan(c3, (int*)scratch, &T3);
-            int x6 = block_excl_scan(c6, (int*)scratch, &T6);
-            w3 = (4 * T3 + 6 * T6 > lds_msg_floats && 3 * T3 + (T3 & 1) + 6 * T6 <= lds_msg_floats) ? 3 : 4;
-            const int base6 = w3 * T3 + (w3 == 3 ? (T3 & 1) : 0);
-            for (int k = 0; k < wpl; ++k) { const int w = w0 + k; if (w < n_words) {
-                const int c = __popc(rmask[w]);
-                if (w * 32 < R6) { wbase[w] = w3 * x3; x3 += c; } else { wbase[w] = base6 + 6 * x6; x6 += c; } } }
-            inbox_floats = base6 + 6 * T6; inbox_floats3 = base6;
-            if (tid == 0) wbase[n_words] = inbox_floats;
-        }
-        __syncthreads();
-        auto dense = [&](int r) { const int w = r >> 5; return w >= n_words ? wbase[n_words] : wbase[w] + (w * 32 < R6 ? w3 : 6) * __popc(rmask[w] & ((1u << (r & 31)) - 1u)); };
-        int my_start[(1024 + BLOCK - 1) / BLOCK + 1];          // first message float of the nodes this lane copies (NN <= 1024)
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; my_start[k] = g <= NN ? dense(bp_start[g]) : 0; }
-        int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
-        C.rec = rec;
-        if (fast_pack) {
-#pragma unroll
-            for (int it0 = 0; it0 < PK_MAXIT; it0 += PK_UNR) {
-                if (it0 >= n_it) break;
-                int ch[PK_UNR], cc[PK_UNR], sl[PK_UNR], sa[PK_UNR], sb[PK_UNR]; bool act[PK_UNR]; int2 rr[PK_UNR];
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) { int first; chunk_of(it0 + u, ch[u], cc[u], first, sl[u]); act[u] = (actbits >> (it0 + u)) & 1u; }
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) {
-                    rr[u] = act[u] ? ((const int2*)C.slot_row)[sl[u]] : make_int2(0, 0);
-                    sa[u] = act[u] ? C.slot_a[sl[u]] : 0; sb[u] = act[u] ? C.slot_b[sl[u]] : 0;
-                }
-#pragma unroll
-                for (int u = 0; u < PK_UNR; ++u) {
-                    if (ch[u] >= n_chunk) continue;                              // (wave-uniform)
-                    const unsigned long long b = __ballot(act[u]);
-                    const int base = chunk_base[ch[u]];
-                    if (act[u]) rec[cls[cc[u]] + base + __popcll(b & ((1ull << pk_lane) - 1ull))] = make_int4(dense(rr[u].x), dense(rr[u].y), sa[u] | (sb[u] << 16), sl[u]);
-                    const int last = cc[u] == CL33 ? nc0 - 1 : (cc[u] == CL36 ? nc0 + nc1 - 1 : n_chunk - 1);
-                    if (pk_lane == 0 && ch[u] == last) n_act[cc[u]] = base + __popcll(b);
-                }
-            }
-            __syncthreads();
-        } else
-            bp_pack_active(C, rec, cls, n_act, (int*)nb0, tid, nt, [&](int sl, int side) { return dense(C.slot_row[sl * 2 + side]); });   // (ends with a barrier)
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; if (g <= NN) bp_start[g] = my_start[k]; }   // rows -> floats
     } else {
         if (PACK) {
             int4* rec = (int4*)R.bp_rec + (size_t)s * R.slot_cap;
@@ -1751,6 +1748,9 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     BP_STAMP(7);
     // leave the accumulators clean for the next force evaluation
     // (only the slots written this step: the others were left at 0 by the prologue); the flags move to active_last
+    // (Round 6, measured and not taken: this tail as a launch of its own behind the solve, as the layout is one in front of it -- solve +
+    //  tail 4.68 -> 5.20 ms at 4096 systems: inside the solve the 1.6 GB of stores overlap with the sweeps of the workgroups on other
+    //  CUs; alone they are a store-bound kernel of their own.)
     int* active_w = R.slot_active + (size_t)s * R.slot_cap;
     int* active_last = R.slot_active_last + (size_t)s * R.slot_cap;
     const float rest = R.p_prob ? 1.f : 0.f;
@@ -2239,9 +2239,16 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
     // (the layout pass borrows the LDS inbox for an activity bit per cached row and a prefix per 32 rows: at most two rows per slot)
     const size_t layout_scratch = (((size_t)2 * R->slot_cap + 64) / 32 * 2 + 2) * sizeof(int);
     const bool dense = compact && R->slot_row && R->row_start && (size_t)lds_msg_floats * sizeof(float) >= layout_scratch;
-    if (!only_fallback && dense)
-        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 1, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
-    else
+    if (!only_fallback && dense) {
+        upk_rotamer_t Rl = *R;
+        // the dense layout as a launch of its own in front of the solve (R->bp_layout allocated by the host node: from 512 systems on),
+        // when its scratch fits a quarter of a CU's LDS; else inside the solve
+        const size_t layout_lds = ((size_t)R->n_node * (BP_NODE_STRIDE + 1) + 64 + N_CLASS + 16) * sizeof(float) + layout_scratch + 64;
+        if (R->bp_layout && layout_lds <= 40 * 1024)
+            hipLaunchKernelGGL(k_rotamer_bp_layout, dim3(L->n_system), dim3(512), layout_lds, ST(L), *R, lds_msg_floats, R->bp_layout);
+        else Rl.bp_layout = nullptr;
+        hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 1, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), Rl, want_energy, only_fallback, lds_msg_floats);
+    } else
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK, 0, 0, 0>), grid, dim3(BP_BLOCK), lds, ST(L), *R, want_energy, only_fallback, lds_msg_floats);
 }
 extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int want_energy) {
@@ -2269,8 +2276,15 @@ extern "C" int upk_rotamer_bp(const upk_launch_t* L, const upk_rotamer_t* R, int
             const size_t split_lds = ((size_t)R->n_node * 14 + 64) * sizeof(float);
             for (int s0 = 0; s0 < L->n_system; s0 += chunk) {
                 const int n = L->n_system - s0 < chunk ? L->n_system - s0 : chunk;
-                if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(n, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
-                else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(n, C), dim3(BPC_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
+                // grid.x rounded up to a multiple of 8 (the surplus workgroups leave at once): workgroup b is dispatched to XCD b mod 8, so the C
+                // workgroups of a system -- linear ids s + c * grid.x -- then share an XCD and their exchange stays in its L2, also when fewer
+                // than 8 systems are solved (placement for speed only: the protocol is placement independent).  One 300-residue system, 6
+                // workgroups: solve 211 -> 200 us.  (Round 6, measured on that placement and not taken: plain stores + sc1 loads and no acquire
+                // fence, which is valid only while the cluster shares an L2: 180 us, 2 235 -> 2 287 steps/s -- 0.9 us per barrier; the rest of a
+                // 10 us sweep is the counter round trips and the phases' own dependent loads.)
+                const int gx = (n + 7) & ~7;
+                if (R->bp_resident) hipLaunchKernelGGL(k_rotamer_bp_cluster<true>, dim3(gx, C), dim3(BPC_BLOCK), 156 * 1024, ST(L), *R, want_energy, C, s0, n, p_cap);
+                else hipLaunchKernelGGL(k_rotamer_bp_cluster<false>, dim3(gx, C), dim3(BPC_BLOCK), split_lds, ST(L), *R, want_energy, C, s0, n, p_cap);
             }
             bp_launch(L, R, want_energy, 1, lds_base, 0);   // rare path: no LDS inbox, so that the (normally empty) launch does not wait for a whole CU's LDS
             return launch_status();

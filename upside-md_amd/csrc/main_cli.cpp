@@ -186,7 +186,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
     int log_level = 1;
     double anneal_factor = 1., anneal_duration = -1.;
     string set_param_file;
-    bool re_raise_signal = false;
+    bool re_raise_signal = false, deriv_agreement = false;
     vector<string> swap_sets, files;
     for (int i = 1; i < argc; ++i) {
         string a = argv[i];
@@ -213,6 +213,7 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
         else if (a == "--anneal-factor") anneal_factor = stod(need("--anneal-factor"));
         else if (a == "--anneal-duration") anneal_duration = stod(need("--anneal-duration"));
         else if (a == "--set-param") set_param_file = need("--set-param");
+        else if (a == "--potential-deriv-agreement") deriv_agreement = true;      // main.cpp:368-372
         else if (a.size() && a[0] == '-') throw string("unsupported flag ") + a;
         else files.push_back(a);
     }
@@ -423,6 +424,50 @@ int upside_main_impl(int argc, const char* const* argv, int verbose) {
             upside_hip_comm_free(e);
             // (which of the two has the wrong files the digests cannot tell: with more than two ranks the odd one out is usually it)
             throw string("the configuration files of ranks 0 and ") + to_string(differs) + " hold different /input/potential groups";
+        }
+    }
+
+    // --potential-deriv-agreement (developer check, main.cpp:279-315 with deriv_engine.cpp:291-342): central differences of the total
+    // potential, eps = 1e-3 per coordinate, against the derivative the backward sweep produced; relative RMS deviation per system
+    // (relative_rms_deviation, deriv_engine.h:345-357: the finite differences are the reference).  All systems of an engine are displaced
+    // in the same coordinate at once: 2 x 3 n_atom force passes per engine whatever the number of systems.
+    if (deriv_agreement) {
+        const float eps = 1e-3f;
+        const size_t n3 = (size_t)n_atom * 3;
+        for (int g = 0; g < n_group; ++g) {
+            DerivEngine* eg = engines[g];
+            const int S = (int)members[g].size();
+            vector<float> pos0 = to_group(g, all_pos.data(), n3), work, en((size_t)S), deriv((size_t)S * n3), ep((size_t)S), em((size_t)S);
+            if (upside_hip_compute(eg, en.data(), deriv.data())) throw string(upside_hip_last_error());
+            if (verbose) {
+                printf("Initial potential:\n");
+                eg->fetch_potentials();
+                for (int l = 0; l < S; ++l) {
+                    if (S > 1) printf("%s\n", files[members[g][l]].c_str());
+                    for (auto& nd : eg->nodes)
+                        if (nd.computation->potential_term) printf("%s: % 4.3f\n", nd.name.c_str(), static_cast<PotentialNode*>(nd.computation.get())->potential[l]);
+                    printf("\n\n");
+                }
+            }
+            vector<double> diff2((size_t)S, 0.), ref2((size_t)S, 0.);
+            for (size_t ni = 0; ni < n3; ++ni) {
+                for (int sign = -1; sign <= 1; sign += 2) {
+                    work = pos0;
+                    for (int l = 0; l < S; ++l) work[(size_t)l * n3 + ni] = pos0[(size_t)l * n3 + ni] + sign * eps;
+                    if (upside_hip_set_pos(eg, work.data()) || upside_hip_compute(eg, sign < 0 ? em.data() : ep.data(), nullptr)) throw string(upside_hip_last_error());
+                }
+                for (int l = 0; l < S; ++l) {
+                    const float fd = (ep[l] - em[l]) * (0.5f / eps);
+                    const double d = (double)fd - (double)deriv[(size_t)l * n3 + ni];
+                    diff2[l] += d * d; ref2[l] += (double)fd * (double)fd;
+                }
+            }
+            if (upside_hip_set_pos(eg, pos0.data())) throw string(upside_hip_last_error());      // (restore the input: the caller is not surprised)
+            for (int l = 0; l < S; ++l) {
+                if (verbose) printf("overall potential relative error: ");
+                printf(" %.5f", sqrt(diff2[l] / ref2[l]));
+                if (verbose) printf("\n");
+            }
         }
     }
 

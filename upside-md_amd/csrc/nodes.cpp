@@ -1215,7 +1215,7 @@ struct RotamerSidechain : public PotentialNode {
     DevBuf<unsigned char> mark;
     DevBuf<int> bp_bar, bp_fallback; DevBuf<float> bp_nbx, bp_dev, bp_en_part, bead_pack; DevBuf<unsigned long long> grad_acc; DevBuf<float> param_tri, param_tri_poly; DevBuf<int> d_bead_orig;
     bool bp_C_chosen = false;
-    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec, row_start, slot_row;
+    DevBuf<int> d_node_nrot, d_bead_node, d_bead_rot, d_nb_start, d_nb_list, n_slot, slot_a, slot_b, slot_of, slot_active, adj_cnt, adj_slot, iters, bp_start, slot_off, class_start, slot_active_last, d_bead_meta, bp_rec, row_start, slot_row, bp_layout;
     DevBuf<float> node_prob, node_off, nb_cur, P, msg_cur, marg, energy;
     DevBuf<const float*> d_prob_out; DevBuf<float*> d_prob_sens; DevBuf<int> d_prob_stride; DevBuf<long> d_prob_sys_stride;
     DevBuf<int> n_bad;
@@ -1289,6 +1289,12 @@ struct RotamerSidechain : public PotentialNode {
         n_slot.alloc(S); slot_a.alloc((size_t)S * R.slot_cap); slot_b.alloc((size_t)S * R.slot_cap); slot_active.alloc((size_t)S * R.slot_cap);
         slot_of.alloc((size_t)S * n_node * n_node); adj_cnt.alloc((size_t)S * n_node); adj_slot.alloc((size_t)S * n_node * R.adj_cap);
         bp_rec.alloc((size_t)S * R.slot_cap * 4);
+        // the dense inbox layout as a launch of its own in front of the one-workgroup solve (kernels_rotamer.hip: k_rotamer_bp_layout) once the
+        // solves of a launch run in several rounds over the CUs (a solve owns a whole CU): UPSIDE_HIP_BP_LAYOUT=0/1 forces it off / on (tests)
+        {
+            const int want = env_int("UPSIDE_HIP_BP_LAYOUT", -1);
+            if (want == 1 || (want < 0 && S >= 512)) { bp_layout.alloc((size_t)S * (n_node + 8)); R.bp_layout = bp_layout.p; }
+        }
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
         row_start.alloc((size_t)S * (n_node + 2)); slot_row.alloc((size_t)S * R.slot_cap * 2);
