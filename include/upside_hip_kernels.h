@@ -310,9 +310,11 @@ typedef struct {
     int* n_bad;                          /* [S] solves that ran into max_iter (rotamer.cpp:784-785), counted on the device */
     int* bp_rec;                         /* [S][slot_cap][4] scratch of the one-workgroup solve: per class, the slots active this step
                                             packed as {offset a, offset b, node a | node b << 16, slot} */
-    int* bp_layout;                      /* [S][n_node + 8] the dense inbox layout of the last solve when k_rotamer_bp_layout computes it in front of the
-                                            one-workgroup solve (first float of every node, active slots per class, inbox sizes, row width); NULL:
-                                            the solve lays its inbox out itself (small batches) */
+    int* bp_layout;                      /* [S][7 n_node + 8] the dense inbox layout of the last solve when k_rotamer_bp_layout computes it
+                                            in front of the one-workgroup solve: first float of every node [n_node + 1], active slots per class [3],
+                                            inbox floats, floats of the rows to 3-state nodes, row width, pad to n_node + 8, then the node
+                                            probabilities with the 1-state partners folded in [n_node][6] (raw float bits); NULL: the solve lays
+                                            its inbox out and folds itself (small batches) */
     long long* bp_trace;                 /* [S][32] 100 MHz phase clocks of the last solve ([16..24): sub-phase stamps), or NULL (diagnostics) */
     float* energy;                       /* [S] Bethe free energy (only when want_energy) */
     /* cluster solve (bp_C > 1 workgroups per system, pair matrices resident in LDS) */
@@ -321,6 +323,8 @@ typedef struct {
     int bp_test_abort;                   /* tests (UPSIDE_HIP_BP_CLUSTER_TEST_ABORT): the last workgroup of every cluster leaves at once, barriers give up early */
     float *bp_nbx, *bp_dev, *bp_en_part; /* [S][2][n_node][8] exchanged node beliefs, [S][2][16] deviations, [S][16] energy partial sums */
 } upk_rotamer_t;
+#define UPK_BP_LAYOUT_PER_NODE 7         /* ints of upk_rotamer_t::bp_layout per system: UPK_BP_LAYOUT_PER_NODE * n_node + UPK_BP_LAYOUT_EXTRA */
+#define UPK_BP_LAYOUT_EXTRA 8
 
 /* pair-list rebuild of flagged systems (replaces EdgeLocator, rotamer.cpp:134-206): clear the node x node table,
  * [upk_pairlist_build marks it through G.mark_table], number the slots by class + adjacency + inbox layout, and

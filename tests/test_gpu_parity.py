@@ -654,6 +654,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_ROT_POLY': '0'},            # side-chain energy pass on the spline-coefficient table (tables too large for the polynomial form)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_COMPACT': '0'},       # one-workgroup BP of 1024 lanes streaming every pair matrix over the cached inbox layout
+    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LAYOUT': '1'},        # one-workgroup BP with the inbox layout and the fold as a launch of their own (the choice from 512 systems on)
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes
@@ -709,7 +710,7 @@ def test_large_batch_solver_on_every_fixture():
     sequences (empty slot classes), named values, truncated solves -- by re-running those tests in a child pytest: once with the
     pinned-matrix solve over the dense inbox, once with the streaming solve over the cached inbox layout (the two compiled solves)"""
     import subprocess
-    for extra in ({}, {'UPSIDE_HIP_BP_COMPACT': '0'}):
+    for extra in ({}, {'UPSIDE_HIP_BP_COMPACT': '0'}, {'UPSIDE_HIP_BP_LAYOUT': '1'}):
         env = dict(os.environ, UPSIDE_HIP_BP_CLUSTER='1', UPSIDE_HIP_BATCH='0', UPSIDE_HIP_GRAPH='0', **extra)
         out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
                               '-k', 'force_pass or degenerate or named_values or truncated or golden'], env=env,

@@ -1358,9 +1358,30 @@ __device__ __forceinline__ BpLayout bp_dense_layout(const upk_rotamer_t& R, cons
     for (int k = 0; k < (int)(sizeof(my_start) / sizeof(int)); ++k) { const int g = tid + k * nt; if (g <= NN) bp_start[g] = my_start[k]; }   // rows -> floats
     return BpLayout{inbox_floats, inbox_floats3, w3};
 }
-// [S][bp_layout_stride(n_node)] ints: first float of every node [n_node + 1], active slots per class [3], inbox floats, floats of the rows
-// to 3-state nodes, row width of those rows
-__host__ __device__ static inline int bp_layout_stride(int n_node) { return n_node + 8; }
+// [S][bp_layout_stride(n_node)] ints (upk_rotamer_t::bp_layout): first float of every node [n_node + 1], active slots per class [3], inbox
+// floats, floats of the rows to 3-state nodes, row width of those rows; from n_node + 8 on the folded node probabilities [n_node][6]
+__host__ __device__ static inline int bp_layout_stride(int n_node) { return (UPK_BP_LAYOUT_PER_NODE * n_node + UPK_BP_LAYOUT_EXTRA); }
+// node probabilities with the edges to 1-state partners folded in (move_edge_prob_to_node2, rotamer.cpp:378-385), four partners per trip:
+// slot ids, then flags, then the matrix rows, each as one batch of loads; the same product order wherever it runs
+__device__ __forceinline__ void bp_fold_node(const upk_rotamer_t& R, const BpCtx& C, const int* adj_cnt, const int* adj_slot, int g, int n, float (&pr)[6]) {
+    const int cnt = adj_cnt[g];
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        int sl[4], act[4]; float row[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sl[u] = adj_slot[g * R.adj_cap + (k0 + u < cnt ? k0 + u : k0)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) act[u] = k0 + u < cnt ? C.active[sl[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) row[u][r] = (r < 3 || n == 6) ? C.P[PIDX6(C.cap, sl[u], 0, r)] : 1.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (act[u])
+#pragma unroll
+                for (int r = 0; r < 6; ++r) if (r < n) pr[r] *= row[u][r];
+    }
+}
 __global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int lds_msg_floats, int* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, NN = R.n_node;
@@ -1375,7 +1396,7 @@ __global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int 
     C.slot_a = R.slot_a + (size_t)s * R.slot_cap; C.slot_b = R.slot_b + (size_t)s * R.slot_cap;
     C.active = R.slot_active + (size_t)s * R.slot_cap; C.slot_off = R.slot_off + (size_t)s * R.slot_cap * 2;
     C.slot_row = R.slot_row + (size_t)s * R.slot_cap * 2;
-    C.P = nullptr; C.inbox = nullptr; C.marg = nullptr;
+    C.P = R.P + (size_t)s * R.slot_cap * 36; C.inbox = nullptr; C.marg = nullptr;
     C.inbox_lds = lds + (((int)((float*)(n_act + 4) - lds) + 3) & ~3);      // row masks and word bases of the layout
     for (int i = tid; i <= NN; i += nt) bp_start[i] = R.row_start[(size_t)s * (NN + 2) + i];
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
@@ -1387,6 +1408,21 @@ __global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int 
     for (int i = tid; i <= NN; i += nt) o[i] = bp_start[i];
     if (tid < 3) o[NN + 1 + tid] = n_act[tid];
     if (tid == 0) { o[NN + 4] = ly.inbox_floats; o[NN + 5] = ly.inbox_floats3; o[NN + 6] = ly.w3; }
+    // the fold of the solve's prologue (a chain of dependent loads per node: slot ids -> flags -> matrix rows)
+    if (!R.node_prob_in_solve) {
+        const int* adj_cnt = R.adj_cnt + (size_t)s * NN;
+        const int* adj_slot = R.adj_slot + (size_t)s * NN * R.adj_cap;
+        float* fo = (float*)(o + NN + 8);
+        for (int g = tid; g < NN; g += nt) {
+            const int n = R.node_nrot[g];
+            float pr[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) pr[r] = R.node_prob[((size_t)s * NN + g) * 6 + r];
+            if (n != 1) bp_fold_node(R, C, adj_cnt, adj_slot, g, n, pr);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) fo[g * 6 + r] = pr[r];
+        }
+    }
 }
 
 // COMPACT: the message inbox is laid out per solve for the slots ACTIVE in this evaluation only, 4 / 6 floats per row instead of
@@ -1511,29 +1547,18 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     BP_STAMP(2);
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     // (four partners per trip: slot ids, then flags, then the rows, each as one batch of loads; same product order)
+    const bool pre_folded = COMPACT && R.bp_layout && !R.node_prob_in_solve;      // (k_rotamer_bp_layout folded: its probabilities replace the ones loaded above)
+    if (pre_folded) {
+        const float* fo = (const float*)(R.bp_layout + (size_t)s * bp_layout_stride(NN) + NN + 8);
+        for (int i = tid; i < NN * 6; i += nt) prob[(i / 6) * NS + i % 6] = fo[i];
+    } else
     for (int g = tid; g < NN; g += nt) {
         const int n = nrot[g];
         if (n == 1) continue;
-        const int cnt = adj_cnt[g];
         float pr[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) pr[r] = prob[g * NS + r];
-        for (int k0 = 0; k0 < cnt; k0 += 4) {
-            int sl[4], act[4]; float row[4][6];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sl[u] = adj_slot[g * R.adj_cap + (k0 + u < cnt ? k0 + u : k0)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) act[u] = k0 + u < cnt ? C.active[sl[u]] : 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 6; ++r) row[u][r] = (r < 3 || n == 6) ? C.P[PIDX6(C.cap, sl[u], 0, r)] : 1.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (act[u])
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) if (r < n) pr[r] *= row[u][r];
-        }
+        bp_fold_node(R, C, adj_cnt, adj_slot, g, n, pr);
 #pragma unroll
         for (int r = 0; r < 6; ++r) if (r < n) prob[g * NS + r] = pr[r];
     }
