@@ -91,3 +91,27 @@ def test_committed_counter_table_was_measured_on_these_kernel_sources():
     for key, entry in table.items():
         assert entry.get('_kernel_sources_sha256') == hbm_traffic.kernel_source_stamp(), \
             '%s: counters collected on other kernel sources (rerun tools/refresh_profiles.sh pmc on the GPU box and publish)' % key
+
+
+def test_counter_calibration_is_what_the_traffic_table_applies():
+    """profiles/counter_calibration.json (tools/ubench/hbm_counters.sh on the GPU box: 1 GiB moved in each of the solve's access shapes):
+    every read shape counts at half its bytes, dense writes exactly; tools/hbm_traffic.py turns FETCH_SIZE / WRITE_SIZE into bytes with
+    those factors, and the committed table says which it used"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hbm_traffic
+    with open(os.path.join(ROOT, 'profiles', 'counter_calibration.json')) as f:
+        cal = json.load(f)
+    reads = {k: v['read_factor'] for k, v in cal.items() if k.startswith('read_')}
+    assert len(reads) >= 5 and all(abs(x - 2.0) < 0.01 for x in reads.values()), reads
+    assert abs(cal['write_16B_per_lane_coalesced']['write_factor'] - 1.0) < 0.01
+    assert 0.9 < cal['write_24B_records_as_6x4B']['write_factor'] < 1.0          # partial-line stores are counted a few per cent high
+    rf, wf = hbm_traffic.calibration()
+    assert abs(rf - 2.0) < 0.01 and abs(wf - 1.0) < 0.01
+    with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
+        table = json.load(f)
+    for key, entry in table.items():
+        st = entry['_step']
+        assert abs(st['read_factor'] - rf) < 1e-6 and abs(st['write_factor'] - wf) < 1e-6, key
+        bp = entry.get('bp:rotamer')
+        if bp:
+            assert abs(bp['bytes_per_launch'] - (rf * bp['fetch_bytes_counted'] + bp['write_bytes'])) < 1e-3 * bp['bytes_per_launch']
