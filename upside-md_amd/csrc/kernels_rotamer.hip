@@ -1255,7 +1255,7 @@ __device__ __forceinline__ BpLayout bp_dense_layout(const upk_rotamer_t& R, cons
     // the flags as a bit per visit; the records are written from those bits once the layout is known.  (The first form walked the
     // slots three times, every visit a dependent global round trip: 36 -> 21 us of the solve's 430; all visits in flight at once,
     // kept in registers for the record pass, measured no better: 24 us.)
-    constexpr int PK_MAXIT = 16, PK_UNR = 4;
+    constexpr int PK_MAXIT = BLOCK <= 256 ? 32 : 16, PK_UNR = 4;      // (visits per wavefront kept as bits of one word: at most 32)
     const int pk_lane = tid & 63, pk_wave = tid >> 6, pk_nwave = nt >> 6;
     const int nc0 = (cls[CL33 + 1] - cls[CL33] + 63) >> 6, nc1 = (cls[CL36 + 1] - cls[CL36] + 63) >> 6, nc2 = (cls[CL66 + 1] - cls[CL66] + 63) >> 6;
     const int n_chunk = nc0 + nc1 + nc2, n_it = (n_chunk + pk_nwave - 1) / pk_nwave;
@@ -1382,7 +1382,13 @@ __device__ __forceinline__ void bp_fold_node(const upk_rotamer_t& R, const BpCtx
                 for (int r = 0; r < 6; ++r) if (r < n) pr[r] *= row[u][r];
     }
 }
-__global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int lds_msg_floats, int* __restrict__ out) {
+// scratch_words: LDS ints behind C.inbox_lds for the row masks and word bases (two per 32 cached rows + 1).  The launcher sizes it for a
+// quarter of the slot capacity (the capacity allows 96 residue pairs per node, a protein has ~30): a system with more rows than that sets
+// word n_node + 7 of its record and its solve lays the inbox out itself.
+#ifndef BPL_THREADS
+#define BPL_THREADS 512
+#endif
+__global__ void __launch_bounds__(BPL_THREADS) k_rotamer_bp_layout(upk_rotamer_t R, int lds_msg_floats, int* __restrict__ out, int scratch_words) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, NN = R.n_node;
     constexpr int NS = BP_NODE_STRIDE;
@@ -1402,9 +1408,11 @@ __global__ void __launch_bounds__(512) k_rotamer_bp_layout(upk_rotamer_t R, int 
     if (tid <= N_CLASS) cls[tid] = R.class_start[(size_t)s * (N_CLASS + 1) + tid];
     if (tid < 3) n_act[tid] = 0;
     __syncthreads();
-    const BpLayout ly = bp_dense_layout<512>(R, s, C, NN, cls, n_act, bp_start, scratch, nb0, lds_msg_floats, tid, nt);
-    __syncthreads();
     int* o = out + (size_t)s * bp_layout_stride(NN);
+    if (2 * ((bp_start[NN] + 31) >> 5) + 1 > scratch_words) { if (tid == 0) o[NN + 7] = 1; return; }      // (uniform: left to the solve)
+    if (tid == 0) o[NN + 7] = 0;
+    const BpLayout ly = bp_dense_layout<BPL_THREADS>(R, s, C, NN, cls, n_act, bp_start, scratch, nb0, lds_msg_floats, tid, nt);
+    __syncthreads();
     for (int i = tid; i <= NN; i += nt) o[i] = bp_start[i];
     if (tid < 3) o[NN + 1 + tid] = n_act[tid];
     if (tid == 0) { o[NN + 4] = ly.inbox_floats; o[NN + 5] = ly.inbox_floats3; o[NN + 6] = ly.w3; }
@@ -1501,8 +1509,8 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     int inbox_floats, inbox_floats3;       // all message floats of this solve, and those of the rows to 3-state nodes (they come first)
     int w3 = 4;                            // floats per row to a 3-state node (dense layout: 4, or 3 when only that makes the inbox fit the LDS)
     if (COMPACT) {
-        if (R.bp_layout) {          // laid out by k_rotamer_bp_layout in front of this launch
-            const int* LY = R.bp_layout + (size_t)s * bp_layout_stride(NN);
+        const int* LY = R.bp_layout ? R.bp_layout + (size_t)s * bp_layout_stride(NN) : nullptr;
+        if (LY && LY[NN + 7] == 0) {          // laid out by k_rotamer_bp_layout in front of this launch
             __syncthreads();        // (bp_start still holds the rows loaded above: nobody reads them)
             for (int i = tid; i <= NN; i += nt) bp_start[i] = LY[i];
             if (tid < 3) n_act[tid] = LY[NN + 1 + tid];
@@ -1547,7 +1555,7 @@ __global__ void __launch_bounds__(BLOCK) k_rotamer_bp(upk_rotamer_t R, int want_
     BP_STAMP(2);
     // fold edges to 1-state partners into the node probabilities (move_edge_prob_to_node2, rotamer.cpp:378-385)
     // (four partners per trip: slot ids, then flags, then the rows, each as one batch of loads; same product order)
-    const bool pre_folded = COMPACT && R.bp_layout && !R.node_prob_in_solve;      // (k_rotamer_bp_layout folded: its probabilities replace the ones loaded above)
+    const bool pre_folded = COMPACT && R.bp_layout && !R.node_prob_in_solve && R.bp_layout[(size_t)s * bp_layout_stride(NN) + NN + 7] == 0;      // (k_rotamer_bp_layout folded: its probabilities replace the ones loaded above)
     if (pre_folded) {
         const float* fo = (const float*)(R.bp_layout + (size_t)s * bp_layout_stride(NN) + NN + 8);
         for (int i = tid; i < NN * 6; i += nt) prob[(i / 6) * NS + i % 6] = fo[i];
@@ -2268,9 +2276,10 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
         upk_rotamer_t Rl = *R;
         // the dense layout as a launch of its own in front of the solve (R->bp_layout allocated by the host node: from 512 systems on),
         // when its scratch fits a quarter of a CU's LDS; else inside the solve
-        const size_t layout_lds = ((size_t)R->n_node * (BP_NODE_STRIDE + 1) + 64 + N_CLASS + 16) * sizeof(float) + layout_scratch + 64;
+        const int scratch_words = (int)((((size_t)2 * (R->slot_cap / 4 + 32) + 64) / 32) * 2 + 2);
+        const size_t layout_lds = ((size_t)R->n_node * (BP_NODE_STRIDE + 1) + 64 + N_CLASS + 16) * sizeof(float) + (size_t)scratch_words * sizeof(int) + 64;
         if (R->bp_layout && layout_lds <= 40 * 1024)
-            hipLaunchKernelGGL(k_rotamer_bp_layout, dim3(L->n_system), dim3(512), layout_lds, ST(L), *R, lds_msg_floats, R->bp_layout);
+            hipLaunchKernelGGL(k_rotamer_bp_layout, dim3(L->n_system), dim3(BPL_THREADS), layout_lds, ST(L), *R, lds_msg_floats, R->bp_layout, scratch_words);
         else Rl.bp_layout = nullptr;
         hipLaunchKernelGGL((k_rotamer_bp<BP_BLOCK / 2, 1, 1, 1, true>), grid, dim3(BP_BLOCK / 2), lds, ST(L), Rl, want_energy, only_fallback, lds_msg_floats);
     } else
