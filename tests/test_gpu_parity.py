@@ -655,6 +655,7 @@ ALT_PATHS = [
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_ENERGY_TABLE': '1'},  # one-workgroup BP taking exp(-E) of the pair matrices itself
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_COMPACT': '0'},       # one-workgroup BP of 1024 lanes streaming every pair matrix over the cached inbox layout
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LAYOUT': '1'},        # one-workgroup BP with the inbox layout and the fold as a launch of their own (the choice from 512 systems on)
+    {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LAYOUT': '2'},        # ... whose scratch is too small for the system: every solve lays its inbox out itself after all
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '0'},    # one-workgroup BP, every message in global memory
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '8'},    # LDS boundary inside the rows to 3-state nodes
     {'UPSIDE_HIP_BP_CLUSTER': '1', 'UPSIDE_HIP_BP_LDS_MSG_KB': '60'},   # LDS boundary inside the rows to 6-state nodes

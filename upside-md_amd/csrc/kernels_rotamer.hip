@@ -2276,7 +2276,9 @@ static void bp_launch(const upk_launch_t* L, const upk_rotamer_t* R, int want_en
         upk_rotamer_t Rl = *R;
         // the dense layout as a launch of its own in front of the solve (R->bp_layout allocated by the host node: from 512 systems on),
         // when its scratch fits a quarter of a CU's LDS; else inside the solve
-        const int scratch_words = (int)((((size_t)2 * (R->slot_cap / 4 + 32) + 64) / 32) * 2 + 2);
+        static int hand_back = -1;      // UPSIDE_HIP_BP_LAYOUT=2 (tests): no scratch at all, so that every system is handed back to its solve
+        if (hand_back < 0) { const char* e = getenv("UPSIDE_HIP_BP_LAYOUT"); hand_back = (e && atoi(e) == 2) ? 1 : 0; }
+        const int scratch_words = hand_back ? 1 : (int)((((size_t)2 * (R->slot_cap / 4 + 32) + 64) / 32) * 2 + 2);
         const size_t layout_lds = ((size_t)R->n_node * (BP_NODE_STRIDE + 1) + 64 + N_CLASS + 16) * sizeof(float) + (size_t)scratch_words * sizeof(int) + 64;
         if (R->bp_layout && layout_lds <= 40 * 1024)
             hipLaunchKernelGGL(k_rotamer_bp_layout, dim3(L->n_system), dim3(BPL_THREADS), layout_lds, ST(L), *R, lds_msg_floats, R->bp_layout, scratch_words);

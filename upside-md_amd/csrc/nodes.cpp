@@ -1293,7 +1293,7 @@ struct RotamerSidechain : public PotentialNode {
         // solves of a launch run in several rounds over the CUs (a solve owns a whole CU): UPSIDE_HIP_BP_LAYOUT=0/1 forces it off / on (tests)
         {
             const int want = env_int("UPSIDE_HIP_BP_LAYOUT", -1);
-            if (want == 1 || (want < 0 && S >= 512)) { bp_layout.alloc((size_t)S * (UPK_BP_LAYOUT_PER_NODE * n_node + UPK_BP_LAYOUT_EXTRA)); R.bp_layout = bp_layout.p; }
+            if (want >= 1 || (want < 0 && S >= 512)) { bp_layout.alloc((size_t)S * (UPK_BP_LAYOUT_PER_NODE * n_node + UPK_BP_LAYOUT_EXTRA)); R.bp_layout = bp_layout.p; }
         }
         iters.alloc(S); n_bad.alloc(S); energy.alloc(S); bp_start.alloc((size_t)S * (n_node + 1)); slot_off.alloc((size_t)S * R.slot_cap * 2);
         class_start.alloc((size_t)S * 6); slot_active_last.alloc((size_t)S * R.slot_cap);
