@@ -133,10 +133,6 @@ struct DerivComputation {   // deriv_engine.h:48-80
     // compute_value (fused_forward) / gather + propagate_deriv (fused_backward) enqueue fused per-element ops ONLY: the engine orders
     // the sweep so that such steps run back to back and share launches (DerivEngine::finalize)
     bool fused_forward = false, fused_backward = false;
-    // A forward step nobody's forward step waits for (a potential term) that is a heavy launch of its own: on the multi-stream schedule the
-    // engine runs it just in front of the LAST node whose list upkeep it joins, i.e. beside the tail of that upkeep chain, instead of in
-    // front of the first one, where it would hold the main stream while lists that are ready wait (DerivEngine::finalize)
-    bool defer_forward = false;
     // Work that depends on the parents' outputs only and is not on every step's critical path (pair-list upkeep).
     // The engine enqueues it on a side stream as soon as the last parent is computed, so a straggling rebuild of a
     // few systems overlaps with the nodes scheduled in between; compute_value() runs after it (event-ordered).

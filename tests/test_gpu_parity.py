@@ -668,8 +668,6 @@ ALT_PATHS = [
     {'UPSIDE_HIP_FUSE_THREADS': '128'},      # ... and with two wavefronts per system
     {'UPSIDE_HIP_NODE_PROB_IN_SOLVE': '0'},  # node probabilities by a kernel of their own (large batches) instead of in the solve's prologue
     {'UPSIDE_HIP_NODE_PROB_IN_SOLVE': '0', 'UPSIDE_HIP_BP_CLUSTER': '6'},   # ... in front of the cluster solve
-    {'UPSIDE_HIP_DEFER_STERICS': '0', 'UPSIDE_HIP_BATCH': '0'},   # multi-stream schedule with the backbone sterics in front of the first pair pass (default: in front of the last joined one)
-    {'UPSIDE_HIP_BATCH': '0', 'UPSIDE_HIP_BP_CLUSTER': '1'},      # ... and the default placement on that schedule at one system
     {'UPSIDE_HIP_BACKBONE_LIST': '0'},       # backbone sterics scanning all residue pairs every step (no cached residue-pair lists)
     {'UPSIDE_HIP_BACKBONE_SKIN': '0.5'},     # ... and with a short margin (rebuilds every other step)
     {'UPSIDE_HIP_SLOT_SPLIT': '1'},          # slot numbering by one workgroup per system (the large-batch choice)

@@ -462,32 +462,6 @@ void DerivEngine::finalize() {
             side[(int)c] = sd;
         }
     }
-    {   // deferred forward steps (DerivComputation::defer_forward: backbone sterics of a large protein) move in front of the LAST forward
-        // step that joins an upkeep chain.  Where they stood -- in front of the first pair pass -- the kernel shares the device with the
-        // list upkeep of all graphs, is stretched from 0.47 to 3.6 ms (4096 x 300 residues) and holds the main stream until every chain
-        // has finished, although the lists of four of the five graphs have been ready for 2 ms by then; behind them it runs beside the tail
-        // of the longest chain (slot numbering, slot stamping: latency bound) and the forward passes of the other graphs start as their
-        // own lists arrive.
-        int last_join = -1;
-        for (size_t k = 0; k < hoisted.size(); ++k)
-            if (!hoisted[k].backward && !hoisted[k].prepare && side.count(hoisted[k].node)) last_join = (int)k;
-        if (last_join >= 0) {
-            std::vector<Step> moved, kept;
-            for (size_t k = 0; k < hoisted.size(); ++k) {
-                const Step& st = hoisted[k];
-                const bool defer = (int)k < last_join && !st.backward && !st.prepare && nodes[st.node].computation->defer_forward;
-                (defer ? moved : kept).push_back(st);
-            }
-            if (!moved.empty()) {
-                std::vector<Step> out;
-                for (auto& st : kept) {
-                    if (!st.backward && !st.prepare && st.node == hoisted[last_join].node) out.insert(out.end(), moved.begin(), moved.end());
-                    out.push_back(st);
-                }
-                hoisted.swap(out);
-            }
-        }
-    }
     schedule.swap(hoisted);
     last_prepare_step = -1;
     for (size_t k = 0; k < schedule.size(); ++k) if (schedule[k].prepare) last_prepare_step = (int)k;

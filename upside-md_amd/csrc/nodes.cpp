@@ -370,7 +370,6 @@ struct BackbonePairs : public PotentialNode {
         src = alignment.scatter.add_source(n_residue, 1, 6, ids);
         alloc_terms(n_residue);
         fused_forward = fused_backward = true;
-        defer_forward = n_residue > 128 && env_int("UPSIDE_HIP_DEFER_STERICS", 1);      // (above 128 residues the forward pass is a kernel of its own: k_backbone_pairs)
         memset(&cache, 0, sizeof(cache));
         if (n_residue > 128 && env_int("UPSIDE_HIP_BACKBONE_LIST", 1)) {
             // residue centres move by ~0.15 A per step: a 3 A skin is rebuilt every ~10 steps and keeps ~45 partners per row at 300 residues
