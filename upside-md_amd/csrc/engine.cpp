@@ -608,7 +608,8 @@ void DerivEngine::run_steps(int n_step) {
     // dependent launches and a graph node boundary is cheaper than an eager one (one / eight 56-residue systems: 193 / 223 against
     // 201 / 233 us per step; one 300-residue system 465 against 474; 64 x 150 residues 716 against 689: off there)
     static const int graph_env = [] { const char* e = getenv("UPSIDE_HIP_GRAPH"); return e ? atoi(e) : -1; }();
-    const int use_graph = graph_env >= 0 ? graph_env : (ctx.L.batch ? 1 : 0);        // (with the merged launches: one stream; a multi-stream capture replays slower than it launches)
+    static const bool sync_diag = getenv("UPSIDE_HIP_FUSE_TRACE") != nullptr;      // (the trace reads its clocks back after every flush: a capturing stream cannot be synchronised)
+    const int use_graph = sync_diag ? 0 : (graph_env >= 0 ? graph_env : (ctx.L.batch ? 1 : 0));        // (with the merged launches: one stream; a multi-stream capture replays slower than it launches)
     int left = n_step;
     while (left > 0) {
         const bool aligned = stage_num == 0 && thermostat_interval == 1 && !ctx.profile && steps_done >= 6;
